@@ -1,0 +1,99 @@
+/*
+ * dot_oracle.h -- CPU restatement of the reference DOT time-step (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity oracle for dot_amd: a plain-C (C99 + optional OpenMP) restatement of the
+ * algorithm of penn-graphics-research/DOT's DOTTimeStepper hot path.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product path
+ * (dot_amd/csrc, libdotmi.so) never links, includes or calls anything in this directory.
+ *
+ * Every function cites the reference file:line it follows (paths relative to /root/reference/src).
+ *
+ * Pinning status (see oracle/README.md and DESIGN.md section "Oracle"):
+ *   - 3x3 SVD, Psi(sigma), dPsi/dsigma, makePD, makePD2d, dF_div_dx_mult: checked against the
+ *     reference's own sources compiled unmodified into oracle/_ref (ref_pin).
+ *   - METIS partition: produced by the reference's vendored METIS 5.1.0 compiled into oracle/_ref.
+ *   - step level: tolerance constant and L-BFGS iteration counts per step published in
+ *     BASELINE.md section 2 (bunny5K FCR/8 parts, bar17K SNH/32 parts).
+ *   - d2Psi/dsigma2, B-coefficients, dP/dF assembly, Hessian scatter, preconditioner, two-loop,
+ *     line search: restated from source, validated by finite differences / algebraic identities
+ *     (the reference's own test strategy, Energy.cpp:1279-1521); the reference's .cpp files for
+ *     these need TBB headers, which this image lacks, so they are NOT compiled here.
+ */
+#ifndef DOT_ORACLE_H
+#define DOT_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DOR_FCR 0 /* FixedCoRotEnergy  */
+#define DOR_SNH 1 /* StableNHEnergy (non-log variant, Types.hpp:37 SNH_WITHLOG off) */
+
+/* ---- element-level math (row-major 3x3) ---- */
+void dor_svd3(const double F[9], double U[9], double S[3], double V[9]);
+double dor_psi(int mat, const double s[3], double mu, double lam);
+void dor_dpsi(int mat, const double s[3], double mu, double lam, double d[3]);
+void dor_d2psi(int mat, const double s[3], double mu, double lam, double A[9]);
+void dor_bleft(int mat, const double s[3], double mu, double lam, double b[3]);
+void dor_make_pd3(double A[9]);
+void dor_make_pd2(double B[4]);
+void dor_dPdF(int mat, const double U[9], const double S[3], const double V[9], double mu,
+              double lam, double w, int project, double M[81]);
+void dor_dFdx_mult_vec(const double P[9], const double A[9], double g[12]);
+/* element Hessian from 4 vertex positions; H is 12x12 row-major */
+void dor_elem_hessian_x(int mat, const double x4[12], const double A[9], double mu, double lam,
+                        double w, int project, double H[144]);
+void dor_elem_energy_grad_x(int mat, const double x4[12], const double A[9], double mu, double lam,
+                            double w, double *psi_w, double g[12]);
+
+/* ---- simulation object ---- */
+typedef struct dor_sim dor_sim;
+
+typedef struct {
+    int iters;         /* L-BFGS iterations this step (innerIterAmt delta) */
+    int ls_halvings;   /* numOfLineSearch delta */
+    int energy_evals;
+    int status;        /* 0 ok, 2 = iteration cap or line-search failure */
+    double E0, g2_0;   /* after initX */
+    double E, g2;      /* at exit */
+    double ms_total, ms_energy, ms_gradient, ms_backsolve, ms_hessian, ms_factor;
+} dor_step_stats;
+
+dor_sim *dor_create(int nV, int nT, const double *Xrest, const int *T, double YM, double PR,
+                    double rho, int material, double dt, int withGravity,
+                    const unsigned char *fixed, const double *x_init, const int *epart,
+                    int nParts, double relTol);
+void dor_destroy(dor_sim *s);
+
+/* scripted Dirichlet motion: x[idx[k]] = pos[3k..] (AnimScripter.cpp:456-466) */
+void dor_move(dor_sim *s, int n, const int *idx, const double *pos);
+int dor_step(dor_sim *s, dor_step_stats *st);
+/* per-iteration log of the last step: alpha, E, g2 (iterStats.txt columns) */
+int dor_last_iter_log(const dor_sim *s, int cap, double *alpha, double *E, double *g2);
+
+void dor_get_state(const dor_sim *s, double *x, double *v, double *xtilde);
+void dor_set_state(dor_sim *s, const double *x, const double *v, const double *xn);
+double dor_target_gres(const dor_sim *s);
+
+/* features / structure getters */
+void dor_get_features(const dor_sim *s, double *A /*nT*9*/, double *vol /*nT*/, double *mass /*nV*/,
+                      double *mu, double *lam);
+void dor_get_dup(const dor_sim *s, int *dup);
+int dor_part_size(const dor_sim *s, int part); /* local vertex count */
+void dor_part_verts(const dor_sim *s, int part, int *l2g);
+
+/* kernel-level entry points (mirror of the C ABI's parity entry points) */
+double dor_eval_energy(dor_sim *s, const double *x);
+void dor_eval_gradient(dor_sim *s, const double *x, double *g);
+void dor_eval_elem_hessians(dor_sim *s, const double *x, double *H /*nT*144*/);
+void dor_refactor(dor_sim *s, const double *x);              /* H(x), H_s, factor */
+void dor_apply_precond(dor_sim *s, const double *r, double *p);
+void dor_spmv(dor_sim *s, const double *p, double *Hp);
+/* dense principal sub-matrix of the assembled global H on a part (n_s*3)^2 row-major */
+void dor_part_dense(const dor_sim *s, int part, double *Hs);
+void dor_set_threads(int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
