@@ -1,0 +1,57 @@
+"""Named workloads (BASELINE.json `configs`).  Each mirrors one of the
+reference's input scripts with the overrides BASELINE.json names; the script *values* are restated
+here so nothing needs /root/reference at run time (meshes come from tests/golden/meshes)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from .scene import Config, Scene, build_scene, load_mesh_npz, partition_rcb, synthetic_bar
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MESH_DIR = os.path.join(_ROOT, "tests", "golden", "meshes")
+PART_DIR = os.path.join(_ROOT, "tests", "golden", "parts")
+
+# name -> (mesh, Config kwargs, nParts)
+WORKLOADS = {
+    # input/bunny5K_LTSS_DOT.txt, FixedCoRot, 8 subdomains (BASELINE.json configs[0])
+    "bunny5K_LTSS": ("bunny5K", dict(energy="FCR", size=1.0, duration=5.0, dt=0.025, rho=1000.0, YM=1e5,
+                                     PR=0.4, script="twistnsns"), 8),
+    # input/bar17K_twist_DOT.txt, StableNH, 32 subdomains (configs[1], the bench workload)
+    "bar17K_twist": ("bar17K", dict(energy="SNH", size=1.0, duration=5.0, dt=0.025, rho=1000.0, YM=1e5,
+                                    PR=0.4, script="twist"), 32),
+    # input/tb1_horse_scalab/horse7K_stretch_DOT.txt (stand-in for the missing horse136K), FCR, 8
+    "horse7K_stretch": ("horse7K", dict(energy="FCR", size=1.0, duration=10.0, dt=0.025, rho=1000.0, YM=1e5,
+                                        PR=0.4, script="stretch"), 8),
+    # input/tb2_monkey_mat_dt/monkey18K_TSS_DOT_E4e5.txt + time 10 0.04, StableNH, 64 subdomains
+    "monkey18K_stiff": ("monkey18K", dict(energy="SNH", size=1.0, duration=10.0, dt=0.04, rho=1000.0, YM=4e5,
+                                          PR=0.4, script="twistnsns_old", rot_deg=40.0, rot_axis=(0.0, 1.0, 0.0),
+                                          handle_ratio=0.02), 64),
+}
+
+
+def load_workload(name: str, nparts: int | None = None):
+    """-> (Scene, epart, nparts).  Partition = committed METIS fixture when it exists for this
+    (mesh, nparts), else the package's own recursive-coordinate-bisection partitioner."""
+    if name.startswith("synbar"):
+        # synbar:<nx>x<ny>x<nz>:<nparts>  e.g. the 1M-tet bar = synbar:140x35x35:256
+        _, dims, npart_s = name.split(":")
+        nx, ny, nz = (int(t) for t in dims.split("x"))
+        V, T = synthetic_bar(nx, ny, nz)
+        cfg = Config(energy="SNH", size=1.0, duration=5.0, dt=0.025, rho=1000.0, YM=1e5, PR=0.4, script="twist")
+        sc = build_scene(cfg, V, T)
+        np_ = int(npart_s) if nparts is None else nparts
+        return sc, partition_rcb(sc.V_rest, sc.T, np_), np_
+    mesh, kw, np_default = WORKLOADS[name]
+    np_ = np_default if nparts is None else nparts
+    V, T = load_mesh_npz(os.path.join(MESH_DIR, mesh + ".npz"))
+    cfg = Config(**kw)
+    cfg.partition_amt = np_
+    sc = build_scene(cfg, V, T)
+    f = os.path.join(PART_DIR, f"{mesh}_{np_}.npy")
+    if os.path.exists(f):
+        epart = np.load(f).astype(np.int32)
+    else:
+        epart = partition_rcb(sc.V_rest, sc.T, np_)
+    return sc, epart, np_

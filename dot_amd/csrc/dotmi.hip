@@ -1,0 +1,1154 @@
+// dotmi.hip -- host side of libdotmi.so: setup, the L-BFGS-H time-step loop, and the C ABI.
+//
+// Control flow mirrors (paths relative to /root/reference/src)
+//   dotmi_create       Optimizer ctor (TimeStepper/Optimizer.cpp:52-196), ADMMDDTimeStepper ctor
+//                      (ADMMDDTimeStepper.cpp:44-443: partition -> local maps), DOTTimeStepper ctor +
+//                      precompute (DOTTimeStepper.cpp:38-178), Mesh::computeFeatures (Mesh.cpp:589-700)
+//   dotmi_step         Optimizer::solve (Optimizer.cpp:327-368) -> DOTTimeStepper::fullyImplicit
+//                      (DOTTimeStepper.cpp:273-346) -> solve_oneStep (:384-504) -> Optimizer::lineSearch
+//                      (Optimizer.cpp:752-881) ; updateHessianAndFactor (DOTTimeStepper.cpp:349-380)
+// The data path is entirely on the device; the host only sequences launches, evaluates the m x m
+// scalar recurrences of the two-loop recursion and takes the accept / halve / converged decisions
+// from one small read-back per line-search trial.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dotmi.h"
+#include "dotmi_internal.hpp"
+#include "elem_math.hpp"
+
+using namespace dotmi;
+
+namespace {
+
+std::string g_create_error;
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch())
+        .count();
+}
+
+__global__ void reduce_rows_kernel(const double *__restrict__ partials, int nblocks, int stride, int K,
+                                   double s0, double s1, int combine, double *__restrict__ out)
+{
+    // single wave; out[j] = sum_b partials[b*stride+j]; combine: out[0] = s0*sum0 + s1*sum1
+    const int lane = threadIdx.x;
+    double first = 0.0;
+    for (int j = 0; j < K; ++j) {
+        double acc = 0.0;
+        for (int b = lane; b < nblocks; b += 64) acc += partials[(size_t)b * stride + j];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) {
+            if (combine) {
+                if (j == 0) first = s0 * acc;
+                else if (j == 1) out[0] = first + s1 * acc;
+            } else {
+                out[j] = acc;
+            }
+        }
+    }
+}
+
+template <class T>
+struct DBuf {
+    T *p = nullptr;
+    size_t n = 0;
+};
+
+}  // namespace
+
+struct dotmi_handle {
+    // configuration
+    int nV = 0, nT = 0, n = 0, mat = 0, hist = 5, iterCap = 10000;
+    double dt = 0, dtSq = 0, grav[3] = {0, 0, 0}, gdtsq[3] = {0, 0, 0}, relTol = 1e-5, alphaMin = 0.1;
+    double targetGRes = 0, density = 0;
+    int device = 0, rank = 0, world = 1, flags = 0;
+    std::string err;
+
+    // host copies
+    std::vector<int> T, epart;
+    std::vector<uint8_t> fixed;
+    std::vector<double> Xrest, A, vol, mass, mu, lam;
+    int nPartsAll = 0, p0 = 0, p1 = 0;  // owned global parts [p0,p1)
+    std::vector<std::vector<int>> partVerts;  // all parts: ascending global vertex ids
+    std::vector<int> dup;
+
+    // device
+    hipStream_t st = nullptr;
+    rocblas_handle blas = nullptr;
+    ncclComm_t comm = nullptr;
+    DevMesh M{};
+    DevParts P{};
+    int *elist = nullptr;
+    int nOwnElem = 0, v0 = 0, v1 = 0;
+    double *x = nullptr, *x_trial = nullptr, *xn = nullptr, *v = nullptr, *xt = nullptr;
+    double *g = nullptr, *g_trial = nullptr, *p = nullptr, *q = nullptr, *z = nullptr, *Hp = nullptr;
+    double *gcont = nullptr, *He = nullptr, *Hval = nullptr, *tmpn = nullptr;
+    double *S[HIST_MAX + 1] = {nullptr}, *Y[HIST_MAX + 1] = {nullptr};
+    double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
+    double *alpha_dev = nullptr;
+    rocblas_int *info_dev = nullptr;
+    int *didx = nullptr;
+    double *dpos = nullptr;
+    size_t dcap = 0;
+    std::vector<void *> allocs;
+    // pinned host
+    double *h_partE = nullptr, *h_partR = nullptr, *h_alpha = nullptr;
+    int nbE = 0;
+
+    // L-BFGS host state (chronological)
+    int m = 0;
+    int order[HIST_MAX + 1] = {0};
+    double ys[HIST_MAX] = {0}, sy[HIST_MAX][HIST_MAX] = {{0}}, b[HIST_MAX] = {0};
+
+    // logs / stats
+    std::vector<double> log_alpha, log_E, log_g2;
+    long long numLineSearch = 0;
+    int energy_evals = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    int64_t precond_bytes = 0;
+};
+
+#define HIPCHECK(h, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+            return DOTMI_E_DEVICE;                                                                \
+        }                                                                                         \
+    } while (0)
+#define RBCHECK(h, call)                                                                          \
+    do {                                                                                          \
+        rocblas_status s_ = (call);                                                               \
+        if (s_ != rocblas_status_success) {                                                       \
+            (h)->err = std::string(#call) + ": rocblas status " + std::to_string((int)s_);        \
+            return DOTMI_E_DEVICE;                                                                \
+        }                                                                                         \
+    } while (0)
+#define NCCLCHECK(h, call)                                                                        \
+    do {                                                                                          \
+        ncclResult_t r_ = (call);                                                                 \
+        if (r_ != ncclSuccess) {                                                                  \
+            (h)->err = std::string(#call) + ": " + ncclGetErrorString(r_);                        \
+            return DOTMI_E_DEVICE;                                                                \
+        }                                                                                         \
+    } while (0)
+
+namespace {
+
+template <class T>
+int dalloc(dotmi_handle *h, T **ptr, size_t count)
+{
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIPCHECK(h, hipMalloc(&p, bytes));
+    h->allocs.push_back(p);
+    *ptr = (T *)p;
+    return 0;
+}
+
+template <class T>
+int upload(dotmi_handle *h, T **ptr, const std::vector<T> &v)
+{
+    int rc = dalloc(h, ptr, v.size());
+    if (rc) return rc;
+    if (!v.empty()) HIPCHECK(h, hipMemcpy(*ptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Mesh::computeFeatures (Mesh.cpp:589-700), computeMassMatrix tets (:552-585)
+void host_features(dotmi_handle *h)
+{
+    const int nV = h->nV, nT = h->nT;
+    h->A.assign((size_t)9 * nT, 0.0);
+    h->vol.assign(nT, 0.0);
+    h->mass.assign(nV, 0.0);
+    for (int e = 0; e < nT; ++e) {
+        const int *t = &h->T[4 * e];
+        const double *p0 = &h->Xrest[3 * t[0]], *p1 = &h->Xrest[3 * t[1]], *p2 = &h->Xrest[3 * t[2]],
+                     *p3 = &h->Xrest[3 * t[3]];
+        Mat3 X0;
+        for (int i = 0; i < 3; ++i) {
+            X0.m[i][0] = p1[i] - p0[i];
+            X0.m[i][1] = p2[i] - p0[i];
+            X0.m[i][2] = p3[i] - p0[i];
+        }
+        const double d = det3(X0), id = 1.0 / d;
+        const double(*m)[3] = X0.m;
+        double *R = &h->A[(size_t)9 * e];
+        R[0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) * id;
+        R[1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) * id;
+        R[2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) * id;
+        R[3] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) * id;
+        R[4] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) * id;
+        R[5] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) * id;
+        R[6] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) * id;
+        R[7] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) * id;
+        R[8] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) * id;
+        h->vol[e] = d / 3.0 / 2.0;  // signed triArea, Mesh.cpp:639
+        double a[3], b[3], c[3];
+        for (int i = 0; i < 3; ++i) {
+            a[i] = p0[i] - p3[i];
+            b[i] = p1[i] - p3[i];
+            c[i] = p2[i] - p3[i];
+        }
+        const double vv = std::fabs(a[0] * (b[1] * c[2] - b[2] * c[1]) + a[1] * (b[2] * c[0] - b[0] * c[2]) +
+                                    a[2] * (b[0] * c[1] - b[1] * c[0])) / 6.0;
+        for (int k = 0; k < 4; ++k) h->mass[t[k]] += vv / 4.0;
+    }
+    for (int v = 0; v < nV; ++v) h->mass[v] *= h->density;
+}
+
+// Optimizer::computeCharNormSq (Optimizer.cpp:613-651)
+double host_target_gres(const dotmi_handle *h)
+{
+    Mat3 Aw;
+    double Bw[3][4];
+    const double S1[3] = {1, 1, 1};
+    if (h->mat == 0) spectral_blocks<0>(S1, h->mu[0], h->lam[0], 1.0, false, Aw, Bw);
+    else spectral_blocks<1>(S1, h->mu[0], h->lam[0], 1.0, false, Aw, Bw);
+    // with U = V = I the 9x9 matrix is exactly the 21 spectral entries (Energy.cpp:1183-1207)
+    double sqH = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) sqH += Aw.m[i][j] * Aw.m[i][j];
+    for (int c = 0; c < 3; ++c)
+        for (int k = 0; k < 4; ++k) sqH += Bw[c][k] * Bw[c][k];
+    std::vector<double> ls(h->nV, 0.0);
+    for (int e = 0; e < h->nT; ++e) {
+        const int *t = &h->T[4 * e];
+        for (int i = 0; i < 4; ++i) {
+            const double *a = &h->Xrest[3 * t[(i + 1) % 4]], *b = &h->Xrest[3 * t[(i + 2) % 4]],
+                         *c = &h->Xrest[3 * t[(i + 3) % 4]];
+            const double u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+            const double w[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]};
+            const double cx = u[1] * w[2] - u[2] * w[1], cy = u[2] * w[0] - u[0] * w[2],
+                         cz = u[0] * w[1] - u[1] * w[0];
+            ls[t[i]] += 0.5 * std::sqrt(cx * cx + cy * cy + cz * cz);
+        }
+    }
+    double sql = 0;
+    for (int v = 0; v < h->nV; ++v) sql += ls[v] * ls[v];
+    // data0 carries exactly one fixed vertex (Mesh.cpp:592-598)
+    const double cn = h->relTol * h->relTol * sqH * sql * (double)(h->nV - 1) / (double)h->nV;
+    return cn * h->dtSq * h->dtSq;
+}
+
+int build_device_mesh(dotmi_handle *h)
+{
+    const int nV = h->nV, nT = h->nT;
+    DevMesh &M = h->M;
+    M.nV = nV;
+    M.nT = nT;
+    M.nTp = (nT + 63) / 64 * 64;
+    // elements
+    {
+        std::vector<int4> T4(nT);
+        for (int e = 0; e < nT; ++e) T4[e] = make_int4(h->T[4 * e], h->T[4 * e + 1], h->T[4 * e + 2], h->T[4 * e + 3]);
+        if (int rc = upload(h, &M.T, T4)) return rc;
+        std::vector<double> Asoa((size_t)9 * M.nTp, 0.0);
+        for (int e = 0; e < nT; ++e)
+            for (int k = 0; k < 9; ++k) Asoa[(size_t)k * M.nTp + e] = h->A[(size_t)9 * e + k];
+        if (int rc = upload(h, &M.A, Asoa)) return rc;
+        if (int rc = upload(h, &M.mu, h->mu)) return rc;
+        if (int rc = upload(h, &M.lam, h->lam)) return rc;
+        if (int rc = upload(h, &M.vol, h->vol)) return rc;
+        if (int rc = upload(h, &M.mass, h->mass)) return rc;
+        if (int rc = upload(h, &M.fixed, h->fixed)) return rc;
+    }
+    // vFLoc
+    std::vector<int> vf_ptr(nV + 1, 0), vf_ent((size_t)4 * nT);
+    for (int e = 0; e < nT; ++e)
+        for (int k = 0; k < 4; ++k) vf_ptr[h->T[4 * e + k] + 1]++;
+    for (int v = 0; v < nV; ++v) vf_ptr[v + 1] += vf_ptr[v];
+    {
+        std::vector<int> cur(vf_ptr.begin(), vf_ptr.end() - 1);
+        for (int e = 0; e < nT; ++e)
+            for (int k = 0; k < 4; ++k) vf_ent[cur[h->T[4 * e + k]]++] = 4 * e + k;
+    }
+    // adjacency incl. self
+    std::vector<int> adj_ptr(nV + 1, 0), adj_idx;
+    {
+        std::vector<std::vector<int>> nb(nV);
+        for (int e = 0; e < nT; ++e)
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) nb[h->T[4 * e + a]].push_back(h->T[4 * e + b]);
+        for (int v = 0; v < nV; ++v) {
+            auto &l = nb[v];
+            l.push_back(v);
+            std::sort(l.begin(), l.end());
+            l.erase(std::unique(l.begin(), l.end()), l.end());
+            adj_ptr[v + 1] = adj_ptr[v] + (int)l.size();
+        }
+        adj_idx.resize(adj_ptr[nV]);
+        for (int v = 0; v < nV; ++v) std::copy(nb[v].begin(), nb[v].end(), adj_idx.begin() + adj_ptr[v]);
+    }
+    M.nnzb = adj_ptr[nV];
+    std::vector<int> blk_row(M.nnzb);
+    for (int v = 0; v < nV; ++v)
+        for (int k = adj_ptr[v]; k < adj_ptr[v + 1]; ++k) blk_row[k] = v;
+    auto find_block = [&](int v, int u) {
+        const int *b = &adj_idx[adj_ptr[v]], *e = &adj_idx[adj_ptr[v + 1]];
+        return (int)(std::lower_bound(b, e, u) - adj_idx.data());
+    };
+    // per-block contributions, ascending element
+    std::vector<int> blk_ptr(M.nnzb + 1, 0), blk_ent((size_t)16 * nT), eblk((size_t)16 * nT);
+    for (int e = 0; e < nT; ++e)
+        for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b) {
+                const int k = find_block(h->T[4 * e + a], h->T[4 * e + b]);
+                eblk[(size_t)16 * e + 4 * a + b] = k;
+                blk_ptr[k + 1]++;
+            }
+    for (int k = 0; k < M.nnzb; ++k) blk_ptr[k + 1] += blk_ptr[k];
+    {
+        std::vector<int> cur(blk_ptr.begin(), blk_ptr.end() - 1);
+        for (int e = 0; e < nT; ++e)
+            for (int ab = 0; ab < 16; ++ab) blk_ent[cur[eblk[(size_t)16 * e + ab]]++] = 16 * e + ab;
+    }
+    if (int rc = upload(h, &M.vf_ptr, vf_ptr)) return rc;
+    if (int rc = upload(h, &M.vf_ent, vf_ent)) return rc;
+    if (int rc = upload(h, &M.adj_ptr, adj_ptr)) return rc;
+    if (int rc = upload(h, &M.adj_idx, adj_idx)) return rc;
+    if (int rc = upload(h, &M.blk_ptr, blk_ptr)) return rc;
+    if (int rc = upload(h, &M.blk_ent, blk_ent)) return rc;
+    if (int rc = upload(h, &M.blk_row, blk_row)) return rc;
+
+    // ---- subdomains (ADMMDDTimeStepper.cpp:88-262) ------------------------------------------------
+    const int nP = h->nPartsAll;
+    h->partVerts.assign(nP, {});
+    {
+        std::vector<int> mark(nV, -1);
+        for (int pI = 0; pI < nP; ++pI) {
+            for (int e = 0; e < nT; ++e)
+                if (h->epart[e] == pI)
+                    for (int k = 0; k < 4; ++k) {
+                        const int v = h->T[4 * e + k];
+                        if (mark[v] != pI) {
+                            mark[v] = pI;
+                            h->partVerts[pI].push_back(v);
+                        }
+                    }
+            std::sort(h->partVerts[pI].begin(), h->partVerts[pI].end());
+        }
+    }
+    h->dup.assign(nV, 0);
+    int nsmax = 0;
+    for (int pI = 0; pI < nP; ++pI) {
+        for (int v : h->partVerts[pI]) h->dup[v]++;
+        nsmax = std::max(nsmax, 3 * (int)h->partVerts[pI].size());
+    }
+    // ownership: contiguous groups of parts balanced by sum n_s^2 (the back-solve cost)
+    {
+        std::vector<double> cost(nP + 1, 0.0);
+        for (int pI = 0; pI < nP; ++pI) {
+            const double ns = 3.0 * h->partVerts[pI].size();
+            cost[pI + 1] = cost[pI] + ns * ns;
+        }
+        auto cut = [&](int r) {
+            if (r <= 0) return 0;
+            if (r >= h->world) return nP;
+            const double target = cost[nP] * r / h->world;
+            int c = (int)(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin());
+            if (c > 0 && target - cost[c - 1] < cost[c] - target) --c;
+            return std::min(std::max(c, 0), nP);
+        };
+        h->p0 = cut(h->rank);
+        h->p1 = cut(h->rank + 1);
+    }
+    DevParts &P = h->P;
+    P.nParts = h->p1 - h->p0;
+    P.nmax = (nsmax + 127) / 128 * 128;
+    std::vector<int> psize(P.nParts), dof_ptr(P.nParts + 1, 0), dofmap;
+    std::vector<int2> tiles;
+    for (int ls = 0; ls < P.nParts; ++ls) {
+        const auto &pv = h->partVerts[h->p0 + ls];
+        psize[ls] = 3 * (int)pv.size();
+        dof_ptr[ls + 1] = dof_ptr[ls] + psize[ls];
+        for (int v : pv)
+            for (int d = 0; d < 3; ++d) dofmap.push_back(3 * v + d);
+        for (int r = 0; r < psize[ls]; r += GEMV_ROWS) tiles.push_back(make_int2(ls, r));
+    }
+    P.ntiles = (int)tiles.size();
+    // merge lists (owned parts only)
+    std::vector<int> vp_ptr(nV + 1, 0), vp_off;
+    {
+        for (int ls = 0; ls < P.nParts; ++ls)
+            for (int v : h->partVerts[h->p0 + ls]) vp_ptr[v + 1]++;
+        for (int v = 0; v < nV; ++v) vp_ptr[v + 1] += vp_ptr[v];
+        vp_off.resize(vp_ptr[nV]);
+        std::vector<int> cur(vp_ptr.begin(), vp_ptr.end() - 1);
+        for (int ls = 0; ls < P.nParts; ++ls) {
+            const auto &pv = h->partVerts[h->p0 + ls];
+            for (int i = 0; i < (int)pv.size(); ++i) vp_off[cur[pv[i]]++] = dof_ptr[ls] + 3 * i;
+        }
+    }
+    // dense fill list
+    std::vector<long long> fill_dst, pad_dst;
+    std::vector<int> fill_src;
+    {
+        std::vector<int> g2l(nV, -1);
+        for (int ls = 0; ls < P.nParts; ++ls) {
+            const auto &pv = h->partVerts[h->p0 + ls];
+            for (int i = 0; i < (int)pv.size(); ++i) g2l[pv[i]] = i;
+            const long long base = (long long)ls * P.nmax * P.nmax;
+            for (int i = 0; i < (int)pv.size(); ++i) {
+                const int v = pv[i];
+                for (int k = adj_ptr[v]; k < adj_ptr[v + 1]; ++k) {
+                    const int j = g2l[adj_idx[k]];
+                    if (j < 0) continue;
+                    fill_dst.push_back(base + (long long)(3 * i) * P.nmax + 3 * j);
+                    fill_src.push_back(k);
+                }
+            }
+            for (int r = psize[ls]; r < P.nmax; ++r) pad_dst.push_back(base + (long long)r * P.nmax + r);
+            for (int v : pv) g2l[v] = -1;
+        }
+    }
+    P.nfill = (int)fill_src.size();
+    P.npad = (int)pad_dst.size();
+    h->precond_bytes = 0;
+    for (int ls = 0; ls < P.nParts; ++ls) h->precond_bytes += (int64_t)psize[ls] * psize[ls] * 8;
+    if (int rc = upload(h, &P.psize, psize)) return rc;
+    if (int rc = upload(h, &P.dof_ptr, dof_ptr)) return rc;
+    if (int rc = upload(h, &P.dofmap, dofmap)) return rc;
+    if (int rc = upload(h, &P.tile, tiles)) return rc;
+    if (int rc = upload(h, &P.vp_ptr, vp_ptr)) return rc;
+    if (int rc = upload(h, &P.vp_off, vp_off)) return rc;
+    if (int rc = upload(h, &P.dup, h->dup)) return rc;
+    if (int rc = upload(h, &P.fill_dst, fill_dst)) return rc;
+    if (int rc = upload(h, &P.fill_src, fill_src)) return rc;
+    if (int rc = upload(h, &P.pad_dst, pad_dst)) return rc;
+    if (int rc = dalloc(h, &P.W, (size_t)P.nParts * P.nmax * P.nmax)) return rc;
+    if (int rc = dalloc(h, &P.psub, (size_t)dof_ptr[P.nParts])) return rc;
+    if (int rc = dalloc(h, &h->info_dev, (size_t)std::max(P.nParts, 1))) return rc;
+
+    // element ownership + inertia vertex slice
+    if (h->world > 1) {
+        std::vector<int> el;
+        for (int e = 0; e < nT; ++e)
+            if (h->epart[e] >= h->p0 && h->epart[e] < h->p1) el.push_back(e);
+        h->nOwnElem = (int)el.size();
+        if (int rc = upload(h, &h->elist, el)) return rc;
+        h->v0 = (int)((long long)nV * h->rank / h->world);
+        h->v1 = (int)((long long)nV * (h->rank + 1) / h->world);
+    } else {
+        h->elist = nullptr;
+        h->nOwnElem = nT;
+        h->v0 = 0;
+        h->v1 = nV;
+    }
+    return 0;
+}
+
+LbfgsArgs lbfgs_args(const dotmi_handle *h)
+{
+    LbfgsArgs L;
+    memset(&L, 0, sizeof(L));
+    L.m = h->m;
+    for (int i = 0; i < h->m; ++i) {
+        L.s[i] = h->S[h->order[i]];
+        L.y[i] = h->Y[h->order[i]];
+        L.ys[i] = h->ys[i];
+        for (int j = 0; j < h->m; ++j) L.sy[i][j] = h->sy[i][j];
+    }
+    return L;
+}
+
+int free_slot(const dotmi_handle *h)
+{
+    for (int s = 0; s <= h->hist; ++s) {
+        bool used = false;
+        for (int i = 0; i < h->m; ++i) used |= (h->order[i] == s);
+        if (!used) return s;
+    }
+    return 0;
+}
+
+// element Hessians -> global H -> dense sub-matrices -> Cholesky -> explicit inverse
+// (DOTTimeStepper::updateHessianAndFactor, DOTTimeStepper.cpp:349-380)
+int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
+{
+    HIPCHECK(h, hipEventRecord(h->ev0, h->st));
+    launch_elem_hessians(h->M, h->mat, h->dtSq, x, h->He, h->st);
+    launch_assemble(h->M, h->He, h->Hval, h->st);
+    launch_dense_fill(h->P, h->Hval, h->st);
+    HIPCHECK(h, hipEventRecord(h->ev1, h->st));
+    if (h->P.nParts > 0) {
+        const rocblas_stride stride = (rocblas_stride)h->P.nmax * h->P.nmax;
+        RBCHECK(h, rocsolver_dpotrf_strided_batched(h->blas, rocblas_fill_lower, h->P.nmax, h->P.W, h->P.nmax,
+                                                    stride, h->info_dev, h->P.nParts));
+        std::vector<rocblas_int> info(h->P.nParts);
+        HIPCHECK(h, hipMemcpyAsync(info.data(), h->info_dev, sizeof(rocblas_int) * h->P.nParts,
+                                   hipMemcpyDeviceToHost, h->st));
+        HIPCHECK(h, hipStreamSynchronize(h->st));
+        for (int i = 0; i < h->P.nParts; ++i)
+            if (info[i] != 0) {
+                h->err = "subdomain " + std::to_string(h->p0 + i) + " Hessian not positive definite (potrf info " +
+                         std::to_string(info[i]) + ")";
+                return DOTMI_E_NOTSPD;
+            }
+        RBCHECK(h, rocsolver_dpotri_strided_batched(h->blas, rocblas_fill_lower, h->P.nmax, h->P.W, h->P.nmax,
+                                                    stride, h->info_dev, h->P.nParts));
+        launch_symmetrize(h->P, h->st);
+    }
+    HIPCHECK(h, hipEventRecord(h->ev2, h->st));
+    HIPCHECK(h, hipEventSynchronize(h->ev2));
+    float a = 0, b = 0;
+    hipEventElapsedTime(&a, h->ev0, h->ev1);
+    hipEventElapsedTime(&b, h->ev1, h->ev2);
+    if (ms_hess) *ms_hess += a;
+    if (ms_fact) *ms_fact += b;
+    HIPCHECK(h, hipGetLastError());
+    return 0;
+}
+
+// p = D^-1 sum_s R_s^T W_s R_s q   (DOTTimeStepper.cpp:406-450); leaves y_i.z partials in partC
+int apply_precond(dotmi_handle *h, const double *q, double *z, const LbfgsArgs &L)
+{
+    launch_gemv(h->P, q, h->st);
+    if (h->world == 1) {
+        launch_merge(h->M, h->P, L, z, h->partC, 1 | 2, h->st);
+    } else {
+        launch_merge(h->M, h->P, L, z, h->partC, 0, h->st);
+        NCCLCHECK(h, ncclAllReduce(z, z, h->n, ncclDouble, ncclSum, h->comm, h->st));
+        launch_div_dup(h->nV, h->P.dup, z, h->st);
+        const double *ys_[HIST_MAX];
+        for (int i = 0; i < L.m; ++i) ys_[i] = L.y[i];
+        if (L.m > 0) launch_multidot(h->n, z, ys_, L.m, h->partC, h->st);
+    }
+    return 0;
+}
+
+// energy + element gradients + vertex gather (+ pair) at `xeval`; results: *E, stats in h_partR
+int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, const LbfgsArgs &L, int slot,
+          double *E)
+{
+    int nb = 0;
+    launch_elem_energy_grad(h->M, h->mat, h->dtSq, xeval, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, h->gcont,
+                            h->partE, &nb, h->st);
+    h->nbE = nb;
+    GatherArgs a;
+    a.gcont = h->gcont;
+    a.x = xeval;
+    a.xt = h->xt;
+    a.g_old = h->g;
+    a.p = h->p;
+    a.alpha_dev = h->alpha_dev;
+    a.g_new = gout;
+    a.s_new = h->S[slot];
+    a.y_new = h->Y[slot];
+    a.iv0 = h->v0;
+    a.iv1 = h->v1;
+    if (h->world == 1) {
+        a.make_pair = make_pair;
+        launch_vertex_gather(h->M, a, L, h->partR, h->st);
+        HIPCHECK(h, hipMemcpyAsync(h->h_partE, h->partE, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, h->st));
+    } else {
+        a.make_pair = 0;
+        launch_vertex_gather(h->M, a, L, h->partR, h->st);
+        // pack E_local behind the gradient and reduce both in one collective
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
+                           gout + h->n);
+        NCCLCHECK(h, ncclAllReduce(gout, gout, h->n + 1, ncclDouble, ncclSum, h->comm, h->st));
+        if (make_pair) launch_pair_stats(h->n, a, L, h->partR, h->st);
+        else {
+            // |g|^2 only
+            const double *vecs[1] = {gout};
+            launch_multidot(h->n, gout, vecs, 1, h->partR, h->st);
+        }
+        HIPCHECK(h, hipMemcpyAsync(h->h_partE, gout + h->n, sizeof(double), hipMemcpyDeviceToHost, h->st));
+    }
+    HIPCHECK(h, hipMemcpyAsync(h->h_partR, h->partR, sizeof(double) * NB_RED * RED_K, hipMemcpyDeviceToHost,
+                               h->st));
+    HIPCHECK(h, hipMemcpyAsync(h->h_alpha, h->alpha_dev, sizeof(double), hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    if (h->world == 1) {
+        double se = 0, si = 0;
+        for (int b = 0; b < nb; ++b) {
+            se += h->h_partE[2 * b];
+            si += h->h_partE[2 * b + 1];
+        }
+        *E = h->dtSq * se + si;
+    } else {
+        *E = h->h_partE[0];
+    }
+    h->energy_evals++;
+    return 0;
+}
+
+void sum_stats(const dotmi_handle *h, int nvals, double *R)
+{
+    for (int j = 0; j < nvals; ++j) {
+        double acc = 0;
+        for (int b = 0; b < NB_RED; ++b) acc += h->h_partR[(size_t)b * RED_K + j];
+        R[j] = acc;
+    }
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char *dotmi_last_error(const dotmi_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dotmi_comm_unique_id(void *out128)
+{
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return DOTMI_E_DEVICE;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    memcpy(out128, &id, 128);
+    return 0;
+}
+
+void dotmi_destroy(dotmi_handle *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    if (h->st) hipStreamSynchronize(h->st);
+    if (h->comm) ncclCommDestroy(h->comm);
+    if (h->blas) rocblas_destroy_handle(h->blas);
+    for (void *p : h->allocs) hipFree(p);
+    if (h->h_partE) hipHostFree(h->h_partE);
+    if (h->h_partR) hipHostFree(h->h_partR);
+    if (h->h_alpha) hipHostFree(h->h_alpha);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->ev2) hipEventDestroy(h->ev2);
+    if (h->st) hipStreamDestroy(h->st);
+    delete h;
+}
+
+static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_params *prm, const double *x_init)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        h->err = "no HIP device available: libdotmi has no CPU fallback";
+        return DOTMI_E_NOGPU;
+    }
+    if (!mesh || !prm || !x_init || mesh->nV <= 0 || mesh->nT <= 0 || !mesh->X_rest || !mesh->T || !mesh->mu ||
+        !mesh->lambda || !mesh->fixed || !mesh->epart || mesh->nParts < 1 || prm->dt <= 0 ||
+        prm->history < 1 || prm->history > HIST_MAX || prm->world < 1 || prm->rank < 0 ||
+        prm->rank >= prm->world || (prm->world > 1 && !prm->comm_id) ||
+        (prm->energy != DOTMI_ENERGY_FCR && prm->energy != DOTMI_ENERGY_SNH)) {
+        h->err = "invalid argument";
+        return DOTMI_E_INVALID;
+    }
+    for (int e = 0; e < mesh->nT; ++e) {
+        if (mesh->epart[e] < 0 || mesh->epart[e] >= mesh->nParts) {
+            h->err = "epart out of range";
+            return DOTMI_E_INVALID;
+        }
+        for (int k = 0; k < 4; ++k)
+            if (mesh->T[4 * e + k] < 0 || mesh->T[4 * e + k] >= mesh->nV) {
+                h->err = "tet index out of range";
+                return DOTMI_E_INVALID;
+            }
+    }
+    h->nV = mesh->nV;
+    h->nT = mesh->nT;
+    h->n = 3 * mesh->nV;
+    h->mat = prm->energy;
+    h->hist = prm->history;
+    h->iterCap = prm->iterCap > 0 ? prm->iterCap : 10000;
+    h->dt = prm->dt;
+    h->dtSq = prm->dt * prm->dt;
+    for (int d = 0; d < 3; ++d) {
+        h->grav[d] = prm->gravity[d];
+        h->gdtsq[d] = h->dtSq * prm->gravity[d];
+    }
+    h->relTol = prm->relTol;
+    h->alphaMin = prm->alphaMin;
+    h->device = prm->device;
+    h->rank = prm->rank;
+    h->world = prm->world;
+    h->flags = prm->flags;
+    h->density = mesh->density;
+    h->nPartsAll = mesh->nParts;
+    h->T.assign(mesh->T, mesh->T + 4 * (size_t)h->nT);
+    h->epart.assign(mesh->epart, mesh->epart + h->nT);
+    h->fixed.assign(mesh->fixed, mesh->fixed + h->nV);
+    h->Xrest.assign(mesh->X_rest, mesh->X_rest + h->n);
+    h->mu.assign(mesh->mu, mesh->mu + h->nT);
+    h->lam.assign(mesh->lambda, mesh->lambda + h->nT);
+
+    HIPCHECK(h, hipSetDevice(h->device));
+    HIPCHECK(h, hipStreamCreate(&h->st));
+    HIPCHECK(h, hipEventCreate(&h->ev0));
+    HIPCHECK(h, hipEventCreate(&h->ev1));
+    HIPCHECK(h, hipEventCreate(&h->ev2));
+    RBCHECK(h, rocblas_create_handle(&h->blas));
+    RBCHECK(h, rocblas_set_stream(h->blas, h->st));
+    if (h->world > 1) {
+        ncclUniqueId id;
+        memcpy(&id, prm->comm_id, 128);
+        NCCLCHECK(h, ncclCommInitRank(&h->comm, h->world, id, h->rank));
+    }
+
+    host_features(h);
+    h->targetGRes = host_target_gres(h);
+    if (int rc = build_device_mesh(h)) return rc;
+
+    const int n = h->n;
+    double **vecs[] = {&h->x, &h->x_trial, &h->xn, &h->v, &h->xt, &h->g, &h->g_trial, &h->p, &h->q, &h->z,
+                       &h->Hp, &h->tmpn};
+    for (double **pp : vecs) {
+        if (int rc = dalloc(h, pp, (size_t)n + 8)) return rc;
+        HIPCHECK(h, hipMemsetAsync(*pp, 0, sizeof(double) * (n + 8), h->st));
+    }
+    for (int s = 0; s <= h->hist; ++s) {
+        if (int rc = dalloc(h, &h->S[s], (size_t)n)) return rc;
+        if (int rc = dalloc(h, &h->Y[s], (size_t)n)) return rc;
+    }
+    if (int rc = dalloc(h, &h->gcont, (size_t)12 * h->nT)) return rc;
+    HIPCHECK(h, hipMemsetAsync(h->gcont, 0, sizeof(double) * 12 * (size_t)h->nT, h->st));
+    if (int rc = dalloc(h, &h->He, (size_t)144 * h->nT)) return rc;
+    if (int rc = dalloc(h, &h->Hval, (size_t)9 * h->M.nnzb)) return rc;
+    if (int rc = dalloc(h, &h->partE, (size_t)2 * 2048)) return rc;
+    double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG};
+    for (double **pp : parts) {
+        if (int rc = dalloc(h, pp, (size_t)NB_RED * RED_K)) return rc;
+        HIPCHECK(h, hipMemsetAsync(*pp, 0, sizeof(double) * NB_RED * RED_K, h->st));
+    }
+    if (int rc = dalloc(h, &h->alpha_dev, 8)) return rc;
+    HIPCHECK(h, hipHostMalloc((void **)&h->h_partE, sizeof(double) * 2 * 2048));
+    HIPCHECK(h, hipHostMalloc((void **)&h->h_partR, sizeof(double) * NB_RED * RED_K));
+    HIPCHECK(h, hipHostMalloc((void **)&h->h_alpha, sizeof(double) * 8));
+
+    // Optimizer.cpp:124-184: result = data0 (+script init), v = 0, x_n = x, x~
+    HIPCHECK(h, hipMemcpyAsync(h->x, x_init, sizeof(double) * n, hipMemcpyHostToDevice, h->st));
+    HIPCHECK(h, hipMemcpyAsync(h->xn, h->x, sizeof(double) * n, hipMemcpyDeviceToDevice, h->st));
+    launch_be_update(h->nV, h->M.fixed, h->x, h->xn, h->v, h->xt, h->dt, h->gdtsq, h->st);
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    // DOTTimeStepper::precompute (DOTTimeStepper.cpp:150-178)
+    return refactor(h, h->x, nullptr, nullptr);
+}
+
+int dotmi_create(const dotmi_mesh *mesh, const dotmi_params *prm, const double *x_init, dotmi_handle **out)
+{
+    if (!out) return DOTMI_E_INVALID;
+    *out = nullptr;
+    dotmi_handle *h = new dotmi_handle();
+    int rc = create_impl(h, mesh, prm, x_init);
+    if (rc != 0) {
+        g_create_error = h->err;
+        dotmi_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+int dotmi_set_state(dotmi_handle *h, const double *x, const double *v, const double *x_n)
+{
+    if (!h || !x || !v) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const size_t bytes = sizeof(double) * h->n;
+    HIPCHECK(h, hipMemcpyAsync(h->x, x, bytes, hipMemcpyHostToDevice, h->st));
+    HIPCHECK(h, hipMemcpyAsync(h->v, v, bytes, hipMemcpyHostToDevice, h->st));
+    HIPCHECK(h, hipMemcpyAsync(h->xn, x_n ? x_n : x, bytes, hipMemcpyHostToDevice, h->st));
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    // x~ = x_n + dt v + dt^2 g on free vertices (Optimizer.cpp:585-610); be_update recomputes v from
+    // (x - x_n)/dt, so build x~ with a temporary that leaves v and x_n untouched
+    HIPCHECK(h, hipMemcpyAsync(h->tmpn, h->xn, bytes, hipMemcpyDeviceToDevice, h->st));
+    // tmp_x = x_n + dt*v  => (tmp_x - x_n)/dt == v up to rounding; avoid that: compute x~ on the host
+    std::vector<double> xt(h->n);
+    const double *xn_h = x_n ? x_n : x;
+    for (int i = 0; i < h->nV; ++i)
+        for (int d = 0; d < 3; ++d) {
+            const int k = 3 * i + d;
+            xt[k] = h->fixed[i] ? xn_h[k] : xn_h[k] + (v[k] * h->dt + h->gdtsq[d]);
+        }
+    HIPCHECK(h, hipMemcpy(h->xt, xt.data(), bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int dotmi_get_state(dotmi_handle *h, double *x, double *v, double *x_tilde)
+{
+    if (!h) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const size_t bytes = sizeof(double) * h->n;
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    if (x) HIPCHECK(h, hipMemcpy(x, h->x, bytes, hipMemcpyDeviceToHost));
+    if (v) HIPCHECK(h, hipMemcpy(v, h->v, bytes, hipMemcpyDeviceToHost));
+    if (x_tilde) HIPCHECK(h, hipMemcpy(x_tilde, h->xt, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int dotmi_set_dirichlet(dotmi_handle *h, int32_t n, const int32_t *idx, const double *pos)
+{
+    if (!h || n < 0 || (n > 0 && (!idx || !pos))) return DOTMI_E_INVALID;
+    if (n == 0) return 0;
+    HIPCHECK(h, hipSetDevice(h->device));
+    for (int i = 0; i < n; ++i)
+        if (idx[i] < 0 || idx[i] >= h->nV) {
+            h->err = "dirichlet index out of range";
+            return DOTMI_E_INVALID;
+        }
+    if ((size_t)n > h->dcap) {
+        if (int rc = dalloc(h, &h->didx, (size_t)n)) return rc;
+        if (int rc = dalloc(h, &h->dpos, (size_t)3 * n)) return rc;
+        h->dcap = n;
+    }
+    HIPCHECK(h, hipMemcpyAsync(h->didx, idx, sizeof(int) * n, hipMemcpyHostToDevice, h->st));
+    HIPCHECK(h, hipMemcpyAsync(h->dpos, pos, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->st));
+    launch_scatter_rows(n, h->didx, h->dpos, h->x, h->st);
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int dotmi_refix(dotmi_handle *h, const uint8_t *fixed)
+{
+    if (!h || !fixed) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    h->fixed.assign(fixed, fixed + h->nV);
+    HIPCHECK(h, hipMemcpy(h->M.fixed, fixed, h->nV, hipMemcpyHostToDevice));
+    return refactor(h, h->x, nullptr, nullptr);
+}
+
+double dotmi_target_gres(const dotmi_handle *h) { return h ? h->targetGRes : 0.0; }
+
+int dotmi_last_iter_log(const dotmi_handle *h, int32_t cap, double *alpha, double *E, double *g2)
+{
+    if (!h) return DOTMI_E_INVALID;
+    const int n = std::min<int>(cap, (int)h->log_alpha.size());
+    for (int i = 0; i < n; ++i) {
+        if (alpha) alpha[i] = h->log_alpha[i];
+        if (E) E[i] = h->log_E[i];
+        if (g2) g2[i] = h->log_g2[i];
+    }
+    return (int)h->log_alpha.size();
+}
+
+int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
+{
+    if (!h) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const double T0 = now_ms();
+    const int n = h->n;
+    h->m = 0;
+    h->energy_evals = 0;
+    h->log_alpha.clear();
+    h->log_E.clear();
+    h->log_g2.clear();
+    const long long ls0 = h->numLineSearch;
+    double ms_hess = 0, ms_fact = 0;
+
+    // initX(2): x += dt v + dt^2 g on free vertices (Optimizer.cpp:442-582)
+    launch_init_x(h->nV, h->M.fixed, h->v, h->dt, h->gdtsq, h->x, h->st);
+    LbfgsArgs L = lbfgs_args(h);
+    double lastE = 0, R[RED_K];
+    if (int rc = trial(h, h->x, h->g, 0, L, 0, &lastE)) return rc;
+    sum_stats(h, 1, R);
+    double g2 = R[0];
+    const double E0 = lastE, g20 = g2;
+
+    int it = 0, status = 0;
+    bool failed = false;
+    const double Tloop = now_ms();
+    do {
+        // ---- two-loop, first half (host scalars) + q ------------------------------------------------
+        double xi[HIST_MAX] = {0};
+        for (int i = h->m - 1; i >= 0; --i) {
+            double sq = -h->b[i];
+            for (int j = h->m - 1; j > i; --j) sq -= xi[j] * h->sy[i][j];
+            xi[i] = sq / h->ys[i];
+        }
+        L = lbfgs_args(h);
+        launch_build_q(n, h->g, L, xi, h->q, h->st);
+        // ---- subdomain back-solve, merge, second half ------------------------------------------------
+        if (int rc = apply_precond(h, h->q, h->z, L)) return rc;
+        launch_build_p(n, h->z, L, h->partC, xi, h->p, h->st);
+        // ---- alpha_0 and the first trial ---------------------------------------------------------------
+        launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st);
+        const double *spart = h->partS;
+        if (h->world > 1) {
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partS, NB_RED, RED_K, 2, 0.0,
+                               0.0, 0, h->partG);
+            NCCLCHECK(h, ncclAllReduce(h->partG, h->partG, 2, ncclDouble, ncclSum, h->comm, h->st));
+            spart = h->partG;  // rows >= 1 stay zero
+        }
+        launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, h->st);
+        const int slot = free_slot(h);
+        double E = 0;
+        if (int rc = trial(h, h->x_trial, h->g_trial, 1, L, slot, &E)) return rc;
+        double alpha = h->h_alpha[0];
+        // ---- back-tracking (Optimizer.cpp:806-833; c1 = 0, lower bound 0) ----------------------------
+        while (E > lastE && alpha > 0.0) {
+            alpha /= 2.0;
+            h->numLineSearch++;
+            if (alpha == 0.0) {
+                failed = true;
+                break;
+            }
+            launch_step_forward(n, h->x, h->p, h->x_trial, nullptr, alpha, 0, h->alphaMin, h->alpha_dev, h->st);
+            if (int rc = trial(h, h->x_trial, h->g_trial, 1, L, slot, &E)) return rc;
+        }
+        if (failed) break;
+        std::swap(h->x, h->x_trial);
+        std::swap(h->g, h->g_trial);
+        lastE = E;
+        // ---- history update (DOTTimeStepper.cpp:474-494) --------------------------------------------
+        sum_stats(h, RED_K, R);
+        g2 = R[0];
+        const double ys_new = R[1], sg_new = R[2];
+        double *siy = R + 3, *snyj = R + 3 + HIST_MAX, *sig = R + 3 + 2 * HIST_MAX;
+        if (ys_new > 0.0) {
+            int m = h->m;
+            int off = 0;
+            if (m == h->hist) {  // drop the oldest pair
+                off = 1;
+                for (int i = 0; i + 1 < m; ++i) {
+                    h->order[i] = h->order[i + 1];
+                    h->ys[i] = h->ys[i + 1];
+                    for (int j = 0; j + 1 < m; ++j) h->sy[i][j] = h->sy[i + 1][j + 1];
+                }
+                m -= 1;
+            }
+            for (int i = 0; i < m; ++i) {
+                h->sy[i][m] = siy[i + off];
+                h->sy[m][i] = snyj[i + off];
+                h->b[i] = sig[i + off];
+            }
+            h->order[m] = slot;
+            h->ys[m] = ys_new;
+            h->sy[m][m] = ys_new;
+            h->b[m] = sg_new;
+            h->m = m + 1;
+        } else {
+            for (int i = 0; i < h->m; ++i) h->b[i] = sig[i];
+        }
+        h->log_alpha.push_back(alpha);
+        h->log_E.push_back(lastE);
+        h->log_g2.push_back(g2);
+        if (++it >= h->iterCap) break;
+    } while (g2 > h->targetGRes);
+    const double Tloop1 = now_ms();
+
+    if (failed) status = 2;
+    else {
+        if (it >= h->iterCap) status = 2;
+        if (int rc = refactor(h, h->x, &ms_hess, &ms_fact)) return rc;
+    }
+    // BE update (Optimizer.cpp:354-361)
+    launch_be_update(h->nV, h->M.fixed, h->x, h->xn, h->v, h->xt, h->dt, h->gdtsq, h->st);
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    HIPCHECK(h, hipGetLastError());
+    if (st) {
+        memset(st, 0, sizeof(*st));
+        st->iters = it;
+        st->ls_halvings = (int)(h->numLineSearch - ls0);
+        st->energy_evals = h->energy_evals;
+        st->status = status;
+        st->E0 = E0;
+        st->g2_0 = g20;
+        st->E = lastE;
+        st->g2 = g2;
+        st->ms_total = now_ms() - T0;
+        st->ms_loop = Tloop1 - Tloop;
+        st->ms_hessian = ms_hess;
+        st->ms_factor = ms_fact;
+        st->precond_launches = it;
+        st->precond_bytes = h->precond_bytes;
+    }
+    return status;
+}
+
+// ---- kernel-level entry points ------------------------------------------------------------------
+static int upload_tmp(dotmi_handle *h, const double *x, double *dst)
+{
+    HIPCHECK(h, hipMemcpyAsync(dst, x, sizeof(double) * h->n, hipMemcpyHostToDevice, h->st));
+    return 0;
+}
+
+int dotmi_eval_energy(dotmi_handle *h, const double *x, double *E)
+{
+    if (!h || !x || !E) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (int rc = upload_tmp(h, x, h->x_trial)) return rc;
+    int nb = 0;
+    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x_trial, h->xt, nullptr, h->nT, 0, h->nV, nullptr, h->partE,
+                            &nb, h->st);
+    HIPCHECK(h, hipMemcpyAsync(h->h_partE, h->partE, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    double se = 0, si = 0;
+    for (int b = 0; b < nb; ++b) {
+        se += h->h_partE[2 * b];
+        si += h->h_partE[2 * b + 1];
+    }
+    *E = h->dtSq * se + si;
+    return 0;
+}
+
+int dotmi_eval_gradient(dotmi_handle *h, const double *x, double *g)
+{
+    if (!h || !x || !g) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (int rc = upload_tmp(h, x, h->x_trial)) return rc;
+    int nb = 0;
+    HIPCHECK(h, hipMemsetAsync(h->gcont, 0, sizeof(double) * 12 * (size_t)h->nT, h->st));
+    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x_trial, h->xt, nullptr, h->nT, 0, h->nV, h->gcont, h->partE,
+                            &nb, h->st);
+    GatherArgs a;
+    memset(&a, 0, sizeof(a));
+    a.gcont = h->gcont;
+    a.x = h->x_trial;
+    a.xt = h->xt;
+    a.g_new = h->g_trial;
+    a.make_pair = 0;
+    a.iv0 = 0;
+    a.iv1 = h->nV;
+    LbfgsArgs L;
+    memset(&L, 0, sizeof(L));
+    launch_vertex_gather(h->M, a, L, h->partR, h->st);
+    HIPCHECK(h, hipMemcpyAsync(g, h->g_trial, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    if (h->world > 1) HIPCHECK(h, hipMemsetAsync(h->gcont, 0, sizeof(double) * 12 * (size_t)h->nT, h->st));
+    return 0;
+}
+
+int dotmi_eval_elem_hessians(dotmi_handle *h, const double *x, double *H)
+{
+    if (!h || !x || !H) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (int rc = upload_tmp(h, x, h->x_trial)) return rc;
+    // scratch copy so the resident He (state of the current preconditioner) is not disturbed
+    double *tmp = nullptr;
+    HIPCHECK(h, hipMalloc((void **)&tmp, sizeof(double) * 144 * (size_t)h->nT));
+    launch_elem_hessians(h->M, h->mat, h->dtSq, h->x_trial, tmp, h->st);
+    hipError_t e = hipMemcpyAsync(H, tmp, sizeof(double) * 144 * (size_t)h->nT, hipMemcpyDeviceToHost, h->st);
+    hipStreamSynchronize(h->st);
+    hipFree(tmp);
+    HIPCHECK(h, e);
+    return 0;
+}
+
+int dotmi_refactor(dotmi_handle *h, const double *x)
+{
+    if (!h) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const double *xd = h->x;
+    if (x) {
+        if (int rc = upload_tmp(h, x, h->x_trial)) return rc;
+        xd = h->x_trial;
+    }
+    return refactor(h, xd, nullptr, nullptr);
+}
+
+int dotmi_apply_precond(dotmi_handle *h, const double *r, double *p)
+{
+    if (!h || !r || !p) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (int rc = upload_tmp(h, r, h->q)) return rc;
+    LbfgsArgs L;
+    memset(&L, 0, sizeof(L));
+    if (int rc = apply_precond(h, h->q, h->z, L)) return rc;
+    HIPCHECK(h, hipMemcpyAsync(p, h->z, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int dotmi_spmv(dotmi_handle *h, const double *p, double *Hp)
+{
+    if (!h || !p || !Hp) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    if (int rc = upload_tmp(h, p, h->tmpn)) return rc;
+    launch_spmv_dots(h->M, h->Hval, h->tmpn, nullptr, h->Hp, 0, h->nV, h->partS, h->st);
+    HIPCHECK(h, hipMemcpyAsync(Hp, h->Hp, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int dotmi_get_features(dotmi_handle *h, double *A, double *vol, double *mass)
+{
+    if (!h) return DOTMI_E_INVALID;
+    if (A) memcpy(A, h->A.data(), sizeof(double) * h->A.size());
+    if (vol) memcpy(vol, h->vol.data(), sizeof(double) * h->vol.size());
+    if (mass) memcpy(mass, h->mass.data(), sizeof(double) * h->mass.size());
+    return 0;
+}
+
+int32_t dotmi_part_size(const dotmi_handle *h, int32_t part)
+{
+    if (!h || part < 0 || part >= h->nPartsAll) return DOTMI_E_INVALID;
+    return 3 * (int32_t)h->partVerts[part].size();
+}
+
+int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *Mout, int32_t *l2g)
+{
+    if (!h || part < h->p0 || part >= h->p1 || !Mout) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const int ls = part - h->p0;
+    const int ns = 3 * (int)h->partVerts[part].size();
+    const int lda = h->P.nmax;
+    double *W = h->P.W + (size_t)ls * lda * lda;
+    double *tmp = nullptr;
+    if (!inverse) {
+        // rebuild H_s from the resident block-CSR into a scratch block
+        HIPCHECK(h, hipMalloc((void **)&tmp, sizeof(double) * (size_t)h->P.nParts * lda * lda));
+        DevParts Pt = h->P;
+        Pt.W = tmp;
+        launch_dense_fill(Pt, h->Hval, h->st);
+        W = tmp + (size_t)ls * lda * lda;
+    }
+    hipError_t e = hipMemcpy2DAsync(Mout, sizeof(double) * ns, W, sizeof(double) * lda, sizeof(double) * ns, ns,
+                                    hipMemcpyDeviceToHost, h->st);
+    hipStreamSynchronize(h->st);
+    if (tmp) hipFree(tmp);
+    HIPCHECK(h, e);
+    if (l2g)
+        for (size_t i = 0; i < h->partVerts[part].size(); ++i) l2g[i] = h->partVerts[part][i];
+    return 0;
+}
+
+int dotmi_bench_precond(dotmi_handle *h, int32_t reps, double *ms_per_launch, int64_t *bytes_per_launch)
+{
+    if (!h || reps < 1) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    launch_gemv(h->P, h->q, h->st);  // warm
+    HIPCHECK(h, hipEventRecord(h->ev0, h->st));
+    for (int i = 0; i < reps; ++i) launch_gemv(h->P, h->q, h->st);
+    HIPCHECK(h, hipEventRecord(h->ev1, h->st));
+    HIPCHECK(h, hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIPCHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (ms_per_launch) *ms_per_launch = ms / reps;
+    if (bytes_per_launch) *bytes_per_launch = h->precond_bytes;
+    return 0;
+}
+
+int dotmi_bench_energy(dotmi_handle *h, int32_t reps, double *ms_per_launch, int64_t *bytes_per_launch)
+{
+    if (!h || reps < 1) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    int nb = 0;
+    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, nullptr,
+                            h->partE, &nb, h->st);
+    HIPCHECK(h, hipEventRecord(h->ev0, h->st));
+    for (int i = 0; i < reps; ++i)
+        launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, nullptr,
+                                h->partE, &nb, h->st);
+    HIPCHECK(h, hipEventRecord(h->ev1, h->st));
+    HIPCHECK(h, hipEventSynchronize(h->ev1));
+    float ms = 0;
+    HIPCHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (ms_per_launch) *ms_per_launch = ms / reps;
+    // 112 B per tet + 56 B per vertex
+    if (bytes_per_launch) *bytes_per_launch = (int64_t)112 * h->nOwnElem + (int64_t)56 * (h->v1 - h->v0);
+    return 0;
+}
+
+}  // extern "C"

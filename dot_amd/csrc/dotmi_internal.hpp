@@ -1,0 +1,114 @@
+// dotmi_internal.hpp -- device-side data layout and kernel launch prototypes of libdotmi.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dotmi {
+
+constexpr int HIST_MAX = 6;     // L-BFGS pairs kept (reference uses 5, DOTTimeStepper.cpp:45)
+constexpr int NB_RED = 128;     // blocks of every reducing kernel (fixed => run-to-run bit-identical sums)
+constexpr int RED_K = 3 * HIST_MAX + 3;  // partial values per block
+constexpr int GEMV_ROWS = 64;   // rows of one subdomain handled by one workgroup of the back-solve kernel
+
+// ---- mesh + topology resident in HBM ------------------------------------------------------------
+struct DevMesh {
+    int nV, nT, nTp;        // nTp = nT padded to 64 (SoA stride)
+    int4 *T;                // nT   vertex ids
+    double *A;              // [9][nTp] rest-shape inverse, SoA (coalesced per-lane loads)
+    double *mu, *lam, *vol; // nT
+    double *mass;           // nV
+    uint8_t *fixed;         // nV
+    // vertex -> incident (elem*4+slot), ascending  (Mesh::vFLoc, Mesh.cpp:609-614)
+    int *vf_ptr, *vf_ent;
+    // block-CSR of the global Hessian: vertex adjacency incl. self, ascending
+    int *adj_ptr, *adj_idx;
+    int nnzb;
+    // per block: contributing (elem*16 + a*4 + b), ascending elem  -> deterministic gather assembly
+    int *blk_ptr, *blk_ent;
+    int *blk_row;           // nnzb: row vertex of each block
+};
+
+// ---- subdomains owned by this rank ---------------------------------------------------------------
+struct DevParts {
+    int nParts;             // owned
+    int nmax;               // max scalar size over ALL parts, padded to 8 (lda of every dense block)
+    int *psize;             // owned: scalar size n_s
+    int *dof_ptr;           // owned+1: offsets into dofmap / psub
+    int *dofmap;            // local scalar dof -> global scalar dof
+    double *W;              // owned * nmax*nmax dense blocks (H_s, then its inverse), row-major, lda = nmax
+    int ntiles;             // total row tiles of GEMV_ROWS
+    int2 *tile;             // tile -> (owned part, first row)
+    double *psub;           // per-part results, concatenated by dof_ptr
+    // merge: per vertex list of positions in psub (all parts on this rank), CSR over vertices
+    int *vp_ptr, *vp_off;
+    int *dup;               // nV (global multiplicity, DOTTimeStepper.cpp:47-56)
+    // dense fill list
+    int nfill;
+    long long *fill_dst;    // offset of the 3x3 block's (0,0) in W
+    int *fill_src;          // block index in Hval
+    int npad;               // identity padding entries
+    long long *pad_dst;
+};
+
+struct LbfgsArgs {
+    int m;
+    const double *s[HIST_MAX];  // chronological, oldest first
+    const double *y[HIST_MAX];
+    double ys[HIST_MAX];        // y_i . s_i
+    double sy[HIST_MAX][HIST_MAX];  // sy[i][j] = s_i . y_j
+};
+
+// ---- kernel launchers (kernels.hip) --------------------------------------------------------------
+// x = x0 + alpha * p; alpha = alpha_scale * clamp(-pg/pHp) from SpMV partials when use_partials
+void launch_step_forward(int n, const double *x0, const double *p, double *x, const double *spmv_partials,
+                         double alpha_host, int use_partials, double alpha_min, double *alpha_out,
+                         hipStream_t st);
+// element pass: partial energy sums (+ inertia) and, optionally, element gradients
+void launch_elem_energy_grad(const DevMesh &M, int mat, double dtSq, const double *x, const double *xt,
+                             const int *elist, int nElem, int v0, int v1, double *gcont /*or null*/,
+                             double *partials, int *nblocks_out, hipStream_t st);
+// vertex gather of element gradients + inertia; optional L-BFGS pair + stats partials
+struct GatherArgs {
+    const double *gcont, *x, *xt, *g_old, *p, *alpha_dev;
+    double *g_new, *s_new, *y_new;
+    int make_pair;
+    int iv0, iv1;  // vertex range whose inertia term m_v (x_v - x~_v) this rank adds
+};
+void launch_vertex_gather(const DevMesh &M, const GatherArgs &a, const LbfgsArgs &L, double *partials,
+                          hipStream_t st);
+// pair + statistics from already summed gradients (multi-GPU: after the all-reduce of g)
+void launch_pair_stats(int n, const GatherArgs &a, const LbfgsArgs &L, double *partials, hipStream_t st);
+// two-loop, first half:  b_i = s_i . g  partials
+void launch_multidot(int n, const double *v, const double *const *vecs, int m, double *partials,
+                     hipStream_t st);
+// q = -g - sum_j xi_j y_j with xi from partials (b) and SY
+void launch_build_q(int n, const double *g, const LbfgsArgs &L, const double *xi_host, double *q,
+                    hipStream_t st);
+// subdomain back-solve: psub_s = W_s * q[dofmap_s]
+void launch_gemv(const DevParts &P, const double *q, hipStream_t st);
+// z = merge(psub) / dup  (+ partial dots y_i . z)
+void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
+                  int with_dots, hipStream_t st);
+// partial dots y_i . z only (multi-GPU path after all-reduce)
+// p = z + sum_j delta_j s_j, delta from c partials, xi and SY
+void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_partials,
+                    const double *xi_host, double *p, hipStream_t st);
+// Hp = H p on rows [v0,v1), partial sums of p.g and p.Hp
+void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
+                      int v0, int v1, double *partials, hipStream_t st);
+// element Hessians (12x12 projected), one wavefront per element in the expansion phase
+void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *x, double *He,
+                          hipStream_t st);
+void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st);
+void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st);
+void launch_symmetrize(const DevParts &P, hipStream_t st);
+// small helpers
+void launch_init_x(int nV, const uint8_t *fixed, const double *v, double dt, const double *gdtsq,
+                   double *x, hipStream_t st);
+void launch_be_update(int nV, const uint8_t *fixed, double *x, double *xn, double *v, double *xt,
+                      double dt, const double *gdtsq, hipStream_t st);
+void launch_scatter_rows(int n, const int *idx, const double *pos, double *x, hipStream_t st);
+void launch_copy(int n, const double *src, double *dst, hipStream_t st);
+void launch_div_dup(int nV, const int *dup, double *z, hipStream_t st);
+
+}  // namespace dotmi

@@ -1,0 +1,905 @@
+// kernels.hip -- hand-written CDNA4 (gfx950) kernels of the DOT time-step hot path.
+//
+// Conventions
+//   * 64-lane wavefronts; workgroups of 256 threads (4 waves) unless noted.
+//   * every floating-point reduction has a fixed shape (fixed block count, fixed tree), so results
+//     are bit-identical run to run -- the reference is bit-deterministic.
+//   * no FP atomics anywhere: scatter steps are written in gather form over precomputed CSR lists
+//     (the reference's own vFLoc form, Energy.cpp:543-563).
+//   * reductions leave per-block partials; the consumer (next kernel's prologue, or the host) sums
+//     them in index order.  That removes every "final reduce" launch from the L-BFGS loop.
+//
+// Reference map (paths relative to /root/reference/src):
+//   elem_energy_grad_kernel   Energy.cpp:294-423 (F, SVD, Psi), :910-972 (P-hat, P, element gradient),
+//                             Optimizer.cpp:1202-1215 (inertia energy)
+//   vertex_gather_kernel      Energy.cpp:543-563, Optimizer.cpp:1239-1252, DOTTimeStepper.cpp:474-494
+//   build_q / build_p         DOTTimeStepper.cpp:386-400, :455-467 (two-loop recursion, compact form)
+//   gemv_kernel + merge       DOTTimeStepper.cpp:406-450 (subdomain back-solve, average by dup)
+//   spmv_dots / step_forward  Optimizer.cpp:1076-1093 (alpha_0), :1023-1042 (x = x0 + alpha p)
+//   elem_hessian_kernel       Energy.cpp:738-777, :1129-1270, IglUtils.hpp:466-479
+//   assemble_kernel           DOTTimeStepper.cpp:588-613, IglUtils.hpp:143-220
+//   dense_fill_kernel         DOTTimeStepper.cpp:619-797 (== principal sub-matrix of the global H)
+#include "dotmi_internal.hpp"
+#include "elem_math.hpp"
+
+namespace dotmi {
+
+// ------------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// sum over a 256-thread block; result valid in thread 0.  sm: >= 4 doubles.
+__device__ __forceinline__ double block_sum256(double v, double *sm)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    return (threadIdx.x == 0) ? ((sm[0] + sm[1]) + (sm[2] + sm[3])) : 0.0;
+}
+
+// every thread of the calling WAVE gets sum_b partials[b*stride + j] (fixed order)
+__device__ __forceinline__ double wave_sum_partials(const double *partials, int nblocks, int stride, int j)
+{
+    const int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int b = lane; b < nblocks; b += 64) acc += partials[(size_t)b * stride + j];
+    acc = wave_sum(acc);
+    return __shfl(acc, 0, 64);
+}
+
+// ------------------------------------------------------------------------------------------------
+// element pass: energy (+ inertia) partials and element gradients
+// ------------------------------------------------------------------------------------------------
+template <int MAT, bool GRAD>
+__global__ __launch_bounds__(256) void elem_energy_grad_kernel(
+    const int4 *__restrict__ T, const double *__restrict__ A, int nTp, const double *__restrict__ mu,
+    const double *__restrict__ lam, const double *__restrict__ vol, const double *__restrict__ mass,
+    const double *__restrict__ x, const double *__restrict__ xt, const int *__restrict__ elist,
+    int nElem, int v0, int v1, double dtSq, double *__restrict__ gcont, double *__restrict__ partials)
+{
+    __shared__ double sm[4];
+    double acc = 0.0;  // dtSq * vol * Psi
+    const int stride = gridDim.x * blockDim.x;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nElem; i += stride) {
+        const int e = elist ? elist[i] : i;
+        const int4 t = T[e];
+        const double x0[3] = {x[3 * t.x], x[3 * t.x + 1], x[3 * t.x + 2]};
+        const double x1[3] = {x[3 * t.y], x[3 * t.y + 1], x[3 * t.y + 2]};
+        const double x2[3] = {x[3 * t.z], x[3 * t.z + 1], x[3 * t.z + 2]};
+        const double x3[3] = {x[3 * t.w], x[3 * t.w + 1], x[3 * t.w + 2]};
+        double Ai[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Ai[r][c] = A[(size_t)(3 * r + c) * nTp + e];
+        Mat3 F;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double d0 = x1[r] - x0[r], d1 = x2[r] - x0[r], d2 = x3[r] - x0[r];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) F.m[r][c] = d0 * Ai[0][c] + d1 * Ai[1][c] + d2 * Ai[2][c];
+        }
+        Mat3 U, V;
+        double S[3];
+        svd3(F, U, S, V);
+        const double m = mu[e], l = lam[e], w = dtSq * vol[e];
+        acc += psi<MAT>(S, m, l) * vol[e];
+        if (GRAD) {
+            double d[3];
+            dpsi<MAT>(S, m, l, d);
+            double P[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    P[r][c] = w * (U.m[r][0] * d[0] * V.m[c][0] + U.m[r][1] * d[1] * V.m[c][1] +
+                                   U.m[r][2] * d[2] * V.m[c][2]);
+            double g[12];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    g[3 + 3 * a + c] = Ai[a][0] * P[c][0] + Ai[a][1] * P[c][1] + Ai[a][2] * P[c][2];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[c] = -g[3 + c] - g[6 + c] - g[9 + c];
+            double2 *out = reinterpret_cast<double2 *>(gcont + (size_t)12 * e);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) out[k] = make_double2(g[2 * k], g[2 * k + 1]);
+        }
+    }
+    // inertia: sum_v 1/2 m_v |x_v - x~_v|^2 over this rank's vertex slice
+    double ine = 0.0;
+    for (int v = v0 + blockIdx.x * blockDim.x + threadIdx.x; v < v1; v += stride) {
+        const double dx = x[3 * v] - xt[3 * v], dy = x[3 * v + 1] - xt[3 * v + 1],
+                     dz = x[3 * v + 2] - xt[3 * v + 2];
+        ine += (dx * dx + dy * dy + dz * dz) * mass[v] / 2.0;
+    }
+    const double se = block_sum256(acc, sm);
+    const double si = block_sum256(ine, sm);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = se;      // to be scaled by dtSq on the host
+        partials[2 * blockIdx.x + 1] = si;
+    }
+}
+
+void launch_elem_energy_grad(const DevMesh &M, int mat, double dtSq, const double *x, const double *xt,
+                             const int *elist, int nElem, int v0, int v1, double *gcont,
+                             double *partials, int *nblocks_out, hipStream_t st)
+{
+    int work = nElem > (v1 - v0) ? nElem : (v1 - v0);
+    int nb = (work + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    *nblocks_out = nb;
+#define DM_LAUNCH(MATV, GRADV)                                                                       \
+    hipLaunchKernelGGL((elem_energy_grad_kernel<MATV, GRADV>), dim3(nb), dim3(256), 0, st, M.T, M.A,  \
+                       M.nTp, M.mu, M.lam, M.vol, M.mass, x, xt, elist, nElem, v0, v1, dtSq, gcont,  \
+                       partials)
+    if (mat == 0) {
+        if (gcont) DM_LAUNCH(0, true);
+        else DM_LAUNCH(0, false);
+    } else {
+        if (gcont) DM_LAUNCH(1, true);
+        else DM_LAUNCH(1, false);
+    }
+#undef DM_LAUNCH
+}
+
+// ------------------------------------------------------------------------------------------------
+// vertex gather of element gradients (+ inertia), new L-BFGS pair and its statistics
+// partial layout per block (m = L.m):
+//   [0] |g_new|^2   [1] y_new.s_new   [2] s_new.g_new
+//   [3+i] s_i.y_new   [3+HIST_MAX+j] s_new.y_j   [3+2*HIST_MAX+i] s_i.g_new
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair_stats_accum(int k, double gn, double sn, double yn, const LbfgsArgs &L,
+                                                 double (&acc)[RED_K])
+{
+    acc[0] += gn * gn;
+    acc[1] += yn * sn;
+    acc[2] += sn * gn;
+    const int m = L.m;
+#pragma unroll
+    for (int i = 0; i < HIST_MAX; ++i) {
+        if (i < m) {
+            const double si = L.s[i][k], yi = L.y[i][k];
+            acc[3 + i] += si * yn;
+            acc[3 + HIST_MAX + i] += sn * yi;
+            acc[3 + 2 * HIST_MAX + i] += si * gn;
+        }
+    }
+}
+
+// block-sum every accumulator and store the first nvals of them as this block's partial row.
+// sm: 4*RED_K doubles.
+__device__ __forceinline__ void write_partials(double (&acc)[RED_K], int nvals, double *partials, double *sm)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RED_K; ++j) {
+        const double s = wave_sum(acc[j]);
+        if (lane == 0) sm[w * RED_K + j] = s;
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < nvals)
+        partials[(size_t)blockIdx.x * RED_K + t] = (sm[t] + sm[RED_K + t]) + (sm[2 * RED_K + t] + sm[3 * RED_K + t]);
+}
+
+__global__ __launch_bounds__(256) void vertex_gather_kernel(
+    int nV, const int *__restrict__ vf_ptr, const int *__restrict__ vf_ent,
+    const uint8_t *__restrict__ fixed, const double *__restrict__ mass, GatherArgs a, LbfgsArgs L,
+    double *__restrict__ partials)
+{
+    __shared__ double sm[4 * RED_K];
+    double acc[RED_K];
+#pragma unroll
+    for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
+    const double alpha = a.make_pair ? *a.alpha_dev : 0.0;
+    const int stride = gridDim.x * blockDim.x;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nV; v += stride) {
+        double g0 = 0, g1 = 0, g2 = 0;
+        if (!fixed[v]) {
+            const int b = vf_ptr[v], e = vf_ptr[v + 1];
+            for (int k = b; k < e; ++k) {
+                const int ent = vf_ent[k];
+                const double *ge = a.gcont + (size_t)12 * (ent >> 2) + 3 * (ent & 3);
+                g0 += ge[0];
+                g1 += ge[1];
+                g2 += ge[2];
+            }
+            if (v >= a.iv0 && v < a.iv1) {
+                const double mv = mass[v];
+                g0 += mv * (a.x[3 * v] - a.xt[3 * v]);
+                g1 += mv * (a.x[3 * v + 1] - a.xt[3 * v + 1]);
+                g2 += mv * (a.x[3 * v + 2] - a.xt[3 * v + 2]);
+            }
+        }
+        a.g_new[3 * v] = g0;
+        a.g_new[3 * v + 1] = g1;
+        a.g_new[3 * v + 2] = g2;
+        if (a.make_pair) {
+            const double gn[3] = {g0, g1, g2};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const int k = 3 * v + d;
+                const double sn = alpha * a.p[k];
+                const double yn = gn[d] - a.g_old[k];
+                a.s_new[k] = sn;
+                a.y_new[k] = yn;
+                pair_stats_accum(k, gn[d], sn, yn, L, acc);
+            }
+        } else {
+            acc[0] += g0 * g0 + g1 * g1 + g2 * g2;
+        }
+    }
+    write_partials(acc, a.make_pair ? RED_K : 1, partials, sm);
+}
+
+void launch_vertex_gather(const DevMesh &M, const GatherArgs &a, const LbfgsArgs &L, double *partials,
+                          hipStream_t st)
+{
+    hipLaunchKernelGGL(vertex_gather_kernel, dim3(NB_RED), dim3(256), 0, st, M.nV, M.vf_ptr, M.vf_ent,
+                       M.fixed, M.mass, a, L, partials);
+}
+
+__global__ __launch_bounds__(256) void pair_stats_kernel(int n, GatherArgs a, LbfgsArgs L,
+                                                         double *__restrict__ partials)
+{
+    __shared__ double sm[4 * RED_K];
+    double acc[RED_K];
+#pragma unroll
+    for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
+    const double alpha = *a.alpha_dev;
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const double gn = a.g_new[k];
+        const double sn = alpha * a.p[k];
+        const double yn = gn - a.g_old[k];
+        a.s_new[k] = sn;
+        a.y_new[k] = yn;
+        pair_stats_accum(k, gn, sn, yn, L, acc);
+    }
+    write_partials(acc, RED_K, partials, sm);
+}
+
+void launch_pair_stats(int n, const GatherArgs &a, const LbfgsArgs &L, double *partials, hipStream_t st)
+{
+    hipLaunchKernelGGL(pair_stats_kernel, dim3(NB_RED), dim3(256), 0, st, n, a, L, partials);
+}
+
+// ------------------------------------------------------------------------------------------------
+// two-loop recursion in compact form
+//   loop 1:  xi_i = (s_i . q_i)/ys_i with s_i.q_i = -b_i - sum_{j>i} xi_j (s_i.y_j)   (host, FP64)
+//            q = -g - sum_j xi_j y_j
+//   loop 2:  beta_i = (y_i . p_i)/ys_i with y_i.p_i = c_i + sum_{j<i} delta_j (s_j.y_i), c_i = y_i.z
+//            delta_i = xi_i - beta_i ;  p = z + sum_j delta_j s_j
+// identical in exact arithmetic to DOTTimeStepper.cpp:386-400 / :455-467
+// ------------------------------------------------------------------------------------------------
+struct XiArgs {
+    double xi[HIST_MAX];
+};
+
+__global__ __launch_bounds__(256) void build_q_kernel(int n, const double *__restrict__ g, LbfgsArgs L,
+                                                      XiArgs X, double *__restrict__ q)
+{
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        double v = -g[k];
+        // newest to oldest, as the reference subtracts them
+#pragma unroll
+        for (int j = HIST_MAX - 1; j >= 0; --j)
+            if (j < L.m) v -= X.xi[j] * L.y[j][k];
+        q[k] = v;
+    }
+}
+
+void launch_build_q(int n, const double *g, const LbfgsArgs &L, const double *xi_host, double *q,
+                    hipStream_t st)
+{
+    XiArgs X;
+    for (int i = 0; i < HIST_MAX; ++i) X.xi[i] = i < L.m ? xi_host[i] : 0.0;
+    int nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(build_q_kernel, dim3(nb), dim3(256), 0, st, n, g, L, X, q);
+}
+
+__global__ __launch_bounds__(256) void build_p_kernel(int n, const double *__restrict__ z, LbfgsArgs L,
+                                                      XiArgs X, const double *__restrict__ c_partials,
+                                                      int c_blocks, double *__restrict__ p)
+{
+    __shared__ double delta[HIST_MAX];
+    if (threadIdx.x < 64) {
+        double d[HIST_MAX];
+#pragma unroll
+        for (int i = 0; i < HIST_MAX; ++i) {
+            d[i] = 0.0;
+            if (i < L.m) {
+                double yp = wave_sum_partials(c_partials, c_blocks, RED_K, i);
+#pragma unroll
+                for (int j = 0; j < HIST_MAX; ++j)
+                    if (j < i) yp += d[j] * L.sy[j][i];
+                d[i] = X.xi[i] - yp / L.ys[i];
+            }
+            if (threadIdx.x == 0) delta[i] = d[i];
+        }
+    }
+    __syncthreads();
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        double v = z[k];
+#pragma unroll
+        for (int j = 0; j < HIST_MAX; ++j)
+            if (j < L.m) v += L.s[j][k] * delta[j];
+        p[k] = v;
+    }
+}
+
+void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_partials,
+                    const double *xi_host, double *p, hipStream_t st)
+{
+    XiArgs X;
+    for (int i = 0; i < HIST_MAX; ++i) X.xi[i] = i < L.m ? xi_host[i] : 0.0;
+    int nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(build_p_kernel, dim3(nb), dim3(256), 0, st, n, z, L, X, c_partials, NB_RED, p);
+}
+
+// generic multi-dot: partials[b][i] = sum_k v[k]*vecs_i[k]   (used on the multi-GPU path)
+struct VecList {
+    const double *v[HIST_MAX];
+};
+__global__ __launch_bounds__(256) void multidot_kernel(int n, const double *__restrict__ v, VecList W, int m,
+                                                       double *__restrict__ partials)
+{
+    __shared__ double sm[4 * RED_K];
+    double acc[RED_K];
+#pragma unroll
+    for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+        const double vk = v[k];
+#pragma unroll
+        for (int i = 0; i < HIST_MAX; ++i)
+            if (i < m) acc[i] += vk * W.v[i][k];
+    }
+    write_partials(acc, m, partials, sm);
+}
+
+void launch_multidot(int n, const double *v, const double *const *vecs, int m, double *partials,
+                     hipStream_t st)
+{
+    VecList W;
+    for (int i = 0; i < HIST_MAX; ++i) W.v[i] = i < m ? vecs[i] : nullptr;
+    hipLaunchKernelGGL(multidot_kernel, dim3(NB_RED), dim3(256), 0, st, n, v, W, m, partials);
+}
+
+// ------------------------------------------------------------------------------------------------
+// subdomain back-solve: psub_s = W_s * q[dofmap_s]   -- the HBM-bound kernel of the L-BFGS loop
+//   algorithmic bytes per launch: sum_s n_s^2 * 8  
+//   one workgroup = GEMV_ROWS rows of one subdomain; the gathered right-hand side lives in LDS;
+//   each wave streams 4 rows at a time, 16 B per lane per row, so one wave-instruction moves 1 KiB.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemv_kernel(const int2 *__restrict__ tile,
+                                                   const int *__restrict__ psize,
+                                                   const int *__restrict__ dof_ptr,
+                                                   const int *__restrict__ dofmap,
+                                                   const double *__restrict__ W, int nmax,
+                                                   const double *__restrict__ q,
+                                                   double *__restrict__ psub)
+{
+    extern __shared__ __attribute__((aligned(16))) double rhs[];  // nmax doubles
+    const int2 tl = tile[blockIdx.x];
+    const int s = tl.x, row0 = tl.y;
+    const int ns = psize[s];
+    const int dof0 = dof_ptr[s];
+    const int ncol = (ns + 127) & ~127;  // <= nmax (nmax is a multiple of 128)
+    for (int c = threadIdx.x; c < ncol; c += 256) rhs[c] = (c < ns) ? q[dofmap[dof0 + c]] : 0.0;
+    __syncthreads();
+    const double *Ws = W + (size_t)s * nmax * nmax;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int rbase = row0 + wv * (GEMV_ROWS / 4);
+#pragma unroll 1
+    for (int rr = 0; rr < GEMV_ROWS / 4; rr += 4) {
+        const int r = rbase + rr;
+        if (r >= ns) break;
+        // rows beyond ns (only in the last tile) are clamped to a valid row and discarded
+        const double *w0 = Ws + (size_t)min(r, ns - 1) * nmax;
+        const double *w1 = Ws + (size_t)min(r + 1, ns - 1) * nmax;
+        const double *w2 = Ws + (size_t)min(r + 2, ns - 1) * nmax;
+        const double *w3 = Ws + (size_t)min(r + 3, ns - 1) * nmax;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll 2
+        for (int c = 2 * lane; c < ncol; c += 128) {
+            const double2 rv = *reinterpret_cast<const double2 *>(rhs + c);
+            const double2 v0 = *reinterpret_cast<const double2 *>(w0 + c);
+            const double2 v1 = *reinterpret_cast<const double2 *>(w1 + c);
+            const double2 v2 = *reinterpret_cast<const double2 *>(w2 + c);
+            const double2 v3 = *reinterpret_cast<const double2 *>(w3 + c);
+            a0 += v0.x * rv.x + v0.y * rv.y;
+            a1 += v1.x * rv.x + v1.y * rv.y;
+            a2 += v2.x * rv.x + v2.y * rv.y;
+            a3 += v3.x * rv.x + v3.y * rv.y;
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        a2 = wave_sum(a2);
+        a3 = wave_sum(a3);
+        if (lane == 0) {
+            psub[dof0 + r] = a0;
+            if (r + 1 < ns) psub[dof0 + r + 1] = a1;
+            if (r + 2 < ns) psub[dof0 + r + 2] = a2;
+            if (r + 3 < ns) psub[dof0 + r + 3] = a3;
+        }
+    }
+}
+
+void launch_gemv(const DevParts &P, const double *q, hipStream_t st)
+{
+    if (P.ntiles == 0) return;
+    hipLaunchKernelGGL(gemv_kernel, dim3(P.ntiles), dim3(256), (size_t)P.nmax * sizeof(double), st, P.tile,
+                       P.psize, P.dof_ptr, P.dofmap, P.W, P.nmax, q, P.psub);
+}
+
+// z_v = (sum over parts containing v of p_s[local v]) / dup_v ; partial dots c_i = y_i . z
+__global__ __launch_bounds__(256) void merge_kernel(int nV, const int *__restrict__ vp_ptr,
+                                                    const int *__restrict__ vp_off,
+                                                    const int *__restrict__ dup,
+                                                    const double *__restrict__ psub, LbfgsArgs L,
+                                                    int with_dots, int divide, double *__restrict__ z,
+                                                    double *__restrict__ partials)
+{
+    __shared__ double sm[4 * RED_K];
+    double acc[RED_K];
+#pragma unroll
+    for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
+    const int stride = gridDim.x * blockDim.x;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nV; v += stride) {
+        double z0 = 0, z1 = 0, z2 = 0;
+        for (int k = vp_ptr[v]; k < vp_ptr[v + 1]; ++k) {
+            const double *ps = psub + vp_off[k];
+            z0 += ps[0];
+            z1 += ps[1];
+            z2 += ps[2];
+        }
+        if (divide) {
+            const int d = dup[v];
+            if (d > 1) {
+                z0 /= d;
+                z1 /= d;
+                z2 /= d;
+            }
+        }
+        z[3 * v] = z0;
+        z[3 * v + 1] = z1;
+        z[3 * v + 2] = z2;
+        if (with_dots) {
+#pragma unroll
+            for (int i = 0; i < HIST_MAX; ++i)
+                if (i < L.m) {
+                    const double *yi = L.y[i] + 3 * v;
+                    acc[i] += yi[0] * z0 + yi[1] * z1 + yi[2] * z2;
+                }
+        }
+    }
+    if (with_dots) write_partials(acc, L.m, partials, sm);
+}
+
+void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
+                  int with_dots, hipStream_t st)
+{
+    // with_dots: bit0 = accumulate y_i.z partials, bit1 = divide by dup
+    hipLaunchKernelGGL(merge_kernel, dim3(NB_RED), dim3(256), 0, st, M.nV, P.vp_ptr, P.vp_off, P.dup,
+                       P.psub, L, with_dots & 1, (with_dots >> 1) & 1, z, partials);
+}
+
+__global__ void div_dup_kernel(int nV, const int *__restrict__ dup, double *__restrict__ z)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nV) return;
+    const int d = dup[v];
+    if (d > 1) {
+        z[3 * v] /= d;
+        z[3 * v + 1] /= d;
+        z[3 * v + 2] /= d;
+    }
+}
+void launch_div_dup(int nV, const int *dup, double *z, hipStream_t st)
+{
+    hipLaunchKernelGGL(div_dup_kernel, dim3((nV + 255) / 256), dim3(256), 0, st, nV, dup, z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// alpha_0 = clamp(-p.g / p.Hp, alphaMin, 1): block-CSR SpMV fused with the two dot products
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const int *__restrict__ adj_ptr,
+                                                        const int *__restrict__ adj_idx,
+                                                        const double *__restrict__ Hval,
+                                                        const double *__restrict__ p,
+                                                        const double *__restrict__ g,
+                                                        double *__restrict__ Hp,
+                                                        double *__restrict__ partials)
+{
+    __shared__ double sm[4];
+    double pg = 0, pHp = 0;
+    const int stride = gridDim.x * blockDim.x;
+    for (int v = v0 + blockIdx.x * blockDim.x + threadIdx.x; v < v1; v += stride) {
+        double a0 = 0, a1 = 0, a2 = 0;
+        for (int k = adj_ptr[v]; k < adj_ptr[v + 1]; ++k) {
+            const double *b = Hval + (size_t)9 * k;
+            const double *pu = p + 3 * adj_idx[k];
+            const double p0 = pu[0], p1 = pu[1], p2 = pu[2];
+            a0 += b[0] * p0 + b[1] * p1 + b[2] * p2;
+            a1 += b[3] * p0 + b[4] * p1 + b[5] * p2;
+            a2 += b[6] * p0 + b[7] * p1 + b[8] * p2;
+        }
+        if (Hp) {
+            Hp[3 * v] = a0;
+            Hp[3 * v + 1] = a1;
+            Hp[3 * v + 2] = a2;
+        }
+        const double q0 = p[3 * v], q1 = p[3 * v + 1], q2 = p[3 * v + 2];
+        pHp += q0 * a0 + q1 * a1 + q2 * a2;
+        if (g) pg += q0 * g[3 * v] + q1 * g[3 * v + 1] + q2 * g[3 * v + 2];
+    }
+    const double s0 = block_sum256(pg, sm);
+    const double s1 = block_sum256(pHp, sm);
+    if (threadIdx.x == 0) {
+        partials[(size_t)blockIdx.x * RED_K] = s0;
+        partials[(size_t)blockIdx.x * RED_K + 1] = s1;
+    }
+}
+
+void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
+                      int v0, int v1, double *partials, hipStream_t st)
+{
+    hipLaunchKernelGGL(spmv_dots_kernel, dim3(NB_RED), dim3(256), 0, st, v0, v1, M.adj_ptr, M.adj_idx, Hval,
+                       p, g, Hp, partials);
+}
+
+__global__ __launch_bounds__(256) void step_forward_kernel(int n, const double *__restrict__ x0,
+                                                           const double *__restrict__ p,
+                                                           double *__restrict__ x,
+                                                           const double *__restrict__ spmv_partials,
+                                                           double alpha_host, int use_partials,
+                                                           double alpha_min, double *__restrict__ alpha_out)
+{
+    __shared__ double sh_alpha;
+    if (threadIdx.x < 64) {
+        double alpha = alpha_host;
+        if (use_partials) {
+            const double pg = wave_sum_partials(spmv_partials, NB_RED, RED_K, 0);
+            const double pHp = wave_sum_partials(spmv_partials, NB_RED, RED_K, 1);
+            alpha = fmax(alpha_min, fmin(1.0, -pg / pHp));  // Optimizer.cpp:1085
+        }
+        if (threadIdx.x == 0) {
+            sh_alpha = alpha;
+            if (blockIdx.x == 0) *alpha_out = alpha;
+        }
+    }
+    __syncthreads();
+    const double alpha = sh_alpha;
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) x[k] = x0[k] + alpha * p[k];
+}
+
+void launch_step_forward(int n, const double *x0, const double *p, double *x, const double *spmv_partials,
+                         double alpha_host, int use_partials, double alpha_min, double *alpha_out,
+                         hipStream_t st)
+{
+    int nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(step_forward_kernel, dim3(nb), dim3(256), 0, st, n, x0, p, x, spmv_partials,
+                       alpha_host, use_partials, alpha_min, alpha_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// element Hessians.  One 64-lane workgroup handles 64 tets:
+//   phase 1 (lane = tet): F, SVD, projected spectral blocks -> LDS (U, V, A_w, B_w, rest inverse)
+//   phase 2 (wave = tet): the 64 lanes expand  M = K Mh K^T (9x9)  and  H = G M G^T (12x12)
+//                         from LDS and write the 144 doubles of H_e as one coalesced 1152-byte row.
+// ------------------------------------------------------------------------------------------------
+constexpr int EH_FIELDS = 9 + 9 + 9 + 12 + 9;  // U V Aw Bw Ainv
+
+template <int MAT>
+__global__ __launch_bounds__(64) void elem_hessian_kernel(const int4 *__restrict__ T,
+                                                          const double *__restrict__ A, int nTp, int nT,
+                                                          const double *__restrict__ mu,
+                                                          const double *__restrict__ lam,
+                                                          const double *__restrict__ vol,
+                                                          const double *__restrict__ x, double dtSq,
+                                                          double *__restrict__ He)
+{
+    __shared__ double pack[EH_FIELDS][64];
+    __shared__ double Msh[81];
+    const int lane = threadIdx.x;
+    const int e = blockIdx.x * 64 + lane;
+    if (e < nT) {
+        const int4 t = T[e];
+        double xs[4][3];
+        const int vid[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) xs[k][d] = x[3 * vid[k] + d];
+        double Ai[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Ai[r][c] = A[(size_t)(3 * r + c) * nTp + e];
+        Mat3 F;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double d0 = xs[1][r] - xs[0][r], d1 = xs[2][r] - xs[0][r], d2 = xs[3][r] - xs[0][r];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) F.m[r][c] = d0 * Ai[0][c] + d1 * Ai[1][c] + d2 * Ai[2][c];
+        }
+        Mat3 U, V, Aw;
+        double S[3], Bw[3][4];
+        svd3(F, U, S, V);
+        spectral_blocks<MAT>(S, mu[e], lam[e], dtSq * vol[e], true, Aw, Bw);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                pack[3 * r + c][lane] = U.m[r][c];
+                pack[9 + 3 * r + c][lane] = V.m[r][c];
+                pack[18 + 3 * r + c][lane] = Aw.m[r][c];
+                pack[39 + 3 * r + c][lane] = Ai[r][c];
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pack[27 + 4 * c + k][lane] = Bw[c][k];
+    }
+    __syncthreads();
+    const int nloc = min(64, nT - blockIdx.x * 64);
+    for (int le = 0; le < nloc; ++le) {
+        // ---- M(ij,rs) = sum_{ab,cd} Mh(ab,cd) U(i,a)V(j,b)U(r,c)V(s,d), 81 entries over 64 lanes
+        for (int idx = lane; idx < 81; idx += 64) {
+            const int ij = idx / 9, rs = idx % 9;
+            const int i = ij / 3, j = ij % 3, r = rs / 3, s = rs % 3;
+            double ui[3], vj[3], ur[3], vs[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                ui[k] = pack[3 * i + k][le];
+                vj[k] = pack[9 + 3 * j + k][le];
+                ur[k] = pack[3 * r + k][le];
+                vs[k] = pack[9 + 3 * s + k][le];
+            }
+            double acc = 0.0;
+            // A block: (aa, cc)
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    acc += pack[18 + 3 * a + c][le] * ui[a] * vj[a] * ur[c] * vs[c];
+            // B blocks for pairs (p,q) = (0,1),(1,2),(2,0), basis order (ab) = (p,q),(q,p).  For (2,0)
+            // that is index 6 then 2, which is exactly the reference's "transposed" fill
+            // M(6,6)=B(0,0), M(6,2)=B(0,1), M(2,6)=B(1,0), M(2,2)=B(1,1)  (Energy.cpp:1203-1207).
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int p_ = c, q_ = (c + 1) % 3;
+                const double b00 = pack[27 + 4 * c + 0][le], b01 = pack[27 + 4 * c + 1][le];
+                const double b10 = pack[27 + 4 * c + 2][le], b11 = pack[27 + 4 * c + 3][le];
+                const double k_pq = ui[p_] * vj[q_], k_qp = ui[q_] * vj[p_];
+                const double l_pq = ur[p_] * vs[q_], l_qp = ur[q_] * vs[p_];
+                acc += b00 * k_pq * l_pq + b01 * k_pq * l_qp + b10 * k_qp * l_pq + b11 * k_qp * l_qp;
+            }
+            Msh[idx] = acc;
+        }
+        __syncthreads();
+        // ---- H(r,q) = sum_{b,b'} coef_r[b] coef_q[b'] M[3c_r+b][3c_q+b'], 144 entries over 64 lanes
+        double *out = He + (size_t)144 * (blockIdx.x * 64 + le);
+        for (int idx = lane; idx < 144; idx += 64) {
+            const int r = idx / 12, q = idx % 12;
+            const int cr = r % 3, cq = q % 3;
+            double fr[3], fq[3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const double a0 = pack[39 + b][le], a1 = pack[39 + 3 + b][le], a2 = pack[39 + 6 + b][le];
+                const double neg = -a0 - a1 - a2;
+                fr[b] = (r < 3) ? neg : ((r < 6) ? a0 : ((r < 9) ? a1 : a2));
+                fq[b] = (q < 3) ? neg : ((q < 6) ? a0 : ((q < 9) ? a1 : a2));
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int b2 = 0; b2 < 3; ++b2) acc += fr[b] * fq[b2] * Msh[9 * (3 * cr + b) + 3 * cq + b2];
+            out[idx] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *x, double *He,
+                          hipStream_t st)
+{
+    const int nb = (M.nT + 63) / 64;
+    if (mat == 0)
+        hipLaunchKernelGGL((elem_hessian_kernel<0>), dim3(nb), dim3(64), 0, st, M.T, M.A, M.nTp, M.nT, M.mu,
+                           M.lam, M.vol, x, dtSq, He);
+    else
+        hipLaunchKernelGGL((elem_hessian_kernel<1>), dim3(nb), dim3(64), 0, st, M.T, M.A, M.nTp, M.nT, M.mu,
+                           M.lam, M.vol, x, dtSq, He);
+}
+
+// global block-CSR assembly in gather form: thread = (block k, entry rc)
+__global__ __launch_bounds__(256) void assemble_kernel(int nnzb, const int *__restrict__ blk_ptr,
+                                                       const int *__restrict__ blk_ent,
+                                                       const int *__restrict__ blk_row,
+                                                       const int *__restrict__ adj_idx,
+                                                       const uint8_t *__restrict__ fixed,
+                                                       const double *__restrict__ mass,
+                                                       const double *__restrict__ He,
+                                                       double *__restrict__ Hval)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)nnzb * 9) return;
+    const int k = (int)(t / 9), rc = (int)(t % 9);
+    const int r = rc / 3, c = rc % 3;
+    const int vr = blk_row[k], vc = adj_idx[k];
+    double acc = 0.0;
+    if (fixed[vr]) {
+        acc = (vr == vc && r == c) ? 1.0 : 0.0;  // IglUtils.hpp:148-157
+    } else if (!fixed[vc]) {
+        for (int i = blk_ptr[k]; i < blk_ptr[k + 1]; ++i) {
+            const int ent = blk_ent[i];
+            const int e = ent >> 4, a = (ent >> 2) & 3, b = ent & 3;
+            acc += He[(size_t)144 * e + 12 * (3 * a + r) + 3 * b + c];
+        }
+        if (vr == vc && r == c) acc += mass[vr];  // DOTTimeStepper.cpp:598-607
+    }
+    Hval[t] = acc;
+}
+
+void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st)
+{
+    const long long tot = (long long)M.nnzb * 9;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, M.nnzb,
+                       M.blk_ptr, M.blk_ent, M.blk_row, M.adj_idx, M.fixed, M.mass, He, Hval);
+}
+
+// dense principal sub-matrices: W_s[(3i+r)*lda + 3j+c] = H[l2g_i, l2g_j][r][c]
+__global__ __launch_bounds__(256) void dense_fill_kernel(int nfill, const long long *__restrict__ dst,
+                                                         const int *__restrict__ src, int lda,
+                                                         const double *__restrict__ Hval,
+                                                         double *__restrict__ W)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)nfill * 9) return;
+    const int f = (int)(t / 9), rc = (int)(t % 9);
+    W[dst[f] + (long long)(rc / 3) * lda + rc % 3] = Hval[(size_t)9 * src[f] + rc];
+}
+__global__ void pad_identity_kernel(int npad, const long long *__restrict__ dst, double *__restrict__ W)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < npad) W[dst[t]] = 1.0;
+}
+
+void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st)
+{
+    hipMemsetAsync(P.W, 0, (size_t)P.nParts * P.nmax * P.nmax * sizeof(double), st);
+    if (P.nfill) {
+        const long long tot = (long long)P.nfill * 9;
+        hipLaunchKernelGGL(dense_fill_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P.nfill,
+                           P.fill_dst, P.fill_src, P.nmax, Hval, P.W);
+    }
+    if (P.npad)
+        hipLaunchKernelGGL(pad_identity_kernel, dim3((P.npad + 255) / 256), dim3(256), 0, st, P.npad,
+                           P.pad_dst, P.W);
+}
+
+// After potri (column-major "lower" == row-major "upper" holds the inverse): mirror it so the
+// back-solve kernel can stream full rows.  32x32 tiles through LDS, both sides coalesced.
+__global__ __launch_bounds__(256) void symmetrize_kernel(double *__restrict__ W, int nmax, int ntile)
+{
+    __shared__ double tile[32][33];
+    // blockIdx.x enumerates (tr >= tc) pairs, blockIdx.y = part
+    int tr = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
+    while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
+    while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
+    const int tc = blockIdx.x - tr * (tr + 1) / 2;
+    if (tr >= ntile) return;
+    double *Ws = W + (size_t)blockIdx.y * nmax * nmax;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // 32 x 8
+    // read the upper tile: rows tc*32.., cols tr*32..
+    for (int i = ly; i < 32; i += 8) tile[i][lx] = Ws[(size_t)(tc * 32 + i) * nmax + tr * 32 + lx];
+    __syncthreads();
+    // write the lower tile: rows tr*32.., cols tc*32..   W[r][c] = upper[c][r]
+    for (int i = ly; i < 32; i += 8) {
+        const int r = tr * 32 + i, c = tc * 32 + lx;
+        if (r > c) Ws[(size_t)r * nmax + c] = tile[lx][i];
+    }
+}
+
+void launch_symmetrize(const DevParts &P, hipStream_t st)
+{
+    if (!P.nParts) return;
+    const int ntile = P.nmax / 32;
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(ntile * (ntile + 1) / 2, P.nParts), dim3(256), 0, st, P.W,
+                       P.nmax, ntile);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small state kernels
+// ------------------------------------------------------------------------------------------------
+struct Vec3Arg {
+    double v[3];
+};
+
+// Optimizer::initX(2) (Optimizer.cpp:472-493, :580-581): x += dt v + dt^2 g on free vertices
+__global__ void init_x_kernel(int nV, const uint8_t *__restrict__ fixed, const double *__restrict__ v,
+                              double dt, Vec3Arg gdtsq, double *__restrict__ x)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nV) return;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double pd = fixed[i] ? 0.0 : dt * v[3 * i + d] + gdtsq.v[d];
+        x[3 * i + d] = x[3 * i + d] + 1.0 * pd;
+    }
+}
+void launch_init_x(int nV, const uint8_t *fixed, const double *v, double dt, const double *gdtsq,
+                   double *x, hipStream_t st)
+{
+    Vec3Arg g = {{gdtsq[0], gdtsq[1], gdtsq[2]}};
+    hipLaunchKernelGGL(init_x_kernel, dim3((nV + 255) / 256), dim3(256), 0, st, nV, fixed, v, dt, g, x);
+}
+
+// BE update (Optimizer.cpp:354-361) + computeXTilta (:585-610)
+__global__ void be_update_kernel(int nV, const uint8_t *__restrict__ fixed, const double *__restrict__ x,
+                                 double *__restrict__ xn, double *__restrict__ v,
+                                 double *__restrict__ xt, double dt, Vec3Arg gdtsq)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nV) return;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int k = 3 * i + d;
+        const double xv = x[k];
+        const double vel = (xv - xn[k]) / dt;
+        v[k] = vel;
+        xn[k] = xv;
+        xt[k] = fixed[i] ? xv : xv + (vel * dt + gdtsq.v[d]);
+    }
+}
+void launch_be_update(int nV, const uint8_t *fixed, double *x, double *xn, double *v, double *xt,
+                      double dt, const double *gdtsq, hipStream_t st)
+{
+    Vec3Arg g = {{gdtsq[0], gdtsq[1], gdtsq[2]}};
+    hipLaunchKernelGGL(be_update_kernel, dim3((nV + 255) / 256), dim3(256), 0, st, nV, fixed, x, xn, v, xt,
+                       dt, g);
+}
+
+__global__ void scatter_rows_kernel(int n, const int *__restrict__ idx, const double *__restrict__ pos,
+                                    double *__restrict__ x)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int v = idx[i];
+    x[3 * v] = pos[3 * i];
+    x[3 * v + 1] = pos[3 * i + 1];
+    x[3 * v + 2] = pos[3 * i + 2];
+}
+void launch_scatter_rows(int n, const int *idx, const double *pos, double *x, hipStream_t st)
+{
+    if (n > 0)
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, idx, pos, x);
+}
+
+void launch_copy(int n, const double *src, double *dst, hipStream_t st)
+{
+    hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st);
+}
+
+}  // namespace dotmi

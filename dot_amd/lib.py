@@ -1,0 +1,113 @@
+"""ctypes binding of libdotmi.so (include/dotmi.h).  No torch types cross this boundary.
+
+The HIP library is the only compute path: if it is missing or no GPU is present every call fails
+loudly -- there is no CPU fallback in the product."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdotmi.so")
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+c_up = C.POINTER(C.c_uint8)
+
+ENERGY_FCR = 0
+ENERGY_SNH = 1
+FLAG_KEEP_ELEM_HESSIANS = 1
+
+
+class Mesh(C.Structure):
+    _fields_ = [("nV", C.c_int32), ("nT", C.c_int32), ("X_rest", c_dp), ("T", c_ip), ("mu", c_dp),
+                ("lam", c_dp), ("density", C.c_double), ("fixed", c_up), ("epart", c_ip),
+                ("nParts", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("energy", C.c_int32), ("dt", C.c_double), ("gravity", C.c_double * 3),
+                ("relTol", C.c_double), ("history", C.c_int32), ("iterCap", C.c_int32),
+                ("alphaMin", C.c_double), ("device", C.c_int32), ("rank", C.c_int32),
+                ("world", C.c_int32), ("comm_id", C.c_void_p), ("flags", C.c_int32)]
+
+
+class StepStats(C.Structure):
+    _fields_ = [("iters", C.c_int32), ("ls_halvings", C.c_int32), ("energy_evals", C.c_int32),
+                ("status", C.c_int32), ("E0", C.c_double), ("g2_0", C.c_double), ("E", C.c_double),
+                ("g2", C.c_double), ("ms_total", C.c_double), ("ms_loop", C.c_double),
+                ("ms_hessian", C.c_double), ("ms_factor", C.c_double), ("ms_precond", C.c_double),
+                ("precond_launches", C.c_int64), ("precond_bytes", C.c_int64)]
+
+
+EXPORTS = [
+    "dotmi_create", "dotmi_destroy", "dotmi_last_error", "dotmi_comm_unique_id", "dotmi_set_state",
+    "dotmi_get_state", "dotmi_set_dirichlet", "dotmi_refix", "dotmi_step", "dotmi_last_iter_log",
+    "dotmi_target_gres", "dotmi_eval_energy", "dotmi_eval_gradient", "dotmi_eval_elem_hessians",
+    "dotmi_refactor", "dotmi_apply_precond", "dotmi_spmv", "dotmi_get_features", "dotmi_part_size",
+    "dotmi_part_matrix", "dotmi_bench_precond", "dotmi_bench_energy",
+]
+
+_lib = None
+
+
+class DotmiError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DotmiError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(or make -C dot_amd/csrc). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    L.dotmi_create.argtypes = [C.POINTER(Mesh), C.POINTER(Params), c_dp, C.POINTER(H)]
+    L.dotmi_create.restype = C.c_int
+    L.dotmi_destroy.argtypes = [H]
+    L.dotmi_destroy.restype = None
+    L.dotmi_last_error.argtypes = [H]
+    L.dotmi_last_error.restype = C.c_char_p
+    L.dotmi_comm_unique_id.argtypes = [C.c_void_p]
+    L.dotmi_set_state.argtypes = [H, c_dp, c_dp, c_dp]
+    L.dotmi_get_state.argtypes = [H, c_dp, c_dp, c_dp]
+    L.dotmi_set_dirichlet.argtypes = [H, C.c_int32, c_ip, c_dp]
+    L.dotmi_refix.argtypes = [H, c_up]
+    L.dotmi_step.argtypes = [H, C.POINTER(StepStats)]
+    L.dotmi_last_iter_log.argtypes = [H, C.c_int32, c_dp, c_dp, c_dp]
+    L.dotmi_target_gres.argtypes = [H]
+    L.dotmi_target_gres.restype = C.c_double
+    L.dotmi_eval_energy.argtypes = [H, c_dp, c_dp]
+    L.dotmi_eval_gradient.argtypes = [H, c_dp, c_dp]
+    L.dotmi_eval_elem_hessians.argtypes = [H, c_dp, c_dp]
+    L.dotmi_refactor.argtypes = [H, c_dp]
+    L.dotmi_apply_precond.argtypes = [H, c_dp, c_dp]
+    L.dotmi_spmv.argtypes = [H, c_dp, c_dp]
+    L.dotmi_get_features.argtypes = [H, c_dp, c_dp, c_dp]
+    L.dotmi_part_size.argtypes = [H, C.c_int32]
+    L.dotmi_part_size.restype = C.c_int32
+    L.dotmi_part_matrix.argtypes = [H, C.c_int32, C.c_int, c_dp, c_ip]
+    L.dotmi_bench_precond.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]
+    L.dotmi_bench_energy.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int or name in ("dotmi_create",):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def dp(a: np.ndarray):
+    return a.ctypes.data_as(c_dp)
+
+
+def ip(a: np.ndarray):
+    return a.ctypes.data_as(c_ip)
+
+
+def up(a: np.ndarray):
+    return a.ctypes.data_as(c_up)

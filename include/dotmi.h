@@ -1,0 +1,145 @@
+/*
+ * dotmi.h -- C ABI of the MI355X-native DOT time-step (libdotmi.so).
+ *
+ * Drop-in boundary for the reference's DOT stepper: a host adapter with the reference's
+ * `DOT::Optimizer<3>` surface (src/TimeStepper/Optimizer.hpp:83-112; picked by the factory in
+ * src/main.cpp:905-938) forwards to these entry points.  Plain pointers and sizes only; caller
+ * owns every host array; the handle owns all device memory, the rocSOLVER handle and (N>1) the
+ * RCCL communicator.  One host thread per handle.  No exceptions cross this boundary.
+ *
+ * Return convention (mirrors Optimizer::solve, Optimizer.cpp:327-368):
+ *   0  ok / stepped
+ *   2  stepped but hit the iteration cap or the line search underflowed (solve() == 2)
+ *  <0  error (DOTMI_E_*); dotmi_last_error() has the text
+ *
+ * All floating point is FP64; indices are int32; positions / velocities / gradients are
+ * nV x 3 row-major (xyz interleaved), exactly the layout of the reference's `velocity` vector
+ * (Optimizer.cpp:357) and of `result.V` rows.
+ */
+#ifndef DOTMI_H
+#define DOTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DOTMI_ENERGY_FCR 0 /* FixedCoRotEnergy   (src/Energy/Physics_Elasticity/FixedCoRotEnergy.cpp) */
+#define DOTMI_ENERGY_SNH 1 /* StableNHEnergy     (src/Energy/Physics_Elasticity/StableNHEnergy.cpp)  */
+
+#define DOTMI_E_INVALID -1  /* bad argument */
+#define DOTMI_E_DEVICE -2   /* HIP / rocSOLVER / RCCL runtime error */
+#define DOTMI_E_NOTSPD -3   /* a subdomain Hessian was not positive definite (potrf info > 0);
+                               the reference dumps the matrix and exit(-1)s, Optimizer.cpp:301-313 */
+#define DOTMI_E_NOGPU -4    /* no usable HIP device: the product path has no CPU fallback */
+
+typedef struct dotmi_handle dotmi_handle;
+
+/* Mesh<3> fields the path consumes (src/Mesh.hpp:38-60): rest positions V_rest, tets F,
+ * per-element Lame parameters u / lambda (Mesh.cpp:741-744), density (lumped mass is derived as in
+ * Mesh.cpp:552-585), the fixed set isFixedVert (after AnimScripter::initAnimScript,
+ * AnimScripter.cpp:29) and the element partition that METIS::partMesh returns
+ * (src/Utils/METIS.hpp:109-140, consumed in ADMMDDTimeStepper.cpp:88-262). */
+typedef struct {
+    int32_t nV, nT;
+    const double *X_rest;  /* nV*3 */
+    const int32_t *T;      /* nT*4, positive orientation */
+    const double *mu;      /* nT */
+    const double *lambda;  /* nT */
+    double density;
+    const uint8_t *fixed;  /* nV, 1 = Dirichlet */
+    const int32_t *epart;  /* nT, values in [0,nParts) */
+    int32_t nParts;
+} dotmi_mesh;
+
+/* Config / Optimizer constants (src/Config.hpp, Optimizer.cpp:98-111, DOTTimeStepper.cpp:45) */
+typedef struct {
+    int32_t energy;    /* DOTMI_ENERGY_* */
+    double dt;         /* Optimizer::setTime */
+    double gravity[3]; /* (0,-9.80665,0) unless turnOffGravity */
+    double relTol;     /* setRelGL2Tol argument, 1e-5 */
+    int32_t history;   /* L-BFGS pairs, 5 */
+    int32_t iterCap;   /* 10000 */
+    double alphaMin;   /* lower clamp of the initial step length, 0.1 (Optimizer.cpp:1085) */
+    int32_t device;    /* HIP device ordinal */
+    int32_t rank;      /* this process' rank among `world` cooperating handles */
+    int32_t world;     /* 1 = single GPU */
+    const void *comm_id; /* world>1: the 128-byte id from dotmi_comm_unique_id (same on all ranks) */
+    int32_t flags;     /* DOTMI_FLAG_* */
+} dotmi_params;
+
+#define DOTMI_FLAG_KEEP_ELEM_HESSIANS 1 /* keep nT*144 doubles resident for dotmi_eval_elem_hessians */
+
+typedef struct {
+    int32_t iters;        /* L-BFGS iterations (innerIterAmt delta, DOTTimeStepper.cpp:338) */
+    int32_t ls_halvings;  /* numOfLineSearch delta (Optimizer.cpp:816) */
+    int32_t energy_evals;
+    int32_t status;       /* 0 / 2 */
+    double E0, g2_0;      /* after initX (iterStats.txt header line, DOTTimeStepper.cpp:299) */
+    double E, g2;         /* at exit */
+    double ms_total;      /* host wall time of the step */
+    double ms_loop;       /* L-BFGS loop */
+    double ms_hessian;    /* element Hessians + global assembly + dense gather (device time) */
+    double ms_factor;     /* potrf + inverse (device time) */
+    double ms_precond;    /* accumulated device time of the subdomain back-solve kernel */
+    int64_t precond_launches;
+    int64_t precond_bytes; /* algorithmic bytes per back-solve launch: sum_s n_s^2 * 8 */
+} dotmi_step_stats;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* Builds all device state, computes restTriInv / volumes / lumped mass / tolerance, and performs
+ * DOTTimeStepper::precompute (DOTTimeStepper.cpp:150-178): Hessian + subdomain factors at x_init.
+ * x_init: nV*3 initial positions (result.V after initAnimScript; usually == X_rest). */
+int dotmi_create(const dotmi_mesh *mesh, const dotmi_params *params, const double *x_init,
+                 dotmi_handle **out);
+void dotmi_destroy(dotmi_handle *h);
+const char *dotmi_last_error(const dotmi_handle *h); /* h may be NULL: last create() error */
+
+/* world>1: rank 0 calls this and ships the 128 bytes to every rank (e.g. torch.distributed
+ * broadcast); all ranks pass it as params.comm_id.  */
+int dotmi_comm_unique_id(void *out128);
+
+/* ---- state ------------------------------------------------------------------------------------ */
+/* (x, v[, x_n]) round-trip = what Optimizer::saveStatus / restart carry (Optimizer.cpp:1096-1177) */
+int dotmi_set_state(dotmi_handle *h, const double *x, const double *v, const double *x_n /*or NULL*/);
+int dotmi_get_state(dotmi_handle *h, double *x, double *v, double *x_tilde /*any may be NULL*/);
+/* scripted handle motion for this step: x[idx[k]] = pos[k] (AnimScripter::stepAnimScript,
+ * AnimScripter.cpp:456-466) */
+int dotmi_set_dirichlet(dotmi_handle *h, int32_t n, const int32_t *idx, const double *pos);
+/* fixed set changed (rubberBandPull release): re-pattern + refactor
+ * (DOTTimeStepper::updatePrecondMtrAndFactorize, DOTTimeStepper.cpp:185-270) */
+int dotmi_refix(dotmi_handle *h, const uint8_t *fixed);
+
+/* ---- the hot path ----------------------------------------------------------------------------- */
+/* One backward-Euler step = Optimizer::solve(1) minus the script move:
+ * DOTTimeStepper::fullyImplicit (DOTTimeStepper.cpp:273-346) + BE update (Optimizer.cpp:354-361). */
+int dotmi_step(dotmi_handle *h, dotmi_step_stats *stats);
+/* per-iteration (alpha, E, ||g||^2) of the last step = iterStats.txt rows (DOTTimeStepper.cpp:304,329) */
+int dotmi_last_iter_log(const dotmi_handle *h, int32_t cap, double *alpha, double *E, double *g2);
+double dotmi_target_gres(const dotmi_handle *h); /* Optimizer::targetGRes (Optimizer.cpp:613-651) */
+
+/* ---- kernel-level entry points (parity tests, adapters that override single hooks) ------------- */
+int dotmi_eval_energy(dotmi_handle *h, const double *x, double *E);        /* Optimizer::computeEnergyVal, :1183 */
+int dotmi_eval_gradient(dotmi_handle *h, const double *x, double *g);      /* Optimizer::computeGradient, :1220 */
+int dotmi_eval_elem_hessians(dotmi_handle *h, const double *x, double *H); /* Energy::computeElemHessianByPK, Energy.cpp:673; nT*144 */
+int dotmi_refactor(dotmi_handle *h, const double *x /*NULL = current*/);   /* DOTTimeStepper::updateHessianAndFactor, :349 */
+int dotmi_apply_precond(dotmi_handle *h, const double *r, double *p);      /* DOTTimeStepper.cpp:406-450 */
+int dotmi_spmv(dotmi_handle *h, const double *p, double *Hp);              /* LinSysSolver::multiply, CHOLMODSolver.cpp:185 */
+/* derived mesh features, any pointer may be NULL: restTriInv nT*9 row-major, triArea nT, mass nV */
+int dotmi_get_features(dotmi_handle *h, double *A, double *vol, double *mass);
+/* dense principal sub-matrix R_s H R_s^T currently on the device (n_s = 3*local verts), row-major;
+ * `inverse` != 0 returns its stored inverse instead. l2g (local vertex -> global) may be NULL. */
+int32_t dotmi_part_size(const dotmi_handle *h, int32_t part);
+int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *M, int32_t *l2g);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* Launch the subdomain back-solve kernel `reps` times on the handle's stream between two HIP events
+ * and return the average milliseconds per launch and the algorithmic bytes per launch. */
+int dotmi_bench_precond(dotmi_handle *h, int32_t reps, double *ms_per_launch, int64_t *bytes_per_launch);
+int dotmi_bench_energy(dotmi_handle *h, int32_t reps, double *ms_per_launch, int64_t *bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOTMI_H */
