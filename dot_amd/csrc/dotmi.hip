@@ -12,7 +12,7 @@
 // from one small read-back per line-search trial.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
-#include <rocsolver/rocsolver.h>
+#include <rocblas/rocblas.h>
 
 #include <algorithm>
 #include <chrono>
@@ -98,7 +98,8 @@ struct dotmi_handle {
     double *S[HIST_MAX + 1] = {nullptr}, *Y[HIST_MAX + 1] = {nullptr};
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
     double *alpha_dev = nullptr;
-    rocblas_int *info_dev = nullptr;
+    int *info_dev = nullptr;
+    size_t tmp_stride = 0;
     int *didx = nullptr;
     double *dpos = nullptr;
     size_t dcap = 0;
@@ -117,6 +118,8 @@ struct dotmi_handle {
     long long numLineSearch = 0;
     int energy_evals = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    std::vector<hipEvent_t> evPre;  // DOTMI_FLAG_TIME_BACKSOLVE: (start, stop) pairs around each back-solve
+    int evUsed = 0;
     int64_t precond_bytes = 0;
 };
 
@@ -350,27 +353,17 @@ int build_device_mesh(dotmi_handle *h)
     }
     // ownership: contiguous groups of parts balanced by sum n_s^2 (the back-solve cost)
     {
-        std::vector<double> cost(nP + 1, 0.0);
-        for (int pI = 0; pI < nP; ++pI) {
-            const double ns = 3.0 * h->partVerts[pI].size();
-            cost[pI + 1] = cost[pI] + ns * ns;
-        }
-        auto cut = [&](int r) {
-            if (r <= 0) return 0;
-            if (r >= h->world) return nP;
-            const double target = cost[nP] * r / h->world;
-            int c = (int)(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin());
-            if (c > 0 && target - cost[c - 1] < cost[c] - target) --c;
-            return std::min(std::max(c, 0), nP);
-        };
-        h->p0 = cut(h->rank);
-        h->p1 = cut(h->rank + 1);
+        std::vector<int32_t> ps(nP), first(h->world + 1);
+        for (int pI = 0; pI < nP; ++pI) ps[pI] = 3 * (int32_t)h->partVerts[pI].size();
+        dotmi_plan_shards(nP, ps.data(), h->world, first.data());
+        h->p0 = first[h->rank];
+        h->p1 = first[h->rank + 1];
     }
     DevParts &P = h->P;
     P.nParts = h->p1 - h->p0;
     P.nmax = (nsmax + 127) / 128 * 128;
     std::vector<int> psize(P.nParts), dof_ptr(P.nParts + 1, 0), dofmap;
-    std::vector<int2> tiles;
+    std::vector<int2> tiles, tilesA;
     for (int ls = 0; ls < P.nParts; ++ls) {
         const auto &pv = h->partVerts[h->p0 + ls];
         psize[ls] = 3 * (int)pv.size();
@@ -378,8 +371,15 @@ int build_device_mesh(dotmi_handle *h)
         for (int v : pv)
             for (int d = 0; d < 3; ++d) dofmap.push_back(3 * v + d);
         for (int r = 0; r < psize[ls]; r += GEMV_ROWS) tiles.push_back(make_int2(ls, r));
+        for (int c = 0; c < psize[ls]; c += 128) tilesA.push_back(make_int2(ls, c));
     }
+    // heavy tiles first: dot-form work ~ ns - row0, axpy-form work ~ c0 + 128
+    std::stable_sort(tiles.begin(), tiles.end(), [&](const int2 &a, const int2 &b) {
+        return psize[a.x] - (a.y & ~127) > psize[b.x] - (b.y & ~127);
+    });
+    std::stable_sort(tilesA.begin(), tilesA.end(), [](const int2 &a, const int2 &b) { return a.y > b.y; });
     P.ntiles = (int)tiles.size();
+    P.ntilesA = (int)tilesA.size();
     // merge lists (owned parts only)
     std::vector<int> vp_ptr(nV + 1, 0), vp_off;
     {
@@ -423,6 +423,7 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = upload(h, &P.dof_ptr, dof_ptr)) return rc;
     if (int rc = upload(h, &P.dofmap, dofmap)) return rc;
     if (int rc = upload(h, &P.tile, tiles)) return rc;
+    if (int rc = upload(h, &P.tileA, tilesA)) return rc;
     if (int rc = upload(h, &P.vp_ptr, vp_ptr)) return rc;
     if (int rc = upload(h, &P.vp_off, vp_off)) return rc;
     if (int rc = upload(h, &P.dup, h->dup)) return rc;
@@ -430,7 +431,10 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = upload(h, &P.fill_src, fill_src)) return rc;
     if (int rc = upload(h, &P.pad_dst, pad_dst)) return rc;
     if (int rc = dalloc(h, &P.W, (size_t)P.nParts * P.nmax * P.nmax)) return rc;
+    h->tmp_stride = (size_t)P.nmax * (P.nmax / 2 + CHOL_NB);
+    if (int rc = dalloc(h, &P.Wtmp, (size_t)P.nParts * h->tmp_stride)) return rc;
     if (int rc = dalloc(h, &P.psub, (size_t)dof_ptr[P.nParts])) return rc;
+    if (int rc = dalloc(h, &P.tsub, (size_t)dof_ptr[P.nParts])) return rc;
     if (int rc = dalloc(h, &h->info_dev, (size_t)std::max(P.nParts, 1))) return rc;
 
     // element ownership + inertia vertex slice
@@ -475,7 +479,53 @@ int free_slot(const dotmi_handle *h)
     return 0;
 }
 
-// element Hessians -> global H -> dense sub-matrices -> Cholesky -> explicit inverse
+// X = chol(A)^-1 in place for every owned dense block (column-major lower), by recursion on
+//   A = [A11 . ; A21 A22]:  X11 = chol(A11)^-1 ; L21 = A21 X11^T ; A22 -= L21 L21^T ;
+//                           X22 = chol(A22)^-1 ; X21 = -X22 (L21 X11)
+// All off-diagonal work is FP64 GEMM (rocBLAS strided-batched over the subdomains); the CHOL_NB base
+// blocks are factored and inverted in LDS by chol_inv_base_kernel.  This replaces rocSOLVER
+// potrf+potri, measured at 1-3.6 TFLOP/s on these sizes against 60-70 TFLOP/s for dgemm
+// (profiles/r01_factor_primitives.txt).  Role in the reference: CHOLMODSolver::factorize
+// (CHOLMODSolver.cpp:143) called from DOTTimeStepper.cpp:363-377.
+int chol_inv_node(dotmi_handle *h, int o, int sz)
+{
+    DevParts &P = h->P;
+    const int lda = P.nmax, batch = P.nParts;
+    const rocblas_stride sA = (rocblas_stride)lda * lda;
+    if (sz <= CHOL_NB) {
+        launch_chol_inv_base(P, o, h->info_dev, h->st);
+        return 0;
+    }
+    const int n1 = ((sz / CHOL_NB) / 2) * CHOL_NB, n2 = sz - n1;
+    if (int rc = chol_inv_node(h, o, n1)) return rc;
+    double *X11 = P.W + o + (size_t)o * lda;
+    double *A21 = P.W + (o + n1) + (size_t)o * lda;
+    double *A22 = P.W + (o + n1) + (size_t)(o + n1) * lda;
+    double *A12 = P.W + o + (size_t)(o + n1) * lda;
+    double *Tb = P.Wtmp;
+    const int ldt = n2;
+    const rocblas_stride sT = (rocblas_stride)h->tmp_stride;
+    const double one = 1.0, zero = 0.0, mone = -1.0;
+    // L21 = A21 * X11^T
+    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_none, rocblas_operation_transpose, n2, n1,
+                                             n1, &one, A21, lda, sA, X11, lda, sA, &zero, Tb, ldt, sT, batch));
+    // A22 -= L21 * L21^T
+    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_none, rocblas_operation_transpose, n2, n2,
+                                             n1, &mone, Tb, ldt, sT, Tb, ldt, sT, &one, A22, lda, sA, batch));
+    // U = L21 * X11 -> stored where A21 was
+    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_none, rocblas_operation_none, n2, n1, n1,
+                                             &one, Tb, ldt, sT, X11, lda, sA, &zero, A21, lda, sA, batch));
+    if (int rc = chol_inv_node(h, o + n1, n2)) return rc;
+    // X21 = -X22 * U
+    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_none, rocblas_operation_none, n2, n1, n2,
+                                             &mone, A22, lda, sA, A21, lda, sA, &zero, Tb, ldt, sT, batch));
+    launch_block_copy(A21, lda, (size_t)sA, Tb, ldt, (size_t)sT, n2, n1, batch, h->st);
+    // the strictly upper block must read as zero when X is used as a dense GEMM operand one level up
+    launch_block_copy(A12, lda, (size_t)sA, nullptr, 0, 0, n1, n2, batch, h->st);
+    return 0;
+}
+
+// element Hessians -> global H -> dense sub-matrices -> inverse Cholesky factors
 // (DOTTimeStepper::updateHessianAndFactor, DOTTimeStepper.cpp:349-380)
 int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
 {
@@ -485,22 +535,18 @@ int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
     launch_dense_fill(h->P, h->Hval, h->st);
     HIPCHECK(h, hipEventRecord(h->ev1, h->st));
     if (h->P.nParts > 0) {
-        const rocblas_stride stride = (rocblas_stride)h->P.nmax * h->P.nmax;
-        RBCHECK(h, rocsolver_dpotrf_strided_batched(h->blas, rocblas_fill_lower, h->P.nmax, h->P.W, h->P.nmax,
-                                                    stride, h->info_dev, h->P.nParts));
-        std::vector<rocblas_int> info(h->P.nParts);
-        HIPCHECK(h, hipMemcpyAsync(info.data(), h->info_dev, sizeof(rocblas_int) * h->P.nParts,
-                                   hipMemcpyDeviceToHost, h->st));
+        HIPCHECK(h, hipMemsetAsync(h->info_dev, 0, sizeof(int) * h->P.nParts, h->st));
+        if (int rc = chol_inv_node(h, 0, h->P.nmax)) return rc;
+        std::vector<int> info(h->P.nParts);
+        HIPCHECK(h, hipMemcpyAsync(info.data(), h->info_dev, sizeof(int) * h->P.nParts, hipMemcpyDeviceToHost,
+                                   h->st));
         HIPCHECK(h, hipStreamSynchronize(h->st));
         for (int i = 0; i < h->P.nParts; ++i)
             if (info[i] != 0) {
-                h->err = "subdomain " + std::to_string(h->p0 + i) + " Hessian not positive definite (potrf info " +
-                         std::to_string(info[i]) + ")";
+                h->err = "subdomain " + std::to_string(h->p0 + i) +
+                         " Hessian not positive definite (pivot " + std::to_string(info[i]) + ")";
                 return DOTMI_E_NOTSPD;
             }
-        RBCHECK(h, rocsolver_dpotri_strided_batched(h->blas, rocblas_fill_lower, h->P.nmax, h->P.W, h->P.nmax,
-                                                    stride, h->info_dev, h->P.nParts));
-        launch_symmetrize(h->P, h->st);
     }
     HIPCHECK(h, hipEventRecord(h->ev2, h->st));
     HIPCHECK(h, hipEventSynchronize(h->ev2));
@@ -516,7 +562,13 @@ int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
 // p = D^-1 sum_s R_s^T W_s R_s q   (DOTTimeStepper.cpp:406-450); leaves y_i.z partials in partC
 int apply_precond(dotmi_handle *h, const double *q, double *z, const LbfgsArgs &L)
 {
+    const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size();
+    if (timed) HIPCHECK(h, hipEventRecord(h->evPre[h->evUsed], h->st));
     launch_gemv(h->P, q, h->st);
+    if (timed) {
+        HIPCHECK(h, hipEventRecord(h->evPre[h->evUsed + 1], h->st));
+        h->evUsed += 2;
+    }
     if (h->world == 1) {
         launch_merge(h->M, h->P, L, z, h->partC, 1 | 2, h->st);
     } else {
@@ -603,6 +655,24 @@ void sum_stats(const dotmi_handle *h, int nvals, double *R)
 // =================================================================================================
 extern "C" {
 
+// host-only: no device is touched
+int dotmi_plan_shards(int32_t nParts, const int32_t *part_scalar_size, int32_t world, int32_t *first_part)
+{
+    if (nParts < 0 || world < 1 || !first_part || (nParts > 0 && !part_scalar_size)) return DOTMI_E_INVALID;
+    std::vector<double> cost(nParts + 1, 0.0);
+    for (int p = 0; p < nParts; ++p) cost[p + 1] = cost[p] + (double)part_scalar_size[p] * part_scalar_size[p];
+    first_part[0] = 0;
+    first_part[world] = nParts;
+    for (int r = 1; r < world; ++r) {
+        const double target = cost[nParts] * r / world;
+        int c = (int)(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin());
+        if (c > 0 && target - cost[c - 1] < cost[c] - target) --c;
+        c = std::min(std::max(c, first_part[r - 1]), nParts);
+        first_part[r] = c;
+    }
+    return 0;
+}
+
 const char *dotmi_last_error(const dotmi_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int dotmi_comm_unique_id(void *out128)
@@ -628,6 +698,7 @@ void dotmi_destroy(dotmi_handle *h)
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev2) hipEventDestroy(h->ev2);
+    for (hipEvent_t e : h->evPre) hipEventDestroy(e);
     if (h->st) hipStreamDestroy(h->st);
     delete h;
 }
@@ -698,6 +769,10 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         NCCLCHECK(h, ncclCommInitRank(&h->comm, h->world, id, h->rank));
     }
 
+    if (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) {
+        h->evPre.resize(2 * 512);
+        for (auto &e : h->evPre) HIPCHECK(h, hipEventCreate(&e));
+    }
     host_features(h);
     h->targetGRes = host_target_gres(h);
     if (int rc = build_device_mesh(h)) return rc;
@@ -841,6 +916,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     const int n = h->n;
     h->m = 0;
     h->energy_evals = 0;
+    h->evUsed = 0;
     h->log_alpha.clear();
     h->log_E.clear();
     h->log_g2.clear();
@@ -961,7 +1037,12 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         st->ms_loop = Tloop1 - Tloop;
         st->ms_hessian = ms_hess;
         st->ms_factor = ms_fact;
-        st->precond_launches = it;
+        st->precond_launches = h->evUsed / 2;
+        for (int k = 0; k + 1 < h->evUsed; k += 2) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, h->evPre[k], h->evPre[k + 1]);
+            st->ms_precond += ms;
+        }
         st->precond_bytes = h->precond_bytes;
     }
     return status;

@@ -8,7 +8,8 @@ namespace dotmi {
 constexpr int HIST_MAX = 6;     // L-BFGS pairs kept (reference uses 5, DOTTimeStepper.cpp:45)
 constexpr int NB_RED = 128;     // blocks of every reducing kernel (fixed => run-to-run bit-identical sums)
 constexpr int RED_K = 3 * HIST_MAX + 3;  // partial values per block
-constexpr int GEMV_ROWS = 64;   // rows of one subdomain handled by one workgroup of the back-solve kernel
+constexpr int GEMV_ROWS = 64;   // memory rows per workgroup of the dot-form back-solve kernel
+constexpr int CHOL_NB = 64;     // base block of the recursive inverse-Cholesky (LDS resident)
 
 // ---- mesh + topology resident in HBM ------------------------------------------------------------
 struct DevMesh {
@@ -35,9 +36,13 @@ struct DevParts {
     int *psize;             // owned: scalar size n_s
     int *dof_ptr;           // owned+1: offsets into dofmap / psub
     int *dofmap;            // local scalar dof -> global scalar dof
-    double *W;              // owned * nmax*nmax dense blocks (H_s, then its inverse), row-major, lda = nmax
-    int ntiles;             // total row tiles of GEMV_ROWS
+    double *W;              // owned * nmax*nmax dense blocks: H_s, then X_s = chol(H_s)^-1 (column-major lower)
+    double *Wtmp;           // owned * nmax*(nmax/2+CHOL_NB) scratch of the recursion
+    int ntiles;             // dot-form tiles (GEMV_ROWS memory rows each), heavy first
     int2 *tile;             // tile -> (owned part, first row)
+    int ntilesA;            // axpy-form tiles (128 columns each), heavy first
+    int2 *tileA;            // tile -> (owned part, first column)
+    double *tsub;           // intermediate t_s = X_s r_s, concatenated by dof_ptr
     double *psub;           // per-part results, concatenated by dof_ptr
     // merge: per vertex list of positions in psub (all parts on this rank), CSR over vertices
     int *vp_ptr, *vp_off;
@@ -84,7 +89,7 @@ void launch_multidot(int n, const double *v, const double *const *vecs, int m, d
 // q = -g - sum_j xi_j y_j with xi from partials (b) and SY
 void launch_build_q(int n, const double *g, const LbfgsArgs &L, const double *xi_host, double *q,
                     hipStream_t st);
-// subdomain back-solve: psub_s = W_s * q[dofmap_s]
+// subdomain back-solve: psub_s = X_s^T (X_s q[dofmap_s])
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st);
 // z = merge(psub) / dup  (+ partial dots y_i . z)
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
@@ -101,7 +106,9 @@ void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *
                           hipStream_t st);
 void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st);
 void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st);
-void launch_symmetrize(const DevParts &P, hipStream_t st);
+void launch_chol_inv_base(const DevParts &P, int o, int *info, hipStream_t st);
+void launch_block_copy(double *dst, int ldd, size_t sd, const double *src, int lds_, size_t ss, int rows,
+                       int cols, int batch, hipStream_t st);
 // small helpers
 void launch_init_x(int nV, const uint8_t *fixed, const double *v, double dt, const double *gdtsq,
                    double *x, hipStream_t st);

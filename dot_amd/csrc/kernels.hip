@@ -383,26 +383,86 @@ void launch_multidot(int n, const double *v, const double *const *vecs, int m, d
 }
 
 // ------------------------------------------------------------------------------------------------
-// subdomain back-solve: psub_s = W_s * q[dofmap_s]   -- the HBM-bound kernel of the L-BFGS loop
-//   algorithmic bytes per launch: sum_s n_s^2 * 8  
-//   one workgroup = GEMV_ROWS rows of one subdomain; the gathered right-hand side lives in LDS;
-//   each wave streams 4 rows at a time, 16 B per lane per row, so one wave-instruction moves 1 KiB.
+// subdomain back-solve  p_s = H_s^-1 r_s = X^T (X r_s),  X = chol(H_s)^-1  (lower triangular)
+//   -- the HBM-bound pair of kernels of the L-BFGS loop.
+// Storage: column-major X, i.e. memory row j holds X(i,j) for i >= j contiguously (zeros for i < j).
+//   trisolve_axpy_kernel  t_i = sum_{j<=i} X(i,j) r_j : lanes own columns i (16 B per lane), the four
+//                         waves of a workgroup stride over memory rows j, no cross-lane reduction.
+//   trisolve_dot_kernel   p_j = sum_{i>=j} X(i,j) t_i : one wave streams 4 memory rows at a time and
+//                         wave-reduces; the vector t lives in LDS.
+// Each stored entry of the triangle is read exactly once per kernel:
+//   algorithmic bytes per back-solve = 2 * sum_s (n_s^2 / 2) * 8 = sum_s n_s^2 * 8  
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemv_kernel(const int2 *__restrict__ tile,
-                                                   const int *__restrict__ psize,
-                                                   const int *__restrict__ dof_ptr,
-                                                   const int *__restrict__ dofmap,
-                                                   const double *__restrict__ W, int nmax,
-                                                   const double *__restrict__ q,
-                                                   double *__restrict__ psub)
+constexpr int TRI_COLS = 128;  // columns per workgroup of the axpy-form kernel
+
+__global__ __launch_bounds__(256) void trisolve_axpy_kernel(const int2 *__restrict__ tile,
+                                                            const int *__restrict__ psize,
+                                                            const int *__restrict__ dof_ptr,
+                                                            const int *__restrict__ dofmap,
+                                                            const double *__restrict__ W, int nmax,
+                                                            const double *__restrict__ q,
+                                                            double *__restrict__ tsub)
 {
-    extern __shared__ __attribute__((aligned(16))) double rhs[];  // nmax doubles
+    extern __shared__ __attribute__((aligned(16))) double rhs[];  // nmax gathered rhs + 4*TRI_COLS reduction
+    const int2 tl = tile[blockIdx.x];
+    const int s = tl.x, c0 = tl.y;
+    const int ns = psize[s];
+    const int dof0 = dof_ptr[s];
+    const int nrow = min(c0 + TRI_COLS, ns);  // memory rows j < nrow contribute to columns [c0,c0+TRI_COLS)
+    for (int j = threadIdx.x; j < nrow; j += 256) rhs[j] = q[dofmap[dof0 + j]];
+    __syncthreads();
+    const double *Ws = W + (size_t)s * nmax * nmax + c0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double2 acc = make_double2(0.0, 0.0);
+    const double *col = Ws + 2 * lane;
+    int j = wv;
+#pragma unroll 1
+    for (; j + 28 < nrow; j += 32) {
+        double2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2 *>(col + (size_t)(j + 4 * u) * nmax);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double r = rhs[j + 4 * u];
+            acc.x += v[u].x * r;
+            acc.y += v[u].y * r;
+        }
+    }
+    for (; j < nrow; j += 4) {
+        const double2 v = *reinterpret_cast<const double2 *>(col + (size_t)j * nmax);
+        const double r = rhs[j];
+        acc.x += v.x * r;
+        acc.y += v.y * r;
+    }
+    double *red = rhs + nmax;
+    __syncthreads();
+    red[wv * TRI_COLS + 2 * lane] = acc.x;
+    red[wv * TRI_COLS + 2 * lane + 1] = acc.y;
+    __syncthreads();
+    if (threadIdx.x < TRI_COLS) {
+        const int c = c0 + threadIdx.x;
+        if (c < ns) {
+            const int t = threadIdx.x;
+            tsub[dof0 + c] = (red[t] + red[TRI_COLS + t]) + (red[2 * TRI_COLS + t] + red[3 * TRI_COLS + t]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void trisolve_dot_kernel(const int2 *__restrict__ tile,
+                                                           const int *__restrict__ psize,
+                                                           const int *__restrict__ dof_ptr,
+                                                           const double *__restrict__ W, int nmax,
+                                                           const double *__restrict__ tsub,
+                                                           double *__restrict__ psub)
+{
+    extern __shared__ __attribute__((aligned(16))) double tv[];  // nmax doubles
     const int2 tl = tile[blockIdx.x];
     const int s = tl.x, row0 = tl.y;
     const int ns = psize[s];
     const int dof0 = dof_ptr[s];
-    const int ncol = (ns + 127) & ~127;  // <= nmax (nmax is a multiple of 128)
-    for (int c = threadIdx.x; c < ncol; c += 256) rhs[c] = (c < ns) ? q[dofmap[dof0 + c]] : 0.0;
+    const int ncol = (ns + 127) & ~127;   // <= nmax
+    const int cbeg = row0 & ~127;         // entries with i < j are zero: start at the aligned diagonal
+    for (int c = cbeg + threadIdx.x; c < ncol; c += 256) tv[c] = (c < ns) ? tsub[dof0 + c] : 0.0;
     __syncthreads();
     const double *Ws = W + (size_t)s * nmax * nmax;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -411,15 +471,14 @@ __global__ __launch_bounds__(256) void gemv_kernel(const int2 *__restrict__ tile
     for (int rr = 0; rr < GEMV_ROWS / 4; rr += 4) {
         const int r = rbase + rr;
         if (r >= ns) break;
-        // rows beyond ns (only in the last tile) are clamped to a valid row and discarded
         const double *w0 = Ws + (size_t)min(r, ns - 1) * nmax;
         const double *w1 = Ws + (size_t)min(r + 1, ns - 1) * nmax;
         const double *w2 = Ws + (size_t)min(r + 2, ns - 1) * nmax;
         const double *w3 = Ws + (size_t)min(r + 3, ns - 1) * nmax;
         double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll 2
-        for (int c = 2 * lane; c < ncol; c += 128) {
-            const double2 rv = *reinterpret_cast<const double2 *>(rhs + c);
+        for (int c = cbeg + 2 * lane; c < ncol; c += 128) {
+            const double2 rv = *reinterpret_cast<const double2 *>(tv + c);
             const double2 v0 = *reinterpret_cast<const double2 *>(w0 + c);
             const double2 v1 = *reinterpret_cast<const double2 *>(w1 + c);
             const double2 v2 = *reinterpret_cast<const double2 *>(w2 + c);
@@ -445,8 +504,109 @@ __global__ __launch_bounds__(256) void gemv_kernel(const int2 *__restrict__ tile
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st)
 {
     if (P.ntiles == 0) return;
-    hipLaunchKernelGGL(gemv_kernel, dim3(P.ntiles), dim3(256), (size_t)P.nmax * sizeof(double), st, P.tile,
-                       P.psize, P.dof_ptr, P.dofmap, P.W, P.nmax, q, P.psub);
+    hipLaunchKernelGGL(trisolve_axpy_kernel, dim3(P.ntilesA), dim3(256),
+                       (size_t)(P.nmax + 4 * TRI_COLS) * sizeof(double), st, P.tileA, P.psize, P.dof_ptr,
+                       P.dofmap, P.W, P.nmax, q, P.tsub);
+    hipLaunchKernelGGL(trisolve_dot_kernel, dim3(P.ntiles), dim3(256), (size_t)P.nmax * sizeof(double), st,
+                       P.tile, P.psize, P.dof_ptr, P.W, P.nmax, P.tsub, P.psub);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dense inverse-Cholesky, base case: X = chol(A_kk)^-1 for one NB x NB diagonal block per workgroup,
+// entirely in LDS.  Column-major storage (memory row j = column j).  The off-diagonal work of the
+// blocked recursion is FP64 GEMM (rocBLAS) -- see factor_parts() in dotmi.hip.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chol_inv_base_kernel(double *__restrict__ W, int nmax, int o,
+                                                            int *__restrict__ info)
+{
+    constexpr int NB = CHOL_NB;
+    __shared__ double a[NB][NB + 1];  // a[i][j] = A(i,j), i >= j
+    __shared__ double x[NB][NB + 1];
+    __shared__ int bad;
+    double *Ws = W + (size_t)blockIdx.x * nmax * nmax + (size_t)o * nmax + o;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int t = tid; t < NB * NB; t += 256) {
+        const int j = t / NB, i = t % NB;  // memory row j, position i
+        a[i][j] = Ws[(size_t)j * nmax + i];
+    }
+    __syncthreads();
+    // right-looking Cholesky with deferred column scaling: one barrier per step
+    for (int k = 0; k < NB; ++k) {
+        const double piv = a[k][k];
+        if (tid == 0 && !(piv > 0.0)) bad = k + 1;
+        const double inv = 1.0 / piv;
+        const int rem = NB - 1 - k;  // trailing size
+        // entries (i,j), k < j <= i < NB, enumerated row-wise over the square and filtered
+        for (int t = tid; t < rem * rem; t += 256) {
+            const int i = k + 1 + t / rem, j = k + 1 + t % rem;
+            if (j <= i) a[i][j] -= a[i][k] * a[j][k] * inv;
+        }
+        __syncthreads();
+    }
+    // scale columns: L(i,k) = a(i,k)/sqrt(a(k,k))
+    for (int t = tid; t < NB * NB; t += 256) {
+        const int k = t / NB, i = t % NB;
+        if (i >= k) {
+            const double d = sqrt(a[k][k]);
+            x[i][k] = (i == k) ? d : a[i][k] / d;
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < NB * NB; t += 256) {
+        const int k = t / NB, i = t % NB;
+        a[i][k] = (i >= k) ? x[i][k] : 0.0;
+    }
+    __syncthreads();
+    // X = L^-1 by forward substitution, one thread per column c
+    if (tid < NB) {
+        const int c = tid;
+        for (int i = 0; i < NB; ++i) {
+            double v = 0.0;
+            if (i == c) v = 1.0 / a[c][c];
+            else if (i > c) {
+                double sacc = 0.0;
+                for (int k = c; k < i; ++k) sacc += a[i][k] * x[k][c];
+                v = -sacc / a[i][i];
+            }
+            x[i][c] = v;
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < NB * NB; t += 256) {
+        const int j = t / NB, i = t % NB;
+        Ws[(size_t)j * nmax + i] = (i >= j) ? x[i][j] : 0.0;
+    }
+    if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + bad);
+}
+
+void launch_chol_inv_base(const DevParts &P, int o, int *info, hipStream_t st)
+{
+    hipLaunchKernelGGL(chol_inv_base_kernel, dim3(P.nParts), dim3(256), 0, st, P.W, P.nmax, o, info);
+}
+
+// dst block <- src block (column-major blocks inside strided batches); zero when src == nullptr
+__global__ __launch_bounds__(256) void block_copy_kernel(double *__restrict__ dst, int ldd, size_t sd,
+                                                         const double *__restrict__ src, int lds_, size_t ss,
+                                                         int rows, int cols)
+{
+    const int b = blockIdx.z;
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int j0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
+    if (i >= rows) return;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u;
+        if (j < cols) dst[sd * b + (size_t)j * ldd + i] = src ? src[ss * b + (size_t)j * lds_ + i] : 0.0;
+    }
+}
+
+void launch_block_copy(double *dst, int ldd, size_t sd, const double *src, int lds_, size_t ss, int rows,
+                       int cols, int batch, hipStream_t st)
+{
+    if (rows <= 0 || cols <= 0 || batch <= 0) return;
+    hipLaunchKernelGGL(block_copy_kernel, dim3((rows + 63) / 64, (cols + 15) / 16, batch), dim3(256), 0, st,
+                       dst, ldd, sd, src, lds_, ss, rows, cols);
 }
 
 // z_v = (sum over parts containing v of p_s[local v]) / dup_v ; partial dots c_i = y_i . z
@@ -797,37 +957,6 @@ void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st)
     if (P.npad)
         hipLaunchKernelGGL(pad_identity_kernel, dim3((P.npad + 255) / 256), dim3(256), 0, st, P.npad,
                            P.pad_dst, P.W);
-}
-
-// After potri (column-major "lower" == row-major "upper" holds the inverse): mirror it so the
-// back-solve kernel can stream full rows.  32x32 tiles through LDS, both sides coalesced.
-__global__ __launch_bounds__(256) void symmetrize_kernel(double *__restrict__ W, int nmax, int ntile)
-{
-    __shared__ double tile[32][33];
-    // blockIdx.x enumerates (tr >= tc) pairs, blockIdx.y = part
-    int tr = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
-    while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
-    while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
-    const int tc = blockIdx.x - tr * (tr + 1) / 2;
-    if (tr >= ntile) return;
-    double *Ws = W + (size_t)blockIdx.y * nmax * nmax;
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;  // 32 x 8
-    // read the upper tile: rows tc*32.., cols tr*32..
-    for (int i = ly; i < 32; i += 8) tile[i][lx] = Ws[(size_t)(tc * 32 + i) * nmax + tr * 32 + lx];
-    __syncthreads();
-    // write the lower tile: rows tr*32.., cols tc*32..   W[r][c] = upper[c][r]
-    for (int i = ly; i < 32; i += 8) {
-        const int r = tr * 32 + i, c = tc * 32 + lx;
-        if (r > c) Ws[(size_t)r * nmax + c] = tile[lx][i];
-    }
-}
-
-void launch_symmetrize(const DevParts &P, hipStream_t st)
-{
-    if (!P.nParts) return;
-    const int ntile = P.nmax / 32;
-    hipLaunchKernelGGL(symmetrize_kernel, dim3(ntile * (ntile + 1) / 2, P.nParts), dim3(256), 0, st, P.W,
-                       P.nmax, ntile);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -228,6 +228,9 @@ class AnimScripter:
                 else:
                     self.turn_lo, self.turn_hi = xv - 0.8, xv + 0.4
         self.handle_idx = np.nonzero(self.fixed)[0].astype(np.int32)
+        # dense per-handle arrays (same order as handle_idx) for the vectorised step
+        self._w = np.array([self.ang_vel.get(int(v), 0.0) for v in self.handle_idx])
+        self._vel = np.array([self.vel.get(int(v), np.zeros(3)) for v in self.handle_idx]).reshape(-1, 3)
         if script == "fall":
             self.init_offset_y = 0.5 * float(np.linalg.norm(V_rest.max(axis=0) - V_rest.min(axis=0)))
         else:
@@ -249,19 +252,19 @@ class AnimScripter:
         if self.turn_vert >= 0:
             xv = x[self.turn_vert, 0]
             flip = (xv <= self.turn_lo) or (xv >= self.turn_hi)
-        newpos = np.array(x[idx], dtype=np.float64)
-        disp = np.zeros_like(newpos)
+        xh = np.array(x[idx], dtype=np.float64)
+        disp = np.zeros_like(xh)
         if self.ang_vel:
-            for k, v in enumerate(idx):
-                R = angle_axis_matrix(self.ang_vel[int(v)] * dt, (1.0, 0.0, 0.0))
-                disp[k] = (R @ (x[v] - self.rot_center) + self.rot_center) - x[v]
+            for w in np.unique(self._w):
+                sel = self._w == w
+                R = angle_axis_matrix(w * dt, (1.0, 0.0, 0.0))
+                rel = xh[sel] - self.rot_center
+                disp[sel] = (rel @ R.T + self.rot_center) - xh[sel]
         if self.vel:
-            for k, v in enumerate(idx):
-                vv = self.vel[int(v)]
-                if flip:
-                    vv[0] *= -1.0
-                disp[k] += vv * dt
-        return idx, newpos + disp
+            if flip:
+                self._vel[:, 0] *= -1.0
+            disp += self._vel * dt
+        return idx, xh + disp
 
 
 @dataclasses.dataclass

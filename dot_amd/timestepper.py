@@ -20,7 +20,7 @@ from .scene import Scene, lame
 class DOTTimeStepper:
     def __init__(self, scene: Scene, epart: np.ndarray, nparts: int, energy: Optional[int] = None,
                  device: int = 0, rank: int = 0, world: int = 1, comm_id: Optional[bytes] = None,
-                 history: int = 5, rel_tol: float = 1e-5, iter_cap: int = 10000):
+                 history: int = 5, rel_tol: float = 1e-5, iter_cap: int = 10000, flags: int = 0):
         L = _lib.load()
         cfg = scene.cfg
         self.scene = scene
@@ -52,7 +52,7 @@ class DOTTimeStepper:
         p.rank, p.world = rank, world
         self._comm = C.create_string_buffer(comm_id, 128) if comm_id is not None else None
         p.comm_id = C.cast(self._comm, C.c_void_p) if self._comm is not None else None
-        p.flags = 0
+        p.flags = flags
         x0 = np.ascontiguousarray(scene.x0, dtype=np.float64)
         h = C.c_void_p()
         rc = L.dotmi_create(C.byref(m), C.byref(p), dp(x0), C.byref(h))

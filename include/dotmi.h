@@ -4,7 +4,7 @@
  * Drop-in boundary for the reference's DOT stepper: a host adapter with the reference's
  * `DOT::Optimizer<3>` surface (src/TimeStepper/Optimizer.hpp:83-112; picked by the factory in
  * src/main.cpp:905-938) forwards to these entry points.  Plain pointers and sizes only; caller
- * owns every host array; the handle owns all device memory, the rocSOLVER handle and (N>1) the
+ * owns every host array; the handle owns all device memory, the rocBLAS handle and (N>1) the
  * RCCL communicator.  One host thread per handle.  No exceptions cross this boundary.
  *
  * Return convention (mirrors Optimizer::solve, Optimizer.cpp:327-368):
@@ -29,8 +29,8 @@ extern "C" {
 #define DOTMI_ENERGY_SNH 1 /* StableNHEnergy     (src/Energy/Physics_Elasticity/StableNHEnergy.cpp)  */
 
 #define DOTMI_E_INVALID -1  /* bad argument */
-#define DOTMI_E_DEVICE -2   /* HIP / rocSOLVER / RCCL runtime error */
-#define DOTMI_E_NOTSPD -3   /* a subdomain Hessian was not positive definite (potrf info > 0);
+#define DOTMI_E_DEVICE -2   /* HIP / rocBLAS / RCCL runtime error */
+#define DOTMI_E_NOTSPD -3   /* a subdomain Hessian was not positive definite (non-positive pivot);
                                the reference dumps the matrix and exit(-1)s, Optimizer.cpp:301-313 */
 #define DOTMI_E_NOGPU -4    /* no usable HIP device: the product path has no CPU fallback */
 
@@ -69,7 +69,8 @@ typedef struct {
     int32_t flags;     /* DOTMI_FLAG_* */
 } dotmi_params;
 
-#define DOTMI_FLAG_KEEP_ELEM_HESSIANS 1 /* keep nT*144 doubles resident for dotmi_eval_elem_hessians */
+#define DOTMI_FLAG_TIME_BACKSOLVE 2 /* bracket every back-solve of dotmi_step with HIP events on the
+                                       handle's stream; totals land in dotmi_step_stats */
 
 typedef struct {
     int32_t iters;        /* L-BFGS iterations (innerIterAmt delta, DOTTimeStepper.cpp:338) */
@@ -81,9 +82,9 @@ typedef struct {
     double ms_total;      /* host wall time of the step */
     double ms_loop;       /* L-BFGS loop */
     double ms_hessian;    /* element Hessians + global assembly + dense gather (device time) */
-    double ms_factor;     /* potrf + inverse (device time) */
-    double ms_precond;    /* accumulated device time of the subdomain back-solve kernel */
-    int64_t precond_launches;
+    double ms_factor;     /* inverse-Cholesky factors of all owned subdomains (device time) */
+    double ms_precond;    /* DOTMI_FLAG_TIME_BACKSOLVE: summed device time of the timed back-solves */
+    int64_t precond_launches; /* how many back-solves were timed (<= 512 per step) */
     int64_t precond_bytes; /* algorithmic bytes per back-solve launch: sum_s n_s^2 * 8 */
 } dotmi_step_stats;
 
@@ -95,6 +96,12 @@ int dotmi_create(const dotmi_mesh *mesh, const dotmi_params *params, const doubl
                  dotmi_handle **out);
 void dotmi_destroy(dotmi_handle *h);
 const char *dotmi_last_error(const dotmi_handle *h); /* h may be NULL: last create() error */
+
+/* Host-only planning helper (touches no device): splits parts 0..nParts-1 into `world` contiguous
+ * groups balanced by sum n_s^2 -- the bytes the back-solve streams per L-BFGS iteration.
+ * first_part has world+1 entries; rank r owns parts [first_part[r], first_part[r+1]).  This is the
+ * split dotmi_create applies; elements follow their part (ADMMDDTimeStepper.cpp:161). */
+int dotmi_plan_shards(int32_t nParts, const int32_t *part_scalar_size, int32_t world, int32_t *first_part);
 
 /* world>1: rank 0 calls this and ships the 128 bytes to every rank (e.g. torch.distributed
  * broadcast); all ranks pass it as params.comm_id.  */
@@ -128,8 +135,9 @@ int dotmi_apply_precond(dotmi_handle *h, const double *r, double *p);      /* DO
 int dotmi_spmv(dotmi_handle *h, const double *p, double *Hp);              /* LinSysSolver::multiply, CHOLMODSolver.cpp:185 */
 /* derived mesh features, any pointer may be NULL: restTriInv nT*9 row-major, triArea nT, mass nV */
 int dotmi_get_features(dotmi_handle *h, double *A, double *vol, double *mass);
-/* dense principal sub-matrix R_s H R_s^T currently on the device (n_s = 3*local verts), row-major;
- * `inverse` != 0 returns its stored inverse instead. l2g (local vertex -> global) may be NULL. */
+/* dense principal sub-matrix R_s H R_s^T currently on the device (n_s = 3*local verts), row-major.
+ * `inverse` != 0 returns the stored factor instead: M (n_s x n_s, row-major) with M[j][i] = X(i,j),
+ * X = chol(H_s)^-1 lower triangular, so that H_s^-1 = M M^T.  l2g (local vertex -> global) may be NULL. */
 int32_t dotmi_part_size(const dotmi_handle *h, int32_t part);
 int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *M, int32_t *l2g);
 

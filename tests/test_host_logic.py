@@ -1,0 +1,155 @@
+"""Host-side logic around the hot path: script parsing, scene construction, scripted Dirichlet
+motion, partitioners, workload table.  No GPU, no oracle."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from dot_amd import scene
+from dot_amd.configs import WORKLOADS, load_workload
+from dot_amd.sharding import owned_elements, part_scalar_sizes, plan_shards, vertex_slice
+
+
+def test_parse_script_tokens(tmp_path):
+    # same token set as the reference's input/bunny5K_LTSS_DOT.txt (values restated)
+    p = tmp_path / "s.txt"
+    p.write_text("energy FCR\ntimeStepper DOT 6\ninexactSolve 0\nwarmStart 2\nresolution 1000\nsize 1\n"
+                 "time 5 0.025\ndensity 1000\nstiffness 100000 0.4\nscript twistnsns\n"
+                 "shape input input/tetMeshes/bunny5K.msh\nview orthographic\nzoom 1\n"
+                 "tol 2\n1e-4\n1e-5\nunknownToken 3\nhandleRatio 0.02\nturnOffGravity\n")
+    cfg = scene.parse_script(str(p))
+    assert cfg.energy == "FCR" and cfg.partition_amt == 6 and cfg.dt == 0.025 and cfg.duration == 5
+    assert cfg.rho == 1000 and cfg.YM == 1e5 and cfg.PR == 0.4 and cfg.script == "twistnsns"
+    assert cfg.shape_path.endswith("bunny5K.msh") and cfg.tol == [1e-4, 1e-5]
+    assert cfg.handle_ratio == 0.02 and not cfg.with_gravity
+    p.write_text("timeStepper DOT 1\n")
+    assert scene.parse_script(str(p)).partition_amt == 4          # "<2 -> 4"
+    p.write_text("timeStepper DOT -1 1024\n")
+    assert scene.parse_script(str(p)).block_size == 1024
+
+
+def test_msh_reader_roundtrip(tmp_path):
+    V = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1]], dtype=float)
+    T = np.array([[0, 1, 2, 3], [1, 2, 3, 4]])
+    f = tmp_path / "m.msh"
+    with open(f, "w") as fh:
+        fh.write("$MeshFormat\n4 0 8\n$EndMeshFormat\n$Entities\n0 0 0 1\n$EndEntities\n$Nodes\n1 5\n0 1 0 5\n")
+        for i, v in enumerate(V):
+            fh.write(f"{i+1} {float(v[0])!r} {float(v[1])!r} {float(v[2])!r}\n")
+        fh.write("$EndNodes\n$Elements\n1 2\n0 1 4 2\n")
+        for i, t in enumerate(T):
+            fh.write(f"{i+1} {t[0]+1} {t[1]+1} {t[2]+1} {t[3]+1}\n")
+        fh.write("$EndElements\n")
+    V2, T2 = scene.read_tet_msh(str(f))
+    assert np.array_equal(V, V2) and np.array_equal(T, T2)
+
+
+def test_normalize_and_handles():
+    rng = np.random.default_rng(0)
+    V = rng.random((200, 3)) * [4, 1, 2] + 3
+    Vn = scene.normalize(V, 1.0)
+    assert np.allclose(Vn.min(axis=0), 0) and np.isclose((Vn.max(axis=0)).max(), 1.0)
+    g0, g1 = scene.find_border_verts(Vn, 0.05)
+    assert (Vn[g0, 0] < 0.05).all() and (Vn[g1, 0] > 0.95).all() and not set(g0) & set(g1)
+    R = scene.angle_axis_matrix(0.3, (1, 0, 0))
+    assert np.allclose(R @ R.T, np.eye(3)) and R[0, 0] == 1.0
+    assert np.allclose(R[1:, 1:], [[math.cos(0.3), -math.sin(0.3)], [math.sin(0.3), math.cos(0.3)]])
+
+
+def test_twist_script_rotates_handles_rigidly():
+    V, T = scene.synthetic_bar(8, 2, 2)
+    cfg = scene.Config(script="twist", dt=0.025, handle_ratio=0.01)
+    sc = scene.build_scene(cfg, V, T)
+    fixed = sc.fixed.astype(bool)
+    assert fixed.sum() == 2 * 9
+    x = sc.x0.copy()
+    idx, pos = sc.scripter.step(x, cfg.dt)
+    assert set(idx) == set(np.nonzero(fixed)[0])
+    c = sc.scripter.rot_center
+    # rigid rotation about the x axis through the bbox centre: distances to the axis preserved
+    r0 = np.linalg.norm((x[idx] - c)[:, 1:], axis=1)
+    r1 = np.linalg.norm((pos - c)[:, 1:], axis=1)
+    assert np.allclose(r0, r1, atol=1e-14) and np.allclose(pos[:, 0], x[idx, 0])
+    # the two ends turn in opposite directions by 0.1*pi*dt (AnimScripter.cpp:138-155)
+    ang = np.arctan2((pos - c)[:, 2], (pos - c)[:, 1]) - np.arctan2((x[idx] - c)[:, 2], (x[idx] - c)[:, 1])
+    ang = (ang + math.pi) % (2 * math.pi) - math.pi
+    off = r0 > 1e-9                                         # vertices on the axis do not move
+    left = x[idx, 0] < 0.5
+    assert np.allclose(np.abs(ang[off]), 0.1 * math.pi * cfg.dt, atol=1e-12)
+    assert (np.sign(ang[off & left]) == -np.sign(ang[off & ~left][0])).all()
+
+
+def test_twistnsns_velocity_flips_at_turning_points():
+    V, T = scene.synthetic_bar(8, 2, 2)
+    cfg = scene.Config(script="twistnsns", dt=0.025)
+    sc = scene.build_scene(cfg, V, T)
+    x = sc.x0.copy()
+    tv = sc.scripter.turn_vert
+    xs = []
+    for _ in range(80):
+        idx, pos = sc.scripter.step(x, cfg.dt)
+        x[idx] = pos
+        xs.append(x[tv, 0])
+    xs = np.array(xs)
+    d = np.diff(xs)
+    assert (np.sign(d[:-1]) != np.sign(d[1:])).sum() >= 1            # it turned around at least once
+    assert xs.max() <= sc.x0[tv, 0] + 0.4 + 1.2 * cfg.dt + 1e-12
+    assert np.allclose(np.abs(d), 1.2 * cfg.dt)                        # |v_x| = 1.2 (AnimScripter.cpp:179-217)
+
+
+def test_unsupported_script_is_rejected():
+    V, T = scene.synthetic_bar(2, 1, 1)
+    with pytest.raises(ValueError):
+        scene.build_scene(scene.Config(script="rubberBandPull"), V, T)
+
+
+def test_synthetic_bar_is_positively_oriented_and_conforming():
+    V, T = scene.synthetic_bar(5, 3, 2)
+    assert T.shape == (5 * 3 * 2 * 6, 4) and V.shape == (6 * 4 * 3, 3)
+    d = V[T[:, 1:]] - V[T[:, :1]]
+    vol = np.einsum("ij,ij->i", d[:, 0], np.cross(d[:, 1], d[:, 2])) / 6
+    assert (vol > 0).all() and np.isclose(vol.sum(), 4.0)
+    # every interior face is shared by exactly two tets
+    faces = np.sort(np.concatenate([T[:, [0, 1, 2]], T[:, [0, 1, 3]], T[:, [0, 2, 3]], T[:, [1, 2, 3]]]), axis=1)
+    _, cnt = np.unique(faces, axis=0, return_counts=True)
+    assert set(cnt) <= {1, 2}
+    Vj, _ = scene.synthetic_bar(5, 3, 2, jitter=0.1)
+    assert np.array_equal(Vj, scene.synthetic_bar(5, 3, 2, jitter=0.1)[0])   # seeded
+
+
+def test_rcb_partition_is_balanced_and_complete():
+    V, T = scene.synthetic_bar(16, 4, 4)
+    for nparts in (2, 5, 8):
+        ep = scene.partition_rcb(V, T, nparts)
+        cnt = np.bincount(ep, minlength=nparts)
+        assert cnt.min() > 0 and cnt.max() - cnt.min() <= max(2, 0.02 * len(T))
+
+
+def test_workload_table_and_fixtures():
+    for name, (mesh, kw, nparts) in WORKLOADS.items():
+        sc, ep, n = load_workload(name)
+        assert n == nparts and ep.shape == (sc.T.shape[0],) and ep.min() == 0 and ep.max() == nparts - 1
+        assert sc.fixed.sum() > 0 and sc.V_rest.max() <= 1.0 + 1e-12
+        d = sc.V_rest[sc.T[:, 1:]] - sc.V_rest[sc.T[:, :1]]
+        assert (np.einsum("ij,ij->i", d[:, 0], np.cross(d[:, 1], d[:, 2])) > 0).all()
+    sc, ep, n = load_workload("bunny5K_LTSS")
+    assert sc.V_rest.shape == (4670, 3) and sc.T.shape == (19379, 4) and sc.fixed.sum() == 23
+    sc, ep, n = load_workload("synbar:4x2x2:3")
+    assert n == 3 and ep.max() == 2
+
+
+def test_shard_plan_properties():
+    sc, ep, nparts = load_workload("bar17K_twist")
+    ps = part_scalar_sizes(sc.T, ep, nparts)
+    assert ps.max() == 3 * 716                                   # "max 716 local verts/part" 
+    for world in (1, 2, 4, 8, 32, 40):
+        first = plan_shards(ps, world)
+        assert first[0] == 0 and first[-1] == nparts and all(a <= b for a, b in zip(first, first[1:]))
+        owned = [owned_elements(ep, first, r) for r in range(world)]
+        assert sum(len(o) for o in owned) == len(ep)
+        if world <= 8:
+            cost = [float((ps[first[r]:first[r + 1]].astype(float) ** 2).sum()) for r in range(world)]
+            assert max(cost) <= 1.25 * (sum(cost) / world)
+    sl = [vertex_slice(101, r, 4) for r in range(4)]
+    assert sl[0][0] == 0 and sl[-1][1] == 101 and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
