@@ -101,11 +101,11 @@ def main():
     # ---- roofline of the dominant hand-written kernel pair, measured inside the timed region ----------
     pre_ms = sum(s.ms_precond for s in stats)
     pre_n = sum(s.precond_launches for s in stats)
-    bytes_per_launch = stats[0].precond_bytes            # sum_s n_s^2 * 8 over the parts of THIS rank
+    bytes_per_launch = stats[0].precond_bytes            # sum_s n_s(n_s+1)/2 * 8 over the parts of THIS rank
     avg_ms = pre_ms / max(pre_n, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if pre_n else 0.0
     roofline = {
-        "bound": "hbm", "kernel": "trisolve_axpy_kernel+trisolve_dot_kernel (subdomain back-solve)",
+        "bound": "hbm", "kernel": "backsolve_kernel (+reduce_partial_p_kernel): subdomain back-solve",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
         "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5),

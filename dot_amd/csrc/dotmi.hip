@@ -362,24 +362,25 @@ int build_device_mesh(dotmi_handle *h)
     DevParts &P = h->P;
     P.nParts = h->p1 - h->p0;
     P.nmax = (nsmax + 127) / 128 * 128;
+    if (P.nmax > 4096) {
+        h->err = "a subdomain has more than 1365 vertices: use more subdomains";
+        return DOTMI_E_INVALID;
+    }
     std::vector<int> psize(P.nParts), dof_ptr(P.nParts + 1, 0), dofmap;
-    std::vector<int2> tiles, tilesA;
+    std::vector<int4> tiles;
     for (int ls = 0; ls < P.nParts; ++ls) {
         const auto &pv = h->partVerts[h->p0 + ls];
         psize[ls] = 3 * (int)pv.size();
         dof_ptr[ls + 1] = dof_ptr[ls] + psize[ls];
         for (int v : pv)
             for (int d = 0; d < 3; ++d) dofmap.push_back(3 * v + d);
-        for (int r = 0; r < psize[ls]; r += GEMV_ROWS) tiles.push_back(make_int2(ls, r));
-        for (int c = 0; c < psize[ls]; c += 128) tilesA.push_back(make_int2(ls, c));
+        const int nt = (psize[ls] + 63) / 64;
+        for (int i = 0; i < nt; ++i) tiles.push_back(make_int4(ls, i * 64, i, 0));
     }
-    // heavy tiles first: dot-form work ~ ns - row0, axpy-form work ~ c0 + 128
-    std::stable_sort(tiles.begin(), tiles.end(), [&](const int2 &a, const int2 &b) {
-        return psize[a.x] - (a.y & ~127) > psize[b.x] - (b.y & ~127);
-    });
-    std::stable_sort(tilesA.begin(), tilesA.end(), [](const int2 &a, const int2 &b) { return a.y > b.y; });
+    // heavy tiles first: work ~ first row + 64
+    std::stable_sort(tiles.begin(), tiles.end(), [](const int4 &a, const int4 &b) { return a.y > b.y; });
     P.ntiles = (int)tiles.size();
-    P.ntilesA = (int)tilesA.size();
+    P.nbmax = P.nmax / 64;
     // merge lists (owned parts only)
     std::vector<int> vp_ptr(nV + 1, 0), vp_off;
     {
@@ -417,13 +418,13 @@ int build_device_mesh(dotmi_handle *h)
     }
     P.nfill = (int)fill_src.size();
     P.npad = (int)pad_dst.size();
+    // every entry of the triangular factor is streamed once per back-solve
     h->precond_bytes = 0;
-    for (int ls = 0; ls < P.nParts; ++ls) h->precond_bytes += (int64_t)psize[ls] * psize[ls] * 8;
+    for (int ls = 0; ls < P.nParts; ++ls) h->precond_bytes += (int64_t)psize[ls] * (psize[ls] + 1) / 2 * 8;
     if (int rc = upload(h, &P.psize, psize)) return rc;
     if (int rc = upload(h, &P.dof_ptr, dof_ptr)) return rc;
     if (int rc = upload(h, &P.dofmap, dofmap)) return rc;
     if (int rc = upload(h, &P.tile, tiles)) return rc;
-    if (int rc = upload(h, &P.tileA, tilesA)) return rc;
     if (int rc = upload(h, &P.vp_ptr, vp_ptr)) return rc;
     if (int rc = upload(h, &P.vp_off, vp_off)) return rc;
     if (int rc = upload(h, &P.dup, h->dup)) return rc;
@@ -434,7 +435,7 @@ int build_device_mesh(dotmi_handle *h)
     h->tmp_stride = (size_t)P.nmax * (P.nmax / 2 + CHOL_NB);
     if (int rc = dalloc(h, &P.Wtmp, (size_t)P.nParts * h->tmp_stride)) return rc;
     if (int rc = dalloc(h, &P.psub, (size_t)dof_ptr[P.nParts])) return rc;
-    if (int rc = dalloc(h, &P.tsub, (size_t)dof_ptr[P.nParts])) return rc;
+    if (int rc = dalloc(h, &P.ppart, (size_t)P.nParts * P.nbmax * P.nmax)) return rc;
     if (int rc = dalloc(h, &h->info_dev, (size_t)std::max(P.nParts, 1))) return rc;
 
     // element ownership + inertia vertex slice
@@ -479,14 +480,15 @@ int free_slot(const dotmi_handle *h)
     return 0;
 }
 
-// X = chol(A)^-1 in place for every owned dense block (column-major lower), by recursion on
-//   A = [A11 . ; A21 A22]:  X11 = chol(A11)^-1 ; L21 = A21 X11^T ; A22 -= L21 L21^T ;
-//                           X22 = chol(A22)^-1 ; X21 = -X22 (L21 X11)
-// All off-diagonal work is FP64 GEMM (rocBLAS strided-batched over the subdomains); the CHOL_NB base
-// blocks are factored and inverted in LDS by chol_inv_base_kernel.  This replaces rocSOLVER
-// potrf+potri, measured at 1-3.6 TFLOP/s on these sizes against 60-70 TFLOP/s for dgemm
-// (profiles/r01_factor_primitives.txt).  Role in the reference: CHOLMODSolver::factorize
-// (CHOLMODSolver.cpp:143) called from DOTTimeStepper.cpp:363-377.
+// Q = R^-1 in place for every owned dense block, H = R^T R (R upper), by recursion on
+//   H = [H11 H12 ; . H22]:  Q11 = R11^-1 ; R12 = Q11^T H12 ; H22 -= R12^T R12 ;
+//                           Q22 = R22^-1 ; Q12 = -(Q11 R12) Q22
+// In column-major terms Q is upper triangular, so memory row i holds row i of X = L^-1 = Q^T, the
+// layout the single-pass back-solve kernel streams.  All off-diagonal work is FP64 GEMM (rocBLAS
+// strided-batched over the subdomains); the CHOL_NB base blocks are factored and inverted in
+// registers by chol_inv_base_kernel.  This replaces rocSOLVER potrf+potri, measured at 1-3.6 TFLOP/s
+// on these sizes against 60-70 TFLOP/s for dgemm (profiles/r01_factor_primitives.txt).  Role in the
+// reference: CHOLMODSolver::factorize (CHOLMODSolver.cpp:143) called from DOTTimeStepper.cpp:363-377.
 int chol_inv_node(dotmi_handle *h, int o, int sz)
 {
     DevParts &P = h->P;
@@ -498,30 +500,31 @@ int chol_inv_node(dotmi_handle *h, int o, int sz)
     }
     const int n1 = ((sz / CHOL_NB) / 2) * CHOL_NB, n2 = sz - n1;
     if (int rc = chol_inv_node(h, o, n1)) return rc;
-    double *X11 = P.W + o + (size_t)o * lda;
-    double *A21 = P.W + (o + n1) + (size_t)o * lda;
-    double *A22 = P.W + (o + n1) + (size_t)(o + n1) * lda;
-    double *A12 = P.W + o + (size_t)(o + n1) * lda;
+    double *Q11 = P.W + o + (size_t)o * lda;
+    double *H12 = P.W + o + (size_t)(o + n1) * lda;
+    double *H22 = P.W + (o + n1) + (size_t)(o + n1) * lda;
+    double *H21 = P.W + (o + n1) + (size_t)o * lda;
     double *Tb = P.Wtmp;
-    const int ldt = n2;
+    const int ldt = n1;
     const rocblas_stride sT = (rocblas_stride)h->tmp_stride;
     const double one = 1.0, zero = 0.0, mone = -1.0;
-    // L21 = A21 * X11^T
-    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_none, rocblas_operation_transpose, n2, n1,
-                                             n1, &one, A21, lda, sA, X11, lda, sA, &zero, Tb, ldt, sT, batch));
-    // A22 -= L21 * L21^T
-    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_none, rocblas_operation_transpose, n2, n2,
-                                             n1, &mone, Tb, ldt, sT, Tb, ldt, sT, &one, A22, lda, sA, batch));
-    // U = L21 * X11 -> stored where A21 was
-    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_none, rocblas_operation_none, n2, n1, n1,
-                                             &one, Tb, ldt, sT, X11, lda, sA, &zero, A21, lda, sA, batch));
+    // R12 = Q11^T * H12
+    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_transpose, rocblas_operation_none, n1, n2,
+                                             n1, &one, Q11, lda, sA, H12, lda, sA, &zero, Tb, ldt, sT, batch));
+    // H22 -= R12^T * R12
+    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_transpose, rocblas_operation_none, n2, n2,
+                                             n1, &mone, Tb, ldt, sT, Tb, ldt, sT, &one, H22, lda, sA, batch));
+    // U = Q11 * R12 -> stored where H12 was
+    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_none, rocblas_operation_none, n1, n2, n1,
+                                             &one, Q11, lda, sA, Tb, ldt, sT, &zero, H12, lda, sA, batch));
     if (int rc = chol_inv_node(h, o + n1, n2)) return rc;
-    // X21 = -X22 * U
-    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_none, rocblas_operation_none, n2, n1, n2,
-                                             &mone, A22, lda, sA, A21, lda, sA, &zero, Tb, ldt, sT, batch));
-    launch_block_copy(A21, lda, (size_t)sA, Tb, ldt, (size_t)sT, n2, n1, batch, h->st);
-    // the strictly upper block must read as zero when X is used as a dense GEMM operand one level up
-    launch_block_copy(A12, lda, (size_t)sA, nullptr, 0, 0, n1, n2, batch, h->st);
+    // Q12 = -U * Q22
+    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_none, rocblas_operation_none, n1, n2, n2,
+                                             &mone, H12, lda, sA, H22, lda, sA, &zero, Tb, ldt, sT, batch));
+    launch_block_copy(H12, lda, (size_t)sA, Tb, ldt, (size_t)sT, n1, n2, batch, h->st);
+    // the strictly lower block must read as zero when Q is used as a dense GEMM operand one level up
+    // and when the back-solve kernel streams whole memory rows
+    launch_block_copy(H21, lda, (size_t)sA, nullptr, 0, 0, n2, n1, batch, h->st);
     return 0;
 }
 

@@ -6,7 +6,7 @@
 namespace dotmi {
 
 constexpr int HIST_MAX = 6;     // L-BFGS pairs kept (reference uses 5, DOTTimeStepper.cpp:45)
-constexpr int NB_RED = 128;     // blocks of every reducing kernel (fixed => run-to-run bit-identical sums)
+constexpr int NB_RED = 256;     // blocks of every reducing kernel (fixed => run-to-run bit-identical sums)
 constexpr int RED_K = 3 * HIST_MAX + 3;  // partial values per block
 constexpr int GEMV_ROWS = 64;   // memory rows per workgroup of the dot-form back-solve kernel
 constexpr int CHOL_NB = 64;     // base block of the recursive inverse-Cholesky (LDS resident)
@@ -36,13 +36,13 @@ struct DevParts {
     int *psize;             // owned: scalar size n_s
     int *dof_ptr;           // owned+1: offsets into dofmap / psub
     int *dofmap;            // local scalar dof -> global scalar dof
-    double *W;              // owned * nmax*nmax dense blocks: H_s, then X_s = chol(H_s)^-1 (column-major lower)
+    double *W;              // owned * nmax*nmax dense blocks: H_s, then X_s = chol(H_s)^-1 with memory row i =
+                            // row i of X_s (column-major upper factor Q = R^-1 of H_s = R^T R)
     double *Wtmp;           // owned * nmax*(nmax/2+CHOL_NB) scratch of the recursion
-    int ntiles;             // dot-form tiles (GEMV_ROWS memory rows each), heavy first
-    int2 *tile;             // tile -> (owned part, first row)
-    int ntilesA;            // axpy-form tiles (128 columns each), heavy first
-    int2 *tileA;            // tile -> (owned part, first column)
-    double *tsub;           // intermediate t_s = X_s r_s, concatenated by dof_ptr
+    int ntiles;             // back-solve jobs: (part, first row, tile index within the part, -), heavy first
+    int4 *tile;
+    int nbmax;              // max row tiles per part
+    double *ppart;          // owned * nbmax * nmax partial results of the back-solve tiles
     double *psub;           // per-part results, concatenated by dof_ptr
     // merge: per vertex list of positions in psub (all parts on this rank), CSR over vertices
     int *vp_ptr, *vp_off;

@@ -194,6 +194,17 @@ __device__ __forceinline__ void write_partials(double (&acc)[RED_K], int nvals, 
         partials[(size_t)blockIdx.x * RED_K + t] = (sm[t] + sm[RED_K + t]) + (sm[2 * RED_K + t] + sm[3 * RED_K + t]);
 }
 
+// sum over the 8 lanes of an aligned lane group (fixed butterfly => deterministic); all 8 get the total
+__device__ __forceinline__ double group8_sum(double v)
+{
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
+// 8 lanes cooperate on one vertex: each sums every 8th incident (element, slot) contribution, the
+// butterfly combines them, then lanes 0..2 of the group own the x, y, z degree of freedom.
 __global__ __launch_bounds__(256) void vertex_gather_kernel(
     int nV, const int *__restrict__ vf_ptr, const int *__restrict__ vf_ent,
     const uint8_t *__restrict__ fixed, const double *__restrict__ mass, GatherArgs a, LbfgsArgs L,
@@ -204,41 +215,38 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
 #pragma unroll
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
     const double alpha = a.make_pair ? *a.alpha_dev : 0.0;
-    const int stride = gridDim.x * blockDim.x;
-    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nV; v += stride) {
+    const int sub = threadIdx.x & 7;
+    const int ngroups = gridDim.x * 32;
+    for (int v = blockIdx.x * 32 + (threadIdx.x >> 3); v < nV; v += ngroups) {
         double g0 = 0, g1 = 0, g2 = 0;
-        if (!fixed[v]) {
-            const int b = vf_ptr[v], e = vf_ptr[v + 1];
-            for (int k = b; k < e; ++k) {
+        const bool fx = fixed[v];
+        if (!fx) {
+            const int e = vf_ptr[v + 1];
+            for (int k = vf_ptr[v] + sub; k < e; k += 8) {
                 const int ent = vf_ent[k];
                 const double *ge = a.gcont + (size_t)12 * (ent >> 2) + 3 * (ent & 3);
                 g0 += ge[0];
                 g1 += ge[1];
                 g2 += ge[2];
             }
-            if (v >= a.iv0 && v < a.iv1) {
-                const double mv = mass[v];
-                g0 += mv * (a.x[3 * v] - a.xt[3 * v]);
-                g1 += mv * (a.x[3 * v + 1] - a.xt[3 * v + 1]);
-                g2 += mv * (a.x[3 * v + 2] - a.xt[3 * v + 2]);
-            }
         }
-        a.g_new[3 * v] = g0;
-        a.g_new[3 * v + 1] = g1;
-        a.g_new[3 * v + 2] = g2;
-        if (a.make_pair) {
-            const double gn[3] = {g0, g1, g2};
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const int k = 3 * v + d;
+        g0 = group8_sum(g0);
+        g1 = group8_sum(g1);
+        g2 = group8_sum(g2);
+        if (sub < 3) {
+            const int k = 3 * v + sub;
+            double gn = (sub == 0) ? g0 : ((sub == 1) ? g1 : g2);
+            if (!fx && v >= a.iv0 && v < a.iv1) gn += mass[v] * (a.x[k] - a.xt[k]);
+            a.g_new[k] = gn;
+            if (a.make_pair) {
                 const double sn = alpha * a.p[k];
-                const double yn = gn[d] - a.g_old[k];
+                const double yn = gn - a.g_old[k];
                 a.s_new[k] = sn;
                 a.y_new[k] = yn;
-                pair_stats_accum(k, gn[d], sn, yn, L, acc);
+                pair_stats_accum(k, gn, sn, yn, L, acc);
+            } else {
+                acc[0] += gn * gn;
             }
-        } else {
-            acc[0] += g0 * g0 + g1 * g1 + g2 * g2;
         }
     }
     write_partials(acc, a.make_pair ? RED_K : 1, partials, sm);
@@ -384,205 +392,233 @@ void launch_multidot(int n, const double *v, const double *const *vecs, int m, d
 
 // ------------------------------------------------------------------------------------------------
 // subdomain back-solve  p_s = H_s^-1 r_s = X^T (X r_s),  X = chol(H_s)^-1  (lower triangular)
-//   -- the HBM-bound pair of kernels of the L-BFGS loop.
-// Storage: column-major X, i.e. memory row j holds X(i,j) for i >= j contiguously (zeros for i < j).
-//   trisolve_axpy_kernel  t_i = sum_{j<=i} X(i,j) r_j : lanes own columns i (16 B per lane), the four
-//                         waves of a workgroup stride over memory rows j, no cross-lane reduction.
-//   trisolve_dot_kernel   p_j = sum_{i>=j} X(i,j) t_i : one wave streams 4 memory rows at a time and
-//                         wave-reduces; the vector t lives in LDS.
-// Each stored entry of the triangle is read exactly once per kernel:
-//   algorithmic bytes per back-solve = 2 * sum_s (n_s^2 / 2) * 8 = sum_s n_s^2 * 8  
+//   -- THE HBM-bound kernel of the L-BFGS loop.
+// Storage: memory row i holds row i of X, X(i,k) for k <= i, contiguously (zeros for k > i); that is
+//   the column-major upper factor Q = R^-1 of H = R^T R that chol_inv_node() produces.
+// One pass: for every memory row i   t_i = row_i . r   and then   p += t_i * row_i
+//   so each stored entry is read from HBM exactly ONCE per back-solve:
+//   algorithmic bytes per launch = sum_s n_s (n_s + 1) / 2 * 8.
+// A workgroup owns BS_ROWS consecutive rows of one subdomain and walks them BS_SUB at a time: the
+// rows sit in VGPRs (16 B per lane per row chunk), their dot products are combined with a transposed
+// butterfly (10 shuffles instead of 48) + one LDS exchange, and the rank-8 update of p is applied
+// from the same registers.  The workgroup's partial p goes to ppart[s][tile][.]; the tiles of a
+// subdomain are summed in fixed order by reduce_partial_p_kernel (no atomics, deterministic).
 // ------------------------------------------------------------------------------------------------
-constexpr int TRI_COLS = 128;  // columns per workgroup of the axpy-form kernel
+constexpr int BS_ROWS = 64;   // memory rows per workgroup
+constexpr int BS_SUB = 8;     // rows held in registers at a time
 
-__global__ __launch_bounds__(256) void trisolve_axpy_kernel(const int2 *__restrict__ tile,
+template <int THREADS, int MAXCH>
+__global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restrict__ job,
                                                             const int *__restrict__ psize,
                                                             const int *__restrict__ dof_ptr,
                                                             const int *__restrict__ dofmap,
                                                             const double *__restrict__ W, int nmax,
                                                             const double *__restrict__ q,
-                                                            double *__restrict__ tsub)
+                                                            double *__restrict__ ppart, int nbmax)
 {
-    extern __shared__ __attribute__((aligned(16))) double rhs[];  // nmax gathered rhs + 4*TRI_COLS reduction
-    const int2 tl = tile[blockIdx.x];
-    const int s = tl.x, c0 = tl.y;
+    constexpr int NW = THREADS / 64;
+    __shared__ double sm[2][NW][BS_SUB];
+    const int4 jb = job[blockIdx.x];
+    const int s = jb.x, i0 = jb.y, tileIdx = jb.z;
     const int ns = psize[s];
     const int dof0 = dof_ptr[s];
-    const int nrow = min(c0 + TRI_COLS, ns);  // memory rows j < nrow contribute to columns [c0,c0+TRI_COLS)
-    for (int j = threadIdx.x; j < nrow; j += 256) rhs[j] = q[dofmap[dof0 + j]];
-    __syncthreads();
-    const double *Ws = W + (size_t)s * nmax * nmax + c0;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double2 acc = make_double2(0.0, 0.0);
-    const double *col = Ws + 2 * lane;
-    int j = wv;
+    const int len = min(i0 + BS_ROWS, ns);     // columns k < len can be non-zero in these rows
+    const int ncol = (len + 127) & ~127;       // <= nmax
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double *Ws = W + (size_t)s * nmax * nmax;
+    double2 r[MAXCH], pacc[MAXCH];
+#pragma unroll
+    for (int m = 0; m < MAXCH; ++m) {
+        const int c = 2 * tid + 2 * THREADS * m;
+        r[m].x = (c < ns) ? q[dofmap[dof0 + c]] : 0.0;
+        r[m].y = (c + 1 < ns) ? q[dofmap[dof0 + c + 1]] : 0.0;
+        pacc[m] = make_double2(0.0, 0.0);
+    }
 #pragma unroll 1
-    for (; j + 28 < nrow; j += 32) {
-        double2 v[8];
+    for (int sb = 0; sb < BS_ROWS / BS_SUB; ++sb) {
+        const int ib = i0 + sb * BS_SUB;
+        if (ib >= ns) break;
+        double2 y[BS_SUB][MAXCH];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const double2 *>(col + (size_t)(j + 4 * u) * nmax);
+        for (int rr = 0; rr < BS_SUB; ++rr) {
+            const double *row = Ws + (size_t)min(ib + rr, ns - 1) * nmax;
+            const bool live = (ib + rr) < ns;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const double r = rhs[j + 4 * u];
-            acc.x += v[u].x * r;
-            acc.y += v[u].y * r;
+            for (int m = 0; m < MAXCH; ++m) {
+                const int c = 2 * tid + 2 * THREADS * m;
+                y[rr][m] = (live && c < ncol) ? *reinterpret_cast<const double2 *>(row + c) : make_double2(0.0, 0.0);
+            }
         }
-    }
-    for (; j < nrow; j += 4) {
-        const double2 v = *reinterpret_cast<const double2 *>(col + (size_t)j * nmax);
-        const double r = rhs[j];
-        acc.x += v.x * r;
-        acc.y += v.y * r;
-    }
-    double *red = rhs + nmax;
-    __syncthreads();
-    red[wv * TRI_COLS + 2 * lane] = acc.x;
-    red[wv * TRI_COLS + 2 * lane + 1] = acc.y;
-    __syncthreads();
-    if (threadIdx.x < TRI_COLS) {
-        const int c = c0 + threadIdx.x;
-        if (c < ns) {
-            const int t = threadIdx.x;
-            tsub[dof0 + c] = (red[t] + red[TRI_COLS + t]) + (red[2 * TRI_COLS + t] + red[3 * TRI_COLS + t]);
+        double d[BS_SUB];
+#pragma unroll
+        for (int rr = 0; rr < BS_SUB; ++rr) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < MAXCH; ++m) acc += y[rr][m].x * r[m].x + y[rr][m].y * r[m].y;
+            d[rr] = acc;
         }
+        // transposed butterfly: 8 values over 64 lanes -> lane group g = lane>>3 holds row g's wave sum
+        double e4[4], e2[2], e1;
+        {
+            const bool hi = lane & 32;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double keep = hi ? d[k + 4] : d[k], send = hi ? d[k] : d[k + 4];
+                e4[k] = keep + __shfl_xor(send, 32, 64);
+            }
+        }
+        {
+            const bool hi = lane & 16;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const double keep = hi ? e4[k + 2] : e4[k], send = hi ? e4[k] : e4[k + 2];
+                e2[k] = keep + __shfl_xor(send, 16, 64);
+            }
+        }
+        {
+            const bool hi = lane & 8;
+            const double keep = hi ? e2[1] : e2[0], send = hi ? e2[0] : e2[1];
+            e1 = keep + __shfl_xor(send, 8, 64);
+        }
+        e1 += __shfl_xor(e1, 4, 64);
+        e1 += __shfl_xor(e1, 2, 64);
+        e1 += __shfl_xor(e1, 1, 64);
+        // lane bits (5,4,3) = (b2,b1,b0): row index = 4*b2 + 2*b1 + b0
+        const int buf = sb & 1;
+        if ((lane & 7) == 0) sm[buf][wv][lane >> 3] = e1;
+        __syncthreads();
+        double t[BS_SUB];
+#pragma unroll
+        for (int rr = 0; rr < BS_SUB; ++rr) {
+            double acc = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc += sm[buf][w][rr];
+            t[rr] = acc;
+        }
+#pragma unroll
+        for (int m = 0; m < MAXCH; ++m)
+#pragma unroll
+            for (int rr = 0; rr < BS_SUB; ++rr) {
+                pacc[m].x += t[rr] * y[rr][m].x;
+                pacc[m].y += t[rr] * y[rr][m].y;
+            }
+    }
+    double *out = ppart + ((size_t)s * nbmax + tileIdx) * nmax;
+#pragma unroll
+    for (int m = 0; m < MAXCH; ++m) {
+        const int c = 2 * tid + 2 * THREADS * m;
+        if (c < ncol) *reinterpret_cast<double2 *>(out + c) = pacc[m];
     }
 }
 
-__global__ __launch_bounds__(256) void trisolve_dot_kernel(const int2 *__restrict__ tile,
-                                                           const int *__restrict__ psize,
-                                                           const int *__restrict__ dof_ptr,
-                                                           const double *__restrict__ W, int nmax,
-                                                           const double *__restrict__ tsub,
-                                                           double *__restrict__ psub)
+// psub_s[k] = sum over the row tiles b >= k / BS_ROWS of ppart[s][b][k]   (fixed order)
+__global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int *__restrict__ psize,
+                                                               const int *__restrict__ dof_ptr,
+                                                               const double *__restrict__ ppart, int nmax,
+                                                               int nbmax, double *__restrict__ psub)
 {
-    extern __shared__ __attribute__((aligned(16))) double tv[];  // nmax doubles
-    const int2 tl = tile[blockIdx.x];
-    const int s = tl.x, row0 = tl.y;
+    const int s = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
     const int ns = psize[s];
-    const int dof0 = dof_ptr[s];
-    const int ncol = (ns + 127) & ~127;   // <= nmax
-    const int cbeg = row0 & ~127;         // entries with i < j are zero: start at the aligned diagonal
-    for (int c = cbeg + threadIdx.x; c < ncol; c += 256) tv[c] = (c < ns) ? tsub[dof0 + c] : 0.0;
-    __syncthreads();
-    const double *Ws = W + (size_t)s * nmax * nmax;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int rbase = row0 + wv * (GEMV_ROWS / 4);
-#pragma unroll 1
-    for (int rr = 0; rr < GEMV_ROWS / 4; rr += 4) {
-        const int r = rbase + rr;
-        if (r >= ns) break;
-        const double *w0 = Ws + (size_t)min(r, ns - 1) * nmax;
-        const double *w1 = Ws + (size_t)min(r + 1, ns - 1) * nmax;
-        const double *w2 = Ws + (size_t)min(r + 2, ns - 1) * nmax;
-        const double *w3 = Ws + (size_t)min(r + 3, ns - 1) * nmax;
-        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll 2
-        for (int c = cbeg + 2 * lane; c < ncol; c += 128) {
-            const double2 rv = *reinterpret_cast<const double2 *>(tv + c);
-            const double2 v0 = *reinterpret_cast<const double2 *>(w0 + c);
-            const double2 v1 = *reinterpret_cast<const double2 *>(w1 + c);
-            const double2 v2 = *reinterpret_cast<const double2 *>(w2 + c);
-            const double2 v3 = *reinterpret_cast<const double2 *>(w3 + c);
-            a0 += v0.x * rv.x + v0.y * rv.y;
-            a1 += v1.x * rv.x + v1.y * rv.y;
-            a2 += v2.x * rv.x + v2.y * rv.y;
-            a3 += v3.x * rv.x + v3.y * rv.y;
-        }
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
-        a2 = wave_sum(a2);
-        a3 = wave_sum(a3);
-        if (lane == 0) {
-            psub[dof0 + r] = a0;
-            if (r + 1 < ns) psub[dof0 + r + 1] = a1;
-            if (r + 2 < ns) psub[dof0 + r + 2] = a2;
-            if (r + 3 < ns) psub[dof0 + r + 3] = a3;
-        }
-    }
+    if (k >= ns) return;
+    const int nb = (ns + BS_ROWS - 1) / BS_ROWS;
+    const double *base = ppart + (size_t)s * nbmax * nmax + k;
+    double acc = 0.0;
+    for (int b = k / BS_ROWS; b < nb; ++b) acc += base[(size_t)b * nmax];
+    psub[dof_ptr[s] + k] = acc;
 }
 
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st)
 {
     if (P.ntiles == 0) return;
-    hipLaunchKernelGGL(trisolve_axpy_kernel, dim3(P.ntilesA), dim3(256),
-                       (size_t)(P.nmax + 4 * TRI_COLS) * sizeof(double), st, P.tileA, P.psize, P.dof_ptr,
-                       P.dofmap, P.W, P.nmax, q, P.tsub);
-    hipLaunchKernelGGL(trisolve_dot_kernel, dim3(P.ntiles), dim3(256), (size_t)P.nmax * sizeof(double), st,
-                       P.tile, P.psize, P.dof_ptr, P.W, P.nmax, P.tsub, P.psub);
+#define DM_BS(THR, CH)                                                                                      \
+    hipLaunchKernelGGL((backsolve_kernel<THR, CH>), dim3(P.ntiles), dim3(THR), 0, st, P.tile, P.psize,      \
+                       P.dof_ptr, P.dofmap, P.W, P.nmax, q, P.ppart, P.nbmax)
+    if (P.nmax <= 1536) DM_BS(256, 3);
+    else if (P.nmax <= 2560) DM_BS(256, 5);
+    else DM_BS(512, 4);  // nmax <= 4096, enforced at create time
+#undef DM_BS
+    hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.psize,
+                       P.dof_ptr, P.ppart, P.nmax, P.nbmax, P.psub);
 }
 
 // ------------------------------------------------------------------------------------------------
-// dense inverse-Cholesky, base case: X = chol(A_kk)^-1 for one NB x NB diagonal block per workgroup,
-// entirely in LDS.  Column-major storage (memory row j = column j).  The off-diagonal work of the
-// blocked recursion is FP64 GEMM (rocBLAS) -- see factor_parts() in dotmi.hip.
+// dense inverse-Cholesky, base case: for one NB x NB diagonal block per wavefront compute
+// L = chol(A_kk), X = L^-1 and store Q_kk = X^T (the inverse of the upper factor R_kk = L^T).
+// The off-diagonal work of the blocked recursion is FP64 GEMM (rocBLAS) -- chol_inv_node() in dotmi.hip.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void chol_inv_base_kernel(double *__restrict__ W, int nmax, int o,
-                                                            int *__restrict__ info)
+__device__ __forceinline__ double readlane_f64(double v, int srclane)
+{
+    union {
+        double d;
+        int i[2];
+    } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], srclane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], srclane);
+    return u.d;
+}
+
+// One wavefront per diagonal block, everything in VGPRs: lane i owns row i of A (then of L), later
+// lane c owns column c of X = L^-1.  Cross-lane operands are wave-uniform broadcasts (v_readlane),
+// so there is no LDS traffic and no barrier in the O(NB^3) part; all loops are fully unrolled so the
+// register arrays are statically indexed.
+__global__ __launch_bounds__(64) void chol_inv_base_kernel(double *__restrict__ W, int nmax, int o,
+                                                           int *__restrict__ info)
 {
     constexpr int NB = CHOL_NB;
-    __shared__ double a[NB][NB + 1];  // a[i][j] = A(i,j), i >= j
-    __shared__ double x[NB][NB + 1];
-    __shared__ int bad;
+    static_assert(NB == 64, "one lane per row");
+    __shared__ double xt[NB][NB + 1];
     double *Ws = W + (size_t)blockIdx.x * nmax * nmax + (size_t)o * nmax + o;
-    const int tid = threadIdx.x;
-    if (tid == 0) bad = 0;
-    for (int t = tid; t < NB * NB; t += 256) {
-        const int j = t / NB, i = t % NB;  // memory row j, position i
-        a[i][j] = Ws[(size_t)j * nmax + i];
-    }
-    __syncthreads();
-    // right-looking Cholesky with deferred column scaling: one barrier per step
+    const int lane = threadIdx.x;
+    double a[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) a[j] = Ws[(size_t)j * nmax + lane];  // a[j] = A(lane, j) (symmetric block)
+    int bad = 0;
+    // right-looking Cholesky with deferred column scaling: A(i,j) -= A(i,k) A(j,k) / A(k,k)
+#pragma unroll
     for (int k = 0; k < NB; ++k) {
-        const double piv = a[k][k];
-        if (tid == 0 && !(piv > 0.0)) bad = k + 1;
-        const double inv = 1.0 / piv;
-        const int rem = NB - 1 - k;  // trailing size
-        // entries (i,j), k < j <= i < NB, enumerated row-wise over the square and filtered
-        for (int t = tid; t < rem * rem; t += 256) {
-            const int i = k + 1 + t / rem, j = k + 1 + t % rem;
-            if (j <= i) a[i][j] -= a[i][k] * a[j][k] * inv;
-        }
-        __syncthreads();
+        const double piv = readlane_f64(a[k], k);
+        if (!(piv > 0.0) && bad == 0) bad = k + 1;
+        const double t = a[k] * (1.0 / piv);
+#pragma unroll
+        for (int j = k + 1; j < NB; ++j) a[j] = __builtin_fma(-t, readlane_f64(a[k], j), a[j]);
     }
-    // scale columns: L(i,k) = a(i,k)/sqrt(a(k,k))
-    for (int t = tid; t < NB * NB; t += 256) {
-        const int k = t / NB, i = t % NB;
-        if (i >= k) {
-            const double d = sqrt(a[k][k]);
-            x[i][k] = (i == k) ? d : a[i][k] / d;
-        }
-    }
-    __syncthreads();
-    for (int t = tid; t < NB * NB; t += 256) {
-        const int k = t / NB, i = t % NB;
-        a[i][k] = (i >= k) ? x[i][k] : 0.0;
-    }
-    __syncthreads();
-    // X = L^-1 by forward substitution, one thread per column c
-    if (tid < NB) {
-        const int c = tid;
-        for (int i = 0; i < NB; ++i) {
-            double v = 0.0;
-            if (i == c) v = 1.0 / a[c][c];
-            else if (i > c) {
-                double sacc = 0.0;
-                for (int k = c; k < i; ++k) sacc += a[i][k] * x[k][c];
-                v = -sacc / a[i][i];
-            }
-            x[i][c] = v;
+    // L(i,k) = A(i,k)/sqrt(A(k,k));  dinv = 1/L(lane,lane)
+    double dinv = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const double d = sqrt(readlane_f64(a[k], k));
+        const double r = 1.0 / d;
+        if (lane == k) {
+            a[k] = d;
+            dinv = r;
+        } else {
+            a[k] *= r;
         }
     }
-    __syncthreads();
-    for (int t = tid; t < NB * NB; t += 256) {
-        const int j = t / NB, i = t % NB;
-        Ws[(size_t)j * nmax + i] = (i >= j) ? x[i][j] : 0.0;
+    // X = L^-1 column by column: lane c solves L x = e_c;  L(i,k) is broadcast from lane i
+    double x[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        double sacc = (lane == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) sacc = __builtin_fma(-readlane_f64(a[k], i), x[k], sacc);
+        x[i] = (lane <= i) ? sacc * readlane_f64(dinv, i) : 0.0;
     }
-    if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + bad);
+    // store Q = X^T column-major, i.e. memory row i, position k <- X(i,k) (zero for k > i); through
+    // LDS so the global store is coalesced
+#pragma unroll
+    for (int i = 0; i < NB; ++i) xt[lane][i] = x[i];  // xt[c][i] = X(i,c)
+    __syncthreads();
+#pragma unroll 8
+    for (int i = 0; i < NB; ++i) Ws[(size_t)i * nmax + lane] = xt[lane][i];
+    if (bad) atomicMax(info + blockIdx.x, o + bad);
 }
 
 void launch_chol_inv_base(const DevParts &P, int o, int *info, hipStream_t st)
 {
-    hipLaunchKernelGGL(chol_inv_base_kernel, dim3(P.nParts), dim3(256), 0, st, P.W, P.nmax, o, info);
+    hipLaunchKernelGGL(chol_inv_base_kernel, dim3(P.nParts), dim3(64), 0, st, P.W, P.nmax, o, info);
 }
 
 // dst block <- src block (column-major blocks inside strided batches); zero when src == nullptr
@@ -690,10 +726,12 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const in
 {
     __shared__ double sm[4];
     double pg = 0, pHp = 0;
-    const int stride = gridDim.x * blockDim.x;
-    for (int v = v0 + blockIdx.x * blockDim.x + threadIdx.x; v < v1; v += stride) {
+    const int sub = threadIdx.x & 7;
+    const int ngroups = gridDim.x * 32;
+    for (int v = v0 + blockIdx.x * 32 + (threadIdx.x >> 3); v < v1; v += ngroups) {
         double a0 = 0, a1 = 0, a2 = 0;
-        for (int k = adj_ptr[v]; k < adj_ptr[v + 1]; ++k) {
+        const int e = adj_ptr[v + 1];
+        for (int k = adj_ptr[v] + sub; k < e; k += 8) {
             const double *b = Hval + (size_t)9 * k;
             const double *pu = p + 3 * adj_idx[k];
             const double p0 = pu[0], p1 = pu[1], p2 = pu[2];
@@ -701,14 +739,19 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const in
             a1 += b[3] * p0 + b[4] * p1 + b[5] * p2;
             a2 += b[6] * p0 + b[7] * p1 + b[8] * p2;
         }
-        if (Hp) {
-            Hp[3 * v] = a0;
-            Hp[3 * v + 1] = a1;
-            Hp[3 * v + 2] = a2;
+        a0 = group8_sum(a0);
+        a1 = group8_sum(a1);
+        a2 = group8_sum(a2);
+        if (sub == 0) {
+            if (Hp) {
+                Hp[3 * v] = a0;
+                Hp[3 * v + 1] = a1;
+                Hp[3 * v + 2] = a2;
+            }
+            const double q0 = p[3 * v], q1 = p[3 * v + 1], q2 = p[3 * v + 2];
+            pHp += q0 * a0 + q1 * a1 + q2 * a2;
+            if (g) pg += q0 * g[3 * v] + q1 * g[3 * v + 1] + q2 * g[3 * v + 2];
         }
-        const double q0 = p[3 * v], q1 = p[3 * v + 1], q2 = p[3 * v + 2];
-        pHp += q0 * a0 + q1 * a1 + q2 * a2;
-        if (g) pg += q0 * g[3 * v] + q1 * g[3 * v + 1] + q2 * g[3 * v + 2];
     }
     const double s0 = block_sum256(pg, sm);
     const double s1 = block_sum256(pHp, sm);

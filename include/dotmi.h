@@ -85,7 +85,8 @@ typedef struct {
     double ms_factor;     /* inverse-Cholesky factors of all owned subdomains (device time) */
     double ms_precond;    /* DOTMI_FLAG_TIME_BACKSOLVE: summed device time of the timed back-solves */
     int64_t precond_launches; /* how many back-solves were timed (<= 512 per step) */
-    int64_t precond_bytes; /* algorithmic bytes per back-solve launch: sum_s n_s^2 * 8 */
+    int64_t precond_bytes; /* algorithmic bytes per back-solve launch: sum_s n_s(n_s+1)/2 * 8 (the
+                              triangular factor is streamed once) */
 } dotmi_step_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -136,8 +137,8 @@ int dotmi_spmv(dotmi_handle *h, const double *p, double *Hp);              /* Li
 /* derived mesh features, any pointer may be NULL: restTriInv nT*9 row-major, triArea nT, mass nV */
 int dotmi_get_features(dotmi_handle *h, double *A, double *vol, double *mass);
 /* dense principal sub-matrix R_s H R_s^T currently on the device (n_s = 3*local verts), row-major.
- * `inverse` != 0 returns the stored factor instead: M (n_s x n_s, row-major) with M[j][i] = X(i,j),
- * X = chol(H_s)^-1 lower triangular, so that H_s^-1 = M M^T.  l2g (local vertex -> global) may be NULL. */
+ * `inverse` != 0 returns the stored factor instead: X = chol(H_s)^-1 (n_s x n_s, row-major, lower
+ * triangular), so that H_s^-1 = X^T X.  l2g (local vertex -> global) may be NULL. */
 int32_t dotmi_part_size(const dotmi_handle *h, int32_t part);
 int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *M, int32_t *l2g);
 

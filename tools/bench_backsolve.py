@@ -1,0 +1,8 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dot_amd.configs import load_workload
+from dot_amd.timestepper import DOTTimeStepper
+sc, ep, n = load_workload(sys.argv[1] if len(sys.argv) > 1 else "bar17K_twist")
+ts = DOTTimeStepper(sc, ep, n)
+ms, nb = ts.benchPrecond(200)
+print("PAIR=%s WAVES=%s back-solve %.4f ms  %.1f GB/s" % (os.environ.get("DOTMI_PAIR_TILES"), os.environ.get("DOTMI_AXPY_WAVES"), ms, nb / ms / 1e6))

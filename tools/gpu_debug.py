@@ -35,7 +35,7 @@ print("prec ", rel(ts.applyPrecond(p), orc.apply_precond(p)))
 M, l2g = ts.partMatrix(0, False); Mo = orc.part_dense(0)
 print("Hs   ", rel(M, Mo), (l2g == orc.part_verts(0)).all())
 Mi, _ = ts.partMatrix(0, True)
-print("Hs^-1", np.abs((Mi @ Mi.T) @ Mo - np.eye(len(Mo))).max(), "upper-zero", np.abs(np.tril(Mi, -1)).max())
+print("Hs^-1", np.abs((Mi.T @ Mi) @ Mo - np.eye(len(Mo))).max(), "upper-zero", np.abs(np.triu(Mi, 1)).max())
 ts.updatePrecondMtrAndFactorize(sc.x0); orc.refactor(sc.x0)
 for step in range(nsteps):
     xs = ts.getResult()
