@@ -91,3 +91,16 @@ def test_invalid_arguments_are_rejected_before_touching_a_device():
     assert L.dotmi_create(None, None, None, None) == -1
     assert L.dotmi_step(None, None) == -1
     assert L.dotmi_target_gres(None) == 0.0
+
+
+def test_cpp_adapter_builds_links_and_fails_loudly_or_steps(tmp_path):
+    """dot_amd/host/DotHipTimeStepper.hpp (the C++ mirror of the Optimizer surface) compiles with plain
+    g++ (no HIP headers), links against libdotmi.so, and either steps (GPU box) or reports the ABI's
+    no-CPU-fallback error (exit 3)."""
+    import subprocess
+    exe = tmp_path / "adapter_check"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", os.path.join(ROOT, "dot_amd", "host", "adapter_check.cpp"),
+                           "-o", str(exe), "-L" + os.path.join(ROOT, "dot_amd"), "-ldotmi",
+                           "-Wl,-rpath," + os.path.join(ROOT, "dot_amd")])
+    rc = subprocess.call([str(exe)])
+    assert rc == (0 if _has_gpu() else 3)

@@ -288,5 +288,8 @@ def test_device_path_against_reference_golden_vectors(golden):
         ge[:, :3] = -(ge[:, 3:6] + ge[:, 6:9] + ge[:, 9:12])
         ge += (mass[:, None] * (x - xt)).reshape(n, 12)
         scale = np.abs(ge).max()
-        assert np.abs(g - ge).max() < 5e-9 * scale, np.abs(g - ge).max() / scale
+        # F = 0 (vector 5) has no unique polar rotation: P = -2 mu U V^T depends on the SVD's arbitrary
+        # U, V there -- every other vector (rest, inverted, rank-2, near-rest, random) must agree
+        ok = np.ones(n, dtype=bool); ok[5] = False
+        assert np.abs(g - ge)[ok].max() < 5e-9 * scale, np.abs(g - ge)[ok].max() / scale
         ts.close()
