@@ -74,6 +74,7 @@ struct dotmi_handle {
     double dt = 0, dtSq = 0, grav[3] = {0, 0, 0}, gdtsq[3] = {0, 0, 0}, relTol = 1e-5, alphaMin = 0.1;
     double targetGRes = 0, density = 0;
     int device = 0, rank = 0, world = 1, flags = 0;
+    bool dist = false;  // world > 1, or DOTMI_FLAG_FORCE_DIST: take the sharded / collective code path
     std::string err;
 
     // host copies
@@ -439,7 +440,7 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = dalloc(h, &h->info_dev, (size_t)std::max(P.nParts, 1))) return rc;
 
     // element ownership + inertia vertex slice
-    if (h->world > 1) {
+    if (h->dist) {
         std::vector<int> el;
         for (int e = 0; e < nT; ++e)
             if (h->epart[e] >= h->p0 && h->epart[e] < h->p1) el.push_back(e);
@@ -508,19 +509,52 @@ int chol_inv_node(dotmi_handle *h, int o, int sz)
     const int ldt = n1;
     const rocblas_stride sT = (rocblas_stride)h->tmp_stride;
     const double one = 1.0, zero = 0.0, mone = -1.0;
-    // R12 = Q11^T * H12
-    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_transpose, rocblas_operation_none, n1, n2,
-                                             n1, &one, Q11, lda, sA, H12, lda, sA, &zero, Tb, ldt, sT, batch));
-    // H22 -= R12^T * R12
-    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_transpose, rocblas_operation_none, n2, n2,
-                                             n1, &mone, Tb, ldt, sT, Tb, ldt, sT, &one, H22, lda, sA, batch));
-    // U = Q11 * R12 -> stored where H12 was
-    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_none, rocblas_operation_none, n1, n2, n1,
-                                             &one, Q11, lda, sA, Tb, ldt, sT, &zero, H12, lda, sA, batch));
+    const rocblas_operation N = rocblas_operation_none, T = rocblas_operation_transpose;
+    // C(m x n) = alpha * op(A) op(B) + beta * C, batched over the owned subdomains
+    auto gemm = [&](rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double *alpha,
+                    const double *A, int la, rocblas_stride sa, const double *B, int lb, rocblas_stride sb,
+                    const double *beta, double *C, int lc, rocblas_stride sc) {
+        return rocblas_dgemm_strided_batched(h->blas, ta, tb, m, n, k, alpha, A, la, sa, B, lb, sb, beta, C, lc, sc,
+                                             batch);
+    };
+    // Q11 and Q22 are upper triangular and only the upper triangle of H22 is needed: on the big nodes
+    // each product is split 2x2 and the structurally-zero / unused quarter is skipped (3 GEMMs
+    // instead of 4 quarter-GEMMs; rocBLAS trmm/syrk are slower than the full dgemm on these sizes,
+    // profiles/r01_factor_primitives.txt).
+    const int a = ((n1 / CHOL_NB) / 2) * CHOL_NB, b = n1 - a;
+    const int c = ((n2 / CHOL_NB) / 2) * CHOL_NB, d = n2 - c;
+    const bool split = n1 >= 512 && a > 0 && c > 0;
+    const double *Qaa = Q11, *Qab = Q11 + (size_t)a * lda, *Qbb = Q11 + a + (size_t)a * lda;
+    if (split) {
+        // R12 = Q11^T H12 :  R_a = Qaa^T H_a ;  R_b = Qab^T H_a + Qbb^T H_b
+        RBCHECK(h, gemm(T, N, a, n2, a, &one, Qaa, lda, sA, H12, lda, sA, &zero, Tb, ldt, sT));
+        RBCHECK(h, gemm(T, N, b, n2, a, &one, Qab, lda, sA, H12, lda, sA, &zero, Tb + a, ldt, sT));
+        RBCHECK(h, gemm(T, N, b, n2, b, &one, Qbb, lda, sA, H12 + a, lda, sA, &one, Tb + a, ldt, sT));
+        // upper blocks of H22 -= R12^T R12
+        const double *Rc = Tb, *Rd = Tb + (size_t)c * ldt;
+        RBCHECK(h, gemm(T, N, c, c, n1, &mone, Rc, ldt, sT, Rc, ldt, sT, &one, H22, lda, sA));
+        RBCHECK(h, gemm(T, N, c, d, n1, &mone, Rc, ldt, sT, Rd, ldt, sT, &one, H22 + (size_t)c * lda, lda, sA));
+        RBCHECK(h, gemm(T, N, d, d, n1, &mone, Rd, ldt, sT, Rd, ldt, sT, &one, H22 + c + (size_t)c * lda, lda, sA));
+        // U = Q11 R12 -> H12 :  U_a = Qaa R_a + Qab R_b ;  U_b = Qbb R_b
+        RBCHECK(h, gemm(N, N, a, n2, a, &one, Qaa, lda, sA, Tb, ldt, sT, &zero, H12, lda, sA));
+        RBCHECK(h, gemm(N, N, a, n2, b, &one, Qab, lda, sA, Tb + a, ldt, sT, &one, H12, lda, sA));
+        RBCHECK(h, gemm(N, N, b, n2, b, &one, Qbb, lda, sA, Tb + a, ldt, sT, &zero, H12 + a, lda, sA));
+    } else {
+        RBCHECK(h, gemm(T, N, n1, n2, n1, &one, Q11, lda, sA, H12, lda, sA, &zero, Tb, ldt, sT));
+        RBCHECK(h, gemm(T, N, n2, n2, n1, &mone, Tb, ldt, sT, Tb, ldt, sT, &one, H22, lda, sA));
+        RBCHECK(h, gemm(N, N, n1, n2, n1, &one, Q11, lda, sA, Tb, ldt, sT, &zero, H12, lda, sA));
+    }
     if (int rc = chol_inv_node(h, o + n1, n2)) return rc;
-    // Q12 = -U * Q22
-    RBCHECK(h, rocblas_dgemm_strided_batched(h->blas, rocblas_operation_none, rocblas_operation_none, n1, n2, n2,
-                                             &mone, H12, lda, sA, H22, lda, sA, &zero, Tb, ldt, sT, batch));
+    // Q12 = -U Q22
+    if (split) {
+        const double *Qcc = H22, *Qcd = H22 + (size_t)c * lda, *Qdd = H22 + c + (size_t)c * lda;
+        const double *Uc = H12, *Ud = H12 + (size_t)c * lda;
+        RBCHECK(h, gemm(N, N, n1, c, c, &mone, Uc, lda, sA, Qcc, lda, sA, &zero, Tb, ldt, sT));
+        RBCHECK(h, gemm(N, N, n1, d, c, &mone, Uc, lda, sA, Qcd, lda, sA, &zero, Tb + (size_t)c * ldt, ldt, sT));
+        RBCHECK(h, gemm(N, N, n1, d, d, &mone, Ud, lda, sA, Qdd, lda, sA, &one, Tb + (size_t)c * ldt, ldt, sT));
+    } else {
+        RBCHECK(h, gemm(N, N, n1, n2, n2, &mone, H12, lda, sA, H22, lda, sA, &zero, Tb, ldt, sT));
+    }
     launch_block_copy(H12, lda, (size_t)sA, Tb, ldt, (size_t)sT, n1, n2, batch, h->st);
     // the strictly lower block must read as zero when Q is used as a dense GEMM operand one level up
     // and when the back-solve kernel streams whole memory rows
@@ -572,7 +606,7 @@ int apply_precond(dotmi_handle *h, const double *q, double *z, const LbfgsArgs &
         HIPCHECK(h, hipEventRecord(h->evPre[h->evUsed + 1], h->st));
         h->evUsed += 2;
     }
-    if (h->world == 1) {
+    if (!h->dist) {
         launch_merge(h->M, h->P, L, z, h->partC, 1 | 2, h->st);
     } else {
         launch_merge(h->M, h->P, L, z, h->partC, 0, h->st);
@@ -605,7 +639,7 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
     a.y_new = h->Y[slot];
     a.iv0 = h->v0;
     a.iv1 = h->v1;
-    if (h->world == 1) {
+    if (!h->dist) {
         a.make_pair = make_pair;
         launch_vertex_gather(h->M, a, L, h->partR, h->st);
         HIPCHECK(h, hipMemcpyAsync(h->h_partE, h->partE, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, h->st));
@@ -628,7 +662,7 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
                                h->st));
     HIPCHECK(h, hipMemcpyAsync(h->h_alpha, h->alpha_dev, sizeof(double), hipMemcpyDeviceToHost, h->st));
     HIPCHECK(h, hipStreamSynchronize(h->st));
-    if (h->world == 1) {
+    if (!h->dist) {
         double se = 0, si = 0;
         for (int b = 0; b < nb; ++b) {
             se += h->h_partE[2 * b];
@@ -766,9 +800,11 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     HIPCHECK(h, hipEventCreate(&h->ev2));
     RBCHECK(h, rocblas_create_handle(&h->blas));
     RBCHECK(h, rocblas_set_stream(h->blas, h->st));
-    if (h->world > 1) {
+    h->dist = h->world > 1 || (h->flags & DOTMI_FLAG_FORCE_DIST);
+    if (h->dist) {
         ncclUniqueId id;
-        memcpy(&id, prm->comm_id, 128);
+        if (h->world > 1) memcpy(&id, prm->comm_id, 128);
+        else NCCLCHECK(h, ncclGetUniqueId(&id));
         NCCLCHECK(h, ncclCommInitRank(&h->comm, h->world, id, h->rank));
     }
 
@@ -954,7 +990,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         // ---- alpha_0 and the first trial ---------------------------------------------------------------
         launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st);
         const double *spart = h->partS;
-        if (h->world > 1) {
+        if (h->dist) {
             hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partS, NB_RED, RED_K, 2, 0.0,
                                0.0, 0, h->partG);
             NCCLCHECK(h, ncclAllReduce(h->partG, h->partG, 2, ncclDouble, ncclSum, h->comm, h->st));
@@ -1100,7 +1136,7 @@ int dotmi_eval_gradient(dotmi_handle *h, const double *x, double *g)
     launch_vertex_gather(h->M, a, L, h->partR, h->st);
     HIPCHECK(h, hipMemcpyAsync(g, h->g_trial, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->st));
     HIPCHECK(h, hipStreamSynchronize(h->st));
-    if (h->world > 1) HIPCHECK(h, hipMemsetAsync(h->gcont, 0, sizeof(double) * 12 * (size_t)h->nT, h->st));
+    if (h->dist) HIPCHECK(h, hipMemsetAsync(h->gcont, 0, sizeof(double) * 12 * (size_t)h->nT, h->st));
     return 0;
 }
 

@@ -19,6 +19,7 @@ c_up = C.POINTER(C.c_uint8)
 ENERGY_FCR = 0
 ENERGY_SNH = 1
 FLAG_TIME_BACKSOLVE = 2
+FLAG_FORCE_DIST = 4
 
 
 class Mesh(C.Structure):

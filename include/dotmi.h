@@ -69,6 +69,8 @@ typedef struct {
     int32_t flags;     /* DOTMI_FLAG_* */
 } dotmi_params;
 
+#define DOTMI_FLAG_FORCE_DIST 4     /* take the sharded code path (element lists, partial sums, RCCL
+                                       all-reduces) even with world == 1: lets a 1-GPU box test it */
 #define DOTMI_FLAG_TIME_BACKSOLVE 2 /* bracket every back-solve of dotmi_step with HIP events on the
                                        handle's stream; totals land in dotmi_step_stats */
 
