@@ -119,6 +119,20 @@ struct dotmi_handle {
     long long numLineSearch = 0;
     int energy_evals = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    // the subdomain factorisation runs as `groups` independent batches on their own streams so that the
+    // latency-bound base blocks / small GEMMs of one batch overlap the large GEMMs of another
+    struct FactorGroup {
+        int first = 0, count = 0;
+        hipStream_t st = nullptr;
+        rocblas_handle blas = nullptr;
+        hipEvent_t done = nullptr;
+    };
+    std::vector<FactorGroup> groups;
+    hipEvent_t evFill = nullptr;
+    // the factor recursion is a fixed sequence of ~250 launches on fixed pointers: captured once into a
+    // hipGraph and replayed every step (removes the host launch cost between its many small kernels)
+    hipGraphExec_t factorGraph = nullptr;
+    int graphState = 0;  // 0 = not tried, 1 = ready, -1 = capture unavailable -> direct launches
     std::vector<hipEvent_t> evPre;  // DOTMI_FLAG_TIME_BACKSOLVE: (start, stop) pairs around each back-solve
     int evUsed = 0;
     int64_t precond_bytes = 0;
@@ -490,22 +504,23 @@ int free_slot(const dotmi_handle *h)
 // registers by chol_inv_base_kernel.  This replaces rocSOLVER potrf+potri, measured at 1-3.6 TFLOP/s
 // on these sizes against 60-70 TFLOP/s for dgemm (profiles/r01_factor_primitives.txt).  Role in the
 // reference: CHOLMODSolver::factorize (CHOLMODSolver.cpp:143) called from DOTTimeStepper.cpp:363-377.
-int chol_inv_node(dotmi_handle *h, int o, int sz)
+int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, int sz)
 {
     DevParts &P = h->P;
-    const int lda = P.nmax, batch = P.nParts;
+    const int lda = P.nmax, batch = G.count;
     const rocblas_stride sA = (rocblas_stride)lda * lda;
+    double *Wg = P.W + (size_t)G.first * sA;
     if (sz <= CHOL_NB) {
-        launch_chol_inv_base(P, o, h->info_dev, h->st);
+        launch_chol_inv_base(Wg, lda, batch, o, h->info_dev + G.first, G.st);
         return 0;
     }
     const int n1 = ((sz / CHOL_NB) / 2) * CHOL_NB, n2 = sz - n1;
-    if (int rc = chol_inv_node(h, o, n1)) return rc;
-    double *Q11 = P.W + o + (size_t)o * lda;
-    double *H12 = P.W + o + (size_t)(o + n1) * lda;
-    double *H22 = P.W + (o + n1) + (size_t)(o + n1) * lda;
-    double *H21 = P.W + (o + n1) + (size_t)o * lda;
-    double *Tb = P.Wtmp;
+    if (int rc = chol_inv_node(h, G, o, n1)) return rc;
+    double *Q11 = Wg + o + (size_t)o * lda;
+    double *H12 = Wg + o + (size_t)(o + n1) * lda;
+    double *H22 = Wg + (o + n1) + (size_t)(o + n1) * lda;
+    double *H21 = Wg + (o + n1) + (size_t)o * lda;
+    double *Tb = P.Wtmp + (size_t)G.first * h->tmp_stride;
     const int ldt = n1;
     const rocblas_stride sT = (rocblas_stride)h->tmp_stride;
     const double one = 1.0, zero = 0.0, mone = -1.0;
@@ -514,7 +529,7 @@ int chol_inv_node(dotmi_handle *h, int o, int sz)
     auto gemm = [&](rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double *alpha,
                     const double *A, int la, rocblas_stride sa, const double *B, int lb, rocblas_stride sb,
                     const double *beta, double *C, int lc, rocblas_stride sc) {
-        return rocblas_dgemm_strided_batched(h->blas, ta, tb, m, n, k, alpha, A, la, sa, B, lb, sb, beta, C, lc, sc,
+        return rocblas_dgemm_strided_batched(G.blas, ta, tb, m, n, k, alpha, A, la, sa, B, lb, sb, beta, C, lc, sc,
                                              batch);
     };
     // Q11 and Q22 are upper triangular and only the upper triangle of H22 is needed: on the big nodes
@@ -544,7 +559,7 @@ int chol_inv_node(dotmi_handle *h, int o, int sz)
         RBCHECK(h, gemm(T, N, n2, n2, n1, &mone, Tb, ldt, sT, Tb, ldt, sT, &one, H22, lda, sA));
         RBCHECK(h, gemm(N, N, n1, n2, n1, &one, Q11, lda, sA, Tb, ldt, sT, &zero, H12, lda, sA));
     }
-    if (int rc = chol_inv_node(h, o + n1, n2)) return rc;
+    if (int rc = chol_inv_node(h, G, o + n1, n2)) return rc;
     // Q12 = -U Q22
     if (split) {
         const double *Qcc = H22, *Qcd = H22 + (size_t)c * lda, *Qdd = H22 + c + (size_t)c * lda;
@@ -555,11 +570,57 @@ int chol_inv_node(dotmi_handle *h, int o, int sz)
     } else {
         RBCHECK(h, gemm(N, N, n1, n2, n2, &mone, H12, lda, sA, H22, lda, sA, &zero, Tb, ldt, sT));
     }
-    launch_block_copy(H12, lda, (size_t)sA, Tb, ldt, (size_t)sT, n1, n2, batch, h->st);
+    launch_block_copy(H12, lda, (size_t)sA, Tb, ldt, (size_t)sT, n1, n2, batch, G.st);
     // the strictly lower block must read as zero when Q is used as a dense GEMM operand one level up
     // and when the back-solve kernel streams whole memory rows
-    launch_block_copy(H21, lda, (size_t)sA, nullptr, 0, 0, n2, n1, batch, h->st);
+    launch_block_copy(H21, lda, (size_t)sA, nullptr, 0, 0, n2, n1, batch, G.st);
     return 0;
+}
+
+// issue (or replay) the inverse-Cholesky recursion of every owned subdomain on h->st
+int issue_factor(dotmi_handle *h)
+{
+    HIPCHECK(h, hipEventRecord(h->evFill, h->st));
+    for (auto &G : h->groups) {
+        if (G.st != h->st) HIPCHECK(h, hipStreamWaitEvent(G.st, h->evFill, 0));
+        if (int rc = chol_inv_node(h, G, 0, h->P.nmax)) return rc;
+        if (G.st != h->st) {
+            HIPCHECK(h, hipEventRecord(G.done, G.st));
+            HIPCHECK(h, hipStreamWaitEvent(h->st, G.done, 0));
+        }
+    }
+    return 0;
+}
+
+int run_factor(dotmi_handle *h)
+{
+    if (h->graphState == 0) {
+        h->graphState = -1;
+        const char *ev = getenv("DOTMI_FACTOR_GRAPH");
+        if (!(ev && atoi(ev) == 0)) {
+            // warm rocBLAS (kernel selection, lazy loads) outside of capture, then capture the same sequence
+            if (int rc = issue_factor(h)) return rc;
+            HIPCHECK(h, hipStreamSynchronize(h->st));
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int rc = issue_factor(h);
+                const hipError_t e = hipStreamEndCapture(h->st, &graph);
+                if (rc == 0 && e == hipSuccess && graph &&
+                    hipGraphInstantiate(&h->factorGraph, graph, nullptr, nullptr, 0) == hipSuccess)
+                    h->graphState = 1;
+                if (graph) hipGraphDestroy(graph);
+            }
+            (void)hipGetLastError();
+            if (h->graphState == 1) return 0;  // the warm-up pass already factored this H
+            // capture failed: the warm-up pass overwrote W in place, which is what this call wanted anyway
+            return 0;
+        }
+    }
+    if (h->graphState == 1) {
+        HIPCHECK(h, hipGraphLaunch(h->factorGraph, h->st));
+        return 0;
+    }
+    return issue_factor(h);
 }
 
 // element Hessians -> global H -> dense sub-matrices -> inverse Cholesky factors
@@ -573,7 +634,7 @@ int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
     HIPCHECK(h, hipEventRecord(h->ev1, h->st));
     if (h->P.nParts > 0) {
         HIPCHECK(h, hipMemsetAsync(h->info_dev, 0, sizeof(int) * h->P.nParts, h->st));
-        if (int rc = chol_inv_node(h, 0, h->P.nmax)) return rc;
+        if (int rc = run_factor(h)) return rc;
         std::vector<int> info(h->P.nParts);
         HIPCHECK(h, hipMemcpyAsync(info.data(), h->info_dev, sizeof(int) * h->P.nParts, hipMemcpyDeviceToHost,
                                    h->st));
@@ -736,6 +797,13 @@ void dotmi_destroy(dotmi_handle *h)
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev2) hipEventDestroy(h->ev2);
     for (hipEvent_t e : h->evPre) hipEventDestroy(e);
+    if (h->factorGraph) hipGraphExecDestroy(h->factorGraph);
+    for (auto &G : h->groups) {
+        if (G.blas && G.blas != h->blas) rocblas_destroy_handle(G.blas);
+        if (G.done) hipEventDestroy(G.done);
+        if (G.st && G.st != h->st) hipStreamDestroy(G.st);
+    }
+    if (h->evFill) hipEventDestroy(h->evFill);
     if (h->st) hipStreamDestroy(h->st);
     delete h;
 }
@@ -815,6 +883,27 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     host_features(h);
     h->targetGRes = host_target_gres(h);
     if (int rc = build_device_mesh(h)) return rc;
+    {
+        const char *ev = getenv("DOTMI_FACTOR_STREAMS");
+        int ng = ev ? atoi(ev) : 1;
+        ng = std::max(1, std::min(ng, std::max(1, h->P.nParts)));
+        HIPCHECK(h, hipEventCreateWithFlags(&h->evFill, hipEventDisableTiming));
+        h->groups.resize(ng);
+        for (int g = 0; g < ng; ++g) {
+            auto &G = h->groups[g];
+            G.first = (int)((long long)h->P.nParts * g / ng);
+            G.count = (int)((long long)h->P.nParts * (g + 1) / ng) - G.first;
+            if (ng == 1) {
+                G.st = h->st;  // single batch: the handle's own stream and rocBLAS handle
+                G.blas = h->blas;
+            } else {
+                HIPCHECK(h, hipStreamCreateWithFlags(&G.st, hipStreamNonBlocking));
+                HIPCHECK(h, hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
+                RBCHECK(h, rocblas_create_handle(&G.blas));
+                RBCHECK(h, rocblas_set_stream(G.blas, G.st));
+            }
+        }
+    }
 
     const int n = h->n;
     double **vecs[] = {&h->x, &h->x_trial, &h->xn, &h->v, &h->xt, &h->g, &h->g_trial, &h->p, &h->q, &h->z,

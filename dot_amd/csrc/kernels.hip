@@ -616,9 +616,9 @@ __global__ __launch_bounds__(64) void chol_inv_base_kernel(double *__restrict__ 
     if (bad) atomicMax(info + blockIdx.x, o + bad);
 }
 
-void launch_chol_inv_base(const DevParts &P, int o, int *info, hipStream_t st)
+void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipStream_t st)
 {
-    hipLaunchKernelGGL(chol_inv_base_kernel, dim3(P.nParts), dim3(64), 0, st, P.W, P.nmax, o, info);
+    hipLaunchKernelGGL(chol_inv_base_kernel, dim3(count), dim3(64), 0, st, W, nmax, o, info);
 }
 
 // dst block <- src block (column-major blocks inside strided batches); zero when src == nullptr
