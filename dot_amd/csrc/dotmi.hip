@@ -964,10 +964,7 @@ int dotmi_set_state(dotmi_handle *h, const double *x, const double *v, const dou
     HIPCHECK(h, hipMemcpyAsync(h->v, v, bytes, hipMemcpyHostToDevice, h->st));
     HIPCHECK(h, hipMemcpyAsync(h->xn, x_n ? x_n : x, bytes, hipMemcpyHostToDevice, h->st));
     HIPCHECK(h, hipStreamSynchronize(h->st));
-    // x~ = x_n + dt v + dt^2 g on free vertices (Optimizer.cpp:585-610); be_update recomputes v from
-    // (x - x_n)/dt, so build x~ with a temporary that leaves v and x_n untouched
-    HIPCHECK(h, hipMemcpyAsync(h->tmpn, h->xn, bytes, hipMemcpyDeviceToDevice, h->st));
-    // tmp_x = x_n + dt*v  => (tmp_x - x_n)/dt == v up to rounding; avoid that: compute x~ on the host
+    // x~ = x_n + dt v + dt^2 g on free vertices, x_n on fixed ones (Optimizer.cpp:585-610)
     std::vector<double> xt(h->n);
     const double *xn_h = x_n ? x_n : x;
     for (int i = 0; i < h->nV; ++i)

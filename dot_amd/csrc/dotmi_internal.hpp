@@ -8,7 +8,6 @@ namespace dotmi {
 constexpr int HIST_MAX = 6;     // L-BFGS pairs kept (reference uses 5, DOTTimeStepper.cpp:45)
 constexpr int NB_RED = 256;     // blocks of every reducing kernel (fixed => run-to-run bit-identical sums)
 constexpr int RED_K = 3 * HIST_MAX + 3;  // partial values per block
-constexpr int GEMV_ROWS = 64;   // memory rows per workgroup of the dot-form back-solve kernel
 constexpr int CHOL_NB = 64;     // base block of the recursive inverse-Cholesky (LDS resident)
 
 // ---- mesh + topology resident in HBM ------------------------------------------------------------
@@ -32,7 +31,7 @@ struct DevMesh {
 // ---- subdomains owned by this rank ---------------------------------------------------------------
 struct DevParts {
     int nParts;             // owned
-    int nmax;               // max scalar size over ALL parts, padded to 8 (lda of every dense block)
+    int nmax;               // max scalar size over ALL parts, padded to 128 (lda of every dense block)
     int *psize;             // owned: scalar size n_s
     int *dof_ptr;           // owned+1: offsets into dofmap / psub
     int *dofmap;            // local scalar dof -> global scalar dof
