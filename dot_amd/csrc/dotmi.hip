@@ -289,11 +289,19 @@ int build_device_mesh(dotmi_handle *h)
     for (int e = 0; e < nT; ++e)
         for (int k = 0; k < 4; ++k) vf_ptr[h->T[4 * e + k] + 1]++;
     for (int v = 0; v < nV; ++v) vf_ptr[v + 1] += vf_ptr[v];
+    std::vector<int4> epos(nT);
     {
         std::vector<int> cur(vf_ptr.begin(), vf_ptr.end() - 1);
-        for (int e = 0; e < nT; ++e)
-            for (int k = 0; k < 4; ++k) vf_ent[cur[h->T[4 * e + k]]++] = 4 * e + k;
+        for (int e = 0; e < nT; ++e) {
+            int pk[4];
+            for (int k = 0; k < 4; ++k) {
+                pk[k] = cur[h->T[4 * e + k]]++;
+                vf_ent[pk[k]] = 4 * e + k;
+            }
+            epos[e] = make_int4(pk[0], pk[1], pk[2], pk[3]);
+        }
     }
+    if (int rc = upload(h, &M.epos, epos)) return rc;
     // adjacency incl. self
     std::vector<int> adj_ptr(nV + 1, 0), adj_idx;
     {
@@ -449,8 +457,8 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = dalloc(h, &P.W, (size_t)P.nParts * P.nmax * P.nmax)) return rc;
     h->tmp_stride = (size_t)P.nmax * (P.nmax / 2 + CHOL_NB);
     if (int rc = dalloc(h, &P.Wtmp, (size_t)P.nParts * h->tmp_stride)) return rc;
-    if (int rc = dalloc(h, &P.psub, (size_t)dof_ptr[P.nParts])) return rc;
     if (int rc = dalloc(h, &P.ppart, (size_t)P.nParts * P.nbmax * P.nmax)) return rc;
+    if (int rc = dalloc(h, &P.psub, (size_t)dof_ptr[P.nParts])) return rc;
     if (int rc = dalloc(h, &h->info_dev, (size_t)std::max(P.nParts, 1))) return rc;
 
     // element ownership + inertia vertex slice
@@ -685,8 +693,12 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
           double *E)
 {
     int nb = 0;
+    // single-GPU: the reduction partials go straight to pinned host memory (zero-copy), so one stream
+    // synchronisation is the only host<->device interaction of a line-search trial
+    double *partE = h->dist ? h->partE : h->h_partE;
+    double *partR = h->dist ? h->partR : h->h_partR;
     launch_elem_energy_grad(h->M, h->mat, h->dtSq, xeval, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, h->gcont,
-                            h->partE, &nb, h->st);
+                            partE, &nb, h->st);
     h->nbE = nb;
     GatherArgs a;
     a.gcont = h->gcont;
@@ -702,8 +714,7 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
     a.iv1 = h->v1;
     if (!h->dist) {
         a.make_pair = make_pair;
-        launch_vertex_gather(h->M, a, L, h->partR, h->st);
-        HIPCHECK(h, hipMemcpyAsync(h->h_partE, h->partE, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, h->st));
+        launch_vertex_gather(h->M, a, L, partR, h->st);
     } else {
         a.make_pair = 0;
         launch_vertex_gather(h->M, a, L, h->partR, h->st);
@@ -718,10 +729,9 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
             launch_multidot(h->n, gout, vecs, 1, h->partR, h->st);
         }
         HIPCHECK(h, hipMemcpyAsync(h->h_partE, gout + h->n, sizeof(double), hipMemcpyDeviceToHost, h->st));
+        HIPCHECK(h, hipMemcpyAsync(h->h_partR, h->partR, sizeof(double) * NB_RED * RED_K, hipMemcpyDeviceToHost,
+                                   h->st));
     }
-    HIPCHECK(h, hipMemcpyAsync(h->h_partR, h->partR, sizeof(double) * NB_RED * RED_K, hipMemcpyDeviceToHost,
-                               h->st));
-    HIPCHECK(h, hipMemcpyAsync(h->h_alpha, h->alpha_dev, sizeof(double), hipMemcpyDeviceToHost, h->st));
     HIPCHECK(h, hipStreamSynchronize(h->st));
     if (!h->dist) {
         double se = 0, si = 0;
@@ -1082,7 +1092,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
             NCCLCHECK(h, ncclAllReduce(h->partG, h->partG, 2, ncclDouble, ncclSum, h->comm, h->st));
             spart = h->partG;  // rows >= 1 stay zero
         }
-        launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, h->st);
+        launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, h->h_alpha, h->st);
         const int slot = free_slot(h);
         double E = 0;
         if (int rc = trial(h, h->x_trial, h->g_trial, 1, L, slot, &E)) return rc;
@@ -1095,7 +1105,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
                 failed = true;
                 break;
             }
-            launch_step_forward(n, h->x, h->p, h->x_trial, nullptr, alpha, 0, h->alphaMin, h->alpha_dev, h->st);
+            launch_step_forward(n, h->x, h->p, h->x_trial, nullptr, alpha, 0, h->alphaMin, h->alpha_dev, h->h_alpha, h->st);
             if (int rc = trial(h, h->x_trial, h->g_trial, 1, L, slot, &E)) return rc;
         }
         if (failed) break;

@@ -20,6 +20,7 @@ struct DevMesh {
     uint8_t *fixed;         // nV
     // vertex -> incident (elem*4+slot), ascending  (Mesh::vFLoc, Mesh.cpp:609-614)
     int *vf_ptr, *vf_ent;
+    int4 *epos;             // nT: position of (elem, slot k) in its vertex's incidence list, k = x,y,z,w
     // block-CSR of the global Hessian: vertex adjacency incl. self, ascending
     int *adj_ptr, *adj_idx;
     int nnzb;
@@ -66,7 +67,7 @@ struct LbfgsArgs {
 // x = x0 + alpha * p; alpha = alpha_scale * clamp(-pg/pHp) from SpMV partials when use_partials
 void launch_step_forward(int n, const double *x0, const double *p, double *x, const double *spmv_partials,
                          double alpha_host, int use_partials, double alpha_min, double *alpha_out,
-                         hipStream_t st);
+                         double *alpha_out_host, hipStream_t st);
 // element pass: partial energy sums (+ inertia) and, optionally, element gradients
 void launch_elem_energy_grad(const DevMesh &M, int mat, double dtSq, const double *x, const double *xt,
                              const int *elist, int nElem, int v0, int v1, double *gcont /*or null*/,

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void elem_energy_grad_kernel(
     const int4 *__restrict__ T, const double *__restrict__ A, int nTp, const double *__restrict__ mu,
     const double *__restrict__ lam, const double *__restrict__ vol, const double *__restrict__ mass,
     const double *__restrict__ x, const double *__restrict__ xt, const int *__restrict__ elist,
-    int nElem, int v0, int v1, double dtSq, double *__restrict__ gcont, double *__restrict__ partials)
+    int nElem, int v0, int v1, double dtSq, const int4 *__restrict__ epos, double *__restrict__ gcont,
+    double *__restrict__ partials)
 {
     __shared__ double sm[4];
     double acc = 0.0;  // dtSq * vol * Psi
@@ -110,9 +111,17 @@ __global__ __launch_bounds__(256) void elem_energy_grad_kernel(
                     g[3 + 3 * a + c] = Ai[a][0] * P[c][0] + Ai[a][1] * P[c][1] + Ai[a][2] * P[c][2];
 #pragma unroll
             for (int c = 0; c < 3; ++c) g[c] = -g[3 + c] - g[6 + c] - g[9 + c];
-            double2 *out = reinterpret_cast<double2 *>(gcont + (size_t)12 * e);
+            // slot k of this tet lands at its position in the vertex's incidence list (vFLoc order), so the
+            // vertex gather reads one contiguous run per vertex and needs no index indirection
+            const int4 ps = epos[e];
+            const int pk[4] = {ps.x, ps.y, ps.z, ps.w};
 #pragma unroll
-            for (int k = 0; k < 6; ++k) out[k] = make_double2(g[2 * k], g[2 * k + 1]);
+            for (int k = 0; k < 4; ++k) {
+                double *o = gcont + (size_t)3 * pk[k];
+                o[0] = g[3 * k];
+                o[1] = g[3 * k + 1];
+                o[2] = g[3 * k + 2];
+            }
         }
     }
     // inertia: sum_v 1/2 m_v |x_v - x~_v|^2 over this rank's vertex slice
@@ -141,8 +150,8 @@ void launch_elem_energy_grad(const DevMesh &M, int mat, double dtSq, const doubl
     *nblocks_out = nb;
 #define DM_LAUNCH(MATV, GRADV)                                                                       \
     hipLaunchKernelGGL((elem_energy_grad_kernel<MATV, GRADV>), dim3(nb), dim3(256), 0, st, M.T, M.A,  \
-                       M.nTp, M.mu, M.lam, M.vol, M.mass, x, xt, elist, nElem, v0, v1, dtSq, gcont,  \
-                       partials)
+                       M.nTp, M.mu, M.lam, M.vol, M.mass, x, xt, elist, nElem, v0, v1, dtSq, M.epos, \
+                       gcont, partials)
     if (mat == 0) {
         if (gcont) DM_LAUNCH(0, true);
         else DM_LAUNCH(0, false);
@@ -223,8 +232,7 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
         if (!fx) {
             const int e = vf_ptr[v + 1];
             for (int k = vf_ptr[v] + sub; k < e; k += 8) {
-                const int ent = vf_ent[k];
-                const double *ge = a.gcont + (size_t)12 * (ent >> 2) + 3 * (ent & 3);
+                const double *ge = a.gcont + (size_t)3 * k;
                 g0 += ge[0];
                 g1 += ge[1];
                 g2 += ge[2];
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restri
     }
 }
 
-// psub_s[k] = sum over the row tiles b >= k / BS_ROWS of ppart[s][b][k]   (fixed order)
+// psub_s[k] = sum over the row tiles b >= k / BS_ROWS of ppart[s][b][k]   (fixed order, coalesced in k)
 __global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int *__restrict__ psize,
                                                                const int *__restrict__ dof_ptr,
                                                                const double *__restrict__ ppart, int nmax,
@@ -773,7 +781,8 @@ __global__ __launch_bounds__(256) void step_forward_kernel(int n, const double *
                                                            double *__restrict__ x,
                                                            const double *__restrict__ spmv_partials,
                                                            double alpha_host, int use_partials,
-                                                           double alpha_min, double *__restrict__ alpha_out)
+                                                           double alpha_min, double *__restrict__ alpha_out,
+                                                           double *__restrict__ alpha_out_host)
 {
     __shared__ double sh_alpha;
     if (threadIdx.x < 64) {
@@ -785,7 +794,10 @@ __global__ __launch_bounds__(256) void step_forward_kernel(int n, const double *
         }
         if (threadIdx.x == 0) {
             sh_alpha = alpha;
-            if (blockIdx.x == 0) *alpha_out = alpha;
+            if (blockIdx.x == 0) {
+                *alpha_out = alpha;
+                if (alpha_out_host) *alpha_out_host = alpha;  // pinned host copy: no D2H memcpy on the hot path
+            }
         }
     }
     __syncthreads();
@@ -796,12 +808,12 @@ __global__ __launch_bounds__(256) void step_forward_kernel(int n, const double *
 
 void launch_step_forward(int n, const double *x0, const double *p, double *x, const double *spmv_partials,
                          double alpha_host, int use_partials, double alpha_min, double *alpha_out,
-                         hipStream_t st)
+                         double *alpha_out_host, hipStream_t st)
 {
     int nb = (n + 255) / 256;
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(step_forward_kernel, dim3(nb), dim3(256), 0, st, n, x0, p, x, spmv_partials,
-                       alpha_host, use_partials, alpha_min, alpha_out);
+                       alpha_host, use_partials, alpha_min, alpha_out, alpha_out_host);
 }
 
 // ------------------------------------------------------------------------------------------------
