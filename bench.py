@@ -104,10 +104,19 @@ def main():
     bytes_per_launch = stats[0].precond_bytes            # sum_s n_s(n_s+1)/2 * 8 over the parts of THIS rank
     avg_ms = pre_ms / max(pre_n, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if pre_n else 0.0
+    # HBM traffic of one back-solve from the PMC counters (FETCH_SIZE / WRITE_SIZE need their own rocprofv3
+    # passes, so they are collected separately on the same kernel + workload and committed under profiles/)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01_backsolve_pmc.json")
+    if world == 1 and os.path.exists(pmc):
+        with open(pmc) as f:
+            rec = json.load(f)
+        if rec.get("workload") == args.workload:
+            traffic = rec["hbm_bytes_per_backsolve"]
     roofline = {
         "bound": "hbm", "kernel": "backsolve_kernel (+reduce_partial_p_kernel): subdomain back-solve",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5),
         "launches_timed": int(pre_n), "share_of_step_time": round(pre_ms / (1e3 * elapsed), 3),
     }

@@ -1,0 +1,180 @@
+// dot_hip -- headless runner with the reference's CLI shape (`DOT_bin 100 <script.txt>`, README.md:76-93,
+// main.cpp:599-989 in mode 100) on top of libdotmi.so.  Host side only: parses the reference's script
+// format, builds the scene, steps with DotHipTimeStepper and writes the reference's output files
+//   output/<name>/iterStats.txt   per step "n 0 E |g|^2" then per iteration "n alpha E |g|^2"
+//                                 (DOTTimeStepper.cpp:299,304,329; Optimizer.cpp:870)
+//   output/<name>/log.txt         "<n>th tol: <targetGRes>" and "Timestep<n> innerIterAmt = ..." lines
+//                                 (Optimizer.cpp:227, DOTTimeStepper.cpp:338)
+//   output/<name>/status<n>       restartable state (Optimizer.cpp:1096-1132)
+//   output/<name>/<n>.obj         surface mesh per step (Optimizer.cpp:1137-1150)
+//   output/<name>/info.txt        nV nT / steps innerIters / wall-clock summary (main.cpp:338-358)
+//
+// usage: dot_hip 100 <script.txt> [--mesh-root DIR] [--parts N] [--energy FCR|SNH] [--epart raw.i32]
+//                [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K]
+#include <chrono>
+#include <cstring>
+#include <iostream>
+#include <sys/stat.h>
+
+#include "DotHipTimeStepper.hpp"
+#include "Scene.hpp"
+
+using namespace dot_amd;
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) {
+        std::fprintf(stderr, "usage: %s 100 <script.txt> [--mesh-root DIR] [--parts N] [--energy FCR|SNH] "
+                             "[--epart raw.i32] [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K]\n", argv[0]);
+        return 2;
+    }
+    if (std::string(argv[1]) != "100") {
+        std::fprintf(stderr, "only the headless mode 100 exists here (viewer / diagnostics / mesh tools are out of scope)\n");
+        return 2;
+    }
+    const std::string scriptPath = argv[2];
+    std::string meshRoot = ".", outDir, epartFile, energyOverride;
+    int partsOverride = -1, frames = -1, device = 0, dumpScene = -1;
+    bool files = true;
+    for (int i = 3; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() -> std::string { if (i + 1 >= argc) throw std::runtime_error("missing value for " + a); return argv[++i]; };
+        if (a == "--mesh-root") meshRoot = next();
+        else if (a == "--parts") partsOverride = std::stoi(next());
+        else if (a == "--energy") energyOverride = next();
+        else if (a == "--epart") epartFile = next();
+        else if (a == "--frames") frames = std::stoi(next());
+        else if (a == "--out") outDir = next();
+        else if (a == "--device") device = std::stoi(next());
+        else if (a == "--no-files") files = false;
+        else if (a == "--dump-scene") dumpScene = std::stoi(next());
+        else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    try {
+        Config cfg = parse_script(scriptPath);
+        if (!energyOverride.empty()) cfg.energy = energyOverride;
+        if (cfg.shapePath.empty()) throw std::runtime_error("script has no `shape input <mesh>` (primitive shapes are 2-D only)");
+        TetMesh mesh = read_tet_msh(cfg.shapePath[0] == '/' ? cfg.shapePath : meshRoot + "/" + cfg.shapePath);
+        normalize(mesh.V, cfg.size, cfg.rotDeg, cfg.rotAxis);
+        std::vector<int> border[2];
+        find_border_verts(mesh.V, cfg.handleRatio, border);
+        AnimScripter scripter(cfg.script, mesh.V, border);
+        std::vector<double> x0 = scripter.initial_positions(mesh.V);
+
+        // --dump-scene K: print the scene the hot path would receive and K scripted moves (no GPU needed)
+        if (dumpScene >= 0) {
+            int nfixed = 0;
+            for (auto f : scripter.fixed) nfixed += f;
+            std::printf("scene nV %d nT %d nfixed %d energy %s dt %.17g\n", mesh.nV(), mesh.nT(), nfixed, cfg.energy.c_str(), cfg.dt);
+            std::vector<double> x = x0, pos;
+            std::vector<int32_t> idx;
+            for (int k = 0; k < dumpScene; ++k) {
+                scripter.step(x, cfg.dt, idx, pos);
+                double sum[3] = {0, 0, 0};
+                for (size_t i = 0; i < idx.size(); ++i)
+                    for (int d = 0; d < 3; ++d) { x[3 * idx[i] + d] = pos[3 * i + d]; sum[d] += pos[3 * i + d]; }
+                std::printf("move %d n %zu sum %.17g %.17g %.17g\n", k, idx.size(), sum[0], sum[1], sum[2]);
+            }
+            return 0;
+        }
+
+        int nParts = partsOverride > 0 ? partsOverride : cfg.partitionAmt;
+        if (cfg.blockSize > 0 && partsOverride <= 0) nParts = mesh.nV() / cfg.blockSize + 1;  // main.cpp:792-798
+        if (nParts < 2) nParts = 4;
+        std::vector<int32_t> epart;
+        if (!epartFile.empty()) {
+            std::ifstream f(epartFile, std::ios::binary);
+            epart.resize(mesh.nT());
+            f.read((char *)epart.data(), sizeof(int32_t) * epart.size());
+            if (!f) throw std::runtime_error("cannot read " + epartFile);
+        } else {
+            epart = partition_rcb(mesh, nParts);  // METIS is third-party; pass --epart for the reference's partition
+        }
+        double mu, lam;
+        lame(cfg.YM, cfg.PR, mu, lam);
+        std::vector<double> u(mesh.nT(), mu), lambda(mesh.nT(), lam);
+        MeshView mv;
+        mv.nV = mesh.nV(); mv.nT = mesh.nT(); mv.V_rest = mesh.V.data(); mv.F = mesh.T.data();
+        mv.u = u.data(); mv.lambda = lambda.data(); mv.density = cfg.rho; mv.isFixedVert = scripter.fixed.data();
+        Options opt;
+        opt.energyType = cfg.energy == "SNH" ? DOTMI_ENERGY_SNH : DOTMI_ENERGY_FCR;
+        opt.withGravity = cfg.withGravity; opt.partitionAmt = nParts; opt.epart = epart.data(); opt.device = device;
+
+        std::string name = scriptPath.substr(scriptPath.find_last_of('/') + 1);
+        name = name.substr(0, name.find_last_of('.'));
+        if (outDir.empty()) outDir = "output/" + name;
+        FILE *fIter = nullptr, *fLog = nullptr;
+        if (files) {
+            mkdir("output", 0755);
+            mkdir(outDir.c_str(), 0755);
+            fIter = std::fopen((outDir + "/iterStats.txt").c_str(), "w");
+            fLog = std::fopen((outDir + "/log.txt").c_str(), "w");
+            if (!fIter || !fLog) throw std::runtime_error("cannot write into " + outDir);
+        }
+        const auto surf = files ? find_surface_tris(mesh) : std::vector<std::array<int, 3>>();
+
+        const double tSetup = now_s();
+        DotHipTimeStepper ts(mv, opt, x0.data());
+        ts.setTime(cfg.duration, cfg.dt);
+        ts.setRelGL2Tol(cfg.tol.empty() ? 1.0e-5 : cfg.tol[0]);
+        ts.setScript([&](const std::vector<double> &x, double dt, std::vector<int32_t> &idx, std::vector<double> &pos,
+                         std::vector<uint8_t> &fx) {
+            const int changed = scripter.step(x, dt, idx, pos);
+            if (changed) fx = scripter.fixed;
+            return changed;
+        });
+        ts.precompute();
+        std::printf("setup %.3f s, nV %d nT %d, %d subdomains, tol %.6e\n", now_s() - tSetup, mesh.nV(), mesh.nT(), nParts, ts.getTargetGRes());
+
+        const int nFrames = frames > 0 ? frames : (int)(cfg.duration / cfg.dt);
+        long lineSearch = 0;
+        double tStep = 0;
+        std::vector<double> al(10001), En(10001), g2(10001);
+        for (int n = 0; n < nFrames; ++n) {
+            if (files) {
+                char buf[512];
+                std::snprintf(buf, sizeof(buf), "%s/status%d", outDir.c_str(), n);
+                ts.saveStatus(buf);
+                std::snprintf(buf, sizeof(buf), "%s/%d.obj", outDir.c_str(), n);
+                const auto x = ts.getResult();
+                if (FILE *fo = std::fopen(buf, "w")) {
+                    for (int v = 0; v < mesh.nV(); ++v) std::fprintf(fo, "v %.10g %.10g %.10g\n", x[3 * v], x[3 * v + 1], x[3 * v + 2]);
+                    for (auto &t : surf) std::fprintf(fo, "f %d %d %d\n", t[0] + 1, t[1] + 1, t[2] + 1);
+                    std::fclose(fo);
+                }
+                std::fprintf(fLog, "%dth tol: %g\n", n, ts.getTargetGRes());
+            }
+            const double t0 = now_s();
+            const int rc = ts.solve(1);
+            tStep += now_s() - t0;
+            if (rc == 1) break;
+            const auto &st = ts.lastStats();
+            lineSearch += st.ls_halvings;
+            if (files) {
+                const int k = dotmi_last_iter_log(ts.handle(), 10001, al.data(), En.data(), g2.data());
+                std::fprintf(fIter, "%d 0 %g %g\n", n, st.E0, st.g2_0);
+                for (int i = 0; i < k; ++i) std::fprintf(fIter, "%d %g %g %g\n", n, al[i], En[i], g2[i]);
+                std::fprintf(fLog, "Timestep%d innerIterAmt = %d, accumulated line search steps %ld\n", n, ts.getInnerIterAmt(), lineSearch);
+                if (rc == 2) std::fprintf(fLog, "!!! maxIter reached for timeStep%d\n", n);
+            }
+            std::printf("FRAME %d ms %.3f iters %d halvings %d E %.17g status %d\n", n, st.ms_total, st.iters, st.ls_halvings, st.E, rc);
+        }
+        if (files) {
+            if (FILE *fi = std::fopen((outDir + "/info.txt").c_str(), "w")) {
+                std::fprintf(fi, "%d %d\n%d %d 0 0 0\nstepping %.6f s\n", mesh.nV(), mesh.nT(), ts.getIterNum(), ts.getInnerIterAmt(), tStep);
+                std::fclose(fi);
+            }
+            std::fclose(fIter);
+            std::fclose(fLog);
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "dot_hip: %s\n", e.what());
+        return 1;
+    }
+}

@@ -300,7 +300,10 @@ def load_scene(script_path: str, mesh_dir: Optional[str] = None) -> Scene:
     if os.path.exists(npz):
         V, T = load_mesh_npz(npz)
     else:
-        V, T = read_tet_msh(cfg.shape_path)
+        path = cfg.shape_path
+        if not os.path.isabs(path) and not os.path.exists(path):
+            path = os.path.join(mesh_dir, path)
+        V, T = read_tet_msh(path)
     return build_scene(cfg, V, T)
 
 

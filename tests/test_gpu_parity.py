@@ -315,3 +315,39 @@ def test_device_path_against_reference_golden_vectors(golden):
         ok = np.ones(n, dtype=bool); ok[[1, 5]] = False
         assert np.abs(g - ge)[ok].max() < 5e-9 * scale, np.abs(g - ge)[ok].max() / scale
         ts.close()
+
+
+def test_cpp_headless_runner_end_to_end(tmp_path):
+    """dot_hip (C++ host layer + C ABI): runs a reference-format script for 3 frames with the METIS
+    fixture partition, must take the same iterations as the Python-driven stepper and write the
+    reference's output files (iterStats.txt / log.txt / status<n> / <n>.obj / info.txt)."""
+    import os, subprocess
+    from tests.test_host_logic import _write_msh
+    from dot_amd.configs import MESH_DIR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "dot_amd", "dot_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "dot_amd", "host")])
+    V, T = scene.load_mesh_npz(os.path.join(MESH_DIR, "bunny5K.npz"))
+    _write_msh(tmp_path / "bunny5K.msh", V, T)
+    (tmp_path / "bunny.txt").write_text("energy FCR\ntimeStepper DOT 8\nwarmStart 2\nsize 1\ntime 5 0.025\ndensity 1000\n"
+                                        "stiffness 100000 0.4\nscript twistnsns\nshape input bunny5K.msh\n")
+    sc, ep, n = load_workload("bunny5K_LTSS")
+    ep.astype(np.int32).tofile(tmp_path / "epart.i32")
+    out = subprocess.check_output([exe, "100", str(tmp_path / "bunny.txt"), "--mesh-root", str(tmp_path), "--epart",
+                                   str(tmp_path / "epart.i32"), "--frames", "3", "--out", str(tmp_path / "out")]).decode()
+    frames = [l.split() for l in out.splitlines() if l.startswith("FRAME")]
+    ts = DOTTimeStepper(sc, ep, n)
+    for k in range(3):
+        assert ts.solve(1) == 0
+        assert int(frames[k][5]) == ts.last_stats.iters
+        assert abs(float(frames[k][9]) - ts.last_stats.E) <= 1e-12 * abs(ts.last_stats.E)
+    ts.close()
+    o = tmp_path / "out"
+    for f in ("iterStats.txt", "log.txt", "info.txt", "status0", "status2", "0.obj", "2.obj"):
+        assert (o / f).exists(), f
+    it = (o / "iterStats.txt").read_text().splitlines()
+    assert it[0].split()[:2] == ["0", "0"] and len(it) == 3 + sum(int(f[5]) for f in frames)
+    st = (o / "status2").read_text().splitlines()
+    assert st[0] == "timestep 2" and st[2] == "position 4670 3" and any(l.startswith("velocity 14010") for l in st)
+    assert "Timestep2 innerIterAmt" in (o / "log.txt").read_text()

@@ -153,3 +153,43 @@ def test_shard_plan_properties():
             assert max(cost) <= 1.25 * (sum(cost) / world)
     sl = [vertex_slice(101, r, 4) for r in range(4)]
     assert sl[0][0] == 0 and sl[-1][1] == 101 and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+
+
+def _write_msh(path, V, T):
+    with open(path, "w") as fh:
+        fh.write("$MeshFormat\n4 0 8\n$EndMeshFormat\n$Entities\n0 0 0 1\n$EndEntities\n$Nodes\n1 %d\n0 1 0 %d\n" % (len(V), len(V)))
+        for i, v in enumerate(V):
+            fh.write("%d %.17g %.17g %.17g\n" % (i + 1, v[0], v[1], v[2]))
+        fh.write("$EndNodes\n$Elements\n1 %d\n0 1 4 %d\n" % (len(T), len(T)))
+        for i, t in enumerate(T):
+            fh.write("%d %d %d %d %d\n" % (i + 1, t[0] + 1, t[1] + 1, t[2] + 1, t[3] + 1))
+        fh.write("$EndElements\n")
+
+
+@pytest.mark.parametrize("script", ["twist", "twistnsns", "stretch", "twistnstretch", "squash", "stretchnsquash"])
+def test_cpp_scene_layer_matches_python(tmp_path, script):
+    """dot_amd/host/Scene.hpp (C++ Config parser, .msh reader, normalise, handles, AnimScripter) against
+    dot_amd/scene.py on the same script + mesh: identical handle sets and scripted positions."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "dot_amd", "dot_hip")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "dot_amd", "host")])
+    V, T = scene.synthetic_bar(10, 3, 2, jitter=0.05)
+    V = V * 1.7 + np.array([3.0, -1.0, 0.5])
+    _write_msh(tmp_path / "bar.msh", V, T)
+    (tmp_path / "s.txt").write_text(f"energy SNH\ntimeStepper DOT 3\nsize 1\ntime 1 0.02\ndensity 1000\n"
+                                    f"stiffness 100000 0.4\nscript {script}\nshape input bar.msh\nhandleRatio 0.05\n")
+    nmove = 40
+    out = subprocess.check_output([exe, "100", str(tmp_path / "s.txt"), "--mesh-root", str(tmp_path),
+                                   "--dump-scene", str(nmove)]).decode().splitlines()
+    sc = scene.load_scene(str(tmp_path / "s.txt"), mesh_dir=str(tmp_path))   # no npz there -> reads the .msh
+    head = out[0].split()
+    assert int(head[2]) == sc.V_rest.shape[0] and int(head[4]) == sc.T.shape[0] and int(head[6]) == int(sc.fixed.sum())
+    x = sc.x0.copy()
+    for k in range(nmove):
+        idx, pos = sc.scripter.step(x, sc.cfg.dt)
+        x[idx] = pos
+        tok = out[1 + k].split()
+        assert int(tok[3]) == len(idx)
+        assert np.allclose([float(tok[5]), float(tok[6]), float(tok[7])], pos.sum(axis=0), rtol=1e-14, atol=1e-13)
