@@ -171,11 +171,11 @@ def lame(YM: float, PR: float) -> Tuple[float, float]:
 
 
 class AnimScripter:
-    """3-D Dirichlet scripts of the reference (AnimScripter.cpp). The fixed set is constant for
-    every script except rubberBandPull (not implemented here)."""
+    """3-D Dirichlet scripts of the reference (AnimScripter.cpp). The fixed set is constant for every
+    script except rubberBandPull, whose release step returns changed=True (-> dotmi_refix)."""
 
     SUPPORTED = ("null", "fall", "hang", "stretch", "squash", "stretchnsquash", "twist",
-                 "twistnstretch", "twistnsns", "twistnsns_old")
+                 "twistnstretch", "twistnsns", "twistnsns_old", "rubberBandPull")
 
     def __init__(self, script: str, V_rest: np.ndarray, border: List[np.ndarray]):
         if script not in self.SUPPORTED:
@@ -194,6 +194,22 @@ class AnimScripter:
         sgn = lambda b: (-1.0) ** b
         if script in ("null", "fall"):
             pass
+        elif script == "rubberBandPull":
+            # AnimScripter.cpp:220-258: top/bottom 2% slabs pulled apart in y, the waist pulled in -x
+            lo, hi = V_rest.min(axis=0), V_rest.max(axis=0)
+            rng = hi - lo
+            self._rb_waist, self._rb_ends = [], []
+            for v in range(nV):
+                y = x0[v, 1]
+                if y < lo[1] + rng[1] * 0.02:
+                    self.fixed[v] = 1; self.vel[v] = np.array([0.0, -0.2, 0.0]); self._rb_ends.append(v)
+                elif y > hi[1] - rng[1] * 0.02:
+                    self.fixed[v] = 1; self.vel[v] = np.array([0.0, 0.2, 0.0]); self._rb_ends.append(v)
+                elif (y < hi[1] - rng[1] * 0.48) and (y > lo[1] + rng[1] * 0.48):
+                    self.fixed[v] = 1; self.vel[v] = np.array([-2.5, 0.0, 0.0]); self._rb_waist.append(v)
+                    if self.turn_vert < 0:
+                        self.turn_vert = v
+                        self.turn_lo = x0[v, 0] - 5.0
         elif script == "hang":
             # AnimScripter.cpp:60-65 AST_HANG: fix the last vertex of each border group
             for grp in border:
@@ -227,6 +243,7 @@ class AnimScripter:
                     self.turn_lo, self.turn_hi = xv - 0.8, xv + 0.4
                 else:
                     self.turn_lo, self.turn_hi = xv - 0.8, xv + 0.4
+        self.changed = False   # set by step() when the fixed set changed (rubberBandPull release)
         self.handle_idx = np.nonzero(self.fixed)[0].astype(np.int32)
         # dense per-handle arrays (same order as handle_idx) for the vectorised step
         self._w = np.array([self.ang_vel.get(int(v), 0.0) for v in self.handle_idx])
@@ -246,8 +263,16 @@ class AnimScripter:
         """Returns (idx, new positions) of the scripted vertices for this step, from the current
         positions x (nV,3).  AnimScripter.cpp:291-470."""
         idx = self.handle_idx
+        self.changed = False
         if idx.size == 0 or self.script in ("hang", "null", "fall"):
             return idx[:0], np.zeros((0, 3))
+        if self.script == "rubberBandPull":
+            if self.turn_vert >= 0 and x[self.turn_vert, 0] <= self.turn_lo:   # AnimScripter.cpp:404-417
+                self.turn_lo = -math.inf
+                self.fixed[self._rb_waist] = 0
+                self._vel[:] = 0.0            # waist released, ends stop
+                self.changed = True
+            return idx, np.array(x[idx], dtype=np.float64) + self._vel * dt
         flip = False
         if self.turn_vert >= 0:
             xv = x[self.turn_vert, 0]

@@ -113,6 +113,11 @@ class DOTTimeStepper:
         pos = np.ascontiguousarray(pos, dtype=np.float64)
         self._check(self._L.dotmi_set_dirichlet(self._h, idx.size, ip(idx), dp(pos)), "set_dirichlet")
 
+    def refix(self, fixed):
+        """fixed set changed: DOTTimeStepper::updatePrecondMtrAndFactorize (DOTTimeStepper.cpp:185-270)"""
+        self._fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+        self._check(self._L.dotmi_refix(self._h, up(self._fixed)), "refix")
+
     def solve(self, maxIter: int = 1) -> int:
         """Optimizer::solve (Optimizer.cpp:327-368): script move, one BE step. 0 stepped, 1 all frames
         done, 2 stepped but hit the iteration cap / line-search failure."""
@@ -122,6 +127,8 @@ class DOTTimeStepper:
             idx, pos = self.scene.scripter.step(x, self.dt)
             if idx.size:
                 self.setDirichlet(idx, pos)
+            if getattr(self.scene.scripter, "changed", False):
+                self.refix(self.scene.scripter.fixed)      # updatePrecondMtrAndFactorize
             if self.globalIterNum >= self.frameAmt:
                 self.globalIterNum += 1
                 return 1

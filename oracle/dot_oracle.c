@@ -1271,6 +1271,15 @@ void dor_set_state(dor_sim *s, const double *x, const double *v, const double *x
 
 double dor_target_gres(const dor_sim *s) { return s->targetGRes; }
 
+/* fixed set changed by the script (rubberBandPull release, AnimScripter.cpp:404-417):
+ * Optimizer::solve -> updatePrecondMtrAndFactorize (DOTTimeStepper.cpp:185-270) re-patterns and
+ * refactors at the current configuration; x~ is NOT recomputed until the end of the step */
+void dor_set_fixed(dor_sim *s, const unsigned char *fixed)
+{
+    memcpy(s->fixed, fixed, s->nV);
+    dor_refactor(s, s->x);
+}
+
 void dor_get_features(const dor_sim *s, double *A, double *vol, double *mass, double *mu, double *lam)
 {
     if (A) memcpy(A, s->A, sizeof(double) * 9 * (size_t)s->nT);

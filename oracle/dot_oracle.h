@@ -74,6 +74,7 @@ int dor_last_iter_log(const dor_sim *s, int cap, double *alpha, double *E, doubl
 void dor_get_state(const dor_sim *s, double *x, double *v, double *xtilde);
 void dor_set_state(dor_sim *s, const double *x, const double *v, const double *xn);
 double dor_target_gres(const dor_sim *s);
+void dor_set_fixed(dor_sim *s, const unsigned char *fixed);
 
 /* features / structure getters */
 void dor_get_features(const dor_sim *s, double *A /*nT*9*/, double *vol /*nT*/, double *mass /*nV*/,

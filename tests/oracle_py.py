@@ -60,6 +60,7 @@ def lib():
         L.dor_set_state.argtypes = [C.c_void_p, c_dp, c_dp, c_dp]
         L.dor_target_gres.argtypes = [C.c_void_p]
         L.dor_target_gres.restype = C.c_double
+        L.dor_set_fixed.argtypes = [C.c_void_p, c_up]
         L.dor_get_features.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]
         L.dor_get_dup.argtypes = [C.c_void_p, c_ip]
         L.dor_part_size.argtypes = [C.c_void_p, C.c_int]
@@ -144,6 +145,10 @@ class OracleSim:
         v = np.ascontiguousarray(v, dtype=np.float64)
         xn_p = _dp(np.ascontiguousarray(xn, dtype=np.float64)) if xn is not None else None
         lib().dor_set_state(self.h, _dp(x), _dp(v), xn_p)
+
+    def set_fixed(self, fixed):
+        fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+        lib().dor_set_fixed(self.h, fixed.ctypes.data_as(c_up))
 
     @property
     def target_gres(self):

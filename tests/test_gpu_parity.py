@@ -205,6 +205,32 @@ def test_sharded_code_path_with_one_rank_rccl():
     a.close(); b.close()
 
 
+def test_refix_release_matches_oracle():
+    """Fixed-set change mid-run (rubberBandPull release path): dotmi_refix = updatePrecondMtrAndFactorize
+    (DOTTimeStepper.cpp:185-270); x~ keeps its pre-release value for that step, as in the reference."""
+    V, T = scene.synthetic_bar(8, 3, 3)
+    cfg = scene.Config(energy="FCR", script="stretch", dt=0.025, rho=1000.0, YM=1e5, PR=0.4, handle_ratio=0.01)
+    sc = scene.build_scene(cfg, V, T)
+    ep = scene.partition_rcb(sc.V_rest, sc.T, 4)
+    ts = DOTTimeStepper(sc, ep, 4)
+    orc = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, 4)
+    for _ in range(3):
+        x = ts.getResult()
+        idx, pos = sc.scripter.step(x, cfg.dt)
+        ts.setDirichlet(idx, pos); orc.move(idx, pos)
+        assert ts.step().iters == orc.step().iters
+    fixed2 = sc.fixed.copy()
+    fixed2[np.nonzero(sc.V_rest[:, 0] > 0.5)[0]] = 0          # release the right handle
+    ts.refix(fixed2); orc.set_fixed(fixed2)
+    for _ in range(3):
+        st, so = ts.step(), orc.step()
+        assert st.iters == so.iters and st.status == 0
+        assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
+    # the released end must have started to relax back
+    assert ts.getResult()[:, 0].max() < x[:, 0].max() + 3 * 0.1 * cfg.dt
+    ts.close(); orc.close()
+
+
 # ---- edge cases ---------------------------------------------------------------------------------------
 def test_no_fixed_vertices_free_fall():
     """`fall` script: no Dirichlet set at all; the body must follow gravity rigidly."""

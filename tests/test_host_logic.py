@@ -101,7 +101,25 @@ def test_twistnsns_velocity_flips_at_turning_points():
 def test_unsupported_script_is_rejected():
     V, T = scene.synthetic_bar(2, 1, 1)
     with pytest.raises(ValueError):
-        scene.build_scene(scene.Config(script="rubberBandPull"), V, T)
+        scene.build_scene(scene.Config(script="bend"), V, T)          # 2-D only script
+
+
+def test_rubber_band_pull_releases_the_waist():
+    V, T = scene.synthetic_bar(2, 40, 2, lx=0.2, ly=4.0, lz=0.2)
+    sc = scene.build_scene(scene.Config(script="rubberBandPull", dt=0.025), V, T)
+    nfix0 = int(sc.fixed.sum())
+    x = sc.x0.copy()
+    released_at = None
+    for k in range(100):
+        idx, pos = sc.scripter.step(x, 0.025)
+        x[idx] = pos
+        if sc.scripter.changed:
+            released_at = k
+            break
+    # the waist travels 5 units at 2.5 units/s: released at t = 2 s = step 80 (AnimScripter.cpp:245-250, :404)
+    assert released_at == 80 and 0 < int(sc.fixed.sum()) < nfix0
+    idx, pos = sc.scripter.step(x, 0.025)
+    assert np.array_equal(pos, x[idx])                                    # everything stopped
 
 
 def test_synthetic_bar_is_positively_oriented_and_conforming():

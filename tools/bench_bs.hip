@@ -8,29 +8,29 @@ using namespace dotmi;
 #define CK(x) do{ auto e_=(x); if((int)e_!=0){printf("fail %s -> %d\n",#x,(int)e_); exit(1);} }while(0)
 
 // variant A: stream only (each lane sums what it loads), same tiling / same loads as backsolve_kernel<256,5>
-template <int THREADS, int MAXCH, int MODE>
+template <int THREADS, int MAXCH, int MODE, int SUBV = 8, bool FULL = false>
 __global__ __launch_bounds__(THREADS) void variant_kernel(const int4 *__restrict__ job, const int *__restrict__ psize,
                                                           const double *__restrict__ W, int nmax, double *__restrict__ out)
 {
     constexpr int NW = THREADS / 64;
-    __shared__ double sm[2][NW][BS_SUB];
+    __shared__ double sm[2][NW][8];
     const int4 jb = job[blockIdx.x];
     const int s = jb.x, i0 = jb.y;
     const int ns = psize[s];
     const int len = min(i0 + BS_ROWS, ns);
-    const int ncol = (len + 127) & ~127;
+    const int ncol = FULL ? nmax : ((len + 127) & ~127);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const double *Ws = W + (size_t)s * nmax * nmax;
     double2 pacc[MAXCH];
 #pragma unroll
     for (int m = 0; m < MAXCH; ++m) pacc[m] = make_double2(0.0, 0.0);
 #pragma unroll 1
-    for (int sb = 0; sb < BS_ROWS / BS_SUB; ++sb) {
-        const int ib = i0 + sb * BS_SUB;
+    for (int sb = 0; sb < BS_ROWS / SUBV; ++sb) {
+        const int ib = i0 + sb * SUBV;
         if (ib >= ns) break;
-        double2 y[BS_SUB][MAXCH];
+        double2 y[SUBV][MAXCH];
 #pragma unroll
-        for (int rr = 0; rr < BS_SUB; ++rr) {
+        for (int rr = 0; rr < SUBV; ++rr) {
             const double *row = Ws + (size_t)min(ib + rr, ns - 1) * nmax;
 #pragma unroll
             for (int m = 0; m < MAXCH; ++m) {
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(THREADS) void variant_kernel(const int4 *__restrict
 #pragma unroll
             for (int m = 0; m < MAXCH; ++m)
 #pragma unroll
-                for (int rr = 0; rr < BS_SUB; ++rr) { pacc[m].x += y[rr][m].x; pacc[m].y += y[rr][m].y; }
+                for (int rr = 0; rr < SUBV; ++rr) { pacc[m].x += y[rr][m].x; pacc[m].y += y[rr][m].y; }
         } else {          // dots + per-wave reduce only (no LDS exchange, no barrier)
             double d[BS_SUB];
 #pragma unroll
@@ -105,6 +105,19 @@ int main(int argc, char **argv)
     timeit("library back-solve (kernel + reduce)", [&] { launch_gemv(P, q, 0); });
     timeit("kernel only", [&] { hipLaunchKernelGGL((backsolve_kernel<256, 5>), dim3(P.ntiles), dim3(256), 0, 0, P.tile, P.psize, P.dof_ptr, P.dofmap, P.W, P.nmax, q, P.ppart, P.nbmax); });
     timeit("variant: stream only (same loads)", [&] { hipLaunchKernelGGL((variant_kernel<256, 5, 0>), dim3(P.ntiles), dim3(256), 0, 0, P.tile, P.psize, P.W, nmax, out); });
+    {
+        const double b0 = bytes;
+        auto t2 = [&](const char *name, double by, auto fn) {
+            fn(); CK(hipEventRecord(e0)); for (int r = 0; r < 50; ++r) fn(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 50;
+            printf("%-46s %8.2f us  %7.1f GB/s\n", name, ms * 1e3, by / ms / 1e6);
+        };
+        const double full = (double)nParts * ns * nmax * 8;
+        t2("stream only, SUB=4 (triangle)", b0, [&] { hipLaunchKernelGGL((variant_kernel<256, 5, 0, 4>), dim3(P.ntiles), dim3(256), 0, 0, P.tile, P.psize, P.W, nmax, out); });
+        t2("stream only, SUB=2 (triangle)", b0, [&] { hipLaunchKernelGGL((variant_kernel<256, 5, 0, 2>), dim3(P.ntiles), dim3(256), 0, 0, P.tile, P.psize, P.W, nmax, out); });
+        t2("stream only, SUB=8 FULL square", full, [&] { hipLaunchKernelGGL((variant_kernel<256, 5, 0, 8, true>), dim3(P.ntiles), dim3(256), 0, 0, P.tile, P.psize, P.W, nmax, out); });
+        t2("stream only, SUB=2 FULL square", full, [&] { hipLaunchKernelGGL((variant_kernel<256, 5, 0, 2, true>), dim3(P.ntiles), dim3(256), 0, 0, P.tile, P.psize, P.W, nmax, out); });
+    }
     timeit("variant: + dots + axpy, no reduce", [&] { hipLaunchKernelGGL((variant_kernel<256, 5, 1>), dim3(P.ntiles), dim3(256), 0, 0, P.tile, P.psize, P.W, nmax, out); });
     timeit("variant: + full wave butterflies", [&] { hipLaunchKernelGGL((variant_kernel<256, 5, 2>), dim3(P.ntiles), dim3(256), 0, 0, P.tile, P.psize, P.W, nmax, out); });
     timeit("variant: + LDS exchange + barrier", [&] { hipLaunchKernelGGL((variant_kernel<256, 5, 3>), dim3(P.ntiles), dim3(256), 0, 0, P.tile, P.psize, P.W, nmax, out); });
