@@ -74,7 +74,10 @@ struct dotmi_handle {
     double dt = 0, dtSq = 0, grav[3] = {0, 0, 0}, gdtsq[3] = {0, 0, 0}, relTol = 1e-5, alphaMin = 0.1;
     double targetGRes = 0, density = 0;
     int device = 0, rank = 0, world = 1, flags = 0;
-    bool dist = false;  // world > 1, or DOTMI_FLAG_FORCE_DIST: take the sharded / collective code path
+    bool dist = false;  // world > 1, or DOTMI_FLAG_FORCE_DIST: subdomains (factor + back-solve) are sharded
+    // element pass + SpMV rows sharded too (one more all-reduce per trial): only pays on big meshes -- for a
+    // 86k-tet mesh the whole element pass is 18 us, cheaper than any collective
+    bool shardElems = false;
     std::string err;
 
     // host copies
@@ -462,7 +465,7 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = dalloc(h, &h->info_dev, (size_t)std::max(P.nParts, 1))) return rc;
 
     // element ownership + inertia vertex slice
-    if (h->dist) {
+    if (h->shardElems) {
         std::vector<int> el;
         for (int e = 0; e < nT; ++e)
             if (h->epart[e] >= h->p0 && h->epart[e] < h->p1) el.push_back(e);
@@ -695,8 +698,8 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
     int nb = 0;
     // single-GPU: the reduction partials go straight to pinned host memory (zero-copy), so one stream
     // synchronisation is the only host<->device interaction of a line-search trial
-    double *partE = h->dist ? h->partE : h->h_partE;
-    double *partR = h->dist ? h->partR : h->h_partR;
+    double *partE = h->shardElems ? h->partE : h->h_partE;
+    double *partR = h->shardElems ? h->partR : h->h_partR;
     launch_elem_energy_grad(h->M, h->mat, h->dtSq, xeval, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, h->gcont,
                             partE, &nb, h->st);
     h->nbE = nb;
@@ -712,7 +715,7 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
     a.y_new = h->Y[slot];
     a.iv0 = h->v0;
     a.iv1 = h->v1;
-    if (!h->dist) {
+    if (!h->shardElems) {
         a.make_pair = make_pair;
         launch_vertex_gather(h->M, a, L, partR, h->st);
     } else {
@@ -733,7 +736,7 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
                                    h->st));
     }
     HIPCHECK(h, hipStreamSynchronize(h->st));
-    if (!h->dist) {
+    if (!h->shardElems) {
         double se = 0, si = 0;
         for (int b = 0; b < nb; ++b) {
             se += h->h_partE[2 * b];
@@ -879,6 +882,10 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     RBCHECK(h, rocblas_create_handle(&h->blas));
     RBCHECK(h, rocblas_set_stream(h->blas, h->st));
     h->dist = h->world > 1 || (h->flags & DOTMI_FLAG_FORCE_DIST);
+    {
+        const char *ev = getenv("DOTMI_SHARD_ELEMS");  // override for testing: 0 / 1
+        h->shardElems = h->dist && (ev ? atoi(ev) != 0 : h->nT >= 400000);
+    }
     if (h->dist) {
         ncclUniqueId id;
         if (h->world > 1) memcpy(&id, prm->comm_id, 128);
@@ -1086,7 +1093,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         // ---- alpha_0 and the first trial ---------------------------------------------------------------
         launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st);
         const double *spart = h->partS;
-        if (h->dist) {
+        if (h->shardElems) {
             hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partS, NB_RED, RED_K, 2, 0.0,
                                0.0, 0, h->partG);
             NCCLCHECK(h, ncclAllReduce(h->partG, h->partG, 2, ncclDouble, ncclSum, h->comm, h->st));
@@ -1232,7 +1239,7 @@ int dotmi_eval_gradient(dotmi_handle *h, const double *x, double *g)
     launch_vertex_gather(h->M, a, L, h->partR, h->st);
     HIPCHECK(h, hipMemcpyAsync(g, h->g_trial, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->st));
     HIPCHECK(h, hipStreamSynchronize(h->st));
-    if (h->dist) HIPCHECK(h, hipMemsetAsync(h->gcont, 0, sizeof(double) * 12 * (size_t)h->nT, h->st));
+    if (h->shardElems) HIPCHECK(h, hipMemsetAsync(h->gcont, 0, sizeof(double) * 12 * (size_t)h->nT, h->st));
     return 0;
 }
 

@@ -184,10 +184,13 @@ def test_state_round_trip_and_solve_surface():
     ts.close()
 
 
-def test_sharded_code_path_with_one_rank_rccl():
-    """DOTMI_FLAG_FORCE_DIST: element lists, partial gradient + packed [g;E] all-reduce, all-reduced
-    back-solve, alpha_0 scalar all-reduce -- the N>1 sequencing with a real (1-rank) RCCL communicator.
+@pytest.mark.parametrize("shard_elems", ["0", "1"])
+def test_sharded_code_path_with_one_rank_rccl(shard_elems, monkeypatch):
+    """DOTMI_FLAG_FORCE_DIST: the N>1 sequencing with a real (1-rank) RCCL communicator -- all-reduced
+    back-solve always; with DOTMI_SHARD_ELEMS=1 (the default for >= 400k tets) also element lists, partial
+    gradient + packed [g;E] all-reduce and the alpha_0 scalar all-reduce.
     Must reproduce the single-GPU path: same iteration counts, positions to rounding."""
+    monkeypatch.setenv("DOTMI_SHARD_ELEMS", shard_elems)
     sc, ep, n = load_workload("bunny5K_LTSS")
     a = DOTTimeStepper(sc, ep, n)
     sc2, _, _ = load_workload("bunny5K_LTSS")
