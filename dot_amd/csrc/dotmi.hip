@@ -525,6 +525,10 @@ int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, in
         launch_chol_inv_base(Wg, lda, batch, o, h->info_dev + G.first, G.st);
         return 0;
     }
+    if (sz == 2 * CHOL_NB) {  // the whole two-block node in one LDS-resident launch
+        launch_chol_inv_node128(Wg, lda, batch, o, h->info_dev + G.first, G.st);
+        return 0;
+    }
     const int n1 = ((sz / CHOL_NB) / 2) * CHOL_NB, n2 = sz - n1;
     if (int rc = chol_inv_node(h, G, o, n1)) return rc;
     double *Q11 = Wg + o + (size_t)o * lda;

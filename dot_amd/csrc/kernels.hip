@@ -567,46 +567,40 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane)
     return u.d;
 }
 
-// One wavefront per diagonal block, everything in VGPRs: lane i owns row i of A (then of L), later
-// lane c owns column c of X = L^-1.  Cross-lane operands are wave-uniform broadcasts (v_readlane),
-// so there is no LDS traffic and no barrier in the O(NB^3) part; all loops are fully unrolled so the
-// register arrays are statically indexed.
-__global__ __launch_bounds__(64) void chol_inv_base_kernel(double *__restrict__ W, int nmax, int o,
-                                                           int *__restrict__ info)
+// One wavefront, everything in VGPRs: on entry lane i holds row i of the symmetric block, a[j] = A(i,j);
+// on exit lane c holds column c of X = chol(A)^-1, x[i] = X(i,c) (zero for i < c).  Cross-lane operands
+// are wave-uniform broadcasts (v_readlane), so there is no LDS traffic and no barrier in the O(NB^3)
+// part; all loops are fully unrolled so the register arrays are statically indexed.
+// Returns 0, or 1 + the index of the first non-positive pivot.
+__device__ __forceinline__ int wave_chol_inv64(double (&a)[CHOL_NB], double (&x)[CHOL_NB], int lane)
 {
     constexpr int NB = CHOL_NB;
     static_assert(NB == 64, "one lane per row");
-    __shared__ double xt[NB][NB + 1];
-    double *Ws = W + (size_t)blockIdx.x * nmax * nmax + (size_t)o * nmax + o;
-    const int lane = threadIdx.x;
-    double a[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) a[j] = Ws[(size_t)j * nmax + lane];  // a[j] = A(lane, j) (symmetric block)
     int bad = 0;
+    double mypiv = 1.0;  // lane k keeps pivot k, so the 64 square roots / reciprocals are done in one go
     // right-looking Cholesky with deferred column scaling: A(i,j) -= A(i,k) A(j,k) / A(k,k)
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         const double piv = readlane_f64(a[k], k);
         if (!(piv > 0.0) && bad == 0) bad = k + 1;
-        const double t = a[k] * (1.0 / piv);
+        if (lane == k) mypiv = piv;
+        // 1/piv: hardware estimate + two Newton steps (full double accuracy, no IEEE-division fix-up code)
+        double rp = __builtin_amdgcn_rcp(piv);
+        rp = __builtin_fma(__builtin_fma(-piv, rp, 1.0), rp, rp);
+        rp = __builtin_fma(__builtin_fma(-piv, rp, 1.0), rp, rp);
+        const double t = a[k] * rp;
 #pragma unroll
         for (int j = k + 1; j < NB; ++j) a[j] = __builtin_fma(-t, readlane_f64(a[k], j), a[j]);
     }
-    // L(i,k) = A(i,k)/sqrt(A(k,k));  dinv = 1/L(lane,lane)
-    double dinv = 0.0;
+    // L(i,k) = A(i,k)/sqrt(A(k,k));  dinv = 1/L(lane,lane): one sqrt and one division per LANE
+    const double dmine = sqrt(mypiv);
+    const double dinv = 1.0 / dmine;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        const double d = sqrt(readlane_f64(a[k], k));
-        const double r = 1.0 / d;
-        if (lane == k) {
-            a[k] = d;
-            dinv = r;
-        } else {
-            a[k] *= r;
-        }
+        const double r = readlane_f64(dinv, k);
+        a[k] = (lane == k) ? dmine : a[k] * r;
     }
     // X = L^-1 column by column: lane c solves L x = e_c;  L(i,k) is broadcast from lane i
-    double x[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         double sacc = (lane == i) ? 1.0 : 0.0;
@@ -614,6 +608,20 @@ __global__ __launch_bounds__(64) void chol_inv_base_kernel(double *__restrict__ 
         for (int k = 0; k < i; ++k) sacc = __builtin_fma(-readlane_f64(a[k], i), x[k], sacc);
         x[i] = (lane <= i) ? sacc * readlane_f64(dinv, i) : 0.0;
     }
+    return bad;
+}
+
+__global__ __launch_bounds__(64) void chol_inv_base_kernel(double *__restrict__ W, int nmax, int o,
+                                                           int *__restrict__ info)
+{
+    constexpr int NB = CHOL_NB;
+    __shared__ double xt[NB][NB + 1];
+    double *Ws = W + (size_t)blockIdx.x * nmax * nmax + (size_t)o * nmax + o;
+    const int lane = threadIdx.x;
+    double a[NB], x[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) a[j] = Ws[(size_t)j * nmax + lane];  // a[j] = A(lane, j) (symmetric block)
+    const int bad = wave_chol_inv64(a, x, lane);
     // store Q = X^T column-major, i.e. memory row i, position k <- X(i,k) (zero for k > i); through
     // LDS so the global store is coalesced
 #pragma unroll
@@ -627,6 +635,152 @@ __global__ __launch_bounds__(64) void chol_inv_base_kernel(double *__restrict__ 
 void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipStream_t st)
 {
     hipLaunchKernelGGL(chol_inv_base_kernel, dim3(count), dim3(64), 0, st, W, nmax, o, info);
+}
+
+// The whole 128 x 128 node of the recursion in one launch (one workgroup per subdomain, LDS resident):
+//   Q11 = R11^-1 ; R12 = Q11^T H12 ; H22 -= R12^T R12 ; Q22 = R22^-1 ; Q12 = -(Q11 R12) Q22 ; H21 = 0
+// The two 64 x 64 factor+invert steps run on wave 0 in registers (wave_chol_inv64); the four 64^3
+// products are done by all 256 threads from LDS (4 x 4 register tiles).  Replaces 2 base launches +
+// 4 tiny batched GEMMs + 2 block copies, whose launch latencies dominated the bottom of the recursion.
+__global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restrict__ W, int nmax, int o,
+                                                               int *__restrict__ info)
+{
+    constexpr int NB = CHOL_NB, LD = NB + 1;
+    __shared__ double X1[NB][LD];  // X11(i,k)
+    __shared__ double Bf[NB][LD];  // H12 -> R12 -> U -> Q12          (row index = first block index)
+    __shared__ double Gf[NB][LD];  // H22 -> H22 - R12^T R12 -> X22(i,k)
+    double *Ws = W + (size_t)blockIdx.x * nmax * nmax;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // column-major element (r, c) of the block matrix lives at Ws[(size_t)c * nmax + r]
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int j = idx / NB, k = idx % NB;
+        Bf[k][j] = Ws[(size_t)(o + NB + j) * nmax + o + k];       // H12(k,j)
+        Gf[k][j] = Ws[(size_t)(o + NB + j) * nmax + o + NB + k];  // H22(k,j)
+    }
+    int bad = 0;
+    if (wv == 0) {
+        double a[NB], x[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[j] = Ws[(size_t)(o + j) * nmax + o + lane];
+        bad = wave_chol_inv64(a, x, lane);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) X1[i][lane] = x[i];
+        if (bad) atomicMax(info + blockIdx.x, o + bad);
+    }
+    __syncthreads();
+    const int i0 = (tid >> 4) * 4, j0 = (tid & 15) * 4;
+    double acc[4][4];
+    // ---- R12(i,j) = sum_k X11(i,k) H12(k,j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+    for (int k = 0; k < NB; ++k) {
+        double xa[4], hb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xa[r] = X1[i0 + r][k];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hb[c] = Bf[k][j0 + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fma(xa[r], hb[c], acc[r][c]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Bf[i0 + r][j0 + c] = acc[r][c];
+    __syncthreads();
+    // ---- H22(c,d) -= sum_k R12(k,c) R12(k,d)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = Gf[i0 + r][j0 + c];
+    for (int k = 0; k < NB; ++k) {
+        double rc[4], rd[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rc[r] = Bf[k][i0 + r];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rd[c] = Bf[k][j0 + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fma(-rc[r], rd[c], acc[r][c]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Gf[i0 + r][j0 + c] = acc[r][c];
+    __syncthreads();
+    // ---- X22 = chol(H22)^-1 on wave 0
+    if (wv == 0) {
+        double a[NB], x[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) a[j] = Gf[lane][j];
+        bad = wave_chol_inv64(a, x, lane);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Gf[i][lane] = x[i];
+        if (bad) atomicMax(info + blockIdx.x, o + NB + bad);
+    }
+    __syncthreads();
+    // ---- U(i,j) = sum_k Q11(i,k) R12(k,j) = sum_k X11(k,i) R12(k,j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+    for (int k = 0; k < NB; ++k) {
+        double xa[4], hb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xa[r] = X1[k][i0 + r];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hb[c] = Bf[k][j0 + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fma(xa[r], hb[c], acc[r][c]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Bf[i0 + r][j0 + c] = acc[r][c];
+    __syncthreads();
+    // ---- Q12(i,j) = -sum_c U(i,c) Q22(c,j) = -sum_c U(i,c) X22(j,c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+    for (int k = 0; k < NB; ++k) {
+        double ua[4], xb[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ua[r] = Bf[i0 + r][k];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xb[c] = Gf[j0 + c][k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fma(-ua[r], xb[c], acc[r][c]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Bf[i0 + r][j0 + c] = acc[r][c];
+    __syncthreads();
+    // ---- store: memory row (o+i) <- [X11(i,:) | 0]; memory row (o+64+j) <- [Q12(:,j) | X22(j,:)]
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx / NB, c = idx % NB;
+        Ws[(size_t)(o + r) * nmax + o + c] = X1[r][c];               // Q11(c,r) = X11(r,c)
+        Ws[(size_t)(o + r) * nmax + o + NB + c] = 0.0;               // H21 block: strictly lower -> zero
+        Ws[(size_t)(o + NB + r) * nmax + o + c] = Bf[c][r];          // Q12(c,r)
+        Ws[(size_t)(o + NB + r) * nmax + o + NB + c] = Gf[r][c];     // Q22(c,r) = X22(r,c)
+    }
+}
+
+void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, hipStream_t st)
+{
+    hipLaunchKernelGGL(chol_inv_node128_kernel, dim3(count), dim3(256), 0, st, W, nmax, o, info);
 }
 
 // dst block <- src block (column-major blocks inside strided batches); zero when src == nullptr
