@@ -234,6 +234,48 @@ def test_refix_release_matches_oracle():
     ts.close(); orc.close()
 
 
+def test_restart_from_saved_state_continues_the_same_trajectory():
+    """status<n> round trip (Optimizer::saveStatus / `restart`, Optimizer.cpp:1096-1177): a fresh stepper fed
+    (x, v) and refactored at x (what precompute does after a restart) must continue like the original run,
+    whose preconditioner was also built at that x."""
+    sc, ep, n = load_workload("bunny5K_LTSS")
+    a = DOTTimeStepper(sc, ep, n)
+    for _ in range(3):
+        a.solve(1)
+    x, v, _ = a.getState()
+    sc2, _, _ = load_workload("bunny5K_LTSS")
+    for _ in range(3):                                   # bring the second scene's scripter to the same phase
+        idx, pos = sc2.scripter.step(sc2.x0 if _ == 0 else xs, sc2.cfg.dt); xs = (sc2.x0 if _ == 0 else xs).copy(); xs[idx] = pos
+    b = DOTTimeStepper(sc2, ep, n)
+    b.setState(x, v)
+    b.updatePrecondMtrAndFactorize()
+    b.globalIterNum = 3
+    for _ in range(2):
+        assert a.solve(1) == 0 and b.solve(1) == 0
+        assert a.last_stats.iters == b.last_stats.iters
+        assert np.abs(a.getResult() - b.getResult()).max() < 1e-10
+    a.close(); b.close()
+
+
+def test_empty_and_unbalanced_parts():
+    """A partition id that owns no element, and one part much larger than the others."""
+    V, T = scene.synthetic_bar(6, 2, 2)
+    cfg = scene.Config(energy="SNH", script="twist", dt=0.025, rho=1000.0, YM=1e5, PR=0.4, handle_ratio=0.01)
+    sc = scene.build_scene(cfg, V, T)
+    ep = scene.partition_rcb(sc.V_rest, sc.T, 3)
+    ep = np.where(ep == 1, 0, ep).astype(np.int32)        # part 1 is now empty, part 0 twice as big
+    ts = DOTTimeStepper(sc, ep, 3)
+    orc = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, 3)
+    for _ in range(2):
+        x = ts.getResult()
+        idx, pos = sc.scripter.step(x, cfg.dt)
+        ts.setDirichlet(idx, pos); orc.move(idx, pos)
+        st, so = ts.step(), orc.step()
+        assert st.iters == so.iters and st.status == 0
+    assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-10
+    ts.close(); orc.close()
+
+
 # ---- edge cases ---------------------------------------------------------------------------------------
 def test_no_fixed_vertices_free_fall():
     """`fall` script: no Dirichlet set at all; the body must follow gravity rigidly."""
