@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/dotmi.h"
@@ -87,6 +88,8 @@ struct dotmi_handle {
     int nPartsAll = 0, p0 = 0, p1 = 0;  // owned global parts [p0,p1)
     std::vector<std::vector<int>> partVerts;  // all parts: ascending global vertex ids
     std::vector<int> dup;
+    std::vector<NdNode> nd;                 // nested-dissection layout shared by the owned parts (root = 0)
+    std::vector<std::vector<int>> partPos;  // owned parts: padded scalar position of partVerts[p][i]
 
     // device
     hipStream_t st = nullptr;
@@ -129,8 +132,25 @@ struct dotmi_handle {
         hipStream_t st = nullptr;
         rocblas_handle blas = nullptr;
         hipEvent_t done = nullptr;
+        size_t tmpOff = 0;  // offset of this branch's scratch inside a part's Wtmp slice
     };
     std::vector<FactorGroup> groups;
+    // the two children of a dissection node are independent: the C child runs on its own stream (a
+    // parallel branch of the captured graph), so the latency-bound diagonal-block kernels of sibling
+    // sub-trees overlap
+    struct Branch {
+        hipStream_t st = nullptr;
+        rocblas_handle blas = nullptr;
+    };
+    std::vector<Branch> branches;  // extra streams of a phase (unit k > 0 runs on branches[k-1]); empty = serial
+    // the nodes of the dissection tree by height: leaves first, the root last; nodes of one height are
+    // independent (forks and joins always go through the group's own stream -- no nested forks)
+    struct FactorUnit {
+        int node = 0;
+        size_t tmpOff = 0;  // disjoint scratch of concurrently running units
+        hipEvent_t fork = nullptr, join = nullptr;
+    };
+    std::vector<std::vector<FactorUnit>> phases;
     hipEvent_t evFill = nullptr;
     // the factor recursion is a fixed sequence of ~250 launches on fixed pointers: captured once into a
     // hipGraph and replayed every step (removes the host launch cost between its many small kernels)
@@ -306,22 +326,8 @@ int build_device_mesh(dotmi_handle *h)
     }
     if (int rc = upload(h, &M.epos, epos)) return rc;
     // adjacency incl. self
-    std::vector<int> adj_ptr(nV + 1, 0), adj_idx;
-    {
-        std::vector<std::vector<int>> nb(nV);
-        for (int e = 0; e < nT; ++e)
-            for (int a = 0; a < 4; ++a)
-                for (int b = 0; b < 4; ++b) nb[h->T[4 * e + a]].push_back(h->T[4 * e + b]);
-        for (int v = 0; v < nV; ++v) {
-            auto &l = nb[v];
-            l.push_back(v);
-            std::sort(l.begin(), l.end());
-            l.erase(std::unique(l.begin(), l.end()), l.end());
-            adj_ptr[v + 1] = adj_ptr[v] + (int)l.size();
-        }
-        adj_idx.resize(adj_ptr[nV]);
-        for (int v = 0; v < nV; ++v) std::copy(nb[v].begin(), nb[v].end(), adj_idx.begin() + adj_ptr[v]);
-    }
+    std::vector<int> adj_ptr, adj_idx;
+    build_adjacency(nV, nT, h->T.data(), adj_ptr, adj_idx);
     M.nnzb = adj_ptr[nV];
     std::vector<int> blk_row(M.nnzb);
     for (int v = 0; v < nV; ++v)
@@ -387,26 +393,75 @@ int build_device_mesh(dotmi_handle *h)
     }
     DevParts &P = h->P;
     P.nParts = h->p1 - h->p0;
-    P.nmax = (nsmax + 127) / 128 * 128;
+    // ---- nested-dissection layout of the owned subdomains ---------------------------------------
+    int ndLevels = 2, ndMin = 768;
+    if (const char *ev = getenv("DOTMI_ND_LEVELS")) ndLevels = std::max(0, atoi(ev));
+    if (const char *ev = getenv("DOTMI_ND_MIN")) ndMin = std::max(128, atoi(ev));
+    std::vector<std::vector<std::vector<int>>> region;  // [node][owned part] -> vertices of the leaf / separator
+    {
+        std::vector<std::vector<int>> sets(P.nParts);
+        for (int ls = 0; ls < P.nParts; ++ls) sets[ls] = h->partVerts[h->p0 + ls];
+        nd_plan(sets, nV, adj_ptr, adj_idx, h->Xrest.data(), ndLevels, ndMin, h->nd, region);
+    }
+    P.nmax = h->nd[0].size;
     if (P.nmax > 4096) {
-        h->err = "a subdomain has more than 1365 vertices: use more subdomains";
+        h->err = "a subdomain is too large (padded dense size " + std::to_string(P.nmax) +
+                 " > 4096, about 1300 vertices): use more subdomains";
         return DOTMI_E_INVALID;
     }
-    std::vector<int> psize(P.nParts), dof_ptr(P.nParts + 1, 0), dofmap;
+    // per part: padded position of every local vertex, tiles of the back-solve, structural non-zeros
+    h->partPos.assign(P.nParts, {});
+    std::vector<int> dofmap((size_t)P.nParts * P.nmax, -1);
     std::vector<int4> tiles;
+    std::vector<std::vector<int2>> ranges(P.nParts);
+    h->precond_bytes = 0;
+    int64_t nnzX = 0;
     for (int ls = 0; ls < P.nParts; ++ls) {
         const auto &pv = h->partVerts[h->p0 + ls];
-        psize[ls] = 3 * (int)pv.size();
-        dof_ptr[ls + 1] = dof_ptr[ls] + psize[ls];
-        for (int v : pv)
-            for (int d = 0; d < 3; ++d) dofmap.push_back(3 * v + d);
-        const int nt = (psize[ls] + 63) / 64;
-        for (int i = 0; i < nt; ++i) tiles.push_back(make_int4(ls, i * 64, i, 0));
+        std::unordered_map<int, int> posOf;
+        posOf.reserve(pv.size() * 2);
+        std::vector<int> usedBefore(P.nmax + 1, 0);  // number of live columns before a padded position
+        std::vector<uint8_t> live(P.nmax, 0);
+        for (size_t nd = 0; nd < h->nd.size(); ++nd) {
+            const NdNode &N = h->nd[nd];
+            const int ro = N.a < 0 ? N.off : N.offS;
+            const auto &rv = region[nd][ls];
+            for (size_t k = 0; k < rv.size(); ++k) {
+                posOf[rv[k]] = ro + 3 * (int)k;
+                for (int d = 0; d < 3; ++d) {
+                    dofmap[(size_t)ls * P.nmax + ro + 3 * k + d] = 3 * rv[k] + d;
+                    live[ro + 3 * k + d] = 1;
+                }
+            }
+        }
+        for (int c = 0; c < P.nmax; ++c) usedBefore[c + 1] = usedBefore[c] + live[c];
+        h->partPos[ls].resize(pv.size());
+        for (size_t i = 0; i < pv.size(); ++i) h->partPos[ls][i] = posOf.at(pv[i]);
+        int b = 0;
+        for (size_t nd = 0; nd < h->nd.size(); ++nd) {
+            const NdNode &N = h->nd[nd];
+            const int ro = N.a < 0 ? N.off : N.offS;  // first row of the region
+            const int cb = N.off;                     // rows of a region start at their node's first column
+            const int used = 3 * (int)region[nd][ls].size();
+            for (int r0 = ro; r0 < ro + used; r0 += 64) {
+                const int rows = std::min(64, ro + used - r0);
+                tiles.push_back(make_int4(ls, r0, b | (rows << 16), cb));
+                ranges[ls].push_back(make_int2(cb, r0 + rows));
+                ++b;
+            }
+            for (int r = ro; r < ro + used; ++r) nnzX += usedBefore[r + 1] - usedBefore[cb];
+        }
     }
-    // heavy tiles first: work ~ first row + 64
-    std::stable_sort(tiles.begin(), tiles.end(), [](const int4 &a, const int4 &b) { return a.y > b.y; });
+    // every structural non-zero of the inverse factors is streamed once per back-solve
+    h->precond_bytes = nnzX * 8;
+    P.nbmax = 1;
+    for (auto &r : ranges) P.nbmax = std::max(P.nbmax, (int)r.size());
+    std::vector<int2> trange((size_t)std::max(P.nParts, 1) * P.nbmax, make_int2(0, 0));
+    for (int ls = 0; ls < P.nParts; ++ls) std::copy(ranges[ls].begin(), ranges[ls].end(), trange.begin() + (size_t)ls * P.nbmax);
+    // heavy tiles first: work ~ rows * row length
+    auto tile_work = [](const int4 &t) { return (long long)(t.z >> 16) * (t.y + 64 - t.w); };
+    std::stable_sort(tiles.begin(), tiles.end(), [&](const int4 &a, const int4 &b) { return tile_work(a) > tile_work(b); });
     P.ntiles = (int)tiles.size();
-    P.nbmax = P.nmax / 64;
     // merge lists (owned parts only)
     std::vector<int> vp_ptr(nV + 1, 0), vp_off;
     {
@@ -417,40 +472,37 @@ int build_device_mesh(dotmi_handle *h)
         std::vector<int> cur(vp_ptr.begin(), vp_ptr.end() - 1);
         for (int ls = 0; ls < P.nParts; ++ls) {
             const auto &pv = h->partVerts[h->p0 + ls];
-            for (int i = 0; i < (int)pv.size(); ++i) vp_off[cur[pv[i]]++] = dof_ptr[ls] + 3 * i;
+            for (int i = 0; i < (int)pv.size(); ++i) vp_off[cur[pv[i]]++] = ls * P.nmax + h->partPos[ls][i];
         }
     }
     // dense fill list
     std::vector<long long> fill_dst, pad_dst;
     std::vector<int> fill_src;
     {
-        std::vector<int> g2l(nV, -1);
+        std::vector<int> g2p(nV, -1);
         for (int ls = 0; ls < P.nParts; ++ls) {
             const auto &pv = h->partVerts[h->p0 + ls];
-            for (int i = 0; i < (int)pv.size(); ++i) g2l[pv[i]] = i;
+            for (int i = 0; i < (int)pv.size(); ++i) g2p[pv[i]] = h->partPos[ls][i];
             const long long base = (long long)ls * P.nmax * P.nmax;
             for (int i = 0; i < (int)pv.size(); ++i) {
                 const int v = pv[i];
                 for (int k = adj_ptr[v]; k < adj_ptr[v + 1]; ++k) {
-                    const int j = g2l[adj_idx[k]];
+                    const int j = g2p[adj_idx[k]];
                     if (j < 0) continue;
-                    fill_dst.push_back(base + (long long)(3 * i) * P.nmax + 3 * j);
+                    fill_dst.push_back(base + (long long)h->partPos[ls][i] * P.nmax + j);
                     fill_src.push_back(k);
                 }
             }
-            for (int r = psize[ls]; r < P.nmax; ++r) pad_dst.push_back(base + (long long)r * P.nmax + r);
-            for (int v : pv) g2l[v] = -1;
+            for (int r = 0; r < P.nmax; ++r)
+                if (dofmap[(size_t)ls * P.nmax + r] < 0) pad_dst.push_back(base + (long long)r * P.nmax + r);
+            for (int v : pv) g2p[v] = -1;
         }
     }
     P.nfill = (int)fill_src.size();
     P.npad = (int)pad_dst.size();
-    // every entry of the triangular factor is streamed once per back-solve
-    h->precond_bytes = 0;
-    for (int ls = 0; ls < P.nParts; ++ls) h->precond_bytes += (int64_t)psize[ls] * (psize[ls] + 1) / 2 * 8;
-    if (int rc = upload(h, &P.psize, psize)) return rc;
-    if (int rc = upload(h, &P.dof_ptr, dof_ptr)) return rc;
     if (int rc = upload(h, &P.dofmap, dofmap)) return rc;
     if (int rc = upload(h, &P.tile, tiles)) return rc;
+    if (int rc = upload(h, &P.trange, trange)) return rc;
     if (int rc = upload(h, &P.vp_ptr, vp_ptr)) return rc;
     if (int rc = upload(h, &P.vp_off, vp_off)) return rc;
     if (int rc = upload(h, &P.dup, h->dup)) return rc;
@@ -458,10 +510,36 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = upload(h, &P.fill_src, fill_src)) return rc;
     if (int rc = upload(h, &P.pad_dst, pad_dst)) return rc;
     if (int rc = dalloc(h, &P.W, (size_t)P.nParts * P.nmax * P.nmax)) return rc;
-    h->tmp_stride = (size_t)P.nmax * (P.nmax / 2 + CHOL_NB);
+    // factorisation schedule: nodes by height; scratch of a node = R12 / U blocks of the dense recursion,
+    // [R_AS; R_CS] of a dissection node; the nodes of one height run concurrently on disjoint scratch
+    {
+        std::vector<int> height(h->nd.size(), 0);
+        int hmax = 0;
+        for (int id = (int)h->nd.size() - 1; id >= 0; --id) {  // children have larger ids than their parent
+            const NdNode &N = h->nd[id];
+            if (N.a >= 0) height[id] = 1 + std::max(height[N.a], height[N.c]);
+            hmax = std::max(hmax, height[id]);
+        }
+        auto dense = [](int sz) { return (size_t)(sz / 2) * (sz / 2 + CHOL_NB) + 64 * 64; };
+        h->phases.assign(hmax + 1, {});
+        h->tmp_stride = 0;
+        for (int ht = 0; ht <= hmax; ++ht) {
+            size_t off = 0;
+            for (size_t id = 0; id < h->nd.size(); ++id) {
+                if (height[id] != ht) continue;
+                const NdNode &N = h->nd[id];
+                dotmi_handle::FactorUnit U;
+                U.node = (int)id;
+                U.tmpOff = off;
+                off += N.a < 0 ? dense(N.size) : std::max((size_t)(N.offS - N.off) * N.sizeS, dense(N.sizeS));
+                h->phases[ht].push_back(U);
+            }
+            h->tmp_stride = std::max(h->tmp_stride, off);
+        }
+    }
     if (int rc = dalloc(h, &P.Wtmp, (size_t)P.nParts * h->tmp_stride)) return rc;
     if (int rc = dalloc(h, &P.ppart, (size_t)P.nParts * P.nbmax * P.nmax)) return rc;
-    if (int rc = dalloc(h, &P.psub, (size_t)dof_ptr[P.nParts])) return rc;
+    if (int rc = dalloc(h, &P.psub, (size_t)P.nParts * P.nmax)) return rc;
     if (int rc = dalloc(h, &h->info_dev, (size_t)std::max(P.nParts, 1))) return rc;
 
     // element ownership + inertia vertex slice
@@ -535,7 +613,7 @@ int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, in
     double *H12 = Wg + o + (size_t)(o + n1) * lda;
     double *H22 = Wg + (o + n1) + (size_t)(o + n1) * lda;
     double *H21 = Wg + (o + n1) + (size_t)o * lda;
-    double *Tb = P.Wtmp + (size_t)G.first * h->tmp_stride;
+    double *Tb = P.Wtmp + (size_t)G.first * h->tmp_stride + G.tmpOff;
     const int ldt = n1;
     const rocblas_stride sT = (rocblas_stride)h->tmp_stride;
     const double one = 1.0, zero = 0.0, mone = -1.0;
@@ -592,13 +670,141 @@ int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, in
     return 0;
 }
 
+// C = alpha * op(Q) B + beta * C for the upper-triangular inverse factor Q of a finished node of the
+// dissection tree (op = transpose when `trans`), batched over the group's subdomains.  B and C point at
+// the first row of the node's range and have `ncols` columns; B and C must not overlap.  Only the blocks
+// of Q that can be non-zero are multiplied: the (A,C) block of a dissection node and the lower triangle
+// of a dense block never enter a GEMM.
+struct TriMult {
+    dotmi_handle *h;
+    const dotmi_handle::FactorGroup &G;
+    double *Wg;
+    int lda, ncols;
+    rocblas_stride sA;
+    double alpha;
+    const double *B;
+    int ldb;
+    rocblas_stride sB;
+    double *C;
+    int ldc;
+    rocblas_stride sC;
+    bool trans;
+
+    const double *Q(int i, int j) const { return Wg + i + (size_t)j * lda; }
+    // C[ro..ro+m) (+)= alpha * op(Q[qi.., qj..]) * B[rb..rb+k)
+    int gemm(int m, int k, int qi, int qj, int rb, int ro, double beta) const
+    {
+        const rocblas_status st = rocblas_dgemm_strided_batched(
+            G.blas, trans ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none, m, ncols, k,
+            &alpha, Q(qi, qj), lda, sA, B + rb, ldb, sB, &beta, C + ro, ldc, sC, G.count);
+        if (st != rocblas_status_success) {
+            h->err = "rocblas_dgemm_strided_batched: status " + std::to_string((int)st);
+            return DOTMI_E_DEVICE;
+        }
+        return 0;
+    }
+    // dense upper-triangular block at [o, o+sz); r = row offset of that block inside B / C
+    int dense(int o, int sz, int r, double beta) const
+    {
+        const int a = ((sz / CHOL_NB) / 2) * CHOL_NB, b = sz - a;
+        if (sz < 512 || a == 0) return gemm(sz, sz, o, o, r, r, beta);
+        if (trans) {  // C_a = Qaa^T B_a ; C_b = Qab^T B_a + Qbb^T B_b
+            if (int rc = dense(o, a, r, beta)) return rc;
+            if (int rc = gemm(b, a, o, o + a, r, r + a, beta)) return rc;
+            return dense(o + a, b, r + a, 1.0);
+        }
+        // C_a = Qaa B_a + Qab B_b ; C_b = Qbb B_b
+        if (int rc = dense(o, a, r, beta)) return rc;
+        if (int rc = gemm(a, b, o, o + a, r + a, r, 1.0)) return rc;
+        return dense(o + a, b, r + a, beta);
+    }
+    // node `id`; r = row offset of the node inside B / C
+    int node(int id, int r, double beta) const
+    {
+        const NdNode &N = h->nd[id];
+        if (N.a < 0) return dense(N.off, N.size, r, beta);
+        const int m = N.offS - N.off;  // rows of [A ; C]
+        if (int rc = node(N.a, r, beta)) return rc;
+        if (int rc = node(N.c, r + h->nd[N.a].size, beta)) return rc;
+        if (N.sizeS == 0) return 0;
+        if (trans) {  // C_S = [Q_AS ; Q_CS]^T B_AC + Q_S^T B_S
+            if (int rc = gemm(N.sizeS, m, N.off, N.offS, r, r + m, beta)) return rc;
+            return dense(N.offS, N.sizeS, r + m, 1.0);
+        }
+        // C_AC += [Q_AS ; Q_CS] B_S ; C_S = Q_S B_S
+        if (int rc = gemm(m, N.sizeS, N.off, N.offS, r + m, r, 1.0)) return rc;
+        return dense(N.offS, N.sizeS, r + m, beta);
+    }
+};
+
+// inverse Cholesky factor of a node of the dissection tree:  with H = [H_A 0 H_AS ; . H_C H_CS ; . . H_S]
+//   Q_A, Q_C            (children, independent)
+//   R = blockdiag(Q_A, Q_C)^T [H_AS ; H_CS]         H_S -= R^T R
+//   U = blockdiag(Q_A, Q_C) R                        Q_S = inverse factor of the updated H_S
+//   [Q_AS ; Q_CS] = -U Q_S
+// The (A,C) block of the factor and of its inverse is structurally zero and is never touched.
+// One call does ONE node: a dense leaf, or the separator steps of a dissection node whose children are
+// finished; issue_factor() walks the tree by height and runs the nodes of one height concurrently.
+int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id)
+{
+    const NdNode &N = h->nd[id];
+    if (N.a < 0) return chol_inv_node(h, G, N.off, N.size);
+    if (N.sizeS == 0) return 0;
+    DevParts &P = h->P;
+    const int lda = P.nmax, batch = G.count, m = N.offS - N.off, ns = N.sizeS, na = h->nd[N.a].size;
+    const rocblas_stride sA = (rocblas_stride)lda * lda, sT = (rocblas_stride)h->tmp_stride;
+    double *Wg = P.W + (size_t)G.first * sA;
+    double *Hxs = Wg + N.off + (size_t)N.offS * lda;   // [H_AS ; H_CS], m x ns
+    double *Hss = Wg + N.offS + (size_t)N.offS * lda;
+    double *Tb = P.Wtmp + (size_t)G.first * h->tmp_stride + G.tmpOff;
+    const double one = 1.0, zero = 0.0, mone = -1.0;
+    const rocblas_operation Nn = rocblas_operation_none, Tt = rocblas_operation_transpose;
+    {
+        TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Hxs, lda, sA, Tb, m, sT, true};
+        if (int rc = tm.node(N.a, 0, 0.0)) return rc;
+        if (int rc = tm.node(N.c, na, 0.0)) return rc;
+    }
+    RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Tt, Nn, ns, ns, m, &mone, Tb, m, sT, Tb, m, sT, &one, Hss, lda, sA,
+                                             batch));
+    {
+        TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Tb, m, sT, Hxs, lda, sA, false};
+        if (int rc = tm.node(N.a, 0, 0.0)) return rc;
+        if (int rc = tm.node(N.c, na, 0.0)) return rc;
+    }
+    if (int rc = chol_inv_node(h, G, N.offS, ns)) return rc;
+    RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Nn, Nn, m, ns, ns, &mone, Hxs, lda, sA, Hss, lda, sA, &zero, Tb, m,
+                                             sT, batch));
+    launch_block_copy(Hxs, lda, (size_t)sA, Tb, m, (size_t)sT, m, ns, batch, G.st);
+    // rows S, columns [A C] of the lower part hold the symmetric fill of H: clear them
+    launch_block_copy(Wg + N.offS + (size_t)N.off * lda, lda, (size_t)sA, nullptr, 0, 0, ns, m, batch, G.st);
+    return 0;
+}
+
 // issue (or replay) the inverse-Cholesky recursion of every owned subdomain on h->st
 int issue_factor(dotmi_handle *h)
 {
     HIPCHECK(h, hipEventRecord(h->evFill, h->st));
     for (auto &G : h->groups) {
         if (G.st != h->st) HIPCHECK(h, hipStreamWaitEvent(G.st, h->evFill, 0));
-        if (int rc = chol_inv_node(h, G, 0, h->P.nmax)) return rc;
+        for (auto &phase : h->phases) {
+            const bool par = !h->branches.empty() && phase.size() > 1;
+            if (par) HIPCHECK(h, hipEventRecord(phase[0].fork, G.st));
+            for (size_t k = 0; k < phase.size(); ++k) {
+                const auto &U = phase[k];
+                dotmi_handle::FactorGroup Gk = G;
+                Gk.tmpOff = U.tmpOff;
+                if (par && k > 0) {
+                    Gk.st = h->branches[k - 1].st;
+                    Gk.blas = h->branches[k - 1].blas;
+                    HIPCHECK(h, hipStreamWaitEvent(Gk.st, phase[0].fork, 0));
+                }
+                if (int rc = chol_inv_tree(h, Gk, U.node)) return rc;
+                if (par && k > 0) {
+                    HIPCHECK(h, hipEventRecord(U.join, Gk.st));
+                    HIPCHECK(h, hipStreamWaitEvent(G.st, U.join, 0));
+                }
+            }
+        }
         if (G.st != h->st) {
             HIPCHECK(h, hipEventRecord(G.done, G.st));
             HIPCHECK(h, hipStreamWaitEvent(h->st, G.done, 0));
@@ -790,6 +996,63 @@ int dotmi_plan_shards(int32_t nParts, const int32_t *part_scalar_size, int32_t w
 
 const char *dotmi_last_error(const dotmi_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+// host-only: the nested-dissection layout build_device_mesh() would use for parts [p0,p1)
+int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xrest, const int32_t *epart,
+                      int32_t nParts, int32_t p0, int32_t p1, int32_t levels, int32_t min_split, int32_t node_cap,
+                      int32_t *nodes, int32_t *n_nodes, int32_t *nmax, int32_t *pos)
+{
+    if (nV < 1 || nT < 1 || !T || !Xrest || !epart || nParts < 1 || p0 < 0 || p1 > nParts || p0 > p1 || !n_nodes ||
+        !nmax)
+        return DOTMI_E_INVALID;
+    for (int e = 0; e < nT; ++e) {
+        if (epart[e] < 0 || epart[e] >= nParts) return DOTMI_E_INVALID;
+        for (int k = 0; k < 4; ++k)
+            if (T[4 * e + k] < 0 || T[4 * e + k] >= nV) return DOTMI_E_INVALID;
+    }
+    std::vector<int> adj_ptr, adj_idx;
+    build_adjacency(nV, nT, T, adj_ptr, adj_idx);
+    std::vector<std::vector<int>> sets(p1 - p0);
+    {
+        std::vector<int> mark(nV, -1);
+        for (int e = 0; e < nT; ++e) {
+            const int pI = epart[e];
+            if (pI < p0 || pI >= p1) continue;
+            for (int k = 0; k < 4; ++k) sets[pI - p0].push_back(T[4 * e + k]);
+        }
+        for (auto &v : sets) {
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+        }
+    }
+    std::vector<NdNode> tree;
+    std::vector<std::vector<std::vector<int>>> region;
+    *nmax = nd_plan(sets, nV, adj_ptr, adj_idx, Xrest, levels < 0 ? 2 : levels, min_split < 128 ? 768 : min_split, tree,
+                    region);
+    *n_nodes = (int32_t)tree.size();
+    if (nodes) {
+        if ((int)tree.size() > node_cap) return DOTMI_E_INVALID;
+        for (size_t i = 0; i < tree.size(); ++i) {
+            const NdNode &N = tree[i];
+            const int32_t row[6] = {N.off, N.size, N.a, N.c, N.offS, N.sizeS};
+            std::copy(row, row + 6, nodes + 6 * i);
+        }
+    }
+    if (pos) {
+        size_t base = 0;
+        for (size_t ls = 0; ls < sets.size(); ++ls) {
+            std::unordered_map<int, int> posOf;
+            for (size_t nd = 0; nd < tree.size(); ++nd) {
+                const int ro = tree[nd].a < 0 ? tree[nd].off : tree[nd].offS;
+                const auto &rv = region[nd][ls];
+                for (size_t k = 0; k < rv.size(); ++k) posOf[rv[k]] = ro + 3 * (int)k;
+            }
+            for (size_t i = 0; i < sets[ls].size(); ++i) pos[base + i] = posOf.at(sets[ls][i]);
+            base += sets[ls].size();
+        }
+    }
+    return 0;
+}
+
 int dotmi_comm_unique_id(void *out128)
 {
     ncclUniqueId id;
@@ -820,6 +1083,15 @@ void dotmi_destroy(dotmi_handle *h)
         if (G.done) hipEventDestroy(G.done);
         if (G.st && G.st != h->st) hipStreamDestroy(G.st);
     }
+    for (auto &B : h->branches) {
+        if (B.blas) rocblas_destroy_handle(B.blas);
+        if (B.st) hipStreamDestroy(B.st);
+    }
+    for (auto &ph : h->phases)
+        for (auto &U : ph) {
+            if (U.fork) hipEventDestroy(U.fork);
+            if (U.join) hipEventDestroy(U.join);
+        }
     if (h->evFill) hipEventDestroy(h->evFill);
     if (h->st) hipStreamDestroy(h->st);
     delete h;
@@ -923,6 +1195,25 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
                 RBCHECK(h, rocblas_create_handle(&G.blas));
                 RBCHECK(h, rocblas_set_stream(G.blas, G.st));
             }
+        }
+    }
+
+    {
+        const char *ev = getenv("DOTMI_ND_PARALLEL");
+        size_t width = 1;
+        for (auto &ph : h->phases) width = std::max(width, ph.size());
+        if (!(ev && atoi(ev) == 0) && h->groups.size() == 1 && h->P.nParts > 0 && width > 1) {
+            h->branches.resize(width - 1);
+            for (auto &B : h->branches) {
+                HIPCHECK(h, hipStreamCreateWithFlags(&B.st, hipStreamNonBlocking));
+                RBCHECK(h, rocblas_create_handle(&B.blas));
+                RBCHECK(h, rocblas_set_stream(B.blas, B.st));
+            }
+            for (auto &ph : h->phases)
+                for (auto &U : ph) {
+                    HIPCHECK(h, hipEventCreateWithFlags(&U.fork, hipEventDisableTiming));
+                    HIPCHECK(h, hipEventCreateWithFlags(&U.join, hipEventDisableTiming));
+                }
         }
     }
 
@@ -1331,11 +1622,16 @@ int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *Mout, 
         launch_dense_fill(Pt, h->Hval, h->st);
         W = tmp + (size_t)ls * lda * lda;
     }
-    hipError_t e = hipMemcpy2DAsync(Mout, sizeof(double) * ns, W, sizeof(double) * lda, sizeof(double) * ns, ns,
-                                    hipMemcpyDeviceToHost, h->st);
+    // the dense block lives in the padded nested-dissection order: gather it back to ascending vertices
+    std::vector<double> full((size_t)lda * lda);
+    hipError_t e = hipMemcpyAsync(full.data(), W, sizeof(double) * full.size(), hipMemcpyDeviceToHost, h->st);
     hipStreamSynchronize(h->st);
     if (tmp) hipFree(tmp);
     HIPCHECK(h, e);
+    const auto &pos = h->partPos[ls];
+    for (int i = 0; i < ns; ++i)
+        for (int j = 0; j < ns; ++j)
+            Mout[(size_t)i * ns + j] = full[(size_t)(pos[i / 3] + i % 3) * lda + pos[j / 3] + j % 3];
     if (l2g)
         for (size_t i = 0; i < h->partVerts[part].size(); ++i) l2g[i] = h->partVerts[part][i];
     return 0;

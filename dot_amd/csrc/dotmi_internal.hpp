@@ -1,6 +1,8 @@
 // dotmi_internal.hpp -- device-side data layout and kernel launch prototypes of libdotmi.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "nd_layout.hpp"
 #include <stdint.h>
 
 namespace dotmi {
@@ -32,18 +34,17 @@ struct DevMesh {
 // ---- subdomains owned by this rank ---------------------------------------------------------------
 struct DevParts {
     int nParts;             // owned
-    int nmax;               // max scalar size over ALL parts, padded to 128 (lda of every dense block)
-    int *psize;             // owned: scalar size n_s
-    int *dof_ptr;           // owned+1: offsets into dofmap / psub
-    int *dofmap;            // local scalar dof -> global scalar dof
+    int nmax;               // padded scalar size of every owned dense block (multiple of 128) = its lda
+    int *dofmap;            // owned * nmax: padded local position -> global scalar dof, -1 = padding
     double *W;              // owned * nmax*nmax dense blocks: H_s, then X_s = chol(H_s)^-1 with memory row i =
                             // row i of X_s (column-major upper factor Q = R^-1 of H_s = R^T R)
-    double *Wtmp;           // owned * nmax*(nmax/2+CHOL_NB) scratch of the recursion
-    int ntiles;             // back-solve jobs: (part, first row, tile index within the part, -), heavy first
-    int4 *tile;
+    double *Wtmp;           // owned * tmp_stride scratch of the recursion
+    int ntiles;             // back-solve jobs, heavy first:
+    int4 *tile;             //   (part, first row, tile index within the part | rows << 16, first column)
     int nbmax;              // max row tiles per part
+    int2 *trange;           // owned * nbmax: columns [first, end) each tile of a part contributes to
     double *ppart;          // owned * nbmax * nmax partial results of the back-solve tiles
-    double *psub;           // per-part results, concatenated by dof_ptr
+    double *psub;           // owned * nmax per-part results (padded positions)
     // merge: per vertex list of positions in psub (all parts on this rank), CSR over vertices
     int *vp_ptr, *vp_off;
     int *dup;               // nV (global multiplicity, DOTTimeStepper.cpp:47-56)

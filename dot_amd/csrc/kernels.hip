@@ -413,141 +413,163 @@ void launch_multidot(int n, const double *v, const double *const *vecs, int m, d
 // subdomain are summed in fixed order by reduce_partial_p_kernel (no atomics, deterministic).
 // ------------------------------------------------------------------------------------------------
 constexpr int BS_ROWS = 64;   // memory rows per workgroup
-constexpr int BS_SUB = 8;     // rows held in registers at a time
 
-template <int THREADS, int MAXCH>
+// One tile with rows of at most 2*THREADS*MAXCH columns, SUB rows in registers at a time.  Short rows
+// (the leaves of the dissection) take many rows per pass, long rows few, so that every pass has about
+// the same number of bytes in flight: the pass count of a tile -- a chain of HBM latency, butterfly
+// and LDS exchange -- is what bounds a tile, not its byte count.
+template <int THREADS, int MAXCH, int SUB>
+__device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restrict__ dofmap,
+                                               const double *__restrict__ W, int nmax,
+                                               const double *__restrict__ q, double *__restrict__ ppart,
+                                               int nbmax, double (*sm)[THREADS / 64][32])
+{
+    constexpr int NW = THREADS / 64;
+    const int s = jb.x, i0 = jb.y, tileIdx = jb.z & 0xffff, cb = jb.w;
+    const int ns = i0 + (jb.z >> 16);          // one past the last live row of this tile
+    // columns cb <= k < ns can be non-zero in these rows (nested dissection: everything left of the
+    // tile's node is structurally zero); whole 128-byte lines are loaded
+    const int ncol = min((ns + 15) & ~15, nmax);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double *Ws = W + (size_t)s * nmax * nmax;
+    const int *dm = dofmap + (size_t)s * nmax;
+    double2 r[MAXCH], pacc[MAXCH];
+#pragma unroll
+    for (int m = 0; m < MAXCH; ++m) {
+        const int c = cb + 2 * tid + 2 * THREADS * m;
+        const int d0 = (c < ncol) ? dm[c] : -1, d1 = (c < ncol) ? dm[c + 1] : -1;
+        r[m].x = d0 >= 0 ? q[d0] : 0.0;
+        r[m].y = d1 >= 0 ? q[d1] : 0.0;
+        pacc[m] = make_double2(0.0, 0.0);
+    }
+#pragma unroll 1
+    for (int sb = 0; sb < BS_ROWS / SUB; ++sb) {
+        const int ib = i0 + sb * SUB;
+        if (ib >= ns) break;
+        double2 y[SUB][MAXCH];
+#pragma unroll
+        for (int rr = 0; rr < SUB; ++rr) {
+            const double *row = Ws + (size_t)min(ib + rr, ns - 1) * nmax;
+            const bool live = (ib + rr) < ns;
+#pragma unroll
+            for (int m = 0; m < MAXCH; ++m) {
+                const int c = cb + 2 * tid + 2 * THREADS * m;
+                y[rr][m] = (live && c < ncol) ? *reinterpret_cast<const double2 *>(row + c) : make_double2(0.0, 0.0);
+            }
+        }
+        const int buf = sb & 1;
+#pragma unroll
+        for (int g = 0; g < SUB / 8; ++g) {
+            double d[8];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < MAXCH; ++m) acc += y[8 * g + rr][m].x * r[m].x + y[8 * g + rr][m].y * r[m].y;
+                d[rr] = acc;
+            }
+            // transposed butterfly: 8 values over 64 lanes -> lane group lane>>3 holds one row's wave sum
+            double e4[4], e2[2], e1;
+            {
+                const bool hi = lane & 32;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double keep = hi ? d[k + 4] : d[k], send = hi ? d[k] : d[k + 4];
+                    e4[k] = keep + __shfl_xor(send, 32, 64);
+                }
+            }
+            {
+                const bool hi = lane & 16;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const double keep = hi ? e4[k + 2] : e4[k], send = hi ? e4[k] : e4[k + 2];
+                    e2[k] = keep + __shfl_xor(send, 16, 64);
+                }
+            }
+            {
+                const bool hi = lane & 8;
+                const double keep = hi ? e2[1] : e2[0], send = hi ? e2[0] : e2[1];
+                e1 = keep + __shfl_xor(send, 8, 64);
+            }
+            e1 += __shfl_xor(e1, 4, 64);
+            e1 += __shfl_xor(e1, 2, 64);
+            e1 += __shfl_xor(e1, 1, 64);
+            // lane bits (5,4,3) = (b2,b1,b0): row index = 4*b2 + 2*b1 + b0
+            if ((lane & 7) == 0) sm[buf][wv][8 * g + (lane >> 3)] = e1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < SUB; ++rr) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += sm[buf][w][rr];
+#pragma unroll
+            for (int m = 0; m < MAXCH; ++m) {
+                pacc[m].x += t * y[rr][m].x;
+                pacc[m].y += t * y[rr][m].y;
+            }
+        }
+    }
+    double *out = ppart + ((size_t)s * nbmax + tileIdx) * nmax;
+#pragma unroll
+    for (int m = 0; m < MAXCH; ++m) {
+        const int c = cb + 2 * tid + 2 * THREADS * m;
+        if (c < ncol) *reinterpret_cast<double2 *>(out + c) = pacc[m];
+    }
+}
+
+template <int THREADS>
 __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restrict__ job,
-                                                            const int *__restrict__ psize,
-                                                            const int *__restrict__ dof_ptr,
                                                             const int *__restrict__ dofmap,
                                                             const double *__restrict__ W, int nmax,
                                                             const double *__restrict__ q,
                                                             double *__restrict__ ppart, int nbmax)
 {
-    constexpr int NW = THREADS / 64;
-    __shared__ double sm[2][NW][BS_SUB];
+    __shared__ double sm[2][THREADS / 64][32];
     const int4 jb = job[blockIdx.x];
-    const int s = jb.x, i0 = jb.y, tileIdx = jb.z;
-    const int ns = psize[s];
-    const int dof0 = dof_ptr[s];
-    const int len = min(i0 + BS_ROWS, ns);     // columns k < len can be non-zero in these rows
-    const int ncol = (len + 127) & ~127;       // <= nmax
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double *Ws = W + (size_t)s * nmax * nmax;
-    double2 r[MAXCH], pacc[MAXCH];
-#pragma unroll
-    for (int m = 0; m < MAXCH; ++m) {
-        const int c = 2 * tid + 2 * THREADS * m;
-        r[m].x = (c < ns) ? q[dofmap[dof0 + c]] : 0.0;
-        r[m].y = (c + 1 < ns) ? q[dofmap[dof0 + c + 1]] : 0.0;
-        pacc[m] = make_double2(0.0, 0.0);
-    }
-#pragma unroll 1
-    for (int sb = 0; sb < BS_ROWS / BS_SUB; ++sb) {
-        const int ib = i0 + sb * BS_SUB;
-        if (ib >= ns) break;
-        double2 y[BS_SUB][MAXCH];
-#pragma unroll
-        for (int rr = 0; rr < BS_SUB; ++rr) {
-            const double *row = Ws + (size_t)min(ib + rr, ns - 1) * nmax;
-            const bool live = (ib + rr) < ns;
-#pragma unroll
-            for (int m = 0; m < MAXCH; ++m) {
-                const int c = 2 * tid + 2 * THREADS * m;
-                y[rr][m] = (live && c < ncol) ? *reinterpret_cast<const double2 *>(row + c) : make_double2(0.0, 0.0);
-            }
-        }
-        double d[BS_SUB];
-#pragma unroll
-        for (int rr = 0; rr < BS_SUB; ++rr) {
-            double acc = 0.0;
-#pragma unroll
-            for (int m = 0; m < MAXCH; ++m) acc += y[rr][m].x * r[m].x + y[rr][m].y * r[m].y;
-            d[rr] = acc;
-        }
-        // transposed butterfly: 8 values over 64 lanes -> lane group g = lane>>3 holds row g's wave sum
-        double e4[4], e2[2], e1;
-        {
-            const bool hi = lane & 32;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double keep = hi ? d[k + 4] : d[k], send = hi ? d[k] : d[k + 4];
-                e4[k] = keep + __shfl_xor(send, 32, 64);
-            }
-        }
-        {
-            const bool hi = lane & 16;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const double keep = hi ? e4[k + 2] : e4[k], send = hi ? e4[k] : e4[k + 2];
-                e2[k] = keep + __shfl_xor(send, 16, 64);
-            }
-        }
-        {
-            const bool hi = lane & 8;
-            const double keep = hi ? e2[1] : e2[0], send = hi ? e2[0] : e2[1];
-            e1 = keep + __shfl_xor(send, 8, 64);
-        }
-        e1 += __shfl_xor(e1, 4, 64);
-        e1 += __shfl_xor(e1, 2, 64);
-        e1 += __shfl_xor(e1, 1, 64);
-        // lane bits (5,4,3) = (b2,b1,b0): row index = 4*b2 + 2*b1 + b0
-        const int buf = sb & 1;
-        if ((lane & 7) == 0) sm[buf][wv][lane >> 3] = e1;
-        __syncthreads();
-        double t[BS_SUB];
-#pragma unroll
-        for (int rr = 0; rr < BS_SUB; ++rr) {
-            double acc = 0.0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) acc += sm[buf][w][rr];
-            t[rr] = acc;
-        }
-#pragma unroll
-        for (int m = 0; m < MAXCH; ++m)
-#pragma unroll
-            for (int rr = 0; rr < BS_SUB; ++rr) {
-                pacc[m].x += t[rr] * y[rr][m].x;
-                pacc[m].y += t[rr] * y[rr][m].y;
-            }
-    }
-    double *out = ppart + ((size_t)s * nbmax + tileIdx) * nmax;
-#pragma unroll
-    for (int m = 0; m < MAXCH; ++m) {
-        const int c = 2 * tid + 2 * THREADS * m;
-        if (c < ncol) *reinterpret_cast<double2 *>(out + c) = pacc[m];
+    const int len = jb.y + (jb.z >> 16) - jb.w;   // longest row of the tile
+    if constexpr (THREADS == 256) {
+        if (len <= 512) backsolve_tile<256, 1, 32>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
+        else if (len <= 1024) backsolve_tile<256, 2, 16>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
+        else if (len <= 1536) backsolve_tile<256, 3, 8>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
+        else backsolve_tile<256, 5, 8>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
+    } else {
+        if (len <= 1024) backsolve_tile<512, 1, 32>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
+        else if (len <= 2048) backsolve_tile<512, 2, 16>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
+        else backsolve_tile<512, 4, 8>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
     }
 }
 
-// psub_s[k] = sum over the row tiles b >= k / BS_ROWS of ppart[s][b][k]   (fixed order, coalesced in k)
-__global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int *__restrict__ psize,
-                                                               const int *__restrict__ dof_ptr,
+// psub_s[k] = sum over the row tiles b of the part whose column range holds k of ppart[s][b][k]
+//   (fixed order, coalesced in k)
+__global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int2 *__restrict__ trange,
                                                                const double *__restrict__ ppart, int nmax,
                                                                int nbmax, double *__restrict__ psub)
 {
     const int s = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
-    const int ns = psize[s];
-    if (k >= ns) return;
-    const int nb = (ns + BS_ROWS - 1) / BS_ROWS;
+    if (k >= nmax) return;
+    const int2 *tr = trange + (size_t)s * nbmax;
     const double *base = ppart + (size_t)s * nbmax * nmax + k;
     double acc = 0.0;
-    for (int b = k / BS_ROWS; b < nb; ++b) acc += base[(size_t)b * nmax];
-    psub[dof_ptr[s] + k] = acc;
+    for (int b = 0; b < nbmax; ++b) {
+        const int2 cr = tr[b];
+        if (k >= cr.x && k < cr.y) acc += base[(size_t)b * nmax];
+    }
+    psub[(size_t)s * nmax + k] = acc;
 }
 
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st)
 {
     if (P.ntiles == 0) return;
-#define DM_BS(THR, CH)                                                                                      \
-    hipLaunchKernelGGL((backsolve_kernel<THR, CH>), dim3(P.ntiles), dim3(THR), 0, st, P.tile, P.psize,      \
-                       P.dof_ptr, P.dofmap, P.W, P.nmax, q, P.ppart, P.nbmax)
-    if (P.nmax <= 1536) DM_BS(256, 3);
-    else if (P.nmax <= 2560) DM_BS(256, 5);
-    else DM_BS(512, 4);  // nmax <= 4096, enforced at create time
-#undef DM_BS
-    hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.psize,
-                       P.dof_ptr, P.ppart, P.nmax, P.nbmax, P.psub);
+    if (P.nmax <= 2560)
+        hipLaunchKernelGGL((backsolve_kernel<256>), dim3(P.ntiles), dim3(256), 0, st, P.tile, P.dofmap, P.W, P.nmax, q,
+                           P.ppart, P.nbmax);
+    else  // nmax <= 4096, enforced at create time
+        hipLaunchKernelGGL((backsolve_kernel<512>), dim3(P.ntiles), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax, q,
+                           P.ppart, P.nbmax);
+    hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.trange,
+                       P.ppart, P.nmax, P.nbmax, P.psub);
 }
 
 // ------------------------------------------------------------------------------------------------

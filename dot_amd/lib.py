@@ -48,7 +48,7 @@ EXPORTS = [
     "dotmi_get_state", "dotmi_set_dirichlet", "dotmi_refix", "dotmi_step", "dotmi_last_iter_log",
     "dotmi_target_gres", "dotmi_eval_energy", "dotmi_eval_gradient", "dotmi_eval_elem_hessians",
     "dotmi_refactor", "dotmi_apply_precond", "dotmi_spmv", "dotmi_get_features", "dotmi_part_size",
-    "dotmi_part_matrix", "dotmi_bench_precond", "dotmi_bench_energy", "dotmi_plan_shards",
+    "dotmi_part_matrix", "dotmi_bench_precond", "dotmi_bench_energy", "dotmi_plan_shards", "dotmi_plan_layout",
 ]
 
 _lib = None
@@ -95,6 +95,8 @@ def load() -> C.CDLL:
     L.dotmi_bench_precond.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]
     L.dotmi_bench_energy.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]
     L.dotmi_plan_shards.argtypes = [C.c_int32, c_ip, C.c_int32, c_ip]
+    L.dotmi_plan_layout.argtypes = [C.c_int32, C.c_int32, c_ip, c_dp, c_ip, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, c_ip, c_ip, c_ip, c_ip]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is C.c_int or name in ("dotmi_create",):

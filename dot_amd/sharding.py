@@ -41,3 +41,32 @@ def owned_elements(epart: np.ndarray, first: List[int], rank: int) -> np.ndarray
 
 def vertex_slice(nV: int, rank: int, world: int) -> Tuple[int, int]:
     return nV * rank // world, nV * (rank + 1) // world
+
+
+def plan_layout(V_rest: np.ndarray, T: np.ndarray, epart: np.ndarray, nparts: int, p0: int = 0, p1: int = -1,
+                levels: int = -1, min_split: int = -1):
+    """Nested-dissection layout of the dense blocks of parts [p0,p1) -- dotmi_plan_layout (host only).
+    Returns (nodes[n,6] = off,size,childA,childC,offS,sizeS ; nmax ; [pos per part], [verts per part])."""
+    import ctypes as C
+
+    from .lib import load
+
+    L = load()
+    p1 = nparts if p1 < 0 else p1
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    V = np.ascontiguousarray(V_rest, dtype=np.float64)
+    ep = np.ascontiguousarray(epart, dtype=np.int32)
+    verts = [np.unique(T[ep == p]).astype(np.int32) for p in range(p0, p1)]
+    pos = np.zeros(max(1, sum(v.size for v in verts)), dtype=np.int32)
+    nodes = np.zeros((256, 6), dtype=np.int32)
+    nn, nmax = C.c_int32(0), C.c_int32(0)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    rc = L.dotmi_plan_layout(V.shape[0], T.shape[0], ip(T), V.ctypes.data_as(C.POINTER(C.c_double)), ip(ep), nparts,
+                             p0, p1, levels, min_split, 256, ip(nodes), C.byref(nn), C.byref(nmax), ip(pos))
+    if rc != 0:
+        raise ValueError(f"dotmi_plan_layout failed ({rc})")
+    out, base = [], 0
+    for v in verts:
+        out.append(pos[base:base + v.size].copy())
+        base += v.size
+    return nodes[:nn.value].copy(), int(nmax.value), out, verts

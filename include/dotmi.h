@@ -106,6 +106,18 @@ const char *dotmi_last_error(const dotmi_handle *h); /* h may be NULL: last crea
  * split dotmi_create applies; elements follow their part (ADMMDDTimeStepper.cpp:161). */
 int dotmi_plan_shards(int32_t nParts, const int32_t *part_scalar_size, int32_t world, int32_t *first_part);
 
+/* Host-only planning helper (touches no device): the nested-dissection layout dotmi_create gives the
+ * dense blocks of parts [p0,p1).  The reference leaves the ordering of each subdomain matrix to CHOLMOD's
+ * analyze step (CHOLMODSolver.cpp:103-141); here every owned subdomain is ordered [A | C | S] recursively
+ * (S a vertex separator, no mesh edge between A and C) on one tree shared by the owned parts, region sizes
+ * padded to the maximum over the parts.  nodes: n_nodes rows of 6 int32 {off, size, childA, childC, offS,
+ * sizeS} (children -1 for a dense leaf, root = row 0); nmax: padded scalar size (multiple of 128);
+ * pos: for every part in [p0,p1), for every local vertex in ascending global id, the padded scalar
+ * position of its first dof.  levels < 0 / min_split < 128 select the defaults.  nodes, pos may be NULL. */
+int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xrest, const int32_t *epart,
+                      int32_t nParts, int32_t p0, int32_t p1, int32_t levels, int32_t min_split,
+                      int32_t node_cap, int32_t *nodes, int32_t *n_nodes, int32_t *nmax, int32_t *pos);
+
 /* world>1: rank 0 calls this and ships the 128 bytes to every rank (e.g. torch.distributed
  * broadcast); all ranks pass it as params.comm_id.  */
 int dotmi_comm_unique_id(void *out128);
@@ -139,8 +151,10 @@ int dotmi_spmv(dotmi_handle *h, const double *p, double *Hp);              /* Li
 /* derived mesh features, any pointer may be NULL: restTriInv nT*9 row-major, triArea nT, mass nV */
 int dotmi_get_features(dotmi_handle *h, double *A, double *vol, double *mass);
 /* dense principal sub-matrix R_s H R_s^T currently on the device (n_s = 3*local verts), row-major.
- * `inverse` != 0 returns the stored factor instead: X = chol(H_s)^-1 (n_s x n_s, row-major, lower
- * triangular), so that H_s^-1 = X^T X.  l2g (local vertex -> global) may be NULL. */
+ * `inverse` != 0 returns the stored factor instead: X with H_s^-1 = X^T X (n_s x n_s, row-major).  On the
+ * device X is the inverse Cholesky factor in the subdomain's nested-dissection order (lower triangular,
+ * block-sparse); both matrices are returned in ascending-vertex order (l2g), i.e. X comes back as
+ * P^T X_nd P.  l2g (local vertex -> global) may be NULL. */
 int32_t dotmi_part_size(const dotmi_handle *h, int32_t part);
 int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *M, int32_t *l2g);
 
