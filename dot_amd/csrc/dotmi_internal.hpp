@@ -34,7 +34,7 @@ struct DevMesh {
 // ---- subdomains owned by this rank ---------------------------------------------------------------
 struct DevParts {
     int nParts;             // owned
-    int nmax;               // padded scalar size of every owned dense block (multiple of 128) = its lda
+    int nmax;               // padded scalar size of every owned dense block (multiple of 64) = its lda
     int *dofmap;            // owned * nmax: padded local position -> global scalar dof, -1 = padding
     double *W;              // owned * nmax*nmax dense blocks: H_s, then X_s = chol(H_s)^-1 with memory row i =
                             // row i of X_s (column-major upper factor Q = R^-1 of H_s = R^T R)

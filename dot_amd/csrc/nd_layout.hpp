@@ -159,7 +159,7 @@ struct NdBuilder {
 
 
 // layout of the given vertex sets (one per owned subdomain): tree[0] is the root, region[node][part] the
-// vertices of the node's leaf block / separator, ascending; returns the padded size (lda, multiple of 128)
+// vertices of the node's leaf block / separator, ascending; returns the padded size (lda, multiple of 64)
 inline int nd_plan(const std::vector<std::vector<int>> &partVerts, int nV, const std::vector<int> &adj_ptr,
                    const std::vector<int> &adj_idx, const double *Xrest, int levels, int minSplit,
                    std::vector<NdNode> &tree, std::vector<std::vector<std::vector<int>>> &region)
@@ -169,14 +169,7 @@ inline int nd_plan(const std::vector<std::vector<int>> &partVerts, int nV, const
     NdBuilder nb{tree, region, adj_ptr, adj_idx, Xrest, std::vector<int>(nV, -1), levels, minSplit};
     std::vector<std::vector<int>> sets(partVerts);
     const int root = nb.build(sets, 0);
-    // the row length (lda) is a multiple of 128: pad the root's last region
-    NdNode &R = tree[root];
-    const int padded = std::max(128, (R.size + 127) / 128 * 128);
-    if (R.a < 0) R.size = padded;
-    else {
-        R.sizeS += padded - R.size;
-        R.size = padded;
-    }
+    if (tree[root].size < 128) tree[root].size = 128;  // only a leaf root can be that small
     nb.layout(root, 0);
     return tree[root].size;
 }

@@ -111,7 +111,7 @@ int dotmi_plan_shards(int32_t nParts, const int32_t *part_scalar_size, int32_t w
  * analyze step (CHOLMODSolver.cpp:103-141); here every owned subdomain is ordered [A | C | S] recursively
  * (S a vertex separator, no mesh edge between A and C) on one tree shared by the owned parts, region sizes
  * padded to the maximum over the parts.  nodes: n_nodes rows of 6 int32 {off, size, childA, childC, offS,
- * sizeS} (children -1 for a dense leaf, root = row 0); nmax: padded scalar size (multiple of 128);
+ * sizeS} (children -1 for a dense leaf, root = row 0); nmax: padded scalar size (multiple of 64);
  * pos: for every part in [p0,p1), for every local vertex in ascending global id, the padded scalar
  * position of its first dof.  levels < 0 / min_split < 128 select the defaults.  nodes, pos may be NULL. */
 int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xrest, const int32_t *epart,

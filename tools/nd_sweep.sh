@@ -1,5 +1,5 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-for cfg in "2 768 1 1" "2 768 0 1" "2 768 1 0" "1 768 1 1" "3 512 1 1"; do set -- $cfg
+python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed"
+for cfg in "2 768 1 1" "3 384 1 1"; do set -- $cfg
 echo "== levels $1 min $2 parallel $3 graph $4"
 DOTMI_ND_LEVELS=$1 DOTMI_ND_MIN=$2 DOTMI_ND_PARALLEL=$3 DOTMI_FACTOR_GRAPH=$4 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
