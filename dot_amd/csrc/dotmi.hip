@@ -113,6 +113,14 @@ struct dotmi_handle {
     std::vector<void *> allocs;
     // pinned host
     double *h_partE = nullptr, *h_partR = nullptr, *h_alpha = nullptr;
+    // device-resident loop control (single-GPU path)
+    bool devLoop = false;
+    DevLoop *ctl = nullptr, *h_ctl = nullptr;  // device / pinned staging
+    int *h_flags = nullptr;                    // pinned: {status, slots done}, written by the controller
+    double *dlog = nullptr;                    // 3 * logCap doubles
+    int *dkind = nullptr;
+    std::vector<int> slotKind;                 // last step: kind of every enqueued slot (1 = ran a back-solve)
+    int logCap = 0, kindCap = 0;
     int nbE = 0;
 
     // L-BFGS host state (chronological)
@@ -947,11 +955,8 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
     }
     HIPCHECK(h, hipStreamSynchronize(h->st));
     if (!h->shardElems) {
-        double se = 0, si = 0;
-        for (int b = 0; b < nb; ++b) {
-            se += h->h_partE[2 * b];
-            si += h->h_partE[2 * b + 1];
-        }
+        const double se = chunked_sum(nb, [&](int b) { return h->h_partE[2 * b]; });
+        const double si = chunked_sum(nb, [&](int b) { return h->h_partE[2 * b + 1]; });
         *E = h->dtSq * se + si;
     } else {
         *E = h->h_partE[0];
@@ -962,11 +967,126 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
 
 void sum_stats(const dotmi_handle *h, int nvals, double *R)
 {
-    for (int j = 0; j < nvals; ++j) {
-        double acc = 0;
-        for (int b = 0; b < NB_RED; ++b) acc += h->h_partR[(size_t)b * RED_K + j];
-        R[j] = acc;
+    for (int j = 0; j < nvals; ++j) R[j] = chunked_sum(NB_RED, [&](int b) { return h->h_partR[(size_t)b * RED_K + j]; });
+}
+
+// One slot of the device-resident loop: the nine kernels of an L-BFGS iteration (or, when the controller
+// asked for a retry, only the three of a line-search trial -- the others return at once) and the controller.
+int enqueue_loop_slot(dotmi_handle *h)
+{
+    const int n = h->n;
+    LbfgsArgs L0;
+    memset(&L0, 0, sizeof(L0));
+    launch_build_q(n, h->g, L0, nullptr, h->q, h->st, h->ctl);
+    const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size();
+    if (timed) HIPCHECK(h, hipEventRecord(h->evPre[h->evUsed], h->st));
+    launch_gemv(h->P, h->q, h->st, h->ctl);
+    if (timed) {
+        HIPCHECK(h, hipEventRecord(h->evPre[h->evUsed + 1], h->st));
+        h->evUsed += 2;
     }
+    launch_merge(h->M, h->P, L0, h->z, h->partC, 1 | 2, h->st, h->ctl);
+    launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
+    launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, 0, h->nV, h->partS, h->st, h->ctl);
+    launch_step_forward(n, h->x, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, h->h_alpha, h->st,
+                        h->ctl);
+    int nb = 0;
+    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x_trial, h->xt, nullptr, h->nT, 0, h->nV, h->gcont, h->partE,
+                            &nb, h->st, h->ctl);
+    GatherArgs a;
+    memset(&a, 0, sizeof(a));
+    a.gcont = h->gcont;
+    a.xt = h->xt;
+    a.p = h->p;
+    a.alpha_dev = h->alpha_dev;
+    a.make_pair = 1;
+    a.iv0 = 0;
+    a.iv1 = h->nV;
+    launch_vertex_gather(h->M, a, L0, h->partR, h->st, h->ctl);
+    launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st);
+    return 0;
+}
+
+// The L-BFGS loop of one time step with the control flow on the device (DevLoop).  The host only keeps
+// the queue a few slots ahead of the controller's progress, which it reads from pinned memory.
+int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *failed)
+{
+    DevLoop &C = *h->h_ctl;
+    memset(&C, 0, sizeof(C));
+    C.iterCap = h->iterCap;
+    C.hist = h->hist;
+    C.tol = h->targetGRes;
+    C.dtSq = h->dtSq;
+    C.E_cur = *lastE;
+    C.g2_cur = *g2;
+    C.x_cur = h->x;
+    C.x_trial = h->x_trial;
+    C.g_cur = h->g;
+    C.g_trial = h->g_trial;
+    for (int s = 0; s <= h->hist; ++s) {
+        C.S[s] = h->S[s];
+        C.Y[s] = h->Y[s];
+    }
+    C.log_alpha = h->dlog;
+    C.log_E = h->dlog + h->logCap;
+    C.log_g2 = h->dlog + 2 * (size_t)h->logCap;
+    C.slot_kind = h->dkind;
+    C.logCap = h->logCap;
+    C.kindCap = h->kindCap;
+    volatile int *flags = h->h_flags;
+    flags[0] = 0;
+    flags[1] = 0;
+    HIPCHECK(h, hipMemcpyAsync(h->ctl, h->h_ctl, sizeof(DevLoop), hipMemcpyHostToDevice, h->st));
+    const int AHEAD = 3;
+    int enq = 0;
+    const double tStart = now_ms();
+    long spins = 0;
+    while (flags[0] == 0) {
+        if (enq - flags[1] < AHEAD) {
+            if (int rc = enqueue_loop_slot(h)) return rc;
+            ++enq;
+        } else if ((++spins & 0xfffff) == 0) {
+            if (hipStreamQuery(h->st) != hipErrorNotReady && flags[0] == 0 && enq - flags[1] >= AHEAD) {
+                // the queue drained without the controller reporting progress: a kernel failed
+                HIPCHECK(h, hipStreamSynchronize(h->st));
+                HIPCHECK(h, hipGetLastError());
+                if (flags[0] == 0 && enq - flags[1] >= AHEAD) {
+                    h->err = "device loop made no progress";
+                    return DOTMI_E_DEVICE;
+                }
+            }
+            if (now_ms() - tStart > 600000.0) {
+                h->err = "device loop timed out";
+                return DOTMI_E_DEVICE;
+            }
+        }
+    }
+    HIPCHECK(h, hipMemcpyAsync(h->h_ctl, h->ctl, sizeof(DevLoop), hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    *it = C.iter;
+    *failed = C.status == 3;
+    *lastE = C.E_cur;
+    *g2 = C.g2_cur;
+    h->x = C.x_cur;
+    h->x_trial = C.x_trial;
+    h->g = C.g_cur;
+    h->g_trial = C.g_trial;
+    h->numLineSearch += C.halvings;
+    h->energy_evals += C.evals;
+    const int nlog = std::min(C.iter, h->logCap);
+    h->log_alpha.resize(nlog);
+    h->log_E.resize(nlog);
+    h->log_g2.resize(nlog);
+    if (nlog > 0) {
+        HIPCHECK(h, hipMemcpy(h->log_alpha.data(), C.log_alpha, sizeof(double) * nlog, hipMemcpyDeviceToHost));
+        HIPCHECK(h, hipMemcpy(h->log_E.data(), C.log_E, sizeof(double) * nlog, hipMemcpyDeviceToHost));
+        HIPCHECK(h, hipMemcpy(h->log_g2.data(), C.log_g2, sizeof(double) * nlog, hipMemcpyDeviceToHost));
+    }
+    // which of the enqueued slots really ran a back-solve (for DOTMI_FLAG_TIME_BACKSOLVE)
+    h->slotKind.assign(enq, 0);
+    const int nk = std::min(std::min(C.slots, enq), h->kindCap);
+    if (nk > 0) HIPCHECK(h, hipMemcpy(h->slotKind.data(), h->dkind, sizeof(int) * nk, hipMemcpyDeviceToHost));
+    return 0;
 }
 
 }  // namespace
@@ -1073,6 +1193,8 @@ void dotmi_destroy(dotmi_handle *h)
     if (h->h_partE) hipHostFree(h->h_partE);
     if (h->h_partR) hipHostFree(h->h_partR);
     if (h->h_alpha) hipHostFree(h->h_alpha);
+    if (h->h_ctl) hipHostFree(h->h_ctl);
+    if (h->h_flags) hipHostFree(h->h_flags);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev2) hipEventDestroy(h->ev2);
@@ -1242,6 +1364,19 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     HIPCHECK(h, hipHostMalloc((void **)&h->h_partE, sizeof(double) * 2 * 2048));
     HIPCHECK(h, hipHostMalloc((void **)&h->h_partR, sizeof(double) * NB_RED * RED_K));
     HIPCHECK(h, hipHostMalloc((void **)&h->h_alpha, sizeof(double) * 8));
+    {
+        const char *ev = getenv("DOTMI_DEVICE_LOOP");
+        h->devLoop = !h->dist && !(h->flags & DOTMI_FLAG_HOST_LOOP) && !(ev && atoi(ev) == 0);
+        h->logCap = std::min(h->iterCap, 10001) + 1;
+        h->kindCap = 4096;
+        HIPCHECK(h, hipHostMalloc((void **)&h->h_ctl, sizeof(DevLoop)));
+        HIPCHECK(h, hipHostMalloc((void **)&h->h_flags, sizeof(int) * 4));
+        HIPCHECK(h, hipMalloc((void **)&h->ctl, sizeof(DevLoop)));
+        h->allocs.push_back(h->ctl);
+        if (int rc = dalloc(h, &h->dlog, (size_t)3 * h->logCap)) return rc;
+        HIPCHECK(h, hipMalloc((void **)&h->dkind, sizeof(int) * h->kindCap));
+        h->allocs.push_back(h->dkind);
+    }
 
     // Optimizer.cpp:124-184: result = data0 (+script init), v = 0, x_n = x, x~
     HIPCHECK(h, hipMemcpyAsync(h->x, x_init, sizeof(double) * n, hipMemcpyHostToDevice, h->st));
@@ -1372,6 +1507,10 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     int it = 0, status = 0;
     bool failed = false;
     const double Tloop = now_ms();
+    h->slotKind.clear();
+    if (h->devLoop) {
+        if (int rc = run_device_loop(h, &lastE, &g2, &it, &failed)) return rc;
+    } else
     do {
         // ---- two-loop, first half (host scalars) + q ------------------------------------------------
         double xi[HIST_MAX] = {0};
@@ -1474,11 +1613,13 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         st->ms_loop = Tloop1 - Tloop;
         st->ms_hessian = ms_hess;
         st->ms_factor = ms_fact;
-        st->precond_launches = h->evUsed / 2;
         for (int k = 0; k + 1 < h->evUsed; k += 2) {
+            // device loop: slots enqueued past the end, and line-search retries, ran no back-solve
+            if (h->devLoop && !((size_t)(k / 2) < h->slotKind.size() && h->slotKind[k / 2] == 1)) continue;
             float ms = 0;
             hipEventElapsedTime(&ms, h->evPre[k], h->evPre[k + 1]);
             st->ms_precond += ms;
+            st->precond_launches++;
         }
         st->precond_bytes = h->precond_bytes;
     }

@@ -64,15 +64,63 @@ struct LbfgsArgs {
     double sy[HIST_MAX][HIST_MAX];  // sy[i][j] = s_i . y_j
 };
 
+// Canonical order of every host- or controller-side sum over per-block partials: SUM_CHUNKS contiguous
+// chunks summed left to right, then the chunk sums left to right.  Host loop and device controller use
+// the same order, so they agree bit for bit, and the dependent add chain is short enough for one wave.
+constexpr int SUM_CHUNKS = 16;
+template <class Get>
+__host__ __device__ inline double chunked_sum(int n, Get get)
+{
+    const int L = (n + SUM_CHUNKS - 1) / SUM_CHUNKS;
+    double tot = 0.0;
+    for (int c = 0; c < SUM_CHUNKS; ++c) {
+        double acc = 0.0;
+        const int e = (c + 1) * L < n ? (c + 1) * L : n;
+        for (int k = c * L; k < e; ++k) acc += get(k);
+        tot += acc;
+    }
+    return tot;
+}
+
+struct XiArgs {
+    double xi[HIST_MAX];
+};
+
+// L-BFGS loop state resident in HBM (single-GPU path).  loop_control_kernel advances it after every
+// line-search trial exactly as the host loop of dotmi_step would, and the loop kernels take their
+// operands from it, so the host can enqueue iterations ahead of the device instead of synchronising
+// once per trial (that round trip was ~30 us of every ~180 us iteration on bar17K).
+struct DevLoop {
+    int status;  // 0 running, 1 converged, 2 iteration cap, 3 line search collapsed (alpha == 0)
+    int phase;   // 0: the next slot computes a new direction; 1: it retries the current one with `alpha`
+    int iter, iterCap, hist, halvings, evals, slots;
+    double tol, dtSq;
+    double alpha;          // step of the next retry
+    double E_cur, g2_cur;  // at x_cur
+    double *x_cur, *x_trial, *g_cur, *g_trial;
+    int slot;              // free history slot that receives the pair of the running trial
+    int order[HIST_MAX + 1];
+    double b[HIST_MAX];    // s_i . g_cur
+    LbfgsArgs L;           // chronological view of the stored pairs (pointers, ys, sy)
+    XiArgs X;              // first half of the two-loop for the next direction
+    double *S[HIST_MAX + 1], *Y[HIST_MAX + 1];
+    double *log_alpha, *log_E, *log_g2;
+    int *slot_kind;        // per slot: 1 new direction, 2 retry (slots after the end are not logged)
+    int logCap, kindCap;
+};
+
 // ---- kernel launchers (kernels.hip) --------------------------------------------------------------
+// Launchers with a trailing `ctl` run in device-loop mode when it is non-null: operands that change from
+// iteration to iteration come from *ctl and the kernel returns at once when the loop has ended (or, for
+// the direction kernels, when the slot is a line-search retry).
 // x = x0 + alpha * p; alpha = alpha_scale * clamp(-pg/pHp) from SpMV partials when use_partials
 void launch_step_forward(int n, const double *x0, const double *p, double *x, const double *spmv_partials,
                          double alpha_host, int use_partials, double alpha_min, double *alpha_out,
-                         double *alpha_out_host, hipStream_t st);
+                         double *alpha_out_host, hipStream_t st, const DevLoop *ctl = nullptr);
 // element pass: partial energy sums (+ inertia) and, optionally, element gradients
 void launch_elem_energy_grad(const DevMesh &M, int mat, double dtSq, const double *x, const double *xt,
                              const int *elist, int nElem, int v0, int v1, double *gcont /*or null*/,
-                             double *partials, int *nblocks_out, hipStream_t st);
+                             double *partials, int *nblocks_out, hipStream_t st, const DevLoop *ctl = nullptr);
 // vertex gather of element gradients + inertia; optional L-BFGS pair + stats partials
 struct GatherArgs {
     const double *gcont, *x, *xt, *g_old, *p, *alpha_dev;
@@ -81,7 +129,7 @@ struct GatherArgs {
     int iv0, iv1;  // vertex range whose inertia term m_v (x_v - x~_v) this rank adds
 };
 void launch_vertex_gather(const DevMesh &M, const GatherArgs &a, const LbfgsArgs &L, double *partials,
-                          hipStream_t st);
+                          hipStream_t st, const DevLoop *ctl = nullptr);
 // pair + statistics from already summed gradients (multi-GPU: after the all-reduce of g)
 void launch_pair_stats(int n, const GatherArgs &a, const LbfgsArgs &L, double *partials, hipStream_t st);
 // two-loop, first half:  b_i = s_i . g  partials
@@ -89,19 +137,23 @@ void launch_multidot(int n, const double *v, const double *const *vecs, int m, d
                      hipStream_t st);
 // q = -g - sum_j xi_j y_j with xi from partials (b) and SY
 void launch_build_q(int n, const double *g, const LbfgsArgs &L, const double *xi_host, double *q,
-                    hipStream_t st);
+                    hipStream_t st, const DevLoop *ctl = nullptr);
 // subdomain back-solve: psub_s = X_s^T (X_s q[dofmap_s])
-void launch_gemv(const DevParts &P, const double *q, hipStream_t st);
+void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr);
 // z = merge(psub) / dup  (+ partial dots y_i . z)
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
-                  int with_dots, hipStream_t st);
+                  int with_dots, hipStream_t st, const DevLoop *ctl = nullptr);
 // partial dots y_i . z only (multi-GPU path after all-reduce)
 // p = z + sum_j delta_j s_j, delta from c partials, xi and SY
 void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_partials,
-                    const double *xi_host, double *p, hipStream_t st);
+                    const double *xi_host, double *p, hipStream_t st, const DevLoop *ctl = nullptr);
 // Hp = H p on rows [v0,v1), partial sums of p.g and p.Hp
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
-                      int v0, int v1, double *partials, hipStream_t st);
+                      int v0, int v1, double *partials, hipStream_t st, const DevLoop *ctl = nullptr);
+// one wavefront: sums the partials of the finished trial and advances *ctl (accept / halve / stop);
+// flags_host (pinned, 2 ints) receives {status, slots done}
+void launch_loop_control(DevLoop *ctl, const double *partE, int nbE, const double *partR,
+                         const double *alpha_dev, int *flags_host, hipStream_t st);
 // element Hessians (12x12 projected), one wavefront per element in the expansion phase
 void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *x, double *He,
                           hipStream_t st);

@@ -64,9 +64,13 @@ __global__ __launch_bounds__(256) void elem_energy_grad_kernel(
     const double *__restrict__ lam, const double *__restrict__ vol, const double *__restrict__ mass,
     const double *__restrict__ x, const double *__restrict__ xt, const int *__restrict__ elist,
     int nElem, int v0, int v1, double dtSq, const int4 *__restrict__ epos, double *__restrict__ gcont,
-    double *__restrict__ partials)
+    double *__restrict__ partials, const DevLoop *__restrict__ ctl)
 {
     __shared__ double sm[4];
+    if (ctl) {
+        if (ctl->status != 0) return;
+        x = ctl->x_trial;
+    }
     double acc = 0.0;  // dtSq * vol * Psi
     const int stride = gridDim.x * blockDim.x;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nElem; i += stride) {
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void elem_energy_grad_kernel(
 
 void launch_elem_energy_grad(const DevMesh &M, int mat, double dtSq, const double *x, const double *xt,
                              const int *elist, int nElem, int v0, int v1, double *gcont,
-                             double *partials, int *nblocks_out, hipStream_t st)
+                             double *partials, int *nblocks_out, hipStream_t st, const DevLoop *ctl)
 {
     int work = nElem > (v1 - v0) ? nElem : (v1 - v0);
     int nb = (work + 255) / 256;
@@ -151,7 +155,7 @@ void launch_elem_energy_grad(const DevMesh &M, int mat, double dtSq, const doubl
 #define DM_LAUNCH(MATV, GRADV)                                                                       \
     hipLaunchKernelGGL((elem_energy_grad_kernel<MATV, GRADV>), dim3(nb), dim3(256), 0, st, M.T, M.A,  \
                        M.nTp, M.mu, M.lam, M.vol, M.mass, x, xt, elist, nElem, v0, v1, dtSq, M.epos, \
-                       gcont, partials)
+                       gcont, partials, ctl)
     if (mat == 0) {
         if (gcont) DM_LAUNCH(0, true);
         else DM_LAUNCH(0, false);
@@ -214,12 +218,25 @@ __device__ __forceinline__ double group8_sum(double v)
 
 // 8 lanes cooperate on one vertex: each sums every 8th incident (element, slot) contribution, the
 // butterfly combines them, then lanes 0..2 of the group own the x, y, z degree of freedom.
+template <bool DEV>
 __global__ __launch_bounds__(256) void vertex_gather_kernel(
     int nV, const int *__restrict__ vf_ptr, const int *__restrict__ vf_ent,
     const uint8_t *__restrict__ fixed, const double *__restrict__ mass, GatherArgs a, LbfgsArgs L,
-    double *__restrict__ partials)
+    double *__restrict__ partials, const DevLoop *__restrict__ ctl)
 {
     __shared__ double sm[4 * RED_K];
+    if constexpr (DEV) {
+        if (ctl->status != 0) return;
+        a.x = ctl->x_trial;
+        a.g_old = ctl->g_cur;
+        a.g_new = ctl->g_trial;
+        a.s_new = ctl->S[ctl->slot];
+        a.y_new = ctl->Y[ctl->slot];
+    }
+    const LbfgsArgs &Lr = [&]() -> const LbfgsArgs & {
+        if constexpr (DEV) return ctl->L;
+        else return L;
+    }();
     double acc[RED_K];
 #pragma unroll
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
                 const double yn = gn - a.g_old[k];
                 a.s_new[k] = sn;
                 a.y_new[k] = yn;
-                pair_stats_accum(k, gn, sn, yn, L, acc);
+                pair_stats_accum(k, gn, sn, yn, Lr, acc);
             } else {
                 acc[0] += gn * gn;
             }
@@ -261,10 +278,14 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
 }
 
 void launch_vertex_gather(const DevMesh &M, const GatherArgs &a, const LbfgsArgs &L, double *partials,
-                          hipStream_t st)
+                          hipStream_t st, const DevLoop *ctl)
 {
-    hipLaunchKernelGGL(vertex_gather_kernel, dim3(NB_RED), dim3(256), 0, st, M.nV, M.vf_ptr, M.vf_ent,
-                       M.fixed, M.mass, a, L, partials);
+    if (ctl)
+        hipLaunchKernelGGL(vertex_gather_kernel<true>, dim3(NB_RED), dim3(256), 0, st, M.nV, M.vf_ptr, M.vf_ent,
+                           M.fixed, M.mass, a, L, partials, ctl);
+    else
+        hipLaunchKernelGGL(vertex_gather_kernel<false>, dim3(NB_RED), dim3(256), 0, st, M.nV, M.vf_ptr, M.vf_ent,
+                           M.fixed, M.mass, a, L, partials, ctl);
 }
 
 __global__ __launch_bounds__(256) void pair_stats_kernel(int n, GatherArgs a, LbfgsArgs L,
@@ -300,50 +321,74 @@ void launch_pair_stats(int n, const GatherArgs &a, const LbfgsArgs &L, double *p
 //            delta_i = xi_i - beta_i ;  p = z + sum_j delta_j s_j
 // identical in exact arithmetic to DOTTimeStepper.cpp:386-400 / :455-467
 // ------------------------------------------------------------------------------------------------
-struct XiArgs {
-    double xi[HIST_MAX];
-};
-
+template <bool DEV>
 __global__ __launch_bounds__(256) void build_q_kernel(int n, const double *__restrict__ g, LbfgsArgs L,
-                                                      XiArgs X, double *__restrict__ q)
+                                                      XiArgs X, double *__restrict__ q,
+                                                      const DevLoop *__restrict__ ctl)
 {
+    if constexpr (DEV) {
+        if (ctl->status != 0 || ctl->phase != 0) return;
+        g = ctl->g_cur;
+    }
+    const LbfgsArgs &Lr = [&]() -> const LbfgsArgs & {
+        if constexpr (DEV) return ctl->L;
+        else return L;
+    }();
+    const XiArgs &Xr = [&]() -> const XiArgs & {
+        if constexpr (DEV) return ctl->X;
+        else return X;
+    }();
     const int stride = gridDim.x * blockDim.x;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
         double v = -g[k];
         // newest to oldest, as the reference subtracts them
 #pragma unroll
         for (int j = HIST_MAX - 1; j >= 0; --j)
-            if (j < L.m) v -= X.xi[j] * L.y[j][k];
+            if (j < Lr.m) v -= Xr.xi[j] * Lr.y[j][k];
         q[k] = v;
     }
 }
 
 void launch_build_q(int n, const double *g, const LbfgsArgs &L, const double *xi_host, double *q,
-                    hipStream_t st)
+                    hipStream_t st, const DevLoop *ctl)
 {
     XiArgs X;
-    for (int i = 0; i < HIST_MAX; ++i) X.xi[i] = i < L.m ? xi_host[i] : 0.0;
+    for (int i = 0; i < HIST_MAX; ++i) X.xi[i] = (xi_host && i < L.m) ? xi_host[i] : 0.0;
     int nb = (n + 255) / 256;
     if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(build_q_kernel, dim3(nb), dim3(256), 0, st, n, g, L, X, q);
+    if (ctl) hipLaunchKernelGGL(build_q_kernel<true>, dim3(nb), dim3(256), 0, st, n, g, L, X, q, ctl);
+    else hipLaunchKernelGGL(build_q_kernel<false>, dim3(nb), dim3(256), 0, st, n, g, L, X, q, ctl);
 }
 
+template <bool DEV>
 __global__ __launch_bounds__(256) void build_p_kernel(int n, const double *__restrict__ z, LbfgsArgs L,
                                                       XiArgs X, const double *__restrict__ c_partials,
-                                                      int c_blocks, double *__restrict__ p)
+                                                      int c_blocks, double *__restrict__ p,
+                                                      const DevLoop *__restrict__ ctl)
 {
     __shared__ double delta[HIST_MAX];
+    if constexpr (DEV) {
+        if (ctl->status != 0 || ctl->phase != 0) return;
+    }
+    const LbfgsArgs &Lr = [&]() -> const LbfgsArgs & {
+        if constexpr (DEV) return ctl->L;
+        else return L;
+    }();
+    const XiArgs &Xr = [&]() -> const XiArgs & {
+        if constexpr (DEV) return ctl->X;
+        else return X;
+    }();
     if (threadIdx.x < 64) {
         double d[HIST_MAX];
 #pragma unroll
         for (int i = 0; i < HIST_MAX; ++i) {
             d[i] = 0.0;
-            if (i < L.m) {
+            if (i < Lr.m) {
                 double yp = wave_sum_partials(c_partials, c_blocks, RED_K, i);
 #pragma unroll
                 for (int j = 0; j < HIST_MAX; ++j)
-                    if (j < i) yp += d[j] * L.sy[j][i];
-                d[i] = X.xi[i] - yp / L.ys[i];
+                    if (j < i) yp += d[j] * Lr.sy[j][i];
+                d[i] = Xr.xi[i] - yp / Lr.ys[i];
             }
             if (threadIdx.x == 0) delta[i] = d[i];
         }
@@ -354,19 +399,20 @@ __global__ __launch_bounds__(256) void build_p_kernel(int n, const double *__res
         double v = z[k];
 #pragma unroll
         for (int j = 0; j < HIST_MAX; ++j)
-            if (j < L.m) v += L.s[j][k] * delta[j];
+            if (j < Lr.m) v += Lr.s[j][k] * delta[j];
         p[k] = v;
     }
 }
 
 void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_partials,
-                    const double *xi_host, double *p, hipStream_t st)
+                    const double *xi_host, double *p, hipStream_t st, const DevLoop *ctl)
 {
     XiArgs X;
-    for (int i = 0; i < HIST_MAX; ++i) X.xi[i] = i < L.m ? xi_host[i] : 0.0;
+    for (int i = 0; i < HIST_MAX; ++i) X.xi[i] = (xi_host && i < L.m) ? xi_host[i] : 0.0;
     int nb = (n + 255) / 256;
     if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(build_p_kernel, dim3(nb), dim3(256), 0, st, n, z, L, X, c_partials, NB_RED, p);
+    if (ctl) hipLaunchKernelGGL(build_p_kernel<true>, dim3(nb), dim3(256), 0, st, n, z, L, X, c_partials, NB_RED, p, ctl);
+    else hipLaunchKernelGGL(build_p_kernel<false>, dim3(nb), dim3(256), 0, st, n, z, L, X, c_partials, NB_RED, p, ctl);
 }
 
 // generic multi-dot: partials[b][i] = sum_k v[k]*vecs_i[k]   (used on the multi-GPU path)
@@ -523,9 +569,11 @@ __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restri
                                                             const int *__restrict__ dofmap,
                                                             const double *__restrict__ W, int nmax,
                                                             const double *__restrict__ q,
-                                                            double *__restrict__ ppart, int nbmax)
+                                                            double *__restrict__ ppart, int nbmax,
+                                                            const DevLoop *__restrict__ ctl)
 {
     __shared__ double sm[2][THREADS / 64][32];
+    if (ctl && (ctl->status != 0 || ctl->phase != 0)) return;
     const int4 jb = job[blockIdx.x];
     const int len = jb.y + (jb.z >> 16) - jb.w;   // longest row of the tile
     if constexpr (THREADS == 256) {
@@ -544,8 +592,10 @@ __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restri
 //   (fixed order, coalesced in k)
 __global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int2 *__restrict__ trange,
                                                                const double *__restrict__ ppart, int nmax,
-                                                               int nbmax, double *__restrict__ psub)
+                                                               int nbmax, double *__restrict__ psub,
+                                                               const DevLoop *__restrict__ ctl)
 {
+    if (ctl && (ctl->status != 0 || ctl->phase != 0)) return;
     const int s = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= nmax) return;
@@ -559,17 +609,17 @@ __global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int2 *__res
     psub[(size_t)s * nmax + k] = acc;
 }
 
-void launch_gemv(const DevParts &P, const double *q, hipStream_t st)
+void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl)
 {
     if (P.ntiles == 0) return;
     if (P.nmax <= 2560)
         hipLaunchKernelGGL((backsolve_kernel<256>), dim3(P.ntiles), dim3(256), 0, st, P.tile, P.dofmap, P.W, P.nmax, q,
-                           P.ppart, P.nbmax);
+                           P.ppart, P.nbmax, ctl);
     else  // nmax <= 4096, enforced at create time
         hipLaunchKernelGGL((backsolve_kernel<512>), dim3(P.ntiles), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax, q,
-                           P.ppart, P.nbmax);
+                           P.ppart, P.nbmax, ctl);
     hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.trange,
-                       P.ppart, P.nmax, P.nbmax, P.psub);
+                       P.ppart, P.nmax, P.nbmax, P.psub, ctl);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -830,14 +880,23 @@ void launch_block_copy(double *dst, int ldd, size_t sd, const double *src, int l
 }
 
 // z_v = (sum over parts containing v of p_s[local v]) / dup_v ; partial dots c_i = y_i . z
+template <bool DEV>
 __global__ __launch_bounds__(256) void merge_kernel(int nV, const int *__restrict__ vp_ptr,
                                                     const int *__restrict__ vp_off,
                                                     const int *__restrict__ dup,
                                                     const double *__restrict__ psub, LbfgsArgs L,
                                                     int with_dots, int divide, double *__restrict__ z,
-                                                    double *__restrict__ partials)
+                                                    double *__restrict__ partials,
+                                                    const DevLoop *__restrict__ ctl)
 {
     __shared__ double sm[4 * RED_K];
+    if constexpr (DEV) {
+        if (ctl->status != 0 || ctl->phase != 0) return;
+    }
+    const LbfgsArgs &Lr = [&]() -> const LbfgsArgs & {
+        if constexpr (DEV) return ctl->L;
+        else return L;
+    }();
     double acc[RED_K];
 #pragma unroll
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
@@ -864,21 +923,26 @@ __global__ __launch_bounds__(256) void merge_kernel(int nV, const int *__restric
         if (with_dots) {
 #pragma unroll
             for (int i = 0; i < HIST_MAX; ++i)
-                if (i < L.m) {
-                    const double *yi = L.y[i] + 3 * v;
+                if (i < Lr.m) {
+                    const double *yi = Lr.y[i] + 3 * v;
                     acc[i] += yi[0] * z0 + yi[1] * z1 + yi[2] * z2;
                 }
         }
     }
-    if (with_dots) write_partials(acc, L.m, partials, sm);
+    // device-loop mode always stores all HIST_MAX columns: the consumer's m is only known on the device
+    if (with_dots) write_partials(acc, DEV ? HIST_MAX : Lr.m, partials, sm);
 }
 
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
-                  int with_dots, hipStream_t st)
+                  int with_dots, hipStream_t st, const DevLoop *ctl)
 {
     // with_dots: bit0 = accumulate y_i.z partials, bit1 = divide by dup
-    hipLaunchKernelGGL(merge_kernel, dim3(NB_RED), dim3(256), 0, st, M.nV, P.vp_ptr, P.vp_off, P.dup,
-                       P.psub, L, with_dots & 1, (with_dots >> 1) & 1, z, partials);
+    if (ctl)
+        hipLaunchKernelGGL(merge_kernel<true>, dim3(NB_RED), dim3(256), 0, st, M.nV, P.vp_ptr, P.vp_off, P.dup, P.psub,
+                           L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl);
+    else
+        hipLaunchKernelGGL(merge_kernel<false>, dim3(NB_RED), dim3(256), 0, st, M.nV, P.vp_ptr, P.vp_off, P.dup, P.psub,
+                           L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl);
 }
 
 __global__ void div_dup_kernel(int nV, const int *__restrict__ dup, double *__restrict__ z)
@@ -906,9 +970,14 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const in
                                                         const double *__restrict__ p,
                                                         const double *__restrict__ g,
                                                         double *__restrict__ Hp,
-                                                        double *__restrict__ partials)
+                                                        double *__restrict__ partials,
+                                                        const DevLoop *__restrict__ ctl)
 {
     __shared__ double sm[4];
+    if (ctl) {
+        if (ctl->status != 0 || ctl->phase != 0) return;
+        g = ctl->g_cur;
+    }
     double pg = 0, pHp = 0;
     const int sub = threadIdx.x & 7;
     const int ngroups = gridDim.x * 32;
@@ -946,10 +1015,10 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const in
 }
 
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
-                      int v0, int v1, double *partials, hipStream_t st)
+                      int v0, int v1, double *partials, hipStream_t st, const DevLoop *ctl)
 {
     hipLaunchKernelGGL(spmv_dots_kernel, dim3(NB_RED), dim3(256), 0, st, v0, v1, M.adj_ptr, M.adj_idx, Hval,
-                       p, g, Hp, partials);
+                       p, g, Hp, partials, ctl);
 }
 
 __global__ __launch_bounds__(256) void step_forward_kernel(int n, const double *__restrict__ x0,
@@ -958,9 +1027,17 @@ __global__ __launch_bounds__(256) void step_forward_kernel(int n, const double *
                                                            const double *__restrict__ spmv_partials,
                                                            double alpha_host, int use_partials,
                                                            double alpha_min, double *__restrict__ alpha_out,
-                                                           double *__restrict__ alpha_out_host)
+                                                           double *__restrict__ alpha_out_host,
+                                                           const DevLoop *__restrict__ ctl)
 {
     __shared__ double sh_alpha;
+    if (ctl) {
+        if (ctl->status != 0) return;
+        x0 = ctl->x_cur;
+        x = ctl->x_trial;
+        use_partials = ctl->phase == 0;   // a retry steps with the halved alpha the controller left
+        alpha_host = ctl->alpha;
+    }
     if (threadIdx.x < 64) {
         double alpha = alpha_host;
         if (use_partials) {
@@ -984,12 +1061,172 @@ __global__ __launch_bounds__(256) void step_forward_kernel(int n, const double *
 
 void launch_step_forward(int n, const double *x0, const double *p, double *x, const double *spmv_partials,
                          double alpha_host, int use_partials, double alpha_min, double *alpha_out,
-                         double *alpha_out_host, hipStream_t st)
+                         double *alpha_out_host, hipStream_t st, const DevLoop *ctl)
 {
     int nb = (n + 255) / 256;
     if (nb > 1024) nb = 1024;
     hipLaunchKernelGGL(step_forward_kernel, dim3(nb), dim3(256), 0, st, n, x0, p, x, spmv_partials,
-                       alpha_host, use_partials, alpha_min, alpha_out, alpha_out_host);
+                       alpha_host, use_partials, alpha_min, alpha_out, alpha_out_host, ctl);
+}
+
+// ------------------------------------------------------------------------------------------------
+// loop controller: what the host loop of dotmi_step does between a trial and the next launch
+// (line search Optimizer.cpp:806-833, history update DOTTimeStepper.cpp:474-494, stopping test
+// Optimizer.cpp:317-330), on the device.  One wavefront; the partial sums are added in block order,
+// the same order the host path uses, so both paths produce the same bits.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__ ctl,
+                                                           const double *__restrict__ partE, int nbE,
+                                                           const double *__restrict__ partR,
+                                                           const double *__restrict__ alpha_dev,
+                                                           int *__restrict__ flags_host)
+{
+    static_assert(sizeof(DevLoop) % 8 == 0, "DevLoop is copied as 8-byte words");
+    static_assert(RED_K <= 32, "two passes of 16 columns");
+    __shared__ double chunk[RED_K + 2][SUM_CHUNKS];
+    __shared__ double R[RED_K + 2];
+    __shared__ DevLoop C;  // the state is worked on in LDS: one wide load, one wide store
+    const int t = threadIdx.x;
+    constexpr int NW8 = (int)(sizeof(DevLoop) / 8);
+    {
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(ctl);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(&C);
+        for (int i = t; i < NW8; i += 256) dst[i] = src[i];
+    }
+    const double alpha_in = *alpha_dev;
+    // chunked_sum() order (dotmi_internal.hpp), one thread per (column, chunk): every load of the kernel is
+    // in flight at once and the dependent add chains are 16 long instead of NB_RED long
+    {
+        const int ch = t & (SUM_CHUNKS - 1);
+        const int colA = t >> 4;          // 0..15
+        const int colB = 16 + (t >> 4);   // 16..RED_K-1 for t < 16*(RED_K-16)
+        const int LR = (NB_RED + SUM_CHUNKS - 1) / SUM_CHUNKS;
+        double a = 0.0, b = 0.0, e = 0.0;
+        for (int k = ch * LR; k < min(NB_RED, (ch + 1) * LR); ++k) a += partR[(size_t)k * RED_K + colA];
+        if (colB < RED_K)
+            for (int k = ch * LR; k < min(NB_RED, (ch + 1) * LR); ++k) b += partR[(size_t)k * RED_K + colB];
+        const int te = t - 16 * (RED_K - 16);  // the next 32 threads: the two energy columns
+        if (te >= 0 && te < 2 * SUM_CHUNKS) {
+            const int LE = (nbE + SUM_CHUNKS - 1) / SUM_CHUNKS, c = te >> 4;
+            for (int k = ch * LE; k < min(nbE, (ch + 1) * LE); ++k) e += partE[2 * k + c];
+            chunk[RED_K + c][ch] = e;
+        }
+        chunk[colA][ch] = a;
+        if (colB < RED_K) chunk[colB][ch] = b;
+    }
+    __syncthreads();
+    if (C.status != 0) return;
+    if (t < RED_K + 2) {
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < SUM_CHUNKS; ++c) acc += chunk[t][c];
+        R[t] = acc;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double alpha = alpha_in;
+    const double E = C.dtSq * R[RED_K] + R[RED_K + 1];
+        C.evals++;
+        if (C.slots < C.kindCap) C.slot_kind[C.slots] = C.phase == 0 ? 1 : 2;
+        C.slots++;
+        if (E > C.E_cur && alpha > 0.0) {
+            // back-tracking (c1 = 0, lower bound 0)
+            alpha /= 2.0;
+            C.halvings++;
+            if (alpha == 0.0) C.status = 3;
+            else {
+                C.phase = 1;
+                C.alpha = alpha;
+            }
+        } else {
+            double *tmp = C.x_cur;
+            C.x_cur = C.x_trial;
+            C.x_trial = tmp;
+            tmp = C.g_cur;
+            C.g_cur = C.g_trial;
+            C.g_trial = tmp;
+            C.E_cur = E;
+            const double g2 = R[0];
+            C.g2_cur = g2;
+            const double ys_new = R[1], sg_new = R[2];
+            const double *siy = R + 3, *snyj = R + 3 + HIST_MAX, *sig = R + 3 + 2 * HIST_MAX;
+            if (ys_new > 0.0) {
+                int m = C.L.m;
+                int off = 0;
+                if (m == C.hist) {  // drop the oldest pair
+                    off = 1;
+                    for (int i = 0; i + 1 < m; ++i) {
+                        C.order[i] = C.order[i + 1];
+                        C.L.ys[i] = C.L.ys[i + 1];
+                        for (int j = 0; j + 1 < m; ++j) C.L.sy[i][j] = C.L.sy[i + 1][j + 1];
+                    }
+                    m -= 1;
+                }
+                for (int i = 0; i < m; ++i) {
+                    C.L.sy[i][m] = siy[i + off];
+                    C.L.sy[m][i] = snyj[i + off];
+                    C.b[i] = sig[i + off];
+                }
+                C.order[m] = C.slot;
+                C.L.ys[m] = ys_new;
+                C.L.sy[m][m] = ys_new;
+                C.b[m] = sg_new;
+                C.L.m = m + 1;
+            } else {
+                for (int i = 0; i < C.L.m; ++i) C.b[i] = sig[i];
+            }
+            if (C.iter < C.logCap) {
+                C.log_alpha[C.iter] = alpha;
+                C.log_E[C.iter] = E;
+                C.log_g2[C.iter] = g2;
+            }
+            C.iter++;
+            if (C.iter >= C.iterCap) C.status = 2;
+            else if (!(g2 > C.tol)) C.status = 1;
+            else {
+                // next direction: first half of the two-loop, operand views, free slot
+                const int m = C.L.m;
+                for (int i = 0; i < HIST_MAX; ++i) C.X.xi[i] = 0.0;
+                for (int i = m - 1; i >= 0; --i) {
+                    double sq = -C.b[i];
+                    for (int j = m - 1; j > i; --j) sq -= C.X.xi[j] * C.L.sy[i][j];
+                    C.X.xi[i] = sq / C.L.ys[i];
+                }
+                for (int i = 0; i < m; ++i) {
+                    C.L.s[i] = C.S[C.order[i]];
+                    C.L.y[i] = C.Y[C.order[i]];
+                }
+                int fs = 0;
+                for (int sl = 0; sl <= C.hist; ++sl) {
+                    bool used = false;
+                    for (int i = 0; i < m; ++i) used |= (C.order[i] == sl);
+                    if (!used) {
+                        fs = sl;
+                        break;
+                    }
+                }
+                C.slot = fs;
+                C.phase = 0;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(ctl);
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&C);
+        for (int i = t; i < NW8; i += 256) dst[i] = src[i];
+    }
+    if (t == 0) {
+        __threadfence_system();
+        flags_host[1] = C.slots;
+        flags_host[0] = C.status;
+    }
+}
+
+void launch_loop_control(DevLoop *ctl, const double *partE, int nbE, const double *partR,
+                         const double *alpha_dev, int *flags_host, hipStream_t st)
+{
+    hipLaunchKernelGGL(loop_control_kernel, dim3(1), dim3(256), 0, st, ctl, partE, nbE, partR, alpha_dev, flags_host);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@ ENERGY_FCR = 0
 ENERGY_SNH = 1
 FLAG_TIME_BACKSOLVE = 2
 FLAG_FORCE_DIST = 4
+FLAG_HOST_LOOP = 8
 
 
 class Mesh(C.Structure):

@@ -73,6 +73,10 @@ typedef struct {
                                        all-reduces) even with world == 1: lets a 1-GPU box test it */
 #define DOTMI_FLAG_TIME_BACKSOLVE 2 /* bracket every back-solve of dotmi_step with HIP events on the
                                        handle's stream; totals land in dotmi_step_stats */
+#define DOTMI_FLAG_HOST_LOOP 8      /* drive the L-BFGS loop from the host (one stream synchronisation per
+                                     * line-search trial) instead of the device-resident loop control; the
+                                     * two produce identical iterates -- kept for A/B tests and always used
+                                     * on the sharded multi-GPU path */
 
 typedef struct {
     int32_t iters;        /* L-BFGS iterations (innerIterAmt delta, DOTTimeStepper.cpp:338) */

@@ -207,6 +207,27 @@ def test_sharded_code_path_with_one_rank_rccl(shard_elems, monkeypatch):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 6), ("monkey18K_stiff", 2)])
+def test_device_loop_control_is_bit_identical_to_host_loop(workload, steps):
+    """The device-resident loop control (DevLoop + loop_control_kernel) replaces one host round trip per
+    line-search trial; it must take exactly the decisions the host loop takes: same iterates bit for bit,
+    same per-iteration log, same counters (DOTMI_FLAG_HOST_LOOP selects the host-driven loop)."""
+    sc, ep, n = load_workload(workload)
+    a = DOTTimeStepper(sc, ep, n)
+    sc2, _, _ = load_workload(workload)
+    b = DOTTimeStepper(sc2, ep, n, flags=dl.FLAG_HOST_LOOP)
+    for k in range(steps):
+        ra, rb = a.solve(1), b.solve(1)
+        assert ra == rb
+        sa, sb = a.last_stats, b.last_stats
+        assert (sa.iters, sa.ls_halvings, sa.energy_evals) == (sb.iters, sb.ls_halvings, sb.energy_evals)
+        assert sa.E == sb.E and sa.g2 == sb.g2
+        for u, w in zip(a.iterLog(), b.iterLog()):
+            assert np.array_equal(u, w)
+        assert np.array_equal(a.getResult(), b.getResult())
+    a.close(); b.close()
+
+
 def test_refix_release_matches_oracle():
     """Fixed-set change mid-run (rubberBandPull release path): dotmi_refix = updatePrecondMtrAndFactorize
     (DOTTimeStepper.cpp:185-270); x~ keeps its pre-release value for that step, as in the reference."""
