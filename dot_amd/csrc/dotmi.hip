@@ -119,8 +119,12 @@ struct dotmi_handle {
     int *h_flags = nullptr;                    // pinned: {status, slots done}, written by the controller
     double *dlog = nullptr;                    // 3 * logCap doubles
     int *dkind = nullptr;
+    std::vector<int> slotTimed;                // per enqueued slot: index of its event pair in evPre, or -1
     std::vector<int> slotKind;                 // last step: kind of every enqueued slot (1 = ran a back-solve)
     int logCap = 0, kindCap = 0;
+    int prevSlots = 0;                         // slots the previous step's loop took (enqueue-ahead horizon)
+    int timeStride = 8;                        // DOTMI_FLAG_TIME_BACKSOLVE brackets every timeStride-th back-solve
+    int timeCount = 0;
     int nbE = 0;
 
     // L-BFGS host state (chronological)
@@ -889,7 +893,8 @@ int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
 // p = D^-1 sum_s R_s^T W_s R_s q   (DOTTimeStepper.cpp:406-450); leaves y_i.z partials in partC
 int apply_precond(dotmi_handle *h, const double *q, double *z, const LbfgsArgs &L)
 {
-    const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size();
+    const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size() &&
+                       (h->timeCount++ % h->timeStride) == 0;
     if (timed) HIPCHECK(h, hipEventRecord(h->evPre[h->evUsed], h->st));
     launch_gemv(h->P, q, h->st);
     if (timed) {
@@ -978,7 +983,10 @@ int enqueue_loop_slot(dotmi_handle *h)
     LbfgsArgs L0;
     memset(&L0, 0, sizeof(L0));
     launch_build_q(n, h->g, L0, nullptr, h->q, h->st, h->ctl);
-    const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size();
+    // an event record costs ~6 us of stream time: sample, do not bracket every launch
+    const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size() &&
+                       (h->timeCount++ % h->timeStride) == 0;
+    h->slotTimed.push_back(timed ? h->evUsed : -1);
     if (timed) HIPCHECK(h, hipEventRecord(h->evPre[h->evUsed], h->st));
     launch_gemv(h->P, h->q, h->st, h->ctl);
     if (timed) {
@@ -988,7 +996,7 @@ int enqueue_loop_slot(dotmi_handle *h)
     launch_merge(h->M, h->P, L0, h->z, h->partC, 1 | 2, h->st, h->ctl);
     launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
     launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, 0, h->nV, h->partS, h->st, h->ctl);
-    launch_step_forward(n, h->x, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, h->h_alpha, h->st,
+    launch_step_forward(n, h->x, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st,
                         h->ctl);
     int nb = 0;
     launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x_trial, h->xt, nullptr, h->nT, 0, h->nV, h->gcont, h->partE,
@@ -1036,21 +1044,24 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     volatile int *flags = h->h_flags;
     flags[0] = 0;
     flags[1] = 0;
+    // blind up to a little before last step's slot count, then two slots ahead of the posted progress
+    const int AHEAD = 2;
+    C.notifyFrom = std::max(0, h->prevSlots - 3);
+    const int notifyFrom = C.notifyFrom;
     HIPCHECK(h, hipMemcpyAsync(h->ctl, h->h_ctl, sizeof(DevLoop), hipMemcpyHostToDevice, h->st));
-    const int AHEAD = 3;
     int enq = 0;
     const double tStart = now_ms();
     long spins = 0;
     while (flags[0] == 0) {
-        if (enq - flags[1] < AHEAD) {
+        if (enq < std::max(notifyFrom, (int)flags[1]) + AHEAD) {
             if (int rc = enqueue_loop_slot(h)) return rc;
             ++enq;
         } else if ((++spins & 0xfffff) == 0) {
-            if (hipStreamQuery(h->st) != hipErrorNotReady && flags[0] == 0 && enq - flags[1] >= AHEAD) {
+            if (hipStreamQuery(h->st) != hipErrorNotReady && flags[0] == 0) {
                 // the queue drained without the controller reporting progress: a kernel failed
                 HIPCHECK(h, hipStreamSynchronize(h->st));
                 HIPCHECK(h, hipGetLastError());
-                if (flags[0] == 0 && enq - flags[1] >= AHEAD) {
+                if (flags[0] == 0 && enq >= std::max(notifyFrom, (int)flags[1]) + AHEAD) {
                     h->err = "device loop made no progress";
                     return DOTMI_E_DEVICE;
                 }
@@ -1064,6 +1075,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     HIPCHECK(h, hipMemcpyAsync(h->h_ctl, h->ctl, sizeof(DevLoop), hipMemcpyDeviceToHost, h->st));
     HIPCHECK(h, hipStreamSynchronize(h->st));
     *it = C.iter;
+    h->prevSlots = C.slots;
     *failed = C.status == 3;
     *lastE = C.E_cur;
     *g2 = C.g2_cur;
@@ -1508,6 +1520,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     bool failed = false;
     const double Tloop = now_ms();
     h->slotKind.clear();
+    h->slotTimed.clear();
     if (h->devLoop) {
         if (int rc = run_device_loop(h, &lastE, &g2, &it, &failed)) return rc;
     } else
@@ -1613,9 +1626,12 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         st->ms_loop = Tloop1 - Tloop;
         st->ms_hessian = ms_hess;
         st->ms_factor = ms_fact;
+        std::vector<char> ran(h->evUsed / 2 + 1, h->devLoop ? 0 : 1);
+        // device loop: slots enqueued past the end, and line-search retries, ran no back-solve
+        for (size_t sl = 0; sl < h->slotTimed.size(); ++sl)
+            if (h->slotTimed[sl] >= 0 && sl < h->slotKind.size() && h->slotKind[sl] == 1) ran[h->slotTimed[sl] / 2] = 1;
         for (int k = 0; k + 1 < h->evUsed; k += 2) {
-            // device loop: slots enqueued past the end, and line-search retries, ran no back-solve
-            if (h->devLoop && !((size_t)(k / 2) < h->slotKind.size() && h->slotKind[k / 2] == 1)) continue;
+            if (!ran[k / 2]) continue;
             float ms = 0;
             hipEventElapsedTime(&ms, h->evPre[k], h->evPre[k + 1]);
             st->ms_precond += ms;

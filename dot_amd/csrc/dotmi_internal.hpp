@@ -94,6 +94,8 @@ struct DevLoop {
     int status;  // 0 running, 1 converged, 2 iteration cap, 3 line search collapsed (alpha == 0)
     int phase;   // 0: the next slot computes a new direction; 1: it retries the current one with `alpha`
     int iter, iterCap, hist, halvings, evals, slots;
+    int notifyFrom;  // the controller posts {status, slots} to pinned host memory from this slot on (and at the end)
+    int pad0;
     double tol, dtSq;
     double alpha;          // step of the next retry
     double E_cur, g2_cur;  // at x_cur

@@ -1216,7 +1216,9 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&C);
         for (int i = t; i < NW8; i += 256) dst[i] = src[i];
     }
-    if (t == 0) {
+    // a store to host memory holds the kernel's end back by several microseconds: only near the expected
+    // end of the loop, where the host needs the progress to stop enqueueing
+    if (t == 0 && (C.status != 0 || C.slots >= C.notifyFrom)) {
         __threadfence_system();
         flags_host[1] = C.slots;
         flags_host[0] = C.status;
