@@ -53,8 +53,94 @@ struct NdBuilder {
     // unbalanced split costs as much as its bigger half twice
     static long long cost(long long a, long long c, long long s)
     {
-        const long long m = std::max(a, c);
-        return 2 * m * m * m + 8 * s * m * m + 8 * s * s * m + s * s * s;
+        // in padded scalar sizes (blocks of 64), raw sizes as the tie-break
+        auto model = [](long long a_, long long c_, long long s_) {
+            const long long m = std::max(a_, c_);
+            return 2 * m * m * m + 8 * s_ * m * m + 8 * s_ * s_ * m + s_ * s_ * s_;
+        };
+        auto r64 = [](long long v) { return (3 * v + 63) / 64 * 64; };
+        return model(r64(a), r64(c), r64(s)) + model(3 * a, 3 * c, 3 * s) / 64;
+    }
+
+    // Smallest vertex separator that an ordered bisection (first t of `ord` | rest) admits: a minimum vertex
+    // cover of the cut edges, from a maximum bipartite matching (Koenig's theorem).  mark[] must hold the
+    // side (0 / 1) of every vertex of `ord`.  Returns the cover; nl / nr = how many of it lie on each side.
+    std::vector<int> lid, bl, br, matchL, matchR, seenR, eptr, eidx;
+    bool augment(int l, int stamp)
+    {
+        for (int e = eptr[l]; e < eptr[l + 1]; ++e) {
+            const int r = eidx[e];
+            if (seenR[r] == stamp) continue;
+            seenR[r] = stamp;
+            if (matchR[r] < 0 || augment(matchR[r], stamp)) {
+                matchR[r] = l;
+                matchL[l] = r;
+                return true;
+            }
+        }
+        return false;
+    }
+    void min_cover(const std::vector<int> &ord, int t, std::vector<int> &cover, int &nl, int &nr)
+    {
+        if (lid.size() != mark.size()) lid.assign(mark.size(), -1);
+        bl.clear(); br.clear(); eptr.assign(1, 0); eidx.clear();
+        for (int i = 0; i < t; ++i) {
+            const int v = ord[i];
+            const size_t e0 = eidx.size();
+            for (int e = adj_ptr[v]; e < adj_ptr[v + 1]; ++e) {
+                const int u = adj_idx[e];
+                if (mark[u] != 1) continue;
+                if (lid[u] < 0) {
+                    lid[u] = (int)br.size();
+                    br.push_back(u);
+                }
+                eidx.push_back(lid[u]);
+            }
+            if (eidx.size() > e0) {
+                bl.push_back(v);
+                eptr.push_back((int)eidx.size());
+            }
+        }
+        for (int u : br) lid[u] = -1;
+        const int nL = (int)bl.size(), nR = (int)br.size();
+        matchL.assign(nL, -1);
+        matchR.assign(nR, -1);
+        seenR.assign(nR, -1);
+        for (int l = 0; l < nL; ++l) augment(l, l);
+        // Z = reachable from the unmatched left vertices by alternating paths
+        std::vector<char> zl(nL, 0), zr(nR, 0);
+        std::vector<int> stack;
+        for (int l = 0; l < nL; ++l)
+            if (matchL[l] < 0) {
+                zl[l] = 1;
+                stack.push_back(l);
+            }
+        while (!stack.empty()) {
+            const int l = stack.back();
+            stack.pop_back();
+            for (int e = eptr[l]; e < eptr[l + 1]; ++e) {
+                const int r = eidx[e];
+                if (zr[r]) continue;
+                zr[r] = 1;
+                const int l2 = matchR[r];
+                if (l2 >= 0 && !zl[l2]) {
+                    zl[l2] = 1;
+                    stack.push_back(l2);
+                }
+            }
+        }
+        cover.clear();
+        nl = nr = 0;
+        for (int l = 0; l < nL; ++l)
+            if (!zl[l]) {
+                cover.push_back(bl[l]);
+                ++nl;
+            }
+        for (int r = 0; r < nR; ++r)
+            if (zr[r]) {
+                cover.push_back(br[r]);
+                ++nr;
+            }
     }
 
     // split `vs` into A | C | S with no edge between A and C
@@ -67,47 +153,31 @@ struct NdBuilder {
             return;
         }
         long long best = -1;
-        int bestAxis = 0, bestT = n / 2, bestSide = 0;
-        std::vector<int> ord(vs);
-        for (int axis = 0; axis < 3; ++axis) {
+        int bestAxis = 0, bestT = n / 2;
+        std::vector<int> ord(vs), cov;
+        auto by_axis = [&](int axis) {
             std::sort(ord.begin(), ord.end(), [&](int u, int v) {
                 const double xu = X[3 * u + axis], xv = X[3 * v + axis];
                 return xu < xv || (xu == xv && u < v);
             });
+        };
+        for (int axis = 0; axis < 3; ++axis) {
+            by_axis(axis);
             for (int k = -8; k <= 8; ++k) {
                 const int t = std::min(n - 1, std::max(1, n / 2 + k * n / 48));
                 for (int i = 0; i < n; ++i) mark[ord[i]] = i < t ? 0 : 1;
-                int sL = 0, sR = 0;
-                for (int i = 0; i < n; ++i) {
-                    const int v = ord[i], side = mark[v];
-                    bool cut = false;
-                    for (int e = adj_ptr[v]; e < adj_ptr[v + 1] && !cut; ++e) {
-                        const int mu = mark[adj_idx[e]];
-                        cut = mu >= 0 && mu != side;
-                    }
-                    if (cut) (side == 0 ? sL : sR)++;
-                }
-                const long long c0 = cost(t - sL, n - t, sL), c1 = cost(t, n - t - sR, sR);
-                if (best < 0 || c0 < best) { best = c0; bestAxis = axis; bestT = t; bestSide = 0; }
-                if (c1 < best) { best = c1; bestAxis = axis; bestT = t; bestSide = 1; }
+                int nl = 0, nr = 0;
+                min_cover(ord, t, cov, nl, nr);
+                const long long c = cost(t - nl, n - t - nr, nl + nr);
+                if (best < 0 || c < best) { best = c; bestAxis = axis; bestT = t; }
             }
-            for (int v : vs) mark[v] = -1;
         }
-        std::sort(ord.begin(), ord.end(), [&](int u, int v) {
-            const double xu = X[3 * u + bestAxis], xv = X[3 * v + bestAxis];
-            return xu < xv || (xu == xv && u < v);
-        });
+        by_axis(bestAxis);
         for (int i = 0; i < n; ++i) mark[ord[i]] = i < bestT ? 0 : 1;
-        for (int i = 0; i < n; ++i) {
-            const int v = ord[i], side = mark[v];
-            bool cut = false;
-            if (side == bestSide)
-                for (int e = adj_ptr[v]; e < adj_ptr[v + 1] && !cut; ++e) {
-                    const int mu = mark[adj_idx[e]];
-                    cut = mu >= 0 && mu != side;
-                }
-            (cut ? S : side == 0 ? A : C).push_back(v);
-        }
+        int nl = 0, nr = 0;
+        min_cover(ord, bestT, cov, nl, nr);
+        for (int v : cov) mark[v] = 2;
+        for (int v : vs) (mark[v] == 2 ? S : mark[v] == 0 ? A : C).push_back(v);
         for (int v : vs) mark[v] = -1;
         std::sort(A.begin(), A.end());
         std::sort(C.begin(), C.end());
