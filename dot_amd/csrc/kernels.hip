@@ -379,12 +379,22 @@ __global__ __launch_bounds__(256) void build_p_kernel(int n, const double *__res
         else return X;
     }();
     if (threadIdx.x < 64) {
+        // all partial columns first (independent loads in flight together), then the short recurrence
+        double c[HIST_MAX];
+#pragma unroll
+        for (int i = 0; i < HIST_MAX; ++i) c[i] = 0.0;
+        for (int b = threadIdx.x; b < c_blocks; b += 64) {
+#pragma unroll
+            for (int i = 0; i < HIST_MAX; ++i) c[i] += c_partials[(size_t)b * RED_K + i];  // columns >= m: unused
+        }
+#pragma unroll
+        for (int i = 0; i < HIST_MAX; ++i) c[i] = __shfl(wave_sum(c[i]), 0, 64);
         double d[HIST_MAX];
 #pragma unroll
         for (int i = 0; i < HIST_MAX; ++i) {
             d[i] = 0.0;
             if (i < Lr.m) {
-                double yp = wave_sum_partials(c_partials, c_blocks, RED_K, i);
+                double yp = c[i];
 #pragma unroll
                 for (int j = 0; j < HIST_MAX; ++j)
                     if (j < i) yp += d[j] * Lr.sy[j][i];
