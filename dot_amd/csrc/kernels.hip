@@ -246,10 +246,26 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
     for (int v = blockIdx.x * 32 + (threadIdx.x >> 3); v < nV; v += ngroups) {
         double g0 = 0, g1 = 0, g2 = 0;
         const bool fx = fixed[v];
+        const int kb = vf_ptr[v], ke = vf_ptr[v + 1];
+        // everything the pair needs that does not depend on the gathered gradient is requested up front, so
+        // the dependent chain of a pass is two memory round trips (incidence range -> contributions)
+        const int k = 3 * v + (sub < 3 ? sub : 0);
+        double ine = 0.0, gold = 0.0, pk = 0.0, si[HIST_MAX], yi[HIST_MAX];
+        if (sub < 3) {
+            if (!fx && v >= a.iv0 && v < a.iv1) ine = mass[v] * (a.x[k] - a.xt[k]);
+            if (a.make_pair) {
+                gold = a.g_old[k];
+                pk = a.p[k];
+#pragma unroll
+                for (int i = 0; i < HIST_MAX; ++i) {
+                    si[i] = (i < Lr.m) ? Lr.s[i][k] : 0.0;
+                    yi[i] = (i < Lr.m) ? Lr.y[i][k] : 0.0;
+                }
+            }
+        }
         if (!fx) {
-            const int e = vf_ptr[v + 1];
-            for (int k = vf_ptr[v] + sub; k < e; k += 8) {
-                const double *ge = a.gcont + (size_t)3 * k;
+            for (int kk = kb + sub; kk < ke; kk += 8) {
+                const double *ge = a.gcont + (size_t)3 * kk;
                 g0 += ge[0];
                 g1 += ge[1];
                 g2 += ge[2];
@@ -259,16 +275,24 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
         g1 = group8_sum(g1);
         g2 = group8_sum(g2);
         if (sub < 3) {
-            const int k = 3 * v + sub;
             double gn = (sub == 0) ? g0 : ((sub == 1) ? g1 : g2);
-            if (!fx && v >= a.iv0 && v < a.iv1) gn += mass[v] * (a.x[k] - a.xt[k]);
+            gn += ine;
             a.g_new[k] = gn;
             if (a.make_pair) {
-                const double sn = alpha * a.p[k];
-                const double yn = gn - a.g_old[k];
+                const double sn = alpha * pk;
+                const double yn = gn - gold;
                 a.s_new[k] = sn;
                 a.y_new[k] = yn;
-                pair_stats_accum(k, gn, sn, yn, Lr, acc);
+                acc[0] += gn * gn;
+                acc[1] += yn * sn;
+                acc[2] += sn * gn;
+#pragma unroll
+                for (int i = 0; i < HIST_MAX; ++i)
+                    if (i < Lr.m) {
+                        acc[3 + i] += si[i] * yn;
+                        acc[3 + HIST_MAX + i] += sn * yi[i];
+                        acc[3 + 2 * HIST_MAX + i] += si[i] * gn;
+                    }
             } else {
                 acc[0] += gn * gn;
             }
@@ -1051,8 +1075,13 @@ __global__ __launch_bounds__(256) void step_forward_kernel(int n, const double *
     if (threadIdx.x < 64) {
         double alpha = alpha_host;
         if (use_partials) {
-            const double pg = wave_sum_partials(spmv_partials, NB_RED, RED_K, 0);
-            const double pHp = wave_sum_partials(spmv_partials, NB_RED, RED_K, 1);
+            double pg = 0.0, pHp = 0.0;  // both columns in flight together; same order as wave_sum_partials
+            for (int b = threadIdx.x; b < NB_RED; b += 64) {
+                pg += spmv_partials[(size_t)b * RED_K];
+                pHp += spmv_partials[(size_t)b * RED_K + 1];
+            }
+            pg = __shfl(wave_sum(pg), 0, 64);
+            pHp = __shfl(wave_sum(pHp), 0, 64);
             alpha = fmax(alpha_min, fmin(1.0, -pg / pHp));  // Optimizer.cpp:1085
         }
         if (threadIdx.x == 0) {
