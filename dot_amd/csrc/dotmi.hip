@@ -436,8 +436,8 @@ int build_device_mesh(dotmi_handle *h)
         std::vector<uint8_t> live(P.nmax, 0);
         for (size_t nd = 0; nd < h->nd.size(); ++nd) {
             const NdNode &N = h->nd[nd];
-            const int ro = N.a < 0 ? N.off : N.offS;
             const auto &rv = region[nd][ls];
+            const int ro = nd_region_first_row(N, 3 * (int)rv.size());
             for (size_t k = 0; k < rv.size(); ++k) {
                 posOf[rv[k]] = ro + 3 * (int)k;
                 for (int d = 0; d < 3; ++d) {
@@ -452,9 +452,11 @@ int build_device_mesh(dotmi_handle *h)
         int b = 0;
         for (size_t nd = 0; nd < h->nd.size(); ++nd) {
             const NdNode &N = h->nd[nd];
-            const int ro = N.a < 0 ? N.off : N.offS;  // first row of the region
-            const int cb = N.off;                     // rows of a region start at their node's first column
             const int used = 3 * (int)region[nd][ls].size();
+            const int ro = nd_region_first_row(N, used);  // first live row of the region
+            // the rows of a region start at their node's first column (a leaf's padding sits in front of its
+            // live rows and is skipped; 16-column granularity keeps the 128-byte lines whole)
+            const int cb = N.a < 0 ? (ro & ~15) : N.off;
             for (int r0 = ro; r0 < ro + used; r0 += 64) {
                 const int rows = std::min(64, ro + used - r0);
                 tiles.push_back(make_int4(ls, r0, b | (rows << 16), cb));
@@ -701,6 +703,7 @@ struct TriMult {
     int ldc;
     rocblas_stride sC;
     bool trans;
+    bool useTail;  // root only: B is H(.., root separator), zero above the last NdNode::tail rows of every leaf
 
     const double *Q(int i, int j) const { return Wg + i + (size_t)j * lda; }
     // C[ro..ro+m) (+)= alpha * op(Q[qi.., qj..]) * B[rb..rb+k)
@@ -734,7 +737,18 @@ struct TriMult {
     int node(int id, int r, double beta) const
     {
         const NdNode &N = h->nd[id];
-        if (N.a < 0) return dense(N.off, N.size, r, beta);
+        if (N.a < 0) {
+            const int h0 = N.size - N.tail;
+            if (!useTail || h0 <= 0 || beta != 0.0) return dense(N.off, N.size, r, beta);
+            if (trans) {
+                // Q^T [0 ; B_b] = [0 ; Q_bb^T B_b]
+                launch_block_copy(C + r, ldc, (size_t)sC, nullptr, 0, 0, h0, ncols, G.count, G.st);
+                return dense(N.off + h0, N.tail, r + h0, beta);
+            }
+            // Q [0 ; R_b] = [Q_ab R_b ; Q_bb R_b]   (the operand is the R the transposed product left)
+            if (int rc = gemm(h0, N.tail, N.off, N.off + h0, r + h0, r, beta)) return rc;
+            return dense(N.off + h0, N.tail, r + h0, beta);
+        }
         const int m = N.offS - N.off;  // rows of [A ; C]
         if (int rc = node(N.a, r, beta)) return rc;
         if (int rc = node(N.c, r + h->nd[N.a].size, beta)) return rc;
@@ -772,14 +786,14 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id)
     const double one = 1.0, zero = 0.0, mone = -1.0;
     const rocblas_operation Nn = rocblas_operation_none, Tt = rocblas_operation_transpose;
     {
-        TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Hxs, lda, sA, Tb, m, sT, true};
+        TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Hxs, lda, sA, Tb, m, sT, true, id == 0};
         if (int rc = tm.node(N.a, 0, 0.0)) return rc;
         if (int rc = tm.node(N.c, na, 0.0)) return rc;
     }
     RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Tt, Nn, ns, ns, m, &mone, Tb, m, sT, Tb, m, sT, &one, Hss, lda, sA,
                                              batch));
     {
-        TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Tb, m, sT, Hxs, lda, sA, false};
+        TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Tb, m, sT, Hxs, lda, sA, false, id == 0};
         if (int rc = tm.node(N.a, 0, 0.0)) return rc;
         if (int rc = tm.node(N.c, na, 0.0)) return rc;
     }
@@ -1174,8 +1188,8 @@ int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xr
         for (size_t ls = 0; ls < sets.size(); ++ls) {
             std::unordered_map<int, int> posOf;
             for (size_t nd = 0; nd < tree.size(); ++nd) {
-                const int ro = tree[nd].a < 0 ? tree[nd].off : tree[nd].offS;
                 const auto &rv = region[nd][ls];
+                const int ro = nd_region_first_row(tree[nd], 3 * (int)rv.size());
                 for (size_t k = 0; k < rv.size(); ++k) posOf[rv[k]] = ro + 3 * (int)k;
             }
             for (size_t i = 0; i < sets[ls].size(); ++i) pos[base + i] = posOf.at(sets[ls][i]);

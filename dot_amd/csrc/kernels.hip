@@ -1017,8 +1017,14 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const in
     const int ngroups = gridDim.x * 32;
     for (int v = v0 + blockIdx.x * 32 + (threadIdx.x >> 3); v < v1; v += ngroups) {
         double a0 = 0, a1 = 0, a2 = 0;
-        const int e = adj_ptr[v + 1];
-        for (int k = adj_ptr[v] + sub; k < e; k += 8) {
+        const int kb = adj_ptr[v], e = adj_ptr[v + 1];
+        // the row's own p and g do not depend on the column loop: request them first
+        double q0 = 0, q1 = 0, q2 = 0, gg0 = 0, gg1 = 0, gg2 = 0;
+        if (sub == 0) {
+            q0 = p[3 * v]; q1 = p[3 * v + 1]; q2 = p[3 * v + 2];
+            if (g) { gg0 = g[3 * v]; gg1 = g[3 * v + 1]; gg2 = g[3 * v + 2]; }
+        }
+        for (int k = kb + sub; k < e; k += 8) {
             const double *b = Hval + (size_t)9 * k;
             const double *pu = p + 3 * adj_idx[k];
             const double p0 = pu[0], p1 = pu[1], p2 = pu[2];
@@ -1035,9 +1041,8 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const in
                 Hp[3 * v + 1] = a1;
                 Hp[3 * v + 2] = a2;
             }
-            const double q0 = p[3 * v], q1 = p[3 * v + 1], q2 = p[3 * v + 2];
             pHp += q0 * a0 + q1 * a1 + q2 * a2;
-            if (g) pg += q0 * g[3 * v] + q1 * g[3 * v + 1] + q2 * g[3 * v + 2];
+            if (g) pg += q0 * gg0 + q1 * gg1 + q2 * gg2;
         }
     }
     const double s0 = block_sum256(pg, sm);

@@ -15,7 +15,13 @@ struct NdNode {
     int off = 0, size = 0;   // padded scalar range [off, off+size) of this node
     int a = -1, c = -1;      // children (both or none)
     int offS = 0, sizeS = 0; // separator block (internal nodes)
+    int tail = 0;            // leaf: only its last `tail` rows can couple to the root separator
 };
+
+// first padded row of a node's own region (leaf block / separator) in a subdomain that has `used` live
+// scalars there: leaves are right-aligned (padding in front) so that the rows coupled to the root separator
+// end exactly at the end of the leaf, separators are left-aligned
+inline int nd_region_first_row(const NdNode &N, int used) { return N.a < 0 ? N.off + N.size - used : N.offS; }
 
 // vertex adjacency incl. self, ascending (the block pattern of the global Hessian)
 inline void build_adjacency(int nV, int nT, const int *T, std::vector<int> &adj_ptr, std::vector<int> &adj_idx)
@@ -48,6 +54,7 @@ struct NdBuilder {
     const double *X;
     std::vector<int> mark;  // nV, -1
     int maxDepth, minSplit;
+    std::vector<std::vector<int>> rootS;  // per part: the root separator (set once the root is split)
 
     // flop model of the node's factorisation; every part is padded to the largest A, C of the batch, so an
     // unbalanced split costs as much as its bigger half twice
@@ -194,7 +201,27 @@ struct NdBuilder {
         for (auto &v : sets) mx = std::max(mx, 3 * (int)v.size());
         auto make_leaf = [&]() {
             tree[id].size = std::max(64, (mx + 63) / 64 * 64);
+            tree[id].tail = tree[id].size;
             region[id] = sets;
+            if (!rootS.empty()) {
+                // vertices next to the root separator last: H(leaf, rootS) is zero above them, which the
+                // root's triangular products exploit (TriMult)
+                int mt = 0;
+                for (int p = 0; p < np; ++p) {
+                    for (int v : rootS[p]) mark[v] = 3;
+                    std::vector<int> in, bd;
+                    for (int v : sets[p]) {
+                        bool adj = false;
+                        for (int e = adj_ptr[v]; e < adj_ptr[v + 1] && !adj; ++e) adj = mark[adj_idx[e]] == 3;
+                        (adj ? bd : in).push_back(v);
+                    }
+                    for (int v : rootS[p]) mark[v] = -1;
+                    mt = std::max(mt, 3 * (int)bd.size());
+                    in.insert(in.end(), bd.begin(), bd.end());
+                    region[id][p] = in;
+                }
+                tree[id].tail = std::min(tree[id].size, (mt + 63) / 64 * 64);
+            }
             return id;
         };
         if (depth >= maxDepth || mx < minSplit) return make_leaf();
@@ -206,6 +233,7 @@ struct NdBuilder {
             ms = std::max(ms, 3 * (int)Ss[p].size());
         }
         if (mc == 0) return make_leaf();
+        if (depth == 0) rootS = Ss;
         const int a = build(As, depth + 1);
         const int c = build(Cs, depth + 1);
         tree[id].a = a;
@@ -229,7 +257,7 @@ struct NdBuilder {
 
 
 // layout of the given vertex sets (one per owned subdomain): tree[0] is the root, region[node][part] the
-// vertices of the node's leaf block / separator, ascending; returns the padded size (lda, multiple of 64)
+// vertices of the node's leaf block / separator in layout order; returns the padded size (lda, multiple of 64)
 inline int nd_plan(const std::vector<std::vector<int>> &partVerts, int nV, const std::vector<int> &adj_ptr,
                    const std::vector<int> &adj_idx, const double *Xrest, int levels, int minSplit,
                    std::vector<NdNode> &tree, std::vector<std::vector<std::vector<int>>> &region)
