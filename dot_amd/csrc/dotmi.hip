@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -534,7 +535,13 @@ int build_device_mesh(dotmi_handle *h)
             if (N.a >= 0) height[id] = 1 + std::max(height[N.a], height[N.c]);
             hmax = std::max(hmax, height[id]);
         }
-        auto dense = [](int sz) { return (size_t)(sz / 2) * (sz / 2 + CHOL_NB) + 64 * 64; };
+        // dense recursion: R12 of every level stays live while the level below runs
+        std::function<size_t(int)> dense = [&](int sz) -> size_t {
+            if (sz <= 2 * CHOL_NB) return 0;
+            const int n1 = ((sz / CHOL_NB) / 2) * CHOL_NB, n2 = sz - n1;
+            const size_t r = (size_t)n1 * n2;
+            return std::max(dense(n1), r + std::max(r, dense(n2)));
+        };
         h->phases.assign(hmax + 1, {});
         h->tmp_stride = 0;
         for (int ht = 0; ht <= hmax; ++ht) {
@@ -545,7 +552,8 @@ int build_device_mesh(dotmi_handle *h)
                 dotmi_handle::FactorUnit U;
                 U.node = (int)id;
                 U.tmpOff = off;
-                off += N.a < 0 ? dense(N.size) : std::max((size_t)(N.offS - N.off) * N.sizeS, dense(N.sizeS));
+                const size_t rs = (size_t)(N.offS - N.off) * N.sizeS;
+                off += (N.a < 0 ? dense(N.size) : rs + std::max(rs, dense(N.sizeS))) + 64;
                 h->phases[ht].push_back(U);
             }
             h->tmp_stride = std::max(h->tmp_stride, off);
@@ -647,6 +655,11 @@ int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, in
     const int c = ((n2 / CHOL_NB) / 2) * CHOL_NB, d = n2 - c;
     const bool split = n1 >= 512 && a > 0 && c > 0;
     const double *Qaa = Q11, *Qab = Q11 + (size_t)a * lda, *Qbb = Q11 + a + (size_t)a * lda;
+    // R12 stays in this level's scratch across the recursion into H22 (which gets the scratch behind it);
+    // afterwards Q12 = -Q11 (R12 Q22) lands directly in H12 -- no staging copy.
+    double *T2 = Tb + (size_t)n1 * n2;
+    dotmi_handle::FactorGroup G2 = G;
+    G2.tmpOff = G.tmpOff + (size_t)n1 * n2;
     if (split) {
         // R12 = Q11^T H12 :  R_a = Qaa^T H_a ;  R_b = Qab^T H_a + Qbb^T H_b
         RBCHECK(h, gemm(T, N, a, n2, a, &one, Qaa, lda, sA, H12, lda, sA, &zero, Tb, ldt, sT));
@@ -657,27 +670,26 @@ int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, in
         RBCHECK(h, gemm(T, N, c, c, n1, &mone, Rc, ldt, sT, Rc, ldt, sT, &one, H22, lda, sA));
         RBCHECK(h, gemm(T, N, c, d, n1, &mone, Rc, ldt, sT, Rd, ldt, sT, &one, H22 + (size_t)c * lda, lda, sA));
         RBCHECK(h, gemm(T, N, d, d, n1, &mone, Rd, ldt, sT, Rd, ldt, sT, &one, H22 + c + (size_t)c * lda, lda, sA));
-        // U = Q11 R12 -> H12 :  U_a = Qaa R_a + Qab R_b ;  U_b = Qbb R_b
-        RBCHECK(h, gemm(N, N, a, n2, a, &one, Qaa, lda, sA, Tb, ldt, sT, &zero, H12, lda, sA));
-        RBCHECK(h, gemm(N, N, a, n2, b, &one, Qab, lda, sA, Tb + a, ldt, sT, &one, H12, lda, sA));
-        RBCHECK(h, gemm(N, N, b, n2, b, &one, Qbb, lda, sA, Tb + a, ldt, sT, &zero, H12 + a, lda, sA));
     } else {
         RBCHECK(h, gemm(T, N, n1, n2, n1, &one, Q11, lda, sA, H12, lda, sA, &zero, Tb, ldt, sT));
         RBCHECK(h, gemm(T, N, n2, n2, n1, &mone, Tb, ldt, sT, Tb, ldt, sT, &one, H22, lda, sA));
-        RBCHECK(h, gemm(N, N, n1, n2, n1, &one, Q11, lda, sA, Tb, ldt, sT, &zero, H12, lda, sA));
     }
-    if (int rc = chol_inv_node(h, G, o + n1, n2)) return rc;
-    // Q12 = -U Q22
+    if (int rc = chol_inv_node(h, G2, o + n1, n2)) return rc;
     if (split) {
+        // T2 = R12 Q22 :  T2_c = R_c Qcc ;  T2_d = R_c Qcd + R_d Qdd
         const double *Qcc = H22, *Qcd = H22 + (size_t)c * lda, *Qdd = H22 + c + (size_t)c * lda;
-        const double *Uc = H12, *Ud = H12 + (size_t)c * lda;
-        RBCHECK(h, gemm(N, N, n1, c, c, &mone, Uc, lda, sA, Qcc, lda, sA, &zero, Tb, ldt, sT));
-        RBCHECK(h, gemm(N, N, n1, d, c, &mone, Uc, lda, sA, Qcd, lda, sA, &zero, Tb + (size_t)c * ldt, ldt, sT));
-        RBCHECK(h, gemm(N, N, n1, d, d, &mone, Ud, lda, sA, Qdd, lda, sA, &one, Tb + (size_t)c * ldt, ldt, sT));
+        const double *Rc = Tb, *Rd = Tb + (size_t)c * ldt;
+        RBCHECK(h, gemm(N, N, n1, c, c, &one, Rc, ldt, sT, Qcc, lda, sA, &zero, T2, ldt, sT));
+        RBCHECK(h, gemm(N, N, n1, d, c, &one, Rc, ldt, sT, Qcd, lda, sA, &zero, T2 + (size_t)c * ldt, ldt, sT));
+        RBCHECK(h, gemm(N, N, n1, d, d, &one, Rd, ldt, sT, Qdd, lda, sA, &one, T2 + (size_t)c * ldt, ldt, sT));
+        // Q12 = -Q11 T2 :  Q12_a = -(Qaa T2_a + Qab T2_b) ;  Q12_b = -Qbb T2_b
+        RBCHECK(h, gemm(N, N, a, n2, a, &mone, Qaa, lda, sA, T2, ldt, sT, &zero, H12, lda, sA));
+        RBCHECK(h, gemm(N, N, a, n2, b, &mone, Qab, lda, sA, T2 + a, ldt, sT, &one, H12, lda, sA));
+        RBCHECK(h, gemm(N, N, b, n2, b, &mone, Qbb, lda, sA, T2 + a, ldt, sT, &zero, H12 + a, lda, sA));
     } else {
-        RBCHECK(h, gemm(N, N, n1, n2, n2, &mone, H12, lda, sA, H22, lda, sA, &zero, Tb, ldt, sT));
+        RBCHECK(h, gemm(N, N, n1, n2, n2, &one, Tb, ldt, sT, H22, lda, sA, &zero, T2, ldt, sT));
+        RBCHECK(h, gemm(N, N, n1, n2, n1, &mone, Q11, lda, sA, T2, ldt, sT, &zero, H12, lda, sA));
     }
-    launch_block_copy(H12, lda, (size_t)sA, Tb, ldt, (size_t)sT, n1, n2, batch, G.st);
     // the strictly lower block must read as zero when Q is used as a dense GEMM operand one level up
     // and when the back-solve kernel streams whole memory rows
     launch_block_copy(H21, lda, (size_t)sA, nullptr, 0, 0, n2, n1, batch, G.st);
@@ -792,15 +804,19 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id)
     }
     RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Tt, Nn, ns, ns, m, &mone, Tb, m, sT, Tb, m, sT, &one, Hss, lda, sA,
                                              batch));
+    // R stays in scratch across the factorisation of the separator block; [Q_AS ; Q_CS] = -blockdiag(Q_A, Q_C) (R Q_S)
+    // is then written straight into place
+    dotmi_handle::FactorGroup G2 = G;
+    G2.tmpOff = G.tmpOff + (size_t)m * ns;
+    if (int rc = chol_inv_node(h, G2, N.offS, ns)) return rc;
+    double *T2 = Tb + (size_t)m * ns;
+    RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Nn, Nn, m, ns, ns, &one, Tb, m, sT, Hss, lda, sA, &zero, T2, m, sT,
+                                             batch));
     {
-        TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Tb, m, sT, Hxs, lda, sA, false, id == 0};
+        TriMult tm{h, G, Wg, lda, ns, sA, -1.0, T2, m, sT, Hxs, lda, sA, false, id == 0};
         if (int rc = tm.node(N.a, 0, 0.0)) return rc;
         if (int rc = tm.node(N.c, na, 0.0)) return rc;
     }
-    if (int rc = chol_inv_node(h, G, N.offS, ns)) return rc;
-    RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Nn, Nn, m, ns, ns, &mone, Hxs, lda, sA, Hss, lda, sA, &zero, Tb, m,
-                                             sT, batch));
-    launch_block_copy(Hxs, lda, (size_t)sA, Tb, m, (size_t)sT, m, ns, batch, G.st);
     // rows S, columns [A C] of the lower part hold the symmetric fill of H: clear them
     launch_block_copy(Wg + N.offS + (size_t)N.off * lda, lda, (size_t)sA, nullptr, 0, 0, ns, m, batch, G.st);
     return 0;
