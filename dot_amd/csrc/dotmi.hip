@@ -106,7 +106,8 @@ struct dotmi_handle {
     double *S[HIST_MAX + 1] = {nullptr}, *Y[HIST_MAX + 1] = {nullptr};
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
     double *alpha_dev = nullptr;
-    int *info_dev = nullptr;
+    int *info_dev = nullptr, *h_info = nullptr;  // per owned part: failing pivot (device / pinned copy)
+    bool wDirty = false;                         // W has been through a factorisation (targeted clearing applies)
     size_t tmp_stride = 0;
     int *didx = nullptr;
     double *dpos = nullptr;
@@ -123,6 +124,7 @@ struct dotmi_handle {
     std::vector<int> slotTimed;                // per enqueued slot: index of its event pair in evPre, or -1
     std::vector<int> slotKind;                 // last step: kind of every enqueued slot (1 = ran a back-solve)
     int logCap = 0, kindCap = 0;
+    int logPending = 0;                        // device-loop log entries not fetched yet
     int prevSlots = 0;                         // slots the previous step's loop took (enqueue-ahead horizon)
     int timeStride = 8;                        // DOTMI_FLAG_TIME_BACKSOLVE brackets every timeStride-th back-solve
     int timeCount = 0;
@@ -563,6 +565,8 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = dalloc(h, &P.ppart, (size_t)P.nParts * P.nbmax * P.nmax)) return rc;
     if (int rc = dalloc(h, &P.psub, (size_t)P.nParts * P.nmax)) return rc;
     if (int rc = dalloc(h, &h->info_dev, (size_t)std::max(P.nParts, 1))) return rc;
+    HIPCHECK(h, hipHostMalloc((void **)&h->h_info, sizeof(int) * std::max(P.nParts, 1)));
+    memset(h->h_info, 0, sizeof(int) * std::max(P.nParts, 1));
 
     // element ownership + inertia vertex slice
     if (h->shardElems) {
@@ -886,31 +890,47 @@ int run_factor(dotmi_handle *h)
     return issue_factor(h);
 }
 
-// element Hessians -> global H -> dense sub-matrices -> inverse Cholesky factors
-// (DOTTimeStepper::updateHessianAndFactor, DOTTimeStepper.cpp:349-380)
-int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
+int refactor_issue(dotmi_handle *h, const double *x)
 {
     HIPCHECK(h, hipEventRecord(h->ev0, h->st));
     launch_elem_hessians(h->M, h->mat, h->dtSq, x, h->He, h->st);
     launch_assemble(h->M, h->He, h->Hval, h->st);
+    // only the blocks the factorisation leaves non-zero are cleared before the refill: the leaf squares and
+    // the separator panels; the (A,C) blocks and the cleared mirror panels stay zero for the handle's life
+    if (h->wDirty) {
+        const size_t sA = (size_t)h->P.nmax * h->P.nmax;
+        for (const NdNode &N : h->nd) {
+            if (N.a < 0)
+                launch_block_copy(h->P.W + N.off + (size_t)N.off * h->P.nmax, h->P.nmax, sA, nullptr, 0, 0, N.size, N.size,
+                                  h->P.nParts, h->st);
+            else if (N.sizeS > 0)  // memory rows S, columns [off, offS + sizeS)
+                launch_block_copy(h->P.W + N.off + (size_t)N.offS * h->P.nmax, h->P.nmax, sA, nullptr, 0, 0,
+                                  N.offS + N.sizeS - N.off, N.sizeS, h->P.nParts, h->st);
+        }
+    } else if (h->P.nParts > 0) {
+        HIPCHECK(h, hipMemsetAsync(h->P.W, 0, (size_t)h->P.nParts * h->P.nmax * h->P.nmax * sizeof(double), h->st));
+        h->wDirty = true;
+    }
     launch_dense_fill(h->P, h->Hval, h->st);
     HIPCHECK(h, hipEventRecord(h->ev1, h->st));
     if (h->P.nParts > 0) {
         HIPCHECK(h, hipMemsetAsync(h->info_dev, 0, sizeof(int) * h->P.nParts, h->st));
         if (int rc = run_factor(h)) return rc;
-        std::vector<int> info(h->P.nParts);
-        HIPCHECK(h, hipMemcpyAsync(info.data(), h->info_dev, sizeof(int) * h->P.nParts, hipMemcpyDeviceToHost,
-                                   h->st));
-        HIPCHECK(h, hipStreamSynchronize(h->st));
-        for (int i = 0; i < h->P.nParts; ++i)
-            if (info[i] != 0) {
-                h->err = "subdomain " + std::to_string(h->p0 + i) +
-                         " Hessian not positive definite (pivot " + std::to_string(info[i]) + ")";
-                return DOTMI_E_NOTSPD;
-            }
+        HIPCHECK(h, hipMemcpyAsync(h->h_info, h->info_dev, sizeof(int) * h->P.nParts, hipMemcpyDeviceToHost, h->st));
     }
     HIPCHECK(h, hipEventRecord(h->ev2, h->st));
-    HIPCHECK(h, hipEventSynchronize(h->ev2));
+    return 0;
+}
+
+// after the stream has been synchronised: SPD check of every owned subdomain and the two timings
+int refactor_finish(dotmi_handle *h, double *ms_hess, double *ms_fact)
+{
+    for (int i = 0; i < h->P.nParts; ++i)
+        if (h->h_info[i] != 0) {
+            h->err = "subdomain " + std::to_string(h->p0 + i) + " Hessian not positive definite (pivot " +
+                     std::to_string(h->h_info[i]) + ")";
+            return DOTMI_E_NOTSPD;
+        }
     float a = 0, b = 0;
     hipEventElapsedTime(&a, h->ev0, h->ev1);
     hipEventElapsedTime(&b, h->ev1, h->ev2);
@@ -918,6 +938,15 @@ int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
     if (ms_fact) *ms_fact += b;
     HIPCHECK(h, hipGetLastError());
     return 0;
+}
+
+// element Hessians -> global H -> dense sub-matrices -> inverse Cholesky factors
+// (DOTTimeStepper::updateHessianAndFactor, DOTTimeStepper.cpp:349-380)
+int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
+{
+    if (int rc = refactor_issue(h, x)) return rc;
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    return refactor_finish(h, ms_hess, ms_fact);
 }
 
 // p = D^-1 sum_s R_s^T W_s R_s q   (DOTTimeStepper.cpp:406-450); leaves y_i.z partials in partC
@@ -1115,19 +1144,13 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     h->g_trial = C.g_trial;
     h->numLineSearch += C.halvings;
     h->energy_evals += C.evals;
-    const int nlog = std::min(C.iter, h->logCap);
-    h->log_alpha.resize(nlog);
-    h->log_E.resize(nlog);
-    h->log_g2.resize(nlog);
-    if (nlog > 0) {
-        HIPCHECK(h, hipMemcpy(h->log_alpha.data(), C.log_alpha, sizeof(double) * nlog, hipMemcpyDeviceToHost));
-        HIPCHECK(h, hipMemcpy(h->log_E.data(), C.log_E, sizeof(double) * nlog, hipMemcpyDeviceToHost));
-        HIPCHECK(h, hipMemcpy(h->log_g2.data(), C.log_g2, sizeof(double) * nlog, hipMemcpyDeviceToHost));
-    }
+    // the per-iteration log stays on the device until somebody asks for it (dotmi_last_iter_log)
+    h->logPending = std::min(C.iter, h->logCap);
     // which of the enqueued slots really ran a back-solve (for DOTMI_FLAG_TIME_BACKSOLVE)
     h->slotKind.assign(enq, 0);
     const int nk = std::min(std::min(C.slots, enq), h->kindCap);
-    if (nk > 0) HIPCHECK(h, hipMemcpy(h->slotKind.data(), h->dkind, sizeof(int) * nk, hipMemcpyDeviceToHost));
+    if (nk > 0 && (h->flags & DOTMI_FLAG_TIME_BACKSOLVE))
+        HIPCHECK(h, hipMemcpy(h->slotKind.data(), h->dkind, sizeof(int) * nk, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -1236,6 +1259,7 @@ void dotmi_destroy(dotmi_handle *h)
     if (h->h_partR) hipHostFree(h->h_partR);
     if (h->h_alpha) hipHostFree(h->h_alpha);
     if (h->h_ctl) hipHostFree(h->h_ctl);
+    if (h->h_info) hipHostFree(h->h_info);
     if (h->h_flags) hipHostFree(h->h_flags);
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
@@ -1513,6 +1537,20 @@ double dotmi_target_gres(const dotmi_handle *h) { return h ? h->targetGRes : 0.0
 int dotmi_last_iter_log(const dotmi_handle *h, int32_t cap, double *alpha, double *E, double *g2)
 {
     if (!h) return DOTMI_E_INVALID;
+    if (h->logPending > 0) {
+        dotmi_handle *hm = const_cast<dotmi_handle *>(h);
+        const int nlog = h->logPending;
+        hm->logPending = 0;
+        hm->log_alpha.resize(nlog);
+        hm->log_E.resize(nlog);
+        hm->log_g2.resize(nlog);
+        if (hipSetDevice(h->device) != hipSuccess ||
+            hipMemcpy(hm->log_alpha.data(), h->dlog, sizeof(double) * nlog, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hm->log_E.data(), h->dlog + h->logCap, sizeof(double) * nlog, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(hm->log_g2.data(), h->dlog + 2 * (size_t)h->logCap, sizeof(double) * nlog, hipMemcpyDeviceToHost) !=
+                hipSuccess)
+            return DOTMI_E_DEVICE;
+    }
     const int n = std::min<int>(cap, (int)h->log_alpha.size());
     for (int i = 0; i < n; ++i) {
         if (alpha) alpha[i] = h->log_alpha[i];
@@ -1534,6 +1572,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     h->log_alpha.clear();
     h->log_E.clear();
     h->log_g2.clear();
+    h->logPending = 0;
     const long long ls0 = h->numLineSearch;
     double ms_hess = 0, ms_fact = 0;
 
@@ -1636,12 +1675,14 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     if (failed) status = 2;
     else {
         if (it >= h->iterCap) status = 2;
-        if (int rc = refactor(h, h->x, &ms_hess, &ms_fact)) return rc;
+        if (int rc = refactor_issue(h, h->x)) return rc;
     }
     // BE update (Optimizer.cpp:354-361)
     launch_be_update(h->nV, h->M.fixed, h->x, h->xn, h->v, h->xt, h->dt, h->gdtsq, h->st);
     HIPCHECK(h, hipStreamSynchronize(h->st));
     HIPCHECK(h, hipGetLastError());
+    if (!failed)
+        if (int rc = refactor_finish(h, &ms_hess, &ms_fact)) return rc;
     if (st) {
         memset(st, 0, sizeof(*st));
         st->iters = it;
@@ -1806,6 +1847,7 @@ int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *Mout, 
         HIPCHECK(h, hipMalloc((void **)&tmp, sizeof(double) * (size_t)h->P.nParts * lda * lda));
         DevParts Pt = h->P;
         Pt.W = tmp;
+        HIPCHECK(h, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)h->P.nParts * lda * lda, h->st));
         launch_dense_fill(Pt, h->Hval, h->st);
         W = tmp + (size_t)ls * lda * lda;
     }

@@ -1462,7 +1462,7 @@ __global__ void pad_identity_kernel(int npad, const long long *__restrict__ dst,
 
 void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st)
 {
-    hipMemsetAsync(P.W, 0, (size_t)P.nParts * P.nmax * P.nmax * sizeof(double), st);
+    // the caller has cleared W (or the blocks of it a factorisation dirtied)
     if (P.nfill) {
         const long long tot = (long long)P.nfill * 9;
         hipLaunchKernelGGL(dense_fill_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P.nfill,
