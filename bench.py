@@ -107,8 +107,10 @@ def main():
     # HBM traffic of one back-solve from the PMC counters (FETCH_SIZE / WRITE_SIZE need their own rocprofv3
     # passes, so they are collected separately on the same kernel + workload and committed under profiles/)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01_backsolve_pmc.json")
-    if world == 1 and os.path.exists(pmc):
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_backsolve_pmc.json")))
+    pmc = pmcs[-1] if pmcs else ""
+    if world == 1 and pmc:
         with open(pmc) as f:
             rec = json.load(f)
         if rec.get("workload") == args.workload:

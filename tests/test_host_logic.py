@@ -211,3 +211,46 @@ def test_cpp_scene_layer_matches_python(tmp_path, script):
         tok = out[1 + k].split()
         assert int(tok[3]) == len(idx)
         assert np.allclose([float(tok[5]), float(tok[6]), float(tok[7])], pos.sum(axis=0), rtol=1e-14, atol=1e-13)
+
+
+@pytest.mark.parametrize("workload,levels", [("bunny5K_LTSS", 2), ("bar17K_twist", 2), ("bar17K_twist", 1),
+                                             ("horse7K_stretch", 3)])
+def test_nested_dissection_layout_is_a_valid_separator_ordering(workload, levels):
+    """dotmi_plan_layout (host only): the order the dense subdomain blocks are laid out in.  What the factor
+    kernels and the back-solve rely on: every local vertex has its own 3 padded slots inside its region; the
+    tree's ranges nest; and no mesh edge joins the A and C sides of any dissection node -- i.e. for every
+    coupled pair the earlier position is not left of the first column the later one's rows start at."""
+    from dot_amd.sharding import plan_layout
+    sc, ep, nparts = load_workload(workload)
+    nodes, nmax, pos, verts = plan_layout(sc.V_rest, sc.T, ep, nparts, levels=levels, min_split=256)
+    assert nmax % 64 == 0 and nmax == nodes[0][1] and nodes[0][0] == 0
+    first_col = np.zeros(nmax, dtype=np.int64)      # first column a row at this position can be non-zero in
+    region_of = -np.ones(nmax, dtype=np.int64)
+    for i, (off, size, a, c, offS, sizeS) in enumerate(nodes):
+        if a < 0:
+            assert c < 0 and size % 64 == 0
+            first_col[off:off + size] = off
+            region_of[off:off + size] = i
+        else:
+            A, C = nodes[a], nodes[c]
+            assert A[0] == off and C[0] == off + A[1] and offS == C[0] + C[1] and size == A[1] + C[1] + sizeS
+            first_col[offS:offS + sizeS] = off
+            region_of[offS:offS + sizeS] = i
+    assert (region_of >= 0).all()
+    # edges of the mesh = couplings of the Hessian
+    E = np.unique(np.sort(np.concatenate([sc.T[:, [i, j]] for i in range(4) for j in range(i + 1, 4)]), axis=1), axis=0)
+    for p, (ps, vs) in enumerate(zip(pos, verts)):
+        assert ps.size == vs.size and ps.min() >= 0 and ps.max() + 3 <= nmax
+        assert (np.diff(np.sort(ps)) >= 3).all()            # three slots per vertex, no overlap
+        assert (region_of[ps] == region_of[ps + 2]).all()   # ... inside one region
+        where = -np.ones(sc.V_rest.shape[0], dtype=np.int64)
+        where[vs] = ps
+        pu, pv = where[E[:, 0]], where[E[:, 1]]
+        both = (pu >= 0) & (pv >= 0)
+        lo, hi = np.minimum(pu, pv)[both], np.maximum(pu, pv)[both]
+        assert (lo >= first_col[hi]).all(), f"part {p}: an edge crosses a dissection"
+    # the layout pays off: strictly fewer structural non-zeros than the dense triangle on the big workload
+    if workload == "bar17K_twist":
+        ps, vs = pos[0], verts[0]
+        nnz = sum(int(((ps >= first_col[q]) & (ps <= q)).sum()) for q in ps)
+        assert nnz < 0.7 * ps.size * (ps.size + 1) / 2

@@ -1,11 +1,10 @@
 timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|^E" | head -20
-for dl in 1 0; do
-echo "== device loop $dl"
-DOTMI_DEVICE_LOOP=$dl timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+for ts in 100000 1536 800 400; do
+echo "== tile split $ts"
+DOTMI_TILE_SPLIT=$ts timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); r=d['roofline']; print(d['value'], d['step_breakdown_ms'], r['avg_launch_ms'], r['launches_timed'], r['frac'], d['iters_per_frame'])
 "
 done
-bash tools/prof_nd.sh 2>&1 | grep -E "loop_control|gather|build_q|step_forward|elem_energy"
