@@ -678,12 +678,12 @@ __device__ __forceinline__ double readlane_f64(double v, int srclane)
 // are wave-uniform broadcasts (v_readlane), so there is no LDS traffic and no barrier in the O(NB^3)
 // part; all loops are fully unrolled so the register arrays are statically indexed.
 // Returns 0, or 1 + the index of the first non-positive pivot.
-__device__ __forceinline__ int wave_chol_inv64(double (&a)[CHOL_NB], double (&x)[CHOL_NB], int lane)
+template <int NB>
+__device__ __forceinline__ int wave_chol_inv(double (&a)[NB], double (&x)[NB], int lane)
 {
-    constexpr int NB = CHOL_NB;
-    static_assert(NB == 64, "one lane per row");
+    static_assert(NB <= 64, "one lane per row");
     int bad = 0;
-    double mypiv = 1.0;  // lane k keeps pivot k, so the 64 square roots / reciprocals are done in one go
+    double mypiv = 1.0;  // lane k keeps pivot k, so the square roots / reciprocals are done in one go
     // right-looking Cholesky with deferred column scaling: A(i,j) -= A(i,k) A(j,k) / A(k,k)
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
@@ -717,36 +717,111 @@ __device__ __forceinline__ int wave_chol_inv64(double (&a)[CHOL_NB], double (&x)
     return bad;
 }
 
-__global__ __launch_bounds__(64) void chol_inv_base_kernel(double *__restrict__ W, int nmax, int o,
-                                                           int *__restrict__ info)
+// 32 x 32 x 32 product on LDS operands by all 256 threads (2 x 2 register tiles):
+//   store(i, j, sum_k A(i,k) B(k,j)).  The caller separates reads and writes of shared operands.
+template <class FA, class FB, class FS>
+__device__ __forceinline__ void lds_gemm32(FA A, FB B, FS store, int tid)
+{
+    const int i0 = (tid >> 4) * 2, j0 = (tid & 15) * 2;
+    double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+        const double a0 = A(i0, k), a1 = A(i0 + 1, k), b0 = B(k, j0), b1 = B(k, j0 + 1);
+        c00 = __builtin_fma(a0, b0, c00);
+        c01 = __builtin_fma(a0, b1, c01);
+        c10 = __builtin_fma(a1, b0, c10);
+        c11 = __builtin_fma(a1, b1, c11);
+    }
+    __syncthreads();
+    store(i0, j0, c00);
+    store(i0, j0 + 1, c01);
+    store(i0 + 1, j0, c10);
+    store(i0 + 1, j0 + 1, c11);
+    __syncthreads();
+}
+
+// X = chol(A)^-1 of a 64 x 64 block held in LDS, by one workgroup of 256 threads: the same 2 x 2 recursion
+// as chol_inv_node(), one level further down -- two 32 x 32 factor+invert steps in the registers of wave 0
+// (a quarter of the 64 x 64 single-wave work each) and four 32^3 products by everybody.
+//   G: A on entry (row-major, symmetric), destroyed.   X: X(i,k) on exit, zero above the diagonal.
+//   T: 32 x 33 scratch.   Returns 0 or 1 + index of the first non-positive pivot (valid in wave 0).
+constexpr int LD64 = CHOL_NB + 1;
+__device__ __forceinline__ int block_chol_inv64(double (*G)[LD64], double (*X)[LD64], double (*T)[33], int tid)
+{
+    const int lane = tid & 63, wv = tid >> 6;
+    int bad = 0;
+    if (wv == 0) {
+        double a[32], x[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) a[j] = G[lane & 31][j];
+        bad = wave_chol_inv<32>(a, x, lane);
+        if (lane < 32) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) X[i][lane] = x[i];
+        }
+    }
+    __syncthreads();
+    // R12(i,j) = sum_k X11(i,k) A12(k,j)
+    lds_gemm32([&](int i, int k) { return X[i][k]; }, [&](int k, int j) { return G[k][32 + j]; },
+               [&](int i, int j, double v) { T[i][j] = v; }, tid);
+    // A22(c,d) -= sum_k R12(k,c) R12(k,d)
+    lds_gemm32([&](int c, int k) { return T[k][c]; }, [&](int k, int d) { return T[k][d]; },
+               [&](int c, int d, double v) { G[32 + c][32 + d] -= v; }, tid);
+    if (wv == 0) {
+        double a[32], x[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) a[j] = G[32 + (lane & 31)][32 + j];
+        const int b2 = wave_chol_inv<32>(a, x, lane);
+        if (bad == 0 && b2) bad = 32 + b2;
+        if (lane < 32) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) X[32 + i][32 + lane] = x[i];
+        }
+    }
+    __syncthreads();
+    // V(c,j) = sum_k R12(k,c) X11(k,j)  -> G11 (free by now)
+    lds_gemm32([&](int c, int k) { return T[k][c]; }, [&](int k, int j) { return X[k][j]; },
+               [&](int c, int j, double v) { G[c][j] = v; }, tid);
+    // X21(i,j) = -sum_c X22(i,c) V(c,j) ;  X12 = 0
+    lds_gemm32([&](int i, int c) { return X[32 + i][32 + c]; }, [&](int c, int j) { return G[c][j]; },
+               [&](int i, int j, double v) {
+                   X[32 + i][j] = -v;
+                   X[i][32 + j] = 0.0;
+               },
+               tid);
+    return bad;
+}
+
+__global__ __launch_bounds__(256) void chol_inv_base_kernel(double *__restrict__ W, int nmax, int o,
+                                                            int *__restrict__ info)
 {
     constexpr int NB = CHOL_NB;
-    __shared__ double xt[NB][NB + 1];
+    __shared__ double G[NB][LD64], X[NB][LD64], T[32][33];
     double *Ws = W + (size_t)blockIdx.x * nmax * nmax + (size_t)o * nmax + o;
-    const int lane = threadIdx.x;
-    double a[NB], x[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) a[j] = Ws[(size_t)j * nmax + lane];  // a[j] = A(lane, j) (symmetric block)
-    const int bad = wave_chol_inv64(a, x, lane);
-    // store Q = X^T column-major, i.e. memory row i, position k <- X(i,k) (zero for k > i); through
-    // LDS so the global store is coalesced
-#pragma unroll
-    for (int i = 0; i < NB; ++i) xt[lane][i] = x[i];  // xt[c][i] = X(i,c)
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int j = idx / NB, i = idx % NB;
+        G[i][j] = Ws[(size_t)j * nmax + i];  // A(i,j): column-major upper block, symmetric
+    }
     __syncthreads();
-#pragma unroll 8
-    for (int i = 0; i < NB; ++i) Ws[(size_t)i * nmax + lane] = xt[lane][i];
-    if (bad) atomicMax(info + blockIdx.x, o + bad);
+    const int bad = block_chol_inv64(G, X, T, tid);
+    // store Q = X^T column-major, i.e. memory row i, position k <- X(i,k) (zero for k > i)
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int i = idx / NB, k = idx % NB;
+        Ws[(size_t)i * nmax + k] = X[i][k];
+    }
+    if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + bad);
 }
 
 void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipStream_t st)
 {
-    hipLaunchKernelGGL(chol_inv_base_kernel, dim3(count), dim3(64), 0, st, W, nmax, o, info);
+    hipLaunchKernelGGL(chol_inv_base_kernel, dim3(count), dim3(256), 0, st, W, nmax, o, info);
 }
 
 // The whole 128 x 128 node of the recursion in one launch (one workgroup per subdomain, LDS resident):
 //   Q11 = R11^-1 ; R12 = Q11^T H12 ; H22 -= R12^T R12 ; Q22 = R22^-1 ; Q12 = -(Q11 R12) Q22 ; H21 = 0
-// The two 64 x 64 factor+invert steps run on wave 0 in registers (wave_chol_inv64); the four 64^3
-// products are done by all 256 threads from LDS (4 x 4 register tiles).  Replaces 2 base launches +
+// The two 64 x 64 factor+invert steps are block_chol_inv64(); the four 64^3 products are done by all 256
+// threads from LDS (4 x 4 register tiles).  Replaces 2 base launches +
 // 4 tiny batched GEMMs + 2 block copies, whose launch latencies dominated the bottom of the recursion.
 __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restrict__ W, int nmax, int o,
                                                                int *__restrict__ info)
@@ -754,24 +829,23 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
     constexpr int NB = CHOL_NB, LD = NB + 1;
     __shared__ double X1[NB][LD];  // X11(i,k)
     __shared__ double Bf[NB][LD];  // H12 -> R12 -> U -> Q12          (row index = first block index)
-    __shared__ double Gf[NB][LD];  // H22 -> H22 - R12^T R12 -> X22(i,k)
+    __shared__ double Gf[NB][LD];  // H11, then H22 -> H22 - R12^T R12
+    __shared__ double X2[NB][LD];  // X22(i,k)
+    __shared__ double Tq[32][33];
     double *Ws = W + (size_t)blockIdx.x * nmax * nmax;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
     // column-major element (r, c) of the block matrix lives at Ws[(size_t)c * nmax + r]
     for (int idx = tid; idx < NB * NB; idx += 256) {
         const int j = idx / NB, k = idx % NB;
+        Gf[k][j] = Ws[(size_t)(o + j) * nmax + o + k];            // H11(k,j)
         Bf[k][j] = Ws[(size_t)(o + NB + j) * nmax + o + k];       // H12(k,j)
-        Gf[k][j] = Ws[(size_t)(o + NB + j) * nmax + o + NB + k];  // H22(k,j)
     }
-    int bad = 0;
-    if (wv == 0) {
-        double a[NB], x[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) a[j] = Ws[(size_t)(o + j) * nmax + o + lane];
-        bad = wave_chol_inv64(a, x, lane);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) X1[i][lane] = x[i];
-        if (bad) atomicMax(info + blockIdx.x, o + bad);
+    __syncthreads();
+    int bad = block_chol_inv64(Gf, X1, Tq, tid);
+    if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + bad);
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int j = idx / NB, k = idx % NB;
+        Gf[k][j] = Ws[(size_t)(o + NB + j) * nmax + o + NB + k];  // H22(k,j)
     }
     __syncthreads();
     const int i0 = (tid >> 4) * 4, j0 = (tid & 15) * 4;
@@ -819,17 +893,9 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
 #pragma unroll
         for (int c = 0; c < 4; ++c) Gf[i0 + r][j0 + c] = acc[r][c];
     __syncthreads();
-    // ---- X22 = chol(H22)^-1 on wave 0
-    if (wv == 0) {
-        double a[NB], x[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) a[j] = Gf[lane][j];
-        bad = wave_chol_inv64(a, x, lane);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) Gf[i][lane] = x[i];
-        if (bad) atomicMax(info + blockIdx.x, o + NB + bad);
-    }
-    __syncthreads();
+    // ---- X22 = chol(H22)^-1
+    bad = block_chol_inv64(Gf, X2, Tq, tid);
+    if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + NB + bad);
     // ---- U(i,j) = sum_k Q11(i,k) R12(k,j) = sum_k X11(k,i) R12(k,j)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -862,7 +928,7 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) ua[r] = Bf[i0 + r][k];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xb[c] = Gf[j0 + c][k];
+        for (int c = 0; c < 4; ++c) xb[c] = X2[j0 + c][k];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -880,7 +946,7 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
         Ws[(size_t)(o + r) * nmax + o + c] = X1[r][c];               // Q11(c,r) = X11(r,c)
         Ws[(size_t)(o + r) * nmax + o + NB + c] = 0.0;               // H21 block: strictly lower -> zero
         Ws[(size_t)(o + NB + r) * nmax + o + c] = Bf[c][r];          // Q12(c,r)
-        Ws[(size_t)(o + NB + r) * nmax + o + NB + c] = Gf[r][c];     // Q22(c,r) = X22(r,c)
+        Ws[(size_t)(o + NB + r) * nmax + o + NB + c] = X2[r][c];     // Q22(c,r) = X22(r,c)
     }
 }
 
