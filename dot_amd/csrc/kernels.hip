@@ -717,86 +717,98 @@ __device__ __forceinline__ int wave_chol_inv(double (&a)[NB], double (&x)[NB], i
     return bad;
 }
 
-// 32 x 32 x 32 product on LDS operands by all 256 threads (2 x 2 register tiles):
+// M x M x M product on LDS operands by all 256 threads (M/16 x M/16 register tiles):
 //   store(i, j, sum_k A(i,k) B(k,j)).  The caller separates reads and writes of shared operands.
-template <class FA, class FB, class FS>
-__device__ __forceinline__ void lds_gemm32(FA A, FB B, FS store, int tid)
+template <int M, class FA, class FB, class FS>
+__device__ __forceinline__ void lds_gemm(FA A, FB B, FS store, int tid)
 {
-    const int i0 = (tid >> 4) * 2, j0 = (tid & 15) * 2;
-    double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0;
+    constexpr int TS = M / 16;
+    const int i0 = (tid >> 4) * TS, j0 = (tid & 15) * TS;
+    double c[TS][TS];
+#pragma unroll
+    for (int r = 0; r < TS; ++r)
+#pragma unroll
+        for (int q = 0; q < TS; ++q) c[r][q] = 0.0;
 #pragma unroll 8
-    for (int k = 0; k < 32; ++k) {
-        const double a0 = A(i0, k), a1 = A(i0 + 1, k), b0 = B(k, j0), b1 = B(k, j0 + 1);
-        c00 = __builtin_fma(a0, b0, c00);
-        c01 = __builtin_fma(a0, b1, c01);
-        c10 = __builtin_fma(a1, b0, c10);
-        c11 = __builtin_fma(a1, b1, c11);
+    for (int k = 0; k < M; ++k) {
+        double a[TS], b[TS];
+#pragma unroll
+        for (int r = 0; r < TS; ++r) a[r] = A(i0 + r, k);
+#pragma unroll
+        for (int q = 0; q < TS; ++q) b[q] = B(k, j0 + q);
+#pragma unroll
+        for (int r = 0; r < TS; ++r)
+#pragma unroll
+            for (int q = 0; q < TS; ++q) c[r][q] = __builtin_fma(a[r], b[q], c[r][q]);
     }
     __syncthreads();
-    store(i0, j0, c00);
-    store(i0, j0 + 1, c01);
-    store(i0 + 1, j0, c10);
-    store(i0 + 1, j0 + 1, c11);
+#pragma unroll
+    for (int r = 0; r < TS; ++r)
+#pragma unroll
+        for (int q = 0; q < TS; ++q) store(i0 + r, j0 + q, c[r][q]);
     __syncthreads();
 }
 
-// X = chol(A)^-1 of a 64 x 64 block held in LDS, by one workgroup of 256 threads: the same 2 x 2 recursion
-// as chol_inv_node(), one level further down -- two 32 x 32 factor+invert steps in the registers of wave 0
-// (a quarter of the 64 x 64 single-wave work each) and four 32^3 products by everybody.
+// X = chol(A)^-1 of the N x N diagonal block at [b0, b0+N) of a 64 x 64 matrix held in LDS, by one workgroup
+// of 256 threads: the same 2 x 2 recursion as chol_inv_node(), continued inside LDS -- the 16 x 16 bottom
+// steps run in the registers of wave 0 (wave_chol_inv), every product is done by everybody.
 //   G: A on entry (row-major, symmetric), destroyed.   X: X(i,k) on exit, zero above the diagonal.
-//   T: 32 x 33 scratch.   Returns 0 or 1 + index of the first non-positive pivot (valid in wave 0).
+//   T32 / T16: 32x33 and 16x17 scratch.   Returns 0 or 1 + index (relative to b0) of the first non-positive
+//   pivot (valid in wave 0).
 constexpr int LD64 = CHOL_NB + 1;
-__device__ __forceinline__ int block_chol_inv64(double (*G)[LD64], double (*X)[LD64], double (*T)[33], int tid)
+template <int N>
+__device__ __forceinline__ int block_chol_inv(double (*G)[LD64], double (*X)[LD64], int b0, double (*T32)[33],
+                                              double (*T16)[17], int tid)
 {
-    const int lane = tid & 63, wv = tid >> 6;
-    int bad = 0;
-    if (wv == 0) {
-        double a[32], x[32];
+    if constexpr (N == 16) {
+        int bad = 0;
+        if ((tid >> 6) == 0) {
+            const int lane = tid & 63;
+            double a[16], x[16];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) a[j] = G[lane & 31][j];
-        bad = wave_chol_inv<32>(a, x, lane);
-        if (lane < 32) {
+            for (int j = 0; j < 16; ++j) a[j] = G[b0 + (lane & 15)][b0 + j];
+            bad = wave_chol_inv<16>(a, x, lane);
+            if (lane < 16) {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) X[i][lane] = x[i];
+                for (int i = 0; i < 16; ++i) X[b0 + i][b0 + lane] = x[i];
+            }
         }
+        __syncthreads();
+        return bad;
+    } else {
+        constexpr int H = N / 2;
+        auto T = [&](int i, int j) -> double & {
+            if constexpr (H == 32) return T32[i][j];
+            else return T16[i][j];
+        };
+        int bad = block_chol_inv<H>(G, X, b0, T32, T16, tid);
+        // R12(i,j) = sum_k X11(i,k) A12(k,j)
+        lds_gemm<H>([&](int i, int k) { return X[b0 + i][b0 + k]; }, [&](int k, int j) { return G[b0 + k][b0 + H + j]; },
+                    [&](int i, int j, double v) { T(i, j) = v; }, tid);
+        // A22(c,d) -= sum_k R12(k,c) R12(k,d)
+        lds_gemm<H>([&](int c, int k) { return T(k, c); }, [&](int k, int d) { return T(k, d); },
+                    [&](int c, int d, double v) { G[b0 + H + c][b0 + H + d] -= v; }, tid);
+        const int b2 = block_chol_inv<H>(G, X, b0 + H, T32, T16, tid);
+        if (bad == 0 && b2) bad = H + b2;
+        // V(c,j) = sum_k R12(k,c) X11(k,j)  -> the A11 area (free by now)
+        lds_gemm<H>([&](int c, int k) { return T(k, c); }, [&](int k, int j) { return X[b0 + k][b0 + j]; },
+                    [&](int c, int j, double v) { G[b0 + c][b0 + j] = v; }, tid);
+        // X21(i,j) = -sum_c X22(i,c) V(c,j) ;  X12 = 0
+        lds_gemm<H>([&](int i, int c) { return X[b0 + H + i][b0 + H + c]; }, [&](int c, int j) { return G[b0 + c][b0 + j]; },
+                    [&](int i, int j, double v) {
+                        X[b0 + H + i][b0 + j] = -v;
+                        X[b0 + i][b0 + H + j] = 0.0;
+                    },
+                    tid);
+        return bad;
     }
-    __syncthreads();
-    // R12(i,j) = sum_k X11(i,k) A12(k,j)
-    lds_gemm32([&](int i, int k) { return X[i][k]; }, [&](int k, int j) { return G[k][32 + j]; },
-               [&](int i, int j, double v) { T[i][j] = v; }, tid);
-    // A22(c,d) -= sum_k R12(k,c) R12(k,d)
-    lds_gemm32([&](int c, int k) { return T[k][c]; }, [&](int k, int d) { return T[k][d]; },
-               [&](int c, int d, double v) { G[32 + c][32 + d] -= v; }, tid);
-    if (wv == 0) {
-        double a[32], x[32];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) a[j] = G[32 + (lane & 31)][32 + j];
-        const int b2 = wave_chol_inv<32>(a, x, lane);
-        if (bad == 0 && b2) bad = 32 + b2;
-        if (lane < 32) {
-#pragma unroll
-            for (int i = 0; i < 32; ++i) X[32 + i][32 + lane] = x[i];
-        }
-    }
-    __syncthreads();
-    // V(c,j) = sum_k R12(k,c) X11(k,j)  -> G11 (free by now)
-    lds_gemm32([&](int c, int k) { return T[k][c]; }, [&](int k, int j) { return X[k][j]; },
-               [&](int c, int j, double v) { G[c][j] = v; }, tid);
-    // X21(i,j) = -sum_c X22(i,c) V(c,j) ;  X12 = 0
-    lds_gemm32([&](int i, int c) { return X[32 + i][32 + c]; }, [&](int c, int j) { return G[c][j]; },
-               [&](int i, int j, double v) {
-                   X[32 + i][j] = -v;
-                   X[i][32 + j] = 0.0;
-               },
-               tid);
-    return bad;
 }
 
 __global__ __launch_bounds__(256) void chol_inv_base_kernel(double *__restrict__ W, int nmax, int o,
                                                             int *__restrict__ info)
 {
     constexpr int NB = CHOL_NB;
-    __shared__ double G[NB][LD64], X[NB][LD64], T[32][33];
+    __shared__ double G[NB][LD64], X[NB][LD64], T32[32][33], T16[16][17];
     double *Ws = W + (size_t)blockIdx.x * nmax * nmax + (size_t)o * nmax + o;
     const int tid = threadIdx.x;
     for (int idx = tid; idx < NB * NB; idx += 256) {
@@ -804,7 +816,7 @@ __global__ __launch_bounds__(256) void chol_inv_base_kernel(double *__restrict__
         G[i][j] = Ws[(size_t)j * nmax + i];  // A(i,j): column-major upper block, symmetric
     }
     __syncthreads();
-    const int bad = block_chol_inv64(G, X, T, tid);
+    const int bad = block_chol_inv<64>(G, X, 0, T32, T16, tid);
     // store Q = X^T column-major, i.e. memory row i, position k <- X(i,k) (zero for k > i)
     for (int idx = tid; idx < NB * NB; idx += 256) {
         const int i = idx / NB, k = idx % NB;
@@ -820,7 +832,7 @@ void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipS
 
 // The whole 128 x 128 node of the recursion in one launch (one workgroup per subdomain, LDS resident):
 //   Q11 = R11^-1 ; R12 = Q11^T H12 ; H22 -= R12^T R12 ; Q22 = R22^-1 ; Q12 = -(Q11 R12) Q22 ; H21 = 0
-// The two 64 x 64 factor+invert steps are block_chol_inv64(); the four 64^3 products are done by all 256
+// The two 64 x 64 factor+invert steps are block_chol_inv<64>(); the four 64^3 products are done by all 256
 // threads from LDS (4 x 4 register tiles).  Replaces 2 base launches +
 // 4 tiny batched GEMMs + 2 block copies, whose launch latencies dominated the bottom of the recursion.
 __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restrict__ W, int nmax, int o,
@@ -831,7 +843,7 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
     __shared__ double Bf[NB][LD];  // H12 -> R12 -> U -> Q12          (row index = first block index)
     __shared__ double Gf[NB][LD];  // H11, then H22 -> H22 - R12^T R12
     __shared__ double X2[NB][LD];  // X22(i,k)
-    __shared__ double Tq[32][33];
+    __shared__ double Tq[32][33], Tr[16][17];
     double *Ws = W + (size_t)blockIdx.x * nmax * nmax;
     const int tid = threadIdx.x;
     // column-major element (r, c) of the block matrix lives at Ws[(size_t)c * nmax + r]
@@ -841,7 +853,7 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
         Bf[k][j] = Ws[(size_t)(o + NB + j) * nmax + o + k];       // H12(k,j)
     }
     __syncthreads();
-    int bad = block_chol_inv64(Gf, X1, Tq, tid);
+    int bad = block_chol_inv<64>(Gf, X1, 0, Tq, Tr, tid);
     if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + bad);
     for (int idx = tid; idx < NB * NB; idx += 256) {
         const int j = idx / NB, k = idx % NB;
@@ -894,7 +906,7 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
         for (int c = 0; c < 4; ++c) Gf[i0 + r][j0 + c] = acc[r][c];
     __syncthreads();
     // ---- X22 = chol(H22)^-1
-    bad = block_chol_inv64(Gf, X2, Tq, tid);
+    bad = block_chol_inv<64>(Gf, X2, 0, Tq, Tr, tid);
     if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + NB + bad);
     // ---- U(i,j) = sum_k Q11(i,k) R12(k,j) = sum_k X11(k,i) R12(k,j)
 #pragma unroll
