@@ -719,9 +719,15 @@ struct TriMult {
     int ldc;
     rocblas_stride sC;
     bool trans;
-    bool useTail;  // root only: B is H(.., root separator), zero above the last NdNode::tail rows of every leaf
+    // root only: the operand couples to the root separator, so it is zero above the last NdNode::tail rows of
+    // every leaf.  The transposed product writes, and the plain product reads, a COMPACT row layout that keeps
+    // only the rows that can be non-zero (leaf tails and separator rows, NdNode::crows); the other side keeps
+    // the padded layout of W.
+    bool compact;
 
     const double *Q(int i, int j) const { return Wg + i + (size_t)j * lda; }
+    int offB(int padded, int comp) const { return (!trans && compact) ? comp : padded; }
+    int offC(int padded, int comp) const { return (trans && compact) ? comp : padded; }
     // C[ro..ro+m) (+)= alpha * op(Q[qi.., qj..]) * B[rb..rb+k)
     int gemm(int m, int k, int qi, int qj, int rb, int ro, double beta) const
     {
@@ -734,48 +740,48 @@ struct TriMult {
         }
         return 0;
     }
-    // dense upper-triangular block at [o, o+sz); r = row offset of that block inside B / C
-    int dense(int o, int sz, int r, double beta) const
+    // dense upper-triangular block at [o, o+sz); rb / rc = row offsets of that block inside B / C
+    int dense(int o, int sz, int rb, int rc, double beta) const
     {
         const int a = ((sz / CHOL_NB) / 2) * CHOL_NB, b = sz - a;
-        if (sz < 512 || a == 0) return gemm(sz, sz, o, o, r, r, beta);
+        if (sz < 512 || a == 0) return gemm(sz, sz, o, o, rb, rc, beta);
         if (trans) {  // C_a = Qaa^T B_a ; C_b = Qab^T B_a + Qbb^T B_b
-            if (int rc = dense(o, a, r, beta)) return rc;
-            if (int rc = gemm(b, a, o, o + a, r, r + a, beta)) return rc;
-            return dense(o + a, b, r + a, 1.0);
+            if (int e = dense(o, a, rb, rc, beta)) return e;
+            if (int e = gemm(b, a, o, o + a, rb, rc + a, beta)) return e;
+            return dense(o + a, b, rb + a, rc + a, 1.0);
         }
         // C_a = Qaa B_a + Qab B_b ; C_b = Qbb B_b
-        if (int rc = dense(o, a, r, beta)) return rc;
-        if (int rc = gemm(a, b, o, o + a, r + a, r, 1.0)) return rc;
-        return dense(o + a, b, r + a, beta);
+        if (int e = dense(o, a, rb, rc, beta)) return e;
+        if (int e = gemm(a, b, o, o + a, rb + a, rc, 1.0)) return e;
+        return dense(o + a, b, rb + a, rc + a, beta);
     }
-    // node `id`; r = row offset of the node inside B / C
-    int node(int id, int r, double beta) const
+    // node `id`; rp / rq = padded / compact row offset of the node inside the operands
+    int node(int id, int rp, int rq, double beta) const
     {
         const NdNode &N = h->nd[id];
         if (N.a < 0) {
-            const int h0 = N.size - N.tail;
-            if (!useTail || h0 <= 0 || beta != 0.0) return dense(N.off, N.size, r, beta);
-            if (trans) {
-                // Q^T [0 ; B_b] = [0 ; Q_bb^T B_b]
-                launch_block_copy(C + r, ldc, (size_t)sC, nullptr, 0, 0, h0, ncols, G.count, G.st);
-                return dense(N.off + h0, N.tail, r + h0, beta);
-            }
-            // Q [0 ; R_b] = [Q_ab R_b ; Q_bb R_b]   (the operand is the R the transposed product left)
-            if (int rc = gemm(h0, N.tail, N.off, N.off + h0, r + h0, r, beta)) return rc;
-            return dense(N.off + h0, N.tail, r + h0, beta);
+            const int h0 = compact ? N.size - N.tail : 0;
+            const int p1 = rp + h0;  // first row of the tail (compact: rq)
+            if (h0 <= 0) return dense(N.off, N.size, offB(rp, rq), offC(rp, rq), beta);
+            // transposed: Q^T [0 ; B_b] = [0 ; Q_bb^T B_b], only the tail rows exist in the compact result
+            if (trans) return dense(N.off + h0, N.tail, p1, rq, beta);
+            // plain: Q [0 ; R_b] = [Q_ab R_b ; Q_bb R_b]
+            if (int e = gemm(h0, N.tail, N.off, N.off + h0, rq, rp, beta)) return e;
+            return dense(N.off + h0, N.tail, rq, p1, beta);
         }
-        const int m = N.offS - N.off;  // rows of [A ; C]
-        if (int rc = node(N.a, r, beta)) return rc;
-        if (int rc = node(N.c, r + h->nd[N.a].size, beta)) return rc;
+        const NdNode &A = h->nd[N.a], &Cn = h->nd[N.c];
+        const int m = N.offS - N.off;  // padded rows of [A ; C]
+        if (int e = node(N.a, rp, rq, beta)) return e;
+        if (int e = node(N.c, rp + A.size, rq + A.crows, beta)) return e;
         if (N.sizeS == 0) return 0;
-        if (trans) {  // C_S = [Q_AS ; Q_CS]^T B_AC + Q_S^T B_S
-            if (int rc = gemm(N.sizeS, m, N.off, N.offS, r, r + m, beta)) return rc;
-            return dense(N.offS, N.sizeS, r + m, 1.0);
+        const int pS = rp + m, qS = rq + A.crows + Cn.crows;
+        if (trans) {  // C_S = [Q_AS ; Q_CS]^T B_AC + Q_S^T B_S   (B in the padded layout)
+            if (int e = gemm(N.sizeS, m, N.off, N.offS, rp, offC(pS, qS), beta)) return e;
+            return dense(N.offS, N.sizeS, pS, offC(pS, qS), 1.0);
         }
-        // C_AC += [Q_AS ; Q_CS] B_S ; C_S = Q_S B_S
-        if (int rc = gemm(m, N.sizeS, N.off, N.offS, r + m, r, 1.0)) return rc;
-        return dense(N.offS, N.sizeS, r + m, beta);
+        // C_AC += [Q_AS ; Q_CS] B_S ; C_S = Q_S B_S   (C in the padded layout)
+        if (int e = gemm(m, N.sizeS, N.off, N.offS, offB(pS, qS), rp, 1.0)) return e;
+        return dense(N.offS, N.sizeS, offB(pS, qS), pS, beta);
     }
 };
 
@@ -793,7 +799,11 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id)
     if (N.a < 0) return chol_inv_node(h, G, N.off, N.size);
     if (N.sizeS == 0) return 0;
     DevParts &P = h->P;
-    const int lda = P.nmax, batch = G.count, m = N.offS - N.off, ns = N.sizeS, na = h->nd[N.a].size;
+    const NdNode &A = h->nd[N.a], &Cn = h->nd[N.c];
+    const int lda = P.nmax, batch = G.count, m = N.offS - N.off, ns = N.sizeS;
+    // the root keeps R = blockdiag(Q_A, Q_C)^T H_XS in compact rows (see TriMult): fewer rows in R^T R and R Q_S
+    const bool compact = id == 0;
+    const int mr = compact ? A.crows + Cn.crows : m;
     const rocblas_stride sA = (rocblas_stride)lda * lda, sT = (rocblas_stride)h->tmp_stride;
     double *Wg = P.W + (size_t)G.first * sA;
     double *Hxs = Wg + N.off + (size_t)N.offS * lda;   // [H_AS ; H_CS], m x ns
@@ -802,24 +812,24 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id)
     const double one = 1.0, zero = 0.0, mone = -1.0;
     const rocblas_operation Nn = rocblas_operation_none, Tt = rocblas_operation_transpose;
     {
-        TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Hxs, lda, sA, Tb, m, sT, true, id == 0};
-        if (int rc = tm.node(N.a, 0, 0.0)) return rc;
-        if (int rc = tm.node(N.c, na, 0.0)) return rc;
+        TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Hxs, lda, sA, Tb, mr, sT, true, compact};
+        if (int rc = tm.node(N.a, 0, 0, 0.0)) return rc;
+        if (int rc = tm.node(N.c, A.size, A.crows, 0.0)) return rc;
     }
-    RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Tt, Nn, ns, ns, m, &mone, Tb, m, sT, Tb, m, sT, &one, Hss, lda, sA,
-                                             batch));
+    RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Tt, Nn, ns, ns, mr, &mone, Tb, mr, sT, Tb, mr, sT, &one, Hss, lda,
+                                             sA, batch));
     // R stays in scratch across the factorisation of the separator block; [Q_AS ; Q_CS] = -blockdiag(Q_A, Q_C) (R Q_S)
     // is then written straight into place
     dotmi_handle::FactorGroup G2 = G;
-    G2.tmpOff = G.tmpOff + (size_t)m * ns;
+    G2.tmpOff = G.tmpOff + (size_t)mr * ns;
     if (int rc = chol_inv_node(h, G2, N.offS, ns)) return rc;
-    double *T2 = Tb + (size_t)m * ns;
-    RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Nn, Nn, m, ns, ns, &one, Tb, m, sT, Hss, lda, sA, &zero, T2, m, sT,
-                                             batch));
+    double *T2 = Tb + (size_t)mr * ns;
+    RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Nn, Nn, mr, ns, ns, &one, Tb, mr, sT, Hss, lda, sA, &zero, T2, mr,
+                                             sT, batch));
     {
-        TriMult tm{h, G, Wg, lda, ns, sA, -1.0, T2, m, sT, Hxs, lda, sA, false, id == 0};
-        if (int rc = tm.node(N.a, 0, 0.0)) return rc;
-        if (int rc = tm.node(N.c, na, 0.0)) return rc;
+        TriMult tm{h, G, Wg, lda, ns, sA, -1.0, T2, mr, sT, Hxs, lda, sA, false, compact};
+        if (int rc = tm.node(N.a, 0, 0, 0.0)) return rc;
+        if (int rc = tm.node(N.c, A.size, A.crows, 0.0)) return rc;
     }
     // rows S, columns [A C] of the lower part hold the symmetric fill of H: clear them
     launch_block_copy(Wg + N.offS + (size_t)N.off * lda, lda, (size_t)sA, nullptr, 0, 0, ns, m, batch, G.st);

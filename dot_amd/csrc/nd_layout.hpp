@@ -16,6 +16,7 @@ struct NdNode {
     int a = -1, c = -1;      // children (both or none)
     int offS = 0, sizeS = 0; // separator block (internal nodes)
     int tail = 0;            // leaf: only its last `tail` rows can couple to the root separator
+    int crows = 0;           // rows of this sub-tree that can couple to the root separator (leaf tails + separators)
 };
 
 // first padded row of a node's own region (leaf block / separator) in a subdomain that has `used` live
@@ -248,10 +249,12 @@ struct NdBuilder {
     {
         NdNode &N = tree[id];
         N.off = off;
+        N.crows = N.tail;
         if (N.a < 0) return;
         layout(N.a, off);
         layout(N.c, off + tree[N.a].size);
         N.offS = off + tree[N.a].size + tree[N.c].size;
+        N.crows = tree[N.a].crows + tree[N.c].crows + N.sizeS;
     }
 };
 
