@@ -1115,7 +1115,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     flags[1] = 0;
     // blind up to a little before last step's slot count, then two slots ahead of the posted progress
     const int AHEAD = 2;
-    C.notifyFrom = std::max(0, h->prevSlots - 3);
+    C.notifyFrom = std::max(0, std::min(h->prevSlots - 3, h->prevSlots * 3 / 4));  // a shorter step wastes few slots
     const int notifyFrom = C.notifyFrom;
     HIPCHECK(h, hipMemcpyAsync(h->ctl, h->h_ctl, sizeof(DevLoop), hipMemcpyHostToDevice, h->st));
     int enq = 0;

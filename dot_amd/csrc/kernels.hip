@@ -622,6 +622,8 @@ __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restri
     }
 }
 
+__device__ const double g_zero_slot = 0.0;
+
 // psub_s[k] = sum over the row tiles b of the part whose column range holds k of ppart[s][b][k]
 //   (fixed order, coalesced in k)
 __global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int2 *__restrict__ trange,
@@ -635,8 +637,22 @@ __global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int2 *__res
     if (k >= nmax) return;
     const int2 *tr = trange + (size_t)s * nbmax;
     const double *base = ppart + (size_t)s * nbmax * nmax + k;
+    // tiles that do not hold column k read a zero instead (select on the address, not a branch around the load),
+    // so the loads of a group of tiles are all in flight together; the order of the sum stays b = 0, 1, ...
     double acc = 0.0;
-    for (int b = 0; b < nbmax; ++b) {
+    int b = 0;
+    for (; b + 8 <= nbmax; b += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int2 cr = tr[b + u];
+            const double *src = (k >= cr.x && k < cr.y) ? base + (size_t)(b + u) * nmax : &g_zero_slot;
+            v[u] = *src;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < nbmax; ++b) {
         const int2 cr = tr[b];
         if (k >= cr.x && k < cr.y) acc += base[(size_t)b * nmax];
     }
