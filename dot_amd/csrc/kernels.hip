@@ -855,10 +855,9 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
                                                                int *__restrict__ info)
 {
     constexpr int NB = CHOL_NB, LD = NB + 1;
-    __shared__ double X1[NB][LD];  // X11(i,k)
+    __shared__ double X1[NB][LD];  // X11(i,k), later X22(i,k)
     __shared__ double Bf[NB][LD];  // H12 -> R12 -> U -> Q12          (row index = first block index)
     __shared__ double Gf[NB][LD];  // H11, then H22 -> H22 - R12^T R12
-    __shared__ double X2[NB][LD];  // X22(i,k)
     __shared__ double Tq[32][33], Tr[16][17];
     double *Ws = W + (size_t)blockIdx.x * nmax * nmax;
     const int tid = threadIdx.x;
@@ -921,9 +920,6 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
 #pragma unroll
         for (int c = 0; c < 4; ++c) Gf[i0 + r][j0 + c] = acc[r][c];
     __syncthreads();
-    // ---- X22 = chol(H22)^-1
-    bad = block_chol_inv<64>(Gf, X2, 0, Tq, Tr, tid);
-    if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + NB + bad);
     // ---- U(i,j) = sum_k Q11(i,k) R12(k,j) = sum_k X11(k,i) R12(k,j)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -946,6 +942,17 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
 #pragma unroll
         for (int c = 0; c < 4; ++c) Bf[i0 + r][j0 + c] = acc[r][c];
     __syncthreads();
+    // X11 is final: write it out and hand its LDS block to X22 (one 64x65 block less, 108 KB instead of 141 KB
+    // per workgroup, so a GEMM workgroup of another branch still fits next to this one on a CU)
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int r = idx / NB, c = idx % NB;
+        Ws[(size_t)(o + r) * nmax + o + c] = X1[r][c];               // Q11(c,r) = X11(r,c)
+        Ws[(size_t)(o + r) * nmax + o + NB + c] = 0.0;               // H21 block: strictly lower -> zero
+    }
+    __syncthreads();
+    // ---- X22 = chol(H22)^-1
+    bad = block_chol_inv<64>(Gf, X1, 0, Tq, Tr, tid);
+    if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + NB + bad);
     // ---- Q12(i,j) = -sum_c U(i,c) Q22(c,j) = -sum_c U(i,c) X22(j,c)
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -956,7 +963,7 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
 #pragma unroll
         for (int r = 0; r < 4; ++r) ua[r] = Bf[i0 + r][k];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) xb[c] = X2[j0 + c][k];
+        for (int c = 0; c < 4; ++c) xb[c] = X1[j0 + c][k];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -968,13 +975,11 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
 #pragma unroll
         for (int c = 0; c < 4; ++c) Bf[i0 + r][j0 + c] = acc[r][c];
     __syncthreads();
-    // ---- store: memory row (o+i) <- [X11(i,:) | 0]; memory row (o+64+j) <- [Q12(:,j) | X22(j,:)]
+    // ---- store: memory row (o+64+j) <- [Q12(:,j) | X22(j,:)]   (rows o+i were written above)
     for (int idx = tid; idx < NB * NB; idx += 256) {
         const int r = idx / NB, c = idx % NB;
-        Ws[(size_t)(o + r) * nmax + o + c] = X1[r][c];               // Q11(c,r) = X11(r,c)
-        Ws[(size_t)(o + r) * nmax + o + NB + c] = 0.0;               // H21 block: strictly lower -> zero
         Ws[(size_t)(o + NB + r) * nmax + o + c] = Bf[c][r];          // Q12(c,r)
-        Ws[(size_t)(o + NB + r) * nmax + o + NB + c] = X2[r][c];     // Q22(c,r) = X22(r,c)
+        Ws[(size_t)(o + NB + r) * nmax + o + NB + c] = X1[r][c];     // Q22(c,r) = X22(r,c)
     }
 }
 
