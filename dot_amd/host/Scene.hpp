@@ -30,6 +30,8 @@ struct Config {  // subset of DOT::Config the DOT path reads; defaults Config.cp
     bool withGravity = true;
     double rotDeg = 0.0, rotAxis[3] = {0, 0, 0}, handleRatio = 0.01;
     std::vector<double> tol;
+    bool restart = false;       // `restart <status file>` (Config.cpp:164-167)
+    std::string statusPath;
 };
 
 inline Config parse_script(const std::string &path)
@@ -64,6 +66,10 @@ inline Config parse_script(const std::string &path)
         } else if (tok == "rotateModel") ss >> c.rotDeg >> c.rotAxis[0] >> c.rotAxis[1] >> c.rotAxis[2];
         else if (tok == "handleRatio") ss >> c.handleRatio;
         else if (tok == "warmStart") ss >> c.warmStart;
+        else if (tok == "restart") {
+            c.restart = true;
+            ss >> c.statusPath;
+        }
         else if (tok == "tol") {
             int n = 0;
             ss >> n;
@@ -111,23 +117,136 @@ inline TetMesh read_tet_msh(const std::string &path)
     return m;
 }
 
+// TetGen pair <prefix>.node / <prefix>.ele as the reference reads it (IglUtils.cpp:751-793): "n 3 0 0" then
+// "id x y z" rows; "n 4 0" then "id a b c d" rows, the indices taken as they are (zero-based files)
+inline TetMesh read_node_ele(const std::string &prefix)
+{
+    TetMesh m;
+    std::ifstream in(prefix + ".node");
+    if (!in) throw std::runtime_error("cannot open mesh " + prefix + ".node");
+    int nN = 0, nDim = 0, z0 = 0, z1 = 0;
+    in >> nN >> nDim >> z0 >> z1;
+    if (!in || nN < 4 || nDim != 3) throw std::runtime_error("malformed " + prefix + ".node");
+    m.V.resize(3 * (size_t)nN);
+    for (int i = 0; i < nN; ++i) {
+        int id;
+        in >> id >> m.V[3 * i] >> m.V[3 * i + 1] >> m.V[3 * i + 2];
+    }
+    if (!in) throw std::runtime_error("malformed " + prefix + ".node");
+    std::ifstream ie(prefix + ".ele");
+    if (!ie) throw std::runtime_error("cannot open mesh " + prefix + ".ele");
+    int nE = 0, nD1 = 0;
+    ie >> nE >> nD1 >> z0;
+    if (!ie || nE < 0 || nD1 != 4) throw std::runtime_error("malformed " + prefix + ".ele");
+    m.T.resize(4 * (size_t)nE);
+    for (int e = 0; e < nE; ++e) {
+        int id;
+        ie >> id >> m.T[4 * e] >> m.T[4 * e + 1] >> m.T[4 * e + 2] >> m.T[4 * e + 3];
+    }
+    if (!ie) throw std::runtime_error("malformed " + prefix + ".ele");
+    return m;
+}
+
+// main.cpp:678-691: no suffix -> .node/.ele pair, ".msh" -> the MSH reader
+inline TetMesh load_tet_mesh(const std::string &path)
+{
+    const size_t slash = path.find_last_of('/'), dot = path.find_last_of('.');
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return read_node_ele(path);
+    if (path.substr(dot) == ".msh") return read_tet_msh(path);
+    throw std::runtime_error("unsupported tet mesh file format: " + path);
+}
+
+// status<n> as Optimizer::saveStatus writes it (Optimizer.cpp:1096-1132) and the ctor reads it back (:126-177)
+inline void read_status(const std::string &path, int nV, int &timestep, std::vector<double> &x, std::vector<double> &v)
+{
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("cannot open status file " + path);
+    x.clear();
+    v.clear();
+    timestep = 0;
+    std::string line;
+    while (std::getline(in, line)) {
+        std::stringstream ss(line);
+        std::string tok;
+        if (!(ss >> tok)) continue;
+        if (tok == "timestep") ss >> timestep;
+        else if (tok == "position") {
+            int rows = 0, cols = 0;
+            ss >> rows >> cols;
+            if (rows != nV || cols != 3) throw std::runtime_error("status file does not match the mesh: " + path);
+            x.resize(3 * (size_t)nV);
+            for (auto &c : x) in >> c;
+        } else if (tok == "velocity") {
+            int n = 0;
+            ss >> n;
+            if (n != 3 * nV) throw std::runtime_error("status file does not match the mesh: " + path);
+            v.resize(3 * (size_t)nV);
+            for (auto &c : v) in >> c;
+        }
+    }
+    if (x.empty() || v.empty() || !in.eof()) throw std::runtime_error("malformed status file " + path);
+}
+
 // boundary faces = faces that belong to exactly one tet, outward orientation
-inline std::vector<std::array<int, 3>> find_surface_tris(const TetMesh &m)
+inline std::vector<std::array<int, 3>> find_surface_tris(const TetMesh &m, std::vector<int> *tri2tet = nullptr)
 {
     static const int FACE[4][3] = {{0, 2, 1}, {0, 3, 2}, {0, 1, 3}, {1, 2, 3}};
-    std::map<std::array<int, 3>, std::pair<int, std::array<int, 3>>> seen;
+    struct Hit {
+        int count, tet;
+        std::array<int, 3> tri;
+    };
+    std::map<std::array<int, 3>, Hit> seen;
     for (int e = 0; e < m.nT(); ++e)
         for (auto &f : FACE) {
             std::array<int, 3> t = {m.T[4 * e + f[0]], m.T[4 * e + f[1]], m.T[4 * e + f[2]]}, key = t;
             std::sort(key.begin(), key.end());
             auto it = seen.find(key);
-            if (it == seen.end()) seen[key] = {1, t};
-            else it->second.first++;
+            if (it == seen.end()) seen[key] = Hit{1, e, t};
+            else it->second.count++;
         }
     std::vector<std::array<int, 3>> out;
+    if (tri2tet) tri2tet->clear();
     for (auto &kv : seen)
-        if (kv.second.first == 1) out.push_back(kv.second.second);
+        if (kv.second.count == 1) {
+            out.push_back(kv.second.tri);
+            if (tri2tet) tri2tet->push_back(kv.second.tet);
+        }
     return out;
+}
+
+// label.obj (one "v <subdomain> 0 0" line per surface triangle) and wire.poly (surface wire frame), the two
+// partition-visualisation files ADMMDDTimeStepper's ctor writes (ADMMDDTimeStepper.cpp:375-442)
+inline void write_partition_files(const std::string &dir, const TetMesh &m, const std::vector<double> &x,
+                                  const std::vector<int32_t> &epart)
+{
+    std::vector<int> tri2tet;
+    const auto surf = find_surface_tris(m, &tri2tet);
+    FILE *out = std::fopen((dir + "/label.obj").c_str(), "w");
+    if (!out) throw std::runtime_error("cannot write into " + dir);
+    for (size_t i = 0; i < surf.size(); ++i) std::fprintf(out, "v %d 0 0\n", (int)epart[tri2tet[i]]);
+    std::fclose(out);
+    std::vector<int> toSurf(m.nV(), -1), toTet;
+    {
+        std::vector<char> on(m.nV(), 0);
+        for (auto &t : surf)
+            for (int k = 0; k < 3; ++k) on[t[k]] = 1;
+        for (int v = 0; v < m.nV(); ++v)
+            if (on[v]) {
+                toSurf[v] = (int)toTet.size();
+                toTet.push_back(v);
+            }
+    }
+    out = std::fopen((dir + "/wire.poly").c_str(), "w");
+    if (!out) throw std::runtime_error("cannot write into " + dir);
+    std::fprintf(out, "POINTS\n");
+    for (size_t i = 0; i < toTet.size(); ++i)
+        std::fprintf(out, "%zu: %le %le %le\n", i + 1, x[3 * toTet[i]], x[3 * toTet[i] + 1], x[3 * toTet[i] + 2]);
+    std::fprintf(out, "POLYS\n");
+    for (size_t f = 0; f < surf.size(); ++f)
+        for (int k = 0; k < 3; ++k)
+            std::fprintf(out, "%zu: %d %d\n", 3 * f + k + 1, toSurf[surf[f][k]] + 1, toSurf[surf[f][(k + 1) % 3]] + 1);
+    std::fprintf(out, "END\n");
+    std::fclose(out);
 }
 
 // Eigen::AngleAxis::toRotationMatrix

@@ -8,6 +8,9 @@
 //   output/<name>/status<n>       restartable state (Optimizer.cpp:1096-1132)
 //   output/<name>/<n>.obj         surface mesh per step (Optimizer.cpp:1137-1150)
 //   output/<name>/info.txt        nV nT / steps innerIters / wall-clock summary (main.cpp:338-358)
+//   output/<name>/label.obj, wire.poly   partition labels of the surface triangles, surface wire frame
+//                                 (ADMMDDTimeStepper.cpp:375-442)
+// Script token `restart <status file>` resumes from a saved status (Optimizer.cpp:126-177).
 //
 // usage: dot_hip 100 <script.txt> [--mesh-root DIR] [--parts N] [--energy FCR|SNH] [--epart raw.i32]
 //                [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K]
@@ -59,29 +62,12 @@ int main(int argc, char **argv)
         Config cfg = parse_script(scriptPath);
         if (!energyOverride.empty()) cfg.energy = energyOverride;
         if (cfg.shapePath.empty()) throw std::runtime_error("script has no `shape input <mesh>` (primitive shapes are 2-D only)");
-        TetMesh mesh = read_tet_msh(cfg.shapePath[0] == '/' ? cfg.shapePath : meshRoot + "/" + cfg.shapePath);
+        TetMesh mesh = load_tet_mesh(cfg.shapePath[0] == '/' ? cfg.shapePath : meshRoot + "/" + cfg.shapePath);
         normalize(mesh.V, cfg.size, cfg.rotDeg, cfg.rotAxis);
         std::vector<int> border[2];
         find_border_verts(mesh.V, cfg.handleRatio, border);
         AnimScripter scripter(cfg.script, mesh.V, border);
         std::vector<double> x0 = scripter.initial_positions(mesh.V);
-
-        // --dump-scene K: print the scene the hot path would receive and K scripted moves (no GPU needed)
-        if (dumpScene >= 0) {
-            int nfixed = 0;
-            for (auto f : scripter.fixed) nfixed += f;
-            std::printf("scene nV %d nT %d nfixed %d energy %s dt %.17g\n", mesh.nV(), mesh.nT(), nfixed, cfg.energy.c_str(), cfg.dt);
-            std::vector<double> x = x0, pos;
-            std::vector<int32_t> idx;
-            for (int k = 0; k < dumpScene; ++k) {
-                scripter.step(x, cfg.dt, idx, pos);
-                double sum[3] = {0, 0, 0};
-                for (size_t i = 0; i < idx.size(); ++i)
-                    for (int d = 0; d < 3; ++d) { x[3 * idx[i] + d] = pos[3 * i + d]; sum[d] += pos[3 * i + d]; }
-                std::printf("move %d n %zu sum %.17g %.17g %.17g\n", k, idx.size(), sum[0], sum[1], sum[2]);
-            }
-            return 0;
-        }
 
         int nParts = partsOverride > 0 ? partsOverride : cfg.partitionAmt;
         if (cfg.blockSize > 0 && partsOverride <= 0) nParts = mesh.nV() / cfg.blockSize + 1;  // main.cpp:792-798
@@ -95,6 +81,42 @@ int main(int argc, char **argv)
         } else {
             epart = partition_rcb(mesh, nParts);  // METIS is third-party; pass --epart for the reference's partition
         }
+        std::string name = scriptPath.substr(scriptPath.find_last_of('/') + 1);
+        name = name.substr(0, name.find_last_of('.'));
+        const bool outGiven = !outDir.empty();
+        if (outDir.empty()) outDir = "output/" + name;
+
+        // --dump-scene K: print the scene the hot path would receive and K scripted moves (no GPU needed);
+        // with --out also the partition files
+        if (dumpScene >= 0) {
+            int nfixed = 0;
+            for (auto f : scripter.fixed) nfixed += f;
+            std::printf("scene nV %d nT %d nfixed %d energy %s dt %.17g\n", mesh.nV(), mesh.nT(), nfixed, cfg.energy.c_str(), cfg.dt);
+            std::vector<double> x = x0, pos;
+            std::vector<int32_t> idx;
+            for (int k = 0; k < dumpScene; ++k) {
+                scripter.step(x, cfg.dt, idx, pos);
+                double sum[3] = {0, 0, 0};
+                for (size_t i = 0; i < idx.size(); ++i)
+                    for (int d = 0; d < 3; ++d) { x[3 * idx[i] + d] = pos[3 * i + d]; sum[d] += pos[3 * i + d]; }
+                std::printf("move %d n %zu sum %.17g %.17g %.17g\n", k, idx.size(), sum[0], sum[1], sum[2]);
+            }
+            if (outGiven) {
+                mkdir(outDir.c_str(), 0755);
+                write_partition_files(outDir, mesh, x0, epart);
+            }
+            if (cfg.restart) {
+                int t = 0;
+                std::vector<double> xs, vs;
+                read_status(cfg.statusPath, mesh.nV(), t, xs, vs);
+                double sx = 0, sv = 0;
+                for (double c : xs) sx += c;
+                for (double c : vs) sv += c;
+                std::printf("restart timestep %d sumx %.17g sumv %.17g\n", t, sx, sv);
+            }
+            return 0;
+        }
+
         double mu, lam;
         lame(cfg.YM, cfg.PR, mu, lam);
         std::vector<double> u(mesh.nT(), mu), lambda(mesh.nT(), lam);
@@ -105,9 +127,6 @@ int main(int argc, char **argv)
         opt.energyType = cfg.energy == "SNH" ? DOTMI_ENERGY_SNH : DOTMI_ENERGY_FCR;
         opt.withGravity = cfg.withGravity; opt.partitionAmt = nParts; opt.epart = epart.data(); opt.device = device;
 
-        std::string name = scriptPath.substr(scriptPath.find_last_of('/') + 1);
-        name = name.substr(0, name.find_last_of('.'));
-        if (outDir.empty()) outDir = "output/" + name;
         FILE *fIter = nullptr, *fLog = nullptr;
         if (files) {
             mkdir("output", 0755);
@@ -115,6 +134,7 @@ int main(int argc, char **argv)
             fIter = std::fopen((outDir + "/iterStats.txt").c_str(), "w");
             fLog = std::fopen((outDir + "/log.txt").c_str(), "w");
             if (!fIter || !fLog) throw std::runtime_error("cannot write into " + outDir);
+            write_partition_files(outDir, mesh, x0, epart);
         }
         const auto surf = files ? find_surface_tris(mesh) : std::vector<std::array<int, 3>>();
 
@@ -129,13 +149,20 @@ int main(int argc, char **argv)
             return changed;
         });
         ts.precompute();
+        int firstFrame = 0;
+        if (cfg.restart) {
+            std::vector<double> xs, vs;
+            read_status(cfg.statusPath, mesh.nV(), firstFrame, xs, vs);
+            ts.restoreState(xs, vs, firstFrame);
+            std::printf("restarted from %s at time step %d\n", cfg.statusPath.c_str(), firstFrame);
+        }
         std::printf("setup %.3f s, nV %d nT %d, %d subdomains, tol %.6e\n", now_s() - tSetup, mesh.nV(), mesh.nT(), nParts, ts.getTargetGRes());
 
         const int nFrames = frames > 0 ? frames : (int)(cfg.duration / cfg.dt);
         long lineSearch = 0;
         double tStep = 0;
         std::vector<double> al(10001), En(10001), g2(10001);
-        for (int n = 0; n < nFrames; ++n) {
+        for (int n = firstFrame; n < nFrames; ++n) {
             if (files) {
                 char buf[512];
                 std::snprintf(buf, sizeof(buf), "%s/status%d", outDir.c_str(), n);

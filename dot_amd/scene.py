@@ -43,6 +43,8 @@ class Config:
     handle_ratio: float = 0.01
     warm_start: int = 2
     tol: Optional[List[float]] = None
+    restart: bool = False          # `restart <status file>` (Config.cpp:164-167)
+    status_path: str = ""
 
     @property
     def energy_id(self) -> int:
@@ -92,6 +94,9 @@ def parse_script(path: str) -> Config:
             cfg.handle_ratio = float(tok[1])
         elif key == "warmStart":
             cfg.warm_start = int(tok[1])
+        elif key == "restart":
+            cfg.restart = True
+            cfg.status_path = tok[1] if len(tok) > 1 else ""
         elif key == "tol":
             n = int(tok[1])
             cfg.tol = [float(lines[i + k]) for k in range(n)]
@@ -116,6 +121,89 @@ def read_tet_msh(path: str) -> Tuple[np.ndarray, np.ndarray]:
     i += 3
     T = np.array([[int(t) for t in lines[i + k].split()[1:5]] for k in range(nT)], dtype=np.int32) - 1
     return V, T
+
+
+def read_node_ele(prefix: str) -> Tuple[np.ndarray, np.ndarray]:
+    """TetGen <prefix>.node / <prefix>.ele the way the reference reads them (IglUtils.cpp:751-793): the element
+    indices are used as they are (zero-based files)."""
+    with open(prefix + ".node") as f:
+        tok = f.read().split()
+    nN, nDim = int(tok[0]), int(tok[1])
+    if nN < 4 or nDim != 3:
+        raise ValueError(f"malformed {prefix}.node")
+    V = np.array(tok[4:4 + 4 * nN], dtype=np.float64).reshape(nN, 4)[:, 1:4].copy()
+    with open(prefix + ".ele") as f:
+        tok = f.read().split()
+    nE, nD1 = int(tok[0]), int(tok[1])
+    if nD1 != 4:
+        raise ValueError(f"malformed {prefix}.ele")
+    T = np.array(tok[3:3 + 5 * nE], dtype=np.int64).reshape(nE, 5)[:, 1:5].astype(np.int32)
+    return V, T
+
+
+def load_tet_mesh(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """main.cpp:678-691: no suffix -> .node/.ele pair, '.msh' -> the MSH reader."""
+    ext = os.path.splitext(path)[1]
+    if ext == "":
+        return read_node_ele(path)
+    if ext == ".msh":
+        return read_tet_msh(path)
+    raise ValueError(f"unsupported tet mesh file format: {path}")
+
+
+def write_status(path: str, timestep: int, x: np.ndarray, v: np.ndarray, xtilde: Optional[np.ndarray] = None) -> None:
+    """status<n> in the reference's text format (Optimizer::saveStatus, Optimizer.cpp:1096-1132)."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1, 3)
+    v = np.asarray(v, dtype=np.float64).reshape(-1)
+    dxe = x - np.asarray(xtilde, dtype=np.float64).reshape(-1, 3) if xtilde is not None else np.zeros_like(x)
+    with open(path, "w") as f:
+        f.write(f"timestep {timestep}\n\nposition {x.shape[0]} 3\n")
+        for r in x:
+            f.write("%e %e %e\n" % tuple(r))
+        f.write(f"\nvelocity {v.size}\n")
+        for c in v:
+            f.write("%e\n" % c)
+        f.write(f"\ndx_Elastic {x.shape[0]} 3\n")
+        for r in dxe:
+            f.write("%e %e %e\n" % tuple(r))
+
+
+def read_status(path: str, nV: int) -> Tuple[int, np.ndarray, np.ndarray]:
+    """(timestep, x (nV,3), v (nV,3)) from a status file (the restart path of Optimizer's ctor, Optimizer.cpp:126-177)."""
+    with open(path) as f:
+        tok = f.read().split()
+    i, timestep, x, v = 0, 0, None, None
+    while i < len(tok):
+        if tok[i] == "timestep":
+            timestep = int(tok[i + 1]); i += 2
+        elif tok[i] == "position":
+            rows, cols = int(tok[i + 1]), int(tok[i + 2])
+            if rows != nV or cols != 3:
+                raise ValueError("status file does not match the mesh")
+            x = np.array(tok[i + 3:i + 3 + 3 * nV], dtype=np.float64).reshape(nV, 3); i += 3 + 3 * nV
+        elif tok[i] == "velocity":
+            n = int(tok[i + 1])
+            if n != 3 * nV:
+                raise ValueError("status file does not match the mesh")
+            v = np.array(tok[i + 2:i + 2 + n], dtype=np.float64).reshape(nV, 3); i += 2 + n
+        elif tok[i] == "dx_Elastic":
+            i += 3 + 3 * int(tok[i + 1])
+        else:
+            i += 1
+    if x is None or v is None:
+        raise ValueError("malformed status file")
+    return timestep, x, v
+
+
+def surface_triangles(T: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Boundary faces (those of exactly one tet) and the tet each belongs to (IglUtils::findSurfaceTris)."""
+    FACE = np.array([[0, 2, 1], [0, 3, 2], [0, 1, 3], [1, 2, 3]])
+    tris = T[:, FACE].reshape(-1, 3)
+    tet = np.repeat(np.arange(T.shape[0]), 4)
+    key = np.sort(tris, axis=1)
+    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+    keep = cnt[inv.reshape(-1)] == 1
+    return tris[keep], tet[keep]
 
 
 def load_mesh_npz(path: str) -> Tuple[np.ndarray, np.ndarray]:
@@ -328,7 +416,7 @@ def load_scene(script_path: str, mesh_dir: Optional[str] = None) -> Scene:
         path = cfg.shape_path
         if not os.path.isabs(path) and not os.path.exists(path):
             path = os.path.join(mesh_dir, path)
-        V, T = read_tet_msh(path)
+        V, T = load_tet_mesh(path)
     return build_scene(cfg, V, T)
 
 

@@ -254,3 +254,50 @@ def test_nested_dissection_layout_is_a_valid_separator_ordering(workload, levels
         ps, vs = pos[0], verts[0]
         nnz = sum(int(((ps >= first_col[q]) & (ps <= q)).sum()) for q in ps)
         assert nnz < 0.7 * ps.size * (ps.size + 1) / 2
+
+
+def test_node_ele_restart_and_partition_files_cpp_vs_python(tmp_path):
+    """The remaining pieces of the reference's file layer, C++ (dot_amd/host) against Python (dot_amd/scene.py):
+    the TetGen .node/.ele reader (IglUtils.cpp:751-793), the `restart <status>` token with the status<n> text format
+    (Optimizer.cpp:126-177, :1096-1132), and the partition files label.obj / wire.poly of
+    ADMMDDTimeStepper.cpp:375-442."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "dot_amd", "dot_hip")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "dot_amd", "host")])
+    V, T = scene.synthetic_bar(6, 2, 2, jitter=0.05)
+    nV, nT = V.shape[0], T.shape[0]
+    with open(tmp_path / "bar.node", "w") as f:                       # zero-based ids, as the reference expects
+        f.write(f"{nV} 3 0 0\n" + "".join(f"{i} {p[0]!r} {p[1]!r} {p[2]!r}\n" for i, p in enumerate(V.tolist())))
+    with open(tmp_path / "bar.ele", "w") as f:
+        f.write(f"{nT} 4 0\n" + "".join(f"{i} {t[0]} {t[1]} {t[2]} {t[3]}\n" for i, t in enumerate(T.tolist())))
+    V2, T2 = scene.load_tet_mesh(str(tmp_path / "bar"))
+    assert np.array_equal(V2, V) and np.array_equal(T2, T)
+    # a status file in the reference's format, referenced by the script
+    rng = np.random.default_rng(5)
+    xs, vs = rng.standard_normal((nV, 3)), rng.standard_normal((nV, 3))
+    scene.write_status(str(tmp_path / "status7"), 7, xs, vs, xs - 0.1)
+    t, xr, vr = scene.read_status(str(tmp_path / "status7"), nV)
+    assert t == 7 and np.allclose(xr, xs, rtol=1e-6) and np.allclose(vr, vs, rtol=1e-6)   # %le keeps 7 digits
+    (tmp_path / "s.txt").write_text("energy FCR\ntimeStepper DOT 3\nsize 1\ntime 1 0.02\ndensity 1000\n"
+                                    "stiffness 100000 0.4\nscript stretch\nshape input bar\nhandleRatio 0.1\n"
+                                    f"restart {tmp_path / 'status7'}\n")
+    cfg = scene.parse_script(str(tmp_path / "s.txt"))
+    assert cfg.restart and cfg.status_path.endswith("status7")
+    ep = scene.partition_rcb(scene.normalize(V, 1.0, 0.0, (0, 1, 0)), T, 3)
+    ep.astype(np.int32).tofile(tmp_path / "ep.i32")
+    out = subprocess.check_output([exe, "100", str(tmp_path / "s.txt"), "--mesh-root", str(tmp_path), "--epart",
+                                   str(tmp_path / "ep.i32"), "--out", str(tmp_path / "o"), "--dump-scene", "0"]
+                                  ).decode().splitlines()
+    head = out[0].split()
+    assert int(head[2]) == nV and int(head[4]) == nT
+    rs = [l for l in out if l.startswith("restart")][0].split()
+    assert int(rs[2]) == 7 and np.isclose(float(rs[4]), xr.sum(), rtol=1e-12) and np.isclose(float(rs[6]), vr.sum(), rtol=1e-12)
+    # label.obj: one line per surface triangle with the subdomain of its tet -- same multiset as Python's
+    tris, tet = scene.surface_triangles(T)
+    labels = sorted(int(l.split()[1]) for l in (tmp_path / "o" / "label.obj").read_text().splitlines())
+    assert labels == sorted(ep[tet].tolist())
+    wire = (tmp_path / "o" / "wire.poly").read_text().splitlines()
+    npts = wire.index("POLYS") - 1
+    assert wire[0] == "POINTS" and wire[-1] == "END" and npts == np.unique(tris).size
+    assert len(wire) == 1 + npts + 1 + 3 * tris.shape[0] + 1
