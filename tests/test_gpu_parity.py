@@ -435,10 +435,18 @@ def test_cpp_headless_runner_end_to_end(tmp_path):
         assert abs(float(frames[k][9]) - ts.last_stats.E) <= 1e-12 * abs(ts.last_stats.E)
     ts.close()
     o = tmp_path / "out"
-    for f in ("iterStats.txt", "log.txt", "info.txt", "status0", "status2", "0.obj", "2.obj"):
+    for f in ("iterStats.txt", "log.txt", "info.txt", "status0", "status2", "0.obj", "2.obj", "label.obj", "wire.poly"):
         assert (o / f).exists(), f
     it = (o / "iterStats.txt").read_text().splitlines()
     assert it[0].split()[:2] == ["0", "0"] and len(it) == 3 + sum(int(f[5]) for f in frames)
     st = (o / "status2").read_text().splitlines()
     assert st[0] == "timestep 2" and st[2] == "position 4670 3" and any(l.startswith("velocity 14010") for l in st)
     assert "Timestep2 innerIterAmt" in (o / "log.txt").read_text()
+    # `restart <status>`: resume at time step 2 from the saved status (7 significant digits in the file)
+    (tmp_path / "bunny_r.txt").write_text((tmp_path / "bunny.txt").read_text() + f"restart {o / 'status2'}\n")
+    out2 = subprocess.check_output([exe, "100", str(tmp_path / "bunny_r.txt"), "--mesh-root", str(tmp_path), "--epart",
+                                    str(tmp_path / "epart.i32"), "--frames", "3", "--out", str(tmp_path / "out2")]).decode()
+    fr2 = [l.split() for l in out2.splitlines() if l.startswith("FRAME")]
+    assert len(fr2) == 1 and fr2[0][1] == "2"
+    assert abs(int(fr2[0][5]) - int(frames[2][5])) <= 1
+    assert abs(float(fr2[0][9]) - float(frames[2][9])) <= 1e-4 * abs(float(frames[2][9]))
