@@ -107,6 +107,8 @@ struct dotmi_handle {
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
     double *alpha_dev = nullptr;
     int *info_dev = nullptr, *h_info = nullptr;  // per owned part: failing pivot (device / pinned copy)
+    int4 *clearSeg = nullptr;                    // row segments (row, first column, columns, -) cleared before a refill
+    int nClearSeg = 0;
     bool wDirty = false;                         // W has been through a factorisation (targeted clearing applies)
     size_t tmp_stride = 0;
     int *didx = nullptr;
@@ -561,6 +563,19 @@ int build_device_mesh(dotmi_handle *h)
             h->tmp_stride = std::max(h->tmp_stride, off);
         }
     }
+    {
+        // the blocks a factorisation leaves non-zero: leaf squares and separator panels (memory rows S, columns from
+        // the node's first column to the end of S)
+        std::vector<int4> segs;
+        for (const NdNode &N : h->nd) {
+            if (N.a < 0)
+                for (int r = N.off; r < N.off + N.size; ++r) segs.push_back(make_int4(r, N.off, N.size, 0));
+            else
+                for (int r = N.offS; r < N.offS + N.sizeS; ++r) segs.push_back(make_int4(r, N.off, N.offS + N.sizeS - N.off, 0));
+        }
+        h->nClearSeg = (int)segs.size();
+        if (int rc = upload(h, &h->clearSeg, segs)) return rc;
+    }
     if (int rc = dalloc(h, &P.Wtmp, (size_t)P.nParts * h->tmp_stride)) return rc;
     if (int rc = dalloc(h, &P.ppart, (size_t)P.nParts * P.nbmax * P.nmax)) return rc;
     if (int rc = dalloc(h, &P.psub, (size_t)P.nParts * P.nmax)) return rc;
@@ -908,15 +923,7 @@ int refactor_issue(dotmi_handle *h, const double *x)
     // only the blocks the factorisation leaves non-zero are cleared before the refill: the leaf squares and
     // the separator panels; the (A,C) blocks and the cleared mirror panels stay zero for the handle's life
     if (h->wDirty) {
-        const size_t sA = (size_t)h->P.nmax * h->P.nmax;
-        for (const NdNode &N : h->nd) {
-            if (N.a < 0)
-                launch_block_copy(h->P.W + N.off + (size_t)N.off * h->P.nmax, h->P.nmax, sA, nullptr, 0, 0, N.size, N.size,
-                                  h->P.nParts, h->st);
-            else if (N.sizeS > 0)  // memory rows S, columns [off, offS + sizeS)
-                launch_block_copy(h->P.W + N.off + (size_t)N.offS * h->P.nmax, h->P.nmax, sA, nullptr, 0, 0,
-                                  N.offS + N.sizeS - N.off, N.sizeS, h->P.nParts, h->st);
-        }
+        launch_clear_segments(h->P, h->clearSeg, h->nClearSeg, h->st);
     } else if (h->P.nParts > 0) {
         HIPCHECK(h, hipMemsetAsync(h->P.W, 0, (size_t)h->P.nParts * h->P.nmax * h->P.nmax * sizeof(double), h->st));
         h->wDirty = true;

@@ -161,6 +161,7 @@ void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *
                           hipStream_t st);
 void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st);
 void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st);
+void launch_clear_segments(const DevParts &P, const int4 *seg, int nseg, hipStream_t st);
 void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipStream_t st);
 void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, hipStream_t st);
 void launch_block_copy(double *dst, int ldd, size_t sd, const double *src, int lds_, size_t ss, int rows,

@@ -1559,6 +1559,22 @@ __global__ void pad_identity_kernel(int npad, const long long *__restrict__ dst,
     if (t < npad) W[dst[t]] = 1.0;
 }
 
+// clear row segments (memory row, first column, columns) of every owned dense block: one launch for all the
+// blocks a factorisation leaves non-zero
+__global__ __launch_bounds__(256) void clear_segments_kernel(const int4 *__restrict__ seg, int nmax,
+                                                             double *__restrict__ W)
+{
+    const int4 sg = seg[blockIdx.x];
+    double *row = W + (size_t)blockIdx.y * nmax * nmax + (size_t)sg.x * nmax + sg.y;
+    for (int c = threadIdx.x; c < sg.z; c += 256) row[c] = 0.0;
+}
+
+void launch_clear_segments(const DevParts &P, const int4 *seg, int nseg, hipStream_t st)
+{
+    if (nseg > 0 && P.nParts > 0)
+        hipLaunchKernelGGL(clear_segments_kernel, dim3(nseg, P.nParts), dim3(256), 0, st, seg, P.nmax, P.W);
+}
+
 void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st)
 {
     // the caller has cleared W (or the blocks of it a factorisation dirtied)
