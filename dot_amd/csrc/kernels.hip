@@ -514,6 +514,7 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
     const double *Ws = W + (size_t)s * nmax * nmax;
     const int *dm = dofmap + (size_t)s * nmax;
     double2 r[MAXCH], pacc[MAXCH];
+    int cend[MAXCH];  // first column this thread's pair of chunk m is NOT loaded for: 0 for identity-padding columns
 #pragma unroll
     for (int m = 0; m < MAXCH; ++m) {
         const int c = cb + 2 * tid + 2 * THREADS * m;
@@ -521,6 +522,8 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
         r[m].x = d0 >= 0 ? q[d0] : 0.0;
         r[m].y = d1 >= 0 ? q[d1] : 0.0;
         pacc[m] = make_double2(0.0, 0.0);
+        // padding columns of live rows hold zeros (separator rows span the padding of every region): not read
+        cend[m] = (d0 >= 0 || d1 >= 0) ? c : 0x7fffffff;
     }
 #pragma unroll 1
     for (int sb = 0; sb < BS_ROWS / SUB; ++sb) {
@@ -530,11 +533,12 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
 #pragma unroll
         for (int rr = 0; rr < SUB; ++rr) {
             const double *row = Ws + (size_t)min(ib + rr, ns - 1) * nmax;
-            const bool live = (ib + rr) < ns;
+            // a row is zero right of its diagonal: stop at the end of its own 128-byte line, not of the tile
+            const int rend = ((ib + rr) < ns) ? min(ncol, (ib + rr + 16) & ~15) : 0;
 #pragma unroll
             for (int m = 0; m < MAXCH; ++m) {
                 const int c = cb + 2 * tid + 2 * THREADS * m;
-                y[rr][m] = (live && c < ncol) ? *reinterpret_cast<const double2 *>(row + c) : make_double2(0.0, 0.0);
+                y[rr][m] = (cend[m] < rend) ? *reinterpret_cast<const double2 *>(row + c) : make_double2(0.0, 0.0);
             }
         }
         const int buf = sb & 1;
