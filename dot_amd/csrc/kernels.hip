@@ -645,16 +645,27 @@ __global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int2 *__res
     // so the loads of a group of tiles are all in flight together; the order of the sum stays b = 0, 1, ...
     double acc = 0.0;
     int b = 0;
-    for (; b + 8 <= nbmax; b += 8) {
-        double v[8];
+    for (; b + 16 <= nbmax; b += 16) {
+        double v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 16; ++u) {
             const int2 cr = tr[b + u];
             const double *src = (k >= cr.x && k < cr.y) ? base + (size_t)(b + u) * nmax : &g_zero_slot;
             v[u] = *src;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
+        for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; b + 4 <= nbmax; b += 4) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int2 cr = tr[b + u];
+            const double *src = (k >= cr.x && k < cr.y) ? base + (size_t)(b + u) * nmax : &g_zero_slot;
+            v[u] = *src;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += v[u];
     }
     for (; b < nbmax; ++b) {
         const int2 cr = tr[b];
