@@ -98,7 +98,7 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     iters = [s.iters for s in stats]
-    # ---- roofline of the dominant hand-written kernel pair, measured inside the timed region ----------
+    # ---- roofline of the dominant hand-written kernel, measured inside the timed region ------------------
     pre_ms = sum(s.ms_precond for s in stats)
     pre_n = sum(s.precond_launches for s in stats)
     bytes_per_launch = stats[0].precond_bytes            # sum_s n_s(n_s+1)/2 * 8 over the parts of THIS rank
@@ -116,7 +116,7 @@ def main():
         if rec.get("workload") == args.workload:
             traffic = rec["hbm_bytes_per_backsolve"]
     roofline = {
-        "bound": "hbm", "kernel": "backsolve_kernel (+reduce_partial_p_kernel): subdomain back-solve, nested-dissection block-sparse inverse factors",
+        "bound": "hbm", "kernel": "backsolve_kernel: subdomain back-solve p_s = X_s^T (X_s r_s), nested-dissection block-sparse inverse factors",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5),

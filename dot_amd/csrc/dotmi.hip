@@ -971,12 +971,8 @@ int apply_precond(dotmi_handle *h, const double *q, double *z, const LbfgsArgs &
 {
     const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size() &&
                        (h->timeCount++ % h->timeStride) == 0;
-    if (timed) HIPCHECK(h, hipEventRecord(h->evPre[h->evUsed], h->st));
-    launch_gemv(h->P, q, h->st);
-    if (timed) {
-        HIPCHECK(h, hipEventRecord(h->evPre[h->evUsed + 1], h->st));
-        h->evUsed += 2;
-    }
+    launch_gemv(h->P, q, h->st, nullptr, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr);
+    if (timed) h->evUsed += 2;
     if (!h->dist) {
         launch_merge(h->M, h->P, L, z, h->partC, 1 | 2, h->st);
     } else {
@@ -1063,12 +1059,9 @@ int enqueue_loop_slot(dotmi_handle *h)
     const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size() &&
                        (h->timeCount++ % h->timeStride) == 0;
     h->slotTimed.push_back(timed ? h->evUsed : -1);
-    if (timed) HIPCHECK(h, hipEventRecord(h->evPre[h->evUsed], h->st));
-    launch_gemv(h->P, h->q, h->st, h->ctl);
-    if (timed) {
-        HIPCHECK(h, hipEventRecord(h->evPre[h->evUsed + 1], h->st));
-        h->evUsed += 2;
-    }
+    launch_gemv(h->P, h->q, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr,
+                timed ? h->evPre[h->evUsed + 1] : nullptr);
+    if (timed) h->evUsed += 2;
     launch_merge(h->M, h->P, L0, h->z, h->partC, 1 | 2, h->st, h->ctl);
     launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
     launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, 0, h->nV, h->partS, h->st, h->ctl);

@@ -141,7 +141,8 @@ void launch_multidot(int n, const double *v, const double *const *vecs, int m, d
 void launch_build_q(int n, const double *g, const LbfgsArgs &L, const double *xi_host, double *q,
                     hipStream_t st, const DevLoop *ctl = nullptr);
 // subdomain back-solve: psub_s = X_s^T (X_s q[dofmap_s])
-void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr);
+void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
+                 hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // z = merge(psub) / dup  (+ partial dots y_i . z)
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
                   int with_dots, hipStream_t st, const DevLoop *ctl = nullptr);

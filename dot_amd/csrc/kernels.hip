@@ -674,15 +674,18 @@ __global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int2 *__res
     psub[(size_t)s * nmax + k] = acc;
 }
 
-void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl)
+void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1)
 {
     if (P.ntiles == 0) return;
+    // optional events bracket the streaming kernel alone (the roofline entry of bench.py is about that kernel)
+    if (ev0) hipEventRecord(ev0, st);
     if (P.nmax <= 2560)
         hipLaunchKernelGGL((backsolve_kernel<256>), dim3(P.ntiles), dim3(256), 0, st, P.tile, P.dofmap, P.W, P.nmax, q,
                            P.ppart, P.nbmax, ctl);
     else  // nmax <= 4096, enforced at create time
         hipLaunchKernelGGL((backsolve_kernel<512>), dim3(P.ntiles), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax, q,
                            P.ppart, P.nbmax, ctl);
+    if (ev1) hipEventRecord(ev1, st);
     hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.trange,
                        P.ppart, P.nmax, P.nbmax, P.psub, ctl);
 }

@@ -71,8 +71,9 @@ typedef struct {
 
 #define DOTMI_FLAG_FORCE_DIST 4     /* take the sharded code path (element lists, partial sums, RCCL
                                        all-reduces) even with world == 1: lets a 1-GPU box test it */
-#define DOTMI_FLAG_TIME_BACKSOLVE 2 /* bracket every back-solve of dotmi_step with HIP events on the
-                                       handle's stream; totals land in dotmi_step_stats */
+#define DOTMI_FLAG_TIME_BACKSOLVE 2 /* bracket every 8th launch of the streaming back-solve kernel inside dotmi_step
+                                       with HIP events on the handle's stream (an event record costs ~6 us of
+                                       stream time); totals land in dotmi_step_stats */
 #define DOTMI_FLAG_HOST_LOOP 8      /* drive the L-BFGS loop from the host (one stream synchronisation per
                                      * line-search trial) instead of the device-resident loop control; the
                                      * two produce identical iterates -- kept for A/B tests and always used
@@ -89,10 +90,10 @@ typedef struct {
     double ms_loop;       /* L-BFGS loop */
     double ms_hessian;    /* element Hessians + global assembly + dense gather (device time) */
     double ms_factor;     /* inverse-Cholesky factors of all owned subdomains (device time) */
-    double ms_precond;    /* DOTMI_FLAG_TIME_BACKSOLVE: summed device time of the timed back-solves */
-    int64_t precond_launches; /* how many back-solves were timed (<= 512 per step) */
-    int64_t precond_bytes; /* algorithmic bytes per back-solve launch: sum_s n_s(n_s+1)/2 * 8 (the
-                              triangular factor is streamed once) */
+    double ms_precond;    /* DOTMI_FLAG_TIME_BACKSOLVE: summed device time of the timed backsolve_kernel launches */
+    int64_t precond_launches; /* how many launches were timed */
+    int64_t precond_bytes; /* algorithmic bytes per back-solve launch: 8 x the structural non-zeros of the
+                              block-sparse inverse factors X_s of this rank (each is streamed once) */
 } dotmi_step_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
