@@ -276,6 +276,7 @@ class AnimScripter:
         bbox = np.stack([V_rest.min(axis=0), V_rest.max(axis=0)])
         self.rot_center = bbox.mean(axis=0)
         self.turn_vert = -1
+        self._last = None   # see track()
         self.turn_lo = -math.inf
         self.turn_hi = math.inf
         x0 = V_rest  # result.V == V_rest at init (main.cpp:712 UV = V)
@@ -354,6 +355,13 @@ class AnimScripter:
         self.changed = False
         if idx.size == 0 or self.script in ("hang", "null", "fall"):
             return idx[:0], np.zeros((0, 3))
+        if x is None:
+            # Scripted vertices are Dirichlet nodes: the solver never moves them, so their current positions are
+            # the ones this scripter set last (the reference reads them from the host mesh for free).  Not valid
+            # for rubberBandPull, whose release frees scripted vertices.
+            if self.script == "rubberBandPull" or self._last is None:
+                raise ValueError("step(None, dt) needs track(x0) first and a script that keeps its fixed set")
+            x = self._last
         if self.script == "rubberBandPull":
             if self.turn_vert >= 0 and x[self.turn_vert, 0] <= self.turn_lo:   # AnimScripter.cpp:404-417
                 self.turn_lo = -math.inf
@@ -377,7 +385,14 @@ class AnimScripter:
             if flip:
                 self._vel[:, 0] *= -1.0
             disp += self._vel * dt
-        return idx, xh + disp
+        pos = xh + disp
+        if self._last is not None:
+            self._last[idx] = pos
+        return idx, pos
+
+    def track(self, x0: np.ndarray) -> None:
+        """Start remembering the scripted positions, so that step(None, dt) works without reading x back."""
+        self._last = np.array(x0, dtype=np.float64, copy=True)
 
 
 @dataclasses.dataclass

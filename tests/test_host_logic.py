@@ -301,3 +301,20 @@ def test_node_ele_restart_and_partition_files_cpp_vs_python(tmp_path):
     npts = wire.index("POLYS") - 1
     assert wire[0] == "POINTS" and wire[-1] == "END" and npts == np.unique(tris).size
     assert len(wire) == 1 + npts + 1 + 3 * tris.shape[0] + 1
+
+
+@pytest.mark.parametrize("workload", ["bar17K_twist", "bunny5K_LTSS", "horse7K_stretch"])
+def test_scripter_tracking_equals_reading_positions_back(workload):
+    """bench.py lets the scripter remember the Dirichlet positions it set (step(None, dt)) instead of reading all
+    positions back each step: must give bit-identical moves, and is refused where it would be wrong."""
+    sc, _, _ = load_workload(workload)
+    sc2, _, _ = load_workload(workload)
+    with pytest.raises(ValueError):
+        sc2.scripter.step(None, sc2.cfg.dt)          # not tracking yet
+    sc2.scripter.track(sc2.x0)
+    x = sc.x0.copy()
+    for _ in range(80):
+        i1, p1 = sc.scripter.step(x, sc.cfg.dt)
+        x[i1] = p1
+        i2, p2 = sc2.scripter.step(None, sc2.cfg.dt)
+        assert np.array_equal(i1, i2) and np.array_equal(p1, p2)
