@@ -1261,16 +1261,37 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
         const int ch = t & (SUM_CHUNKS - 1);
         const int colA = t >> 4;          // 0..15
         const int colB = 16 + (t >> 4);   // 16..RED_K-1 for t < 16*(RED_K-16)
-        const int LR = (NB_RED + SUM_CHUNKS - 1) / SUM_CHUNKS;
+        constexpr int LR = (NB_RED + SUM_CHUNKS - 1) / SUM_CHUNKS;
+        static_assert(LR * SUM_CHUNKS == NB_RED, "chunks of equal length");
         double a = 0.0, b = 0.0, e = 0.0;
-        for (int k = ch * LR; k < min(NB_RED, (ch + 1) * LR); ++k) a += partR[(size_t)k * RED_K + colA];
-        if (colB < RED_K)
-            for (int k = ch * LR; k < min(NB_RED, (ch + 1) * LR); ++k) b += partR[(size_t)k * RED_K + colB];
+        // all loads of a chunk first (independent), then the adds in order
+        double va[LR], vb[LR];
+#pragma unroll
+        for (int k = 0; k < LR; ++k) va[k] = partR[(size_t)(ch * LR + k) * RED_K + colA];
+        if (colB < RED_K) {
+#pragma unroll
+            for (int k = 0; k < LR; ++k) vb[k] = partR[(size_t)(ch * LR + k) * RED_K + colB];
+        }
         const int te = t - 16 * (RED_K - 16);  // the next 32 threads: the two energy columns
         if (te >= 0 && te < 2 * SUM_CHUNKS) {
             const int LE = (nbE + SUM_CHUNKS - 1) / SUM_CHUNKS, c = te >> 4;
-            for (int k = ch * LE; k < min(nbE, (ch + 1) * LE); ++k) e += partE[2 * k + c];
+            const int k0 = ch * LE, k1 = min(nbE, (ch + 1) * LE);
+            int k = k0;
+            for (; k + 8 <= k1; k += 8) {
+                double ve[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) ve[u] = partE[2 * (k + u) + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e += ve[u];
+            }
+            for (; k < k1; ++k) e += partE[2 * k + c];
             chunk[RED_K + c][ch] = e;
+        }
+#pragma unroll
+        for (int k = 0; k < LR; ++k) a += va[k];
+        if (colB < RED_K) {
+#pragma unroll
+            for (int k = 0; k < LR; ++k) b += vb[k];
         }
         chunk[colA][ch] = a;
         if (colB < RED_K) chunk[colB][ch] = b;
@@ -1309,32 +1330,71 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
             C.E_cur = E;
             const double g2 = R[0];
             C.g2_cur = g2;
+            // The history update and the first half of the two-loop below are the host loop's statements
+            // (dotmi_step) with every array held in registers: all loops are unrolled to HIST_MAX with guards, so
+            // nothing is indexed dynamically and no LDS round trip sits in the dependent chain.  The operations
+            // and their order are the host's, so the two loops stay bit-identical.
+            constexpr int H = HIST_MAX;
             const double ys_new = R[1], sg_new = R[2];
-            const double *siy = R + 3, *snyj = R + 3 + HIST_MAX, *sig = R + 3 + 2 * HIST_MAX;
+            double siy[H], snyj[H], sig[H], ys[H], b[H], sy[H][H], xi[H];
+            int order[H];
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                siy[i] = R[3 + i];
+                snyj[i] = R[3 + H + i];
+                sig[i] = R[3 + 2 * H + i];
+                ys[i] = C.L.ys[i];
+                b[i] = C.b[i];
+                order[i] = C.order[i];
+#pragma unroll
+                for (int jj = 0; jj < H; ++jj) sy[i][jj] = C.L.sy[i][jj];
+            }
+            int m = C.L.m;
+            const int hist = C.hist, newslot = C.slot;
             if (ys_new > 0.0) {
-                int m = C.L.m;
                 int off = 0;
-                if (m == C.hist) {  // drop the oldest pair
+                if (m == hist) {  // drop the oldest pair
                     off = 1;
-                    for (int i = 0; i + 1 < m; ++i) {
-                        C.order[i] = C.order[i + 1];
-                        C.L.ys[i] = C.L.ys[i + 1];
-                        for (int j = 0; j + 1 < m; ++j) C.L.sy[i][j] = C.L.sy[i + 1][j + 1];
+#pragma unroll
+                    for (int i = 0; i + 1 < H; ++i) {
+                        order[i] = order[i + 1];
+                        ys[i] = ys[i + 1];
+#pragma unroll
+                        for (int jj = 0; jj + 1 < H; ++jj) sy[i][jj] = sy[i + 1][jj + 1];
                     }
                     m -= 1;
                 }
-                for (int i = 0; i < m; ++i) {
-                    C.L.sy[i][m] = siy[i + off];
-                    C.L.sy[m][i] = snyj[i + off];
-                    C.b[i] = sig[i + off];
+#pragma unroll
+                for (int i = 0; i < H; ++i) {
+                    // value i + off of the three statistic rows
+                    const double a_siy = (off && i + 1 < H) ? siy[i + 1 < H ? i + 1 : i] : siy[i];
+                    const double a_sny = (off && i + 1 < H) ? snyj[i + 1 < H ? i + 1 : i] : snyj[i];
+                    const double a_sig = (off && i + 1 < H) ? sig[i + 1 < H ? i + 1 : i] : sig[i];
+                    if (i < m) {
+#pragma unroll
+                        for (int jj = 0; jj < H; ++jj)
+                            if (jj == m) {
+                                sy[i][jj] = a_siy;   // sy[i][m]
+                            }
+#pragma unroll
+                        for (int ii = 0; ii < H; ++ii)
+                            if (ii == m) sy[ii][i] = a_sny;   // sy[m][i]
+                        b[i] = a_sig;
+                    }
                 }
-                C.order[m] = C.slot;
-                C.L.ys[m] = ys_new;
-                C.L.sy[m][m] = ys_new;
-                C.b[m] = sg_new;
-                C.L.m = m + 1;
+#pragma unroll
+                for (int i = 0; i < H; ++i)
+                    if (i == m) {
+                        order[i] = newslot;
+                        ys[i] = ys_new;
+                        sy[i][i] = ys_new;
+                        b[i] = sg_new;
+                    }
+                m += 1;
             } else {
-                for (int i = 0; i < C.L.m; ++i) C.b[i] = sig[i];
+#pragma unroll
+                for (int i = 0; i < H; ++i)
+                    if (i < m) b[i] = sig[i];
             }
             if (C.iter < C.logCap) {
                 C.log_alpha[C.iter] = alpha;
@@ -1342,32 +1402,51 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
                 C.log_g2[C.iter] = g2;
             }
             C.iter++;
+#pragma unroll
+            for (int i = 0; i < H; ++i) xi[i] = 0.0;
+            int fs = C.slot;
             if (C.iter >= C.iterCap) C.status = 2;
             else if (!(g2 > C.tol)) C.status = 1;
             else {
-                // next direction: first half of the two-loop, operand views, free slot
-                const int m = C.L.m;
-                for (int i = 0; i < HIST_MAX; ++i) C.X.xi[i] = 0.0;
-                for (int i = m - 1; i >= 0; --i) {
-                    double sq = -C.b[i];
-                    for (int j = m - 1; j > i; --j) sq -= C.X.xi[j] * C.L.sy[i][j];
-                    C.X.xi[i] = sq / C.L.ys[i];
-                }
-                for (int i = 0; i < m; ++i) {
-                    C.L.s[i] = C.S[C.order[i]];
-                    C.L.y[i] = C.Y[C.order[i]];
-                }
-                int fs = 0;
-                for (int sl = 0; sl <= C.hist; ++sl) {
+                // next direction: first half of the two-loop, free slot
+#pragma unroll
+                for (int i = H - 1; i >= 0; --i)
+                    if (i < m) {
+                        double sq = -b[i];
+#pragma unroll
+                        for (int jj = H - 1; jj > i; --jj)
+                            if (jj < m) sq -= xi[jj] * sy[i][jj];
+                        xi[i] = sq / ys[i];
+                    }
+                fs = 0;
+                bool found = false;
+#pragma unroll
+                for (int sl = 0; sl <= H; ++sl) {
                     bool used = false;
-                    for (int i = 0; i < m; ++i) used |= (C.order[i] == sl);
-                    if (!used) {
+#pragma unroll
+                    for (int i = 0; i < H; ++i) used |= (i < m && order[i] == sl);
+                    if (!found && sl <= hist && !used) {
                         fs = sl;
-                        break;
+                        found = true;
                     }
                 }
-                C.slot = fs;
                 C.phase = 0;
+            }
+            // back to the shared copy (stores only; the operand views take their pointers from the slot table)
+            C.L.m = m;
+            C.slot = fs;
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                C.L.ys[i] = ys[i];
+                C.b[i] = b[i];
+                C.order[i] = order[i];
+                C.X.xi[i] = xi[i];
+#pragma unroll
+                for (int jj = 0; jj < H; ++jj) C.L.sy[i][jj] = sy[i][jj];
+                if (i < m) {
+                    C.L.s[i] = C.S[order[i]];
+                    C.L.y[i] = C.Y[order[i]];
+                }
             }
         }
     }
