@@ -450,3 +450,33 @@ def test_cpp_headless_runner_end_to_end(tmp_path):
     assert len(fr2) == 1 and fr2[0][1] == "2"
     assert abs(int(fr2[0][5]) - int(frames[2][5])) <= 1
     assert abs(float(fr2[0][9]) - float(frames[2][9])) <= 1e-4 * abs(float(frames[2][9]))
+
+
+@pytest.mark.parametrize("levels,nd_min", [("0", "768"), ("1", "512"), ("3", "256")])
+def test_every_dissection_depth_gives_the_same_preconditioner(levels, nd_min, monkeypatch):
+    """The ordering of the subdomain blocks does not enter the mathematics: dense blocks (0 levels), one level and
+    three levels of nested dissection must all reproduce the oracle's preconditioner and steps."""
+    monkeypatch.setenv("DOTMI_ND_LEVELS", levels)
+    monkeypatch.setenv("DOTMI_ND_MIN", nd_min)
+    sc, ep, n = load_workload("bunny5K_LTSS")
+    cfg = sc.cfg
+    ts = DOTTimeStepper(sc, ep, n)
+    orc = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, n,
+                      cfg.with_gravity)
+    rng = np.random.default_rng(3)
+    x = sc.x0 + 2e-3 * rng.standard_normal(sc.x0.shape)
+    ts.updatePrecondMtrAndFactorize(x); orc.refactor(x)
+    r = rng.standard_normal(x.shape); r[sc.fixed.astype(bool)] = 0
+    assert rel(ts.applyPrecond(r), orc.apply_precond(r)) < 1e-9
+    M, _ = ts.partMatrix(1, False)
+    X, _ = ts.partMatrix(1, True)
+    assert np.abs((X.T @ X) @ M - np.eye(len(M))).max() < 1e-9
+    ts.updatePrecondMtrAndFactorize(sc.x0); orc.refactor(sc.x0)
+    for _ in range(3):
+        xs = ts.getResult()
+        idx, pos = sc.scripter.step(xs, cfg.dt)
+        ts.setDirichlet(idx, pos); orc.move(idx, pos)
+        st, so = ts.step(), orc.step()
+        assert (st.iters, st.ls_halvings) == (so.iters, so.ls_halvings)
+        assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
+    ts.close(); orc.close()
