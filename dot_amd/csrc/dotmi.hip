@@ -114,6 +114,9 @@ struct dotmi_handle {
     int *didx = nullptr;
     double *dpos = nullptr;
     size_t dcap = 0;
+    std::vector<int32_t> didxHost;  // last scripted index set (uploaded only when it changes)
+    double *dposPinned = nullptr;
+    hipEvent_t evDir = nullptr;
     std::vector<void *> allocs;
     // pinned host
     double *h_partE = nullptr, *h_partR = nullptr, *h_alpha = nullptr;
@@ -1269,6 +1272,8 @@ void dotmi_destroy(dotmi_handle *h)
     if (h->h_partR) hipHostFree(h->h_partR);
     if (h->h_alpha) hipHostFree(h->h_alpha);
     if (h->h_ctl) hipHostFree(h->h_ctl);
+    if (h->dposPinned) hipHostFree(h->dposPinned);
+    if (h->evDir) hipEventDestroy(h->evDir);
     if (h->h_info) hipHostFree(h->h_info);
     if (h->h_flags) hipHostFree(h->h_flags);
     if (h->ev0) hipEventDestroy(h->ev0);
@@ -1526,10 +1531,23 @@ int dotmi_set_dirichlet(dotmi_handle *h, int32_t n, const int32_t *idx, const do
         if (int rc = dalloc(h, &h->dpos, (size_t)3 * n)) return rc;
         h->dcap = n;
     }
-    HIPCHECK(h, hipMemcpyAsync(h->didx, idx, sizeof(int) * n, hipMemcpyHostToDevice, h->st));
-    HIPCHECK(h, hipMemcpyAsync(h->dpos, pos, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->st));
+    // the scripted set is the same every step: the indices go up only when they change, the positions through a
+    // pinned staging buffer, and nothing waits here (the stream orders the scatter before the step's kernels)
+    if (h->didxHost.size() != (size_t)n || memcmp(h->didxHost.data(), idx, sizeof(int32_t) * n) != 0) {
+        HIPCHECK(h, hipStreamSynchronize(h->st));
+        h->didxHost.assign(idx, idx + n);
+        if (h->dposPinned) hipHostFree(h->dposPinned);
+    if (h->evDir) hipEventDestroy(h->evDir);
+        h->dposPinned = nullptr;
+        HIPCHECK(h, hipHostMalloc((void **)&h->dposPinned, sizeof(double) * 3 * n));
+        HIPCHECK(h, hipMemcpyAsync(h->didx, h->didxHost.data(), sizeof(int) * n, hipMemcpyHostToDevice, h->st));
+    }
+    if (!h->evDir) HIPCHECK(h, hipEventCreateWithFlags(&h->evDir, hipEventDisableTiming));
+    else HIPCHECK(h, hipEventSynchronize(h->evDir));  // the previous upload out of the staging buffer (normally long done)
+    memcpy(h->dposPinned, pos, sizeof(double) * 3 * n);
+    HIPCHECK(h, hipMemcpyAsync(h->dpos, h->dposPinned, sizeof(double) * 3 * n, hipMemcpyHostToDevice, h->st));
+    HIPCHECK(h, hipEventRecord(h->evDir, h->st));
     launch_scatter_rows(n, h->didx, h->dpos, h->x, h->st);
-    HIPCHECK(h, hipStreamSynchronize(h->st));
     return 0;
 }
 
