@@ -107,7 +107,7 @@ def main():
     # ---- roofline of the dominant hand-written kernel, measured inside the timed region ------------------
     pre_ms = sum(s.ms_precond for s in stats)
     pre_n = sum(s.precond_launches for s in stats)
-    bytes_per_launch = stats[0].precond_bytes            # sum_s n_s(n_s+1)/2 * 8 over the parts of THIS rank
+    bytes_per_launch = stats[0].precond_bytes            # 8 x structural non-zeros of the inverse factors of THIS rank's parts
     avg_ms = pre_ms / max(pre_n, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if pre_n else 0.0
     # HBM traffic of one back-solve from the PMC counters (FETCH_SIZE / WRITE_SIZE need their own rocprofv3

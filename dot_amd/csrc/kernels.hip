@@ -14,7 +14,12 @@
 //                             Optimizer.cpp:1202-1215 (inertia energy)
 //   vertex_gather_kernel      Energy.cpp:543-563, Optimizer.cpp:1239-1252, DOTTimeStepper.cpp:474-494
 //   build_q / build_p         DOTTimeStepper.cpp:386-400, :455-467 (two-loop recursion, compact form)
-//   gemv_kernel + merge       DOTTimeStepper.cpp:406-450 (subdomain back-solve, average by dup)
+//   backsolve_kernel + reduce_partial_p + merge
+//                             DOTTimeStepper.cpp:406-450 (subdomain back-solve, average by dup)
+//   loop_control_kernel       Optimizer.cpp:806-833 (line search), DOTTimeStepper.cpp:474-494 (history),
+//                             Optimizer.cpp:317-330 (stopping test) -- the host loop's control flow, on device
+//   chol_inv_base / chol_inv_node128 (+ rocBLAS dgemm from dotmi.hip)
+//                             CHOLMODSolver.cpp:143 factorize, as a block-sparse inverse-Cholesky
 //   spmv_dots / step_forward  Optimizer.cpp:1076-1093 (alpha_0), :1023-1042 (x = x0 + alpha p)
 //   elem_hessian_kernel       Energy.cpp:738-777, :1129-1270, IglUtils.hpp:466-479
 //   assemble_kernel           DOTTimeStepper.cpp:588-613, IglUtils.hpp:143-220
@@ -482,15 +487,18 @@ void launch_multidot(int n, const double *v, const double *const *vecs, int m, d
 // subdomain back-solve  p_s = H_s^-1 r_s = X^T (X r_s),  X = chol(H_s)^-1  (lower triangular)
 //   -- THE HBM-bound kernel of the L-BFGS loop.
 // Storage: memory row i holds row i of X, X(i,k) for k <= i, contiguously (zeros for k > i); that is
-//   the column-major upper factor Q = R^-1 of H = R^T R that chol_inv_node() produces.
+//   the column-major upper factor Q = R^-1 of H = R^T R that chol_inv_tree() produces.  In the
+//   nested-dissection order of the subdomain (nd_layout.hpp) row i is non-zero only from the first
+//   column of its tree node on, so X is block-sparse.
 // One pass: for every memory row i   t_i = row_i . r   and then   p += t_i * row_i
 //   so each stored entry is read from HBM exactly ONCE per back-solve:
-//   algorithmic bytes per launch = sum_s n_s (n_s + 1) / 2 * 8.
-// A workgroup owns BS_ROWS consecutive rows of one subdomain and walks them BS_SUB at a time: the
-// rows sit in VGPRs (16 B per lane per row chunk), their dot products are combined with a transposed
-// butterfly (10 shuffles instead of 48) + one LDS exchange, and the rank-8 update of p is applied
-// from the same registers.  The workgroup's partial p goes to ppart[s][tile][.]; the tiles of a
-// subdomain are summed in fixed order by reduce_partial_p_kernel (no atomics, deterministic).
+//   algorithmic bytes per launch = 8 x the structural non-zeros of all X_s (dotmi_step_stats.precond_bytes).
+// A workgroup owns up to BS_ROWS consecutive rows of one tree region of one subdomain and walks them a
+// few at a time: the rows sit in VGPRs (16 B per lane per row chunk), their dot products are combined
+// with a transposed butterfly (10 shuffles instead of 48) + one LDS exchange, and the rank-k update of
+// p is applied from the same registers.  Loads stop at the 128-byte line of each row's diagonal and
+// skip the identity-padding columns.  The workgroup's partial p goes to ppart[s][tile][.]; the tiles
+// of a subdomain are summed in fixed order by reduce_partial_p_kernel (no atomics, deterministic).
 // ------------------------------------------------------------------------------------------------
 constexpr int BS_ROWS = 64;   // memory rows per workgroup
 
