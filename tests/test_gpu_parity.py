@@ -480,3 +480,25 @@ def test_every_dissection_depth_gives_the_same_preconditioner(levels, nd_min, mo
         assert (st.iters, st.ls_halvings) == (so.iters, so.ls_halvings)
         assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
     ts.close(); orc.close()
+
+
+@pytest.mark.parametrize("history", [2, 5, 6])
+def test_iteration_cap_and_history_lengths_in_both_loops(history):
+    """Iteration cap (return code 2, Optimizer.cpp:317-330) and the L-BFGS history rotation at other lengths than
+    the reference's 5 -- the device-resident loop control and the host loop must agree bit for bit, and a capped
+    step must stop exactly at the cap."""
+    sc, ep, n = load_workload("bunny5K_LTSS")
+    a = DOTTimeStepper(sc, ep, n, history=history, iter_cap=7)
+    sc2, _, _ = load_workload("bunny5K_LTSS")
+    b = DOTTimeStepper(sc2, ep, n, history=history, iter_cap=7, flags=dl.FLAG_HOST_LOOP)
+    capped = 0
+    for k in range(5):
+        ra, rb = a.solve(1), b.solve(1)
+        assert ra == rb and ra in (0, 2)
+        sa, sb = a.last_stats, b.last_stats
+        assert (sa.iters, sa.ls_halvings, sa.energy_evals, sa.status) == (sb.iters, sb.ls_halvings, sb.energy_evals, sb.status)
+        assert sa.iters <= 7 and (ra == 2) == (sa.iters == 7 and sa.g2 > a.targetGRes or sa.status == 2)
+        capped += ra == 2
+        assert np.array_equal(a.getResult(), b.getResult())
+    assert capped >= 1          # the twisting bunny needs 9-12 iterations per step
+    a.close(); b.close()
