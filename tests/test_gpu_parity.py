@@ -502,3 +502,28 @@ def test_iteration_cap_and_history_lengths_in_both_loops(history):
         assert np.array_equal(a.getResult(), b.getResult())
     assert capped >= 1          # the twisting bunny needs 9-12 iterations per step
     a.close(); b.close()
+
+
+def test_iteration_counts_equal_the_reference_published_runs():
+    """L-BFGS iterations per step of the reference itself (compiled oracle run of the
+    upstream code).  bar17K / StableNH / 32 METIS parts: 16 20 25 26 26 26 26 27 27 27 with no back-tracking;
+    bunny5K / FCR / 8 parts: 11 10 9 9 9 10 11 11 12 12 13 14 ... (exact while the trajectory is well conditioned,
+    steps 0-8; the reference itself moves by +-1 from step 9 on under a 1-ulp BLAS change)."""
+    sc, ep, n = load_workload("bar17K_twist")
+    ts = DOTTimeStepper(sc, ep, n)
+    its, halv = [], 0
+    for _ in range(10):
+        assert ts.solve(1) == 0
+        its.append(ts.last_stats.iters); halv += ts.last_stats.ls_halvings
+    ts.close()
+    assert its == [16, 20, 25, 26, 26, 26, 26, 27, 27, 27] and halv == 0
+    sc, ep, n = load_workload("bunny5K_LTSS")
+    ts = DOTTimeStepper(sc, ep, n)
+    assert abs(ts.targetGRes - 2.75467e-05) < 1e-10
+    ref = [11, 10, 9, 9, 9, 10, 11, 11, 12, 12, 13, 14]
+    its = []
+    for _ in range(12):
+        assert ts.solve(1) == 0
+        its.append(ts.last_stats.iters)
+    ts.close()
+    assert its[:9] == ref[:9] and all(abs(a - b) <= 1 for a, b in zip(its[9:], ref[9:]))
