@@ -167,6 +167,7 @@ struct dotmi_handle {
     // independent (forks and joins always go through the group's own stream -- no nested forks)
     struct FactorUnit {
         int node = 0;
+        int part = 0;       // see chol_inv_tree()
         size_t tmpOff = 0;  // disjoint scratch of concurrently running units
         hipEvent_t fork = nullptr, join = nullptr;
     };
@@ -565,6 +566,22 @@ int build_device_mesh(dotmi_handle *h)
             }
             h->tmp_stride = std::max(h->tmp_stride, off);
         }
+        // the root is alone in the last phase: its two triangular products split into their child-A and child-C
+        // halves (disjoint rows of the same scratch), which run on two branches
+        const char *sr = getenv("DOTMI_ND_SPLIT_ROOT");
+        if (hmax > 0 && !(sr && atoi(sr) == 0) && h->phases.back().size() == 1 && h->nd[0].sizeS > 0) {
+            const dotmi_handle::FactorUnit R = h->phases.back()[0];
+            h->phases.pop_back();
+            for (int st = 0; st < 3; ++st) {
+                std::vector<dotmi_handle::FactorUnit> ph;
+                for (int part : (st == 0 ? std::vector<int>{1, 2} : st == 1 ? std::vector<int>{3} : std::vector<int>{4, 5})) {
+                    dotmi_handle::FactorUnit U = R;
+                    U.part = part;
+                    ph.push_back(U);
+                }
+                h->phases.push_back(ph);
+            }
+        }
     }
     {
         // the blocks a factorisation leaves non-zero: leaf squares and separator panels (memory rows S, columns from
@@ -811,7 +828,9 @@ struct TriMult {
 // The (A,C) block of the factor and of its inverse is structurally zero and is never touched.
 // One call does ONE node: a dense leaf, or the separator steps of a dissection node whose children are
 // finished; issue_factor() walks the tree by height and runs the nodes of one height concurrently.
-int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id)
+// `part`: 0 = the whole node; for a dissection node that is split over parallel branches 1 / 2 = the transposed
+// product for child A / C, 3 = the separator block itself, 4 / 5 = the final product for child A / C.
+int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id, int part = 0)
 {
     const NdNode &N = h->nd[id];
     if (N.a < 0) return chol_inv_node(h, G, N.off, N.size);
@@ -829,28 +848,36 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id)
     double *Tb = P.Wtmp + (size_t)G.first * h->tmp_stride + G.tmpOff;
     const double one = 1.0, zero = 0.0, mone = -1.0;
     const rocblas_operation Nn = rocblas_operation_none, Tt = rocblas_operation_transpose;
-    {
+    if (part == 0 || part == 1 || part == 2) {
         TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Hxs, lda, sA, Tb, mr, sT, true, compact};
-        if (int rc = tm.node(N.a, 0, 0, 0.0)) return rc;
-        if (int rc = tm.node(N.c, A.size, A.crows, 0.0)) return rc;
+        if (part != 2)
+            if (int rc = tm.node(N.a, 0, 0, 0.0)) return rc;
+        if (part != 1)
+            if (int rc = tm.node(N.c, A.size, A.crows, 0.0)) return rc;
+        if (part != 0) return 0;
     }
-    RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Tt, Nn, ns, ns, mr, &mone, Tb, mr, sT, Tb, mr, sT, &one, Hss, lda,
-                                             sA, batch));
-    // R stays in scratch across the factorisation of the separator block; [Q_AS ; Q_CS] = -blockdiag(Q_A, Q_C) (R Q_S)
-    // is then written straight into place
-    dotmi_handle::FactorGroup G2 = G;
-    G2.tmpOff = G.tmpOff + (size_t)mr * ns;
-    if (int rc = chol_inv_node(h, G2, N.offS, ns)) return rc;
     double *T2 = Tb + (size_t)mr * ns;
-    RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Nn, Nn, mr, ns, ns, &one, Tb, mr, sT, Hss, lda, sA, &zero, T2, mr,
-                                             sT, batch));
+    if (part == 0 || part == 3) {
+        RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Tt, Nn, ns, ns, mr, &mone, Tb, mr, sT, Tb, mr, sT, &one, Hss, lda,
+                                                 sA, batch));
+        // R stays in scratch across the factorisation of the separator block; [Q_AS ; Q_CS] = -blockdiag(Q_A, Q_C)
+        // (R Q_S) is then written straight into place
+        dotmi_handle::FactorGroup G2 = G;
+        G2.tmpOff = G.tmpOff + (size_t)mr * ns;
+        if (int rc = chol_inv_node(h, G2, N.offS, ns)) return rc;
+        RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Nn, Nn, mr, ns, ns, &one, Tb, mr, sT, Hss, lda, sA, &zero, T2, mr,
+                                                 sT, batch));
+        // rows S, columns [A C] of the lower part hold the symmetric fill of H: clear them
+        launch_block_copy(Wg + N.offS + (size_t)N.off * lda, lda, (size_t)sA, nullptr, 0, 0, ns, m, batch, G.st);
+        if (part != 0) return 0;
+    }
     {
         TriMult tm{h, G, Wg, lda, ns, sA, -1.0, T2, mr, sT, Hxs, lda, sA, false, compact};
-        if (int rc = tm.node(N.a, 0, 0, 0.0)) return rc;
-        if (int rc = tm.node(N.c, A.size, A.crows, 0.0)) return rc;
+        if (part != 5)
+            if (int rc = tm.node(N.a, 0, 0, 0.0)) return rc;
+        if (part != 4)
+            if (int rc = tm.node(N.c, A.size, A.crows, 0.0)) return rc;
     }
-    // rows S, columns [A C] of the lower part hold the symmetric fill of H: clear them
-    launch_block_copy(Wg + N.offS + (size_t)N.off * lda, lda, (size_t)sA, nullptr, 0, 0, ns, m, batch, G.st);
     return 0;
 }
 
@@ -872,7 +899,7 @@ int issue_factor(dotmi_handle *h)
                     Gk.blas = h->branches[k - 1].blas;
                     HIPCHECK(h, hipStreamWaitEvent(Gk.st, phase[0].fork, 0));
                 }
-                if (int rc = chol_inv_tree(h, Gk, U.node)) return rc;
+                if (int rc = chol_inv_tree(h, Gk, U.node, U.part)) return rc;
                 if (par && k > 0) {
                     HIPCHECK(h, hipEventRecord(U.join, Gk.st));
                     HIPCHECK(h, hipStreamWaitEvent(G.st, U.join, 0));

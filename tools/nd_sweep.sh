@@ -1,7 +1,7 @@
 timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|^E" | head -20
-for dl in 1 0; do
-echo "== device loop $dl"
-DOTMI_DEVICE_LOOP=$dl timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+for sr in 1 0; do
+echo "== split root $sr"
+DOTMI_ND_SPLIT_ROOT=$sr timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):
