@@ -132,6 +132,19 @@ def main():
         "share_of_step_time": round(avg_ms * sum(iters) / (1e3 * elapsed), 3),
     }
 
+    # ---- second roofline: the once-per-step factorisation against the dense FP64 matrix-core peak ----------------
+    FP64_MFMA_PEAK = 78.6   # TFLOP/s, MI355X FP64 matrix = vector peak (256 CUs x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
+    fact_ms = float(np.mean([s.ms_factor for s in stats]))
+    fact_tf = stats[0].factor_flops / (fact_ms * 1e-3) / 1e12 if fact_ms > 0 else 0.0
+    roofline_factor = {
+        "bound": "mfma", "kernel": "block-sparse inverse-Cholesky of the subdomain blocks (rocBLAS dgemm_strided_batched "
+        "+ chol_inv_node128 / chol_inv_base), once per step",
+        "achieved": round(fact_tf, 2), "peak": FP64_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(fact_tf / FP64_MFMA_PEAK, 4),
+        "flop_per_factorisation": float(stats[0].factor_flops), "avg_ms": round(fact_ms, 4),
+        "note": "flop as executed (identity padding included); the phase is bound by chains of small dependent kernels, "
+                "see profiles/r01_factor_experiments.txt",
+    }
+
     out = None
     if rank == 0:
         out = {
@@ -154,6 +167,7 @@ def main():
                 "back_solve_kernels": round(avg_ms * float(np.mean(iters)), 3),
             },
             "roofline": roofline,
+            "roofline_factor": roofline_factor,
         }
         # ---- CPU baseline on this box's host cores: bounded sample of the same workload ---------------
         if not args.no_cpu_baseline and world == 1:

@@ -180,6 +180,7 @@ struct dotmi_handle {
     std::vector<hipEvent_t> evPre;  // DOTMI_FLAG_TIME_BACKSOLVE: (start, stop) pairs around each back-solve
     int evUsed = 0;
     int64_t precond_bytes = 0;
+    double flopCount = 0, factorFlops = 0;  // running counter of the recursion; FP64 flop of one factorisation
 };
 
 #define HIPCHECK(h, call)                                                                         \
@@ -661,10 +662,12 @@ int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, in
     const rocblas_stride sA = (rocblas_stride)lda * lda;
     double *Wg = P.W + (size_t)G.first * sA;
     if (sz <= CHOL_NB) {
+        h->flopCount += 2.0 / 3.0 * 64.0 * 64.0 * 64.0 * batch;  // factor + triangular inverse
         launch_chol_inv_base(Wg, lda, batch, o, h->info_dev + G.first, G.st);
         return 0;
     }
     if (sz == 2 * CHOL_NB) {  // the whole two-block node in one LDS-resident launch
+        h->flopCount += 2.0 / 3.0 * 128.0 * 128.0 * 128.0 * batch;
         launch_chol_inv_node128(Wg, lda, batch, o, h->info_dev + G.first, G.st);
         return 0;
     }
@@ -683,6 +686,7 @@ int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, in
     auto gemm = [&](rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double *alpha,
                     const double *A, int la, rocblas_stride sa, const double *B, int lb, rocblas_stride sb,
                     const double *beta, double *C, int lc, rocblas_stride sc) {
+        h->flopCount += 2.0 * m * n * k * batch;
         return rocblas_dgemm_strided_batched(G.blas, ta, tb, m, n, k, alpha, A, la, sa, B, lb, sb, beta, C, lc, sc,
                                              batch);
     };
@@ -766,6 +770,7 @@ struct TriMult {
     // C[ro..ro+m) (+)= alpha * op(Q[qi.., qj..]) * B[rb..rb+k)
     int gemm(int m, int k, int qi, int qj, int rb, int ro, double beta) const
     {
+        h->flopCount += 2.0 * m * ncols * k * G.count;
         const rocblas_status st = rocblas_dgemm_strided_batched(
             G.blas, trans ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none, m, ncols, k,
             &alpha, Q(qi, qj), lda, sA, B + rb, ldb, sB, &beta, C + ro, ldc, sC, G.count);
@@ -858,6 +863,7 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id, i
     }
     double *T2 = Tb + (size_t)mr * ns;
     if (part == 0 || part == 3) {
+        h->flopCount += 2.0 * ns * ns * mr * batch + 2.0 * mr * ns * ns * batch;  // R^T R and R Q_S below
         RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Tt, Nn, ns, ns, mr, &mone, Tb, mr, sT, Tb, mr, sT, &one, Hss, lda,
                                                  sA, batch));
         // R stays in scratch across the factorisation of the separator block; [Q_AS ; Q_CS] = -blockdiag(Q_A, Q_C)
@@ -921,7 +927,9 @@ int run_factor(dotmi_handle *h)
         const char *ev = getenv("DOTMI_FACTOR_GRAPH");
         if (!(ev && atoi(ev) == 0)) {
             // warm rocBLAS (kernel selection, lazy loads) outside of capture, then capture the same sequence
+            h->flopCount = 0;
             if (int rc = issue_factor(h)) return rc;
+            h->factorFlops = h->flopCount;
             HIPCHECK(h, hipStreamSynchronize(h->st));
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(h->st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
@@ -942,7 +950,10 @@ int run_factor(dotmi_handle *h)
         HIPCHECK(h, hipGraphLaunch(h->factorGraph, h->st));
         return 0;
     }
-    return issue_factor(h);
+    h->flopCount = 0;
+    const int rc = issue_factor(h);
+    h->factorFlops = h->flopCount;
+    return rc;
 }
 
 int refactor_issue(dotmi_handle *h, const double *x)
@@ -1764,6 +1775,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
             st->precond_launches++;
         }
         st->precond_bytes = h->precond_bytes;
+        st->factor_flops = h->factorFlops;
     }
     return status;
 }

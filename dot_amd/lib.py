@@ -41,7 +41,8 @@ class StepStats(C.Structure):
                 ("status", C.c_int32), ("E0", C.c_double), ("g2_0", C.c_double), ("E", C.c_double),
                 ("g2", C.c_double), ("ms_total", C.c_double), ("ms_loop", C.c_double),
                 ("ms_hessian", C.c_double), ("ms_factor", C.c_double), ("ms_precond", C.c_double),
-                ("precond_launches", C.c_int64), ("precond_bytes", C.c_int64)]
+                ("precond_launches", C.c_int64), ("precond_bytes", C.c_int64),
+                ("factor_flops", C.c_double)]
 
 
 EXPORTS = [

@@ -94,6 +94,8 @@ typedef struct {
     int64_t precond_launches; /* how many launches were timed */
     int64_t precond_bytes; /* algorithmic bytes per back-solve launch: 8 x the structural non-zeros of the
                               block-sparse inverse factors X_s of this rank (each is streamed once) */
+    double factor_flops;  /* FP64 flop of one factorisation of this rank's subdomains as executed (GEMMs incl. the
+                             identity padding + diagonal blocks): ms_factor's MFMA roofline */
 } dotmi_step_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
