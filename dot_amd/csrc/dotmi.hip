@@ -758,11 +758,18 @@ struct TriMult {
     int ldc;
     rocblas_stride sC;
     bool trans;
-    // root only: the operand couples to the root separator, so it is zero above the last NdNode::tail rows of
-    // every leaf.  The transposed product writes, and the plain product reads, a COMPACT row layout that keeps
-    // only the rows that can be non-zero (leaf tails and separator rows, NdNode::crows); the other side keeps
-    // the padded layout of W.
+    // The operand couples to the separator of the node whose step this is, so it is zero above the last rows of
+    // every leaf below it: NdNode::tail rows for the root (kind 0), NdNode::tail1 rows for the leaf's parent (kind
+    // 1).  The transposed product writes, and the plain product reads, a COMPACT row layout that keeps only the rows
+    // that can be non-zero (leaf tails and separator rows); the other side keeps the padded layout of W.
     bool compact;
+    int kind;
+    // kind 1 only holds for the leaves directly below the step's node (`direct`); anything deeper is taken dense
+    int leaf_tail(const NdNode &N, bool direct) const { return kind == 0 ? N.tail : (direct ? N.tail1 : N.size); }
+    int comp_rows(const NdNode &N, bool direct) const
+    {
+        return kind == 0 ? N.crows : ((N.a < 0 && direct) ? N.tail1 : N.size);
+    }
 
     const double *Q(int i, int j) const { return Wg + i + (size_t)j * lda; }
     int offB(int padded, int comp) const { return (!trans && compact) ? comp : padded; }
@@ -796,25 +803,26 @@ struct TriMult {
         return dense(o + a, b, rb + a, rc + a, beta);
     }
     // node `id`; rp / rq = padded / compact row offset of the node inside the operands
-    int node(int id, int rp, int rq, double beta) const
+    int node(int id, int rp, int rq, double beta, bool direct = true) const
     {
         const NdNode &N = h->nd[id];
         if (N.a < 0) {
-            const int h0 = compact ? N.size - N.tail : 0;
+            const int tl = leaf_tail(N, direct);
+            const int h0 = compact ? N.size - tl : 0;
             const int p1 = rp + h0;  // first row of the tail (compact: rq)
             if (h0 <= 0) return dense(N.off, N.size, offB(rp, rq), offC(rp, rq), beta);
             // transposed: Q^T [0 ; B_b] = [0 ; Q_bb^T B_b], only the tail rows exist in the compact result
-            if (trans) return dense(N.off + h0, N.tail, p1, rq, beta);
+            if (trans) return dense(N.off + h0, tl, p1, rq, beta);
             // plain: Q [0 ; R_b] = [Q_ab R_b ; Q_bb R_b]
-            if (int e = gemm(h0, N.tail, N.off, N.off + h0, rq, rp, beta)) return e;
-            return dense(N.off + h0, N.tail, rq, p1, beta);
+            if (int e = gemm(h0, tl, N.off, N.off + h0, rq, rp, beta)) return e;
+            return dense(N.off + h0, tl, rq, p1, beta);
         }
         const NdNode &A = h->nd[N.a], &Cn = h->nd[N.c];
         const int m = N.offS - N.off;  // padded rows of [A ; C]
-        if (int e = node(N.a, rp, rq, beta)) return e;
-        if (int e = node(N.c, rp + A.size, rq + A.crows, beta)) return e;
+        if (int e = node(N.a, rp, rq, beta, false)) return e;
+        if (int e = node(N.c, rp + A.size, rq + comp_rows(A, false), beta, false)) return e;
         if (N.sizeS == 0) return 0;
-        const int pS = rp + m, qS = rq + A.crows + Cn.crows;
+        const int pS = rp + m, qS = rq + comp_rows(A, false) + comp_rows(Cn, false);
         if (trans) {  // C_S = [Q_AS ; Q_CS]^T B_AC + Q_S^T B_S   (B in the padded layout)
             if (int e = gemm(N.sizeS, m, N.off, N.offS, rp, offC(pS, qS), beta)) return e;
             return dense(N.offS, N.sizeS, pS, offC(pS, qS), 1.0);
@@ -843,9 +851,11 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id, i
     DevParts &P = h->P;
     const NdNode &A = h->nd[N.a], &Cn = h->nd[N.c];
     const int lda = P.nmax, batch = G.count, m = N.offS - N.off, ns = N.sizeS;
-    // the root keeps R = blockdiag(Q_A, Q_C)^T H_XS in compact rows (see TriMult): fewer rows in R^T R and R Q_S
-    const bool compact = id == 0;
-    const int mr = compact ? A.crows + Cn.crows : m;
+    // R = blockdiag(Q_A, Q_C)^T H_XS is kept in compact rows (see TriMult): fewer rows in R^T R and R Q_S
+    const bool compact = true;
+    const int kind = id == 0 ? 0 : 1;
+    auto crows = [&](const NdNode &X) { return kind == 0 ? X.crows : (X.a < 0 ? X.tail1 : X.size); };  // direct children
+    const int mr = crows(A) + crows(Cn);
     const rocblas_stride sA = (rocblas_stride)lda * lda, sT = (rocblas_stride)h->tmp_stride;
     double *Wg = P.W + (size_t)G.first * sA;
     double *Hxs = Wg + N.off + (size_t)N.offS * lda;   // [H_AS ; H_CS], m x ns
@@ -854,11 +864,11 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id, i
     const double one = 1.0, zero = 0.0, mone = -1.0;
     const rocblas_operation Nn = rocblas_operation_none, Tt = rocblas_operation_transpose;
     if (part == 0 || part == 1 || part == 2) {
-        TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Hxs, lda, sA, Tb, mr, sT, true, compact};
+        TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Hxs, lda, sA, Tb, mr, sT, true, compact, kind};
         if (part != 2)
             if (int rc = tm.node(N.a, 0, 0, 0.0)) return rc;
         if (part != 1)
-            if (int rc = tm.node(N.c, A.size, A.crows, 0.0)) return rc;
+            if (int rc = tm.node(N.c, A.size, crows(A), 0.0)) return rc;
         if (part != 0) return 0;
     }
     double *T2 = Tb + (size_t)mr * ns;
@@ -878,11 +888,11 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id, i
         if (part != 0) return 0;
     }
     {
-        TriMult tm{h, G, Wg, lda, ns, sA, -1.0, T2, mr, sT, Hxs, lda, sA, false, compact};
+        TriMult tm{h, G, Wg, lda, ns, sA, -1.0, T2, mr, sT, Hxs, lda, sA, false, compact, kind};
         if (part != 5)
             if (int rc = tm.node(N.a, 0, 0, 0.0)) return rc;
         if (part != 4)
-            if (int rc = tm.node(N.c, A.size, A.crows, 0.0)) return rc;
+            if (int rc = tm.node(N.c, A.size, crows(A), 0.0)) return rc;
     }
     return 0;
 }

@@ -17,6 +17,7 @@ struct NdNode {
     int offS = 0, sizeS = 0; // separator block (internal nodes)
     int tail = 0;            // leaf: only its last `tail` rows can couple to the root separator
     int crows = 0;           // rows of this sub-tree that can couple to the root separator (leaf tails + separators)
+    int tail1 = 0;           // leaf: only its last `tail1` rows can couple to its PARENT's separator (tail1 >= tail)
 };
 
 // first padded row of a node's own region (leaf block / separator) in a subdomain that has `used` live
@@ -192,7 +193,7 @@ struct NdBuilder {
         std::sort(S.begin(), S.end());
     }
 
-    int build(std::vector<std::vector<int>> &sets, int depth)
+    int build(std::vector<std::vector<int>> &sets, int depth, const std::vector<std::vector<int>> *parentS = nullptr)
     {
         const int id = (int)tree.size();
         tree.emplace_back();
@@ -202,26 +203,37 @@ struct NdBuilder {
         for (auto &v : sets) mx = std::max(mx, 3 * (int)v.size());
         auto make_leaf = [&]() {
             tree[id].size = std::max(64, (mx + 63) / 64 * 64);
-            tree[id].tail = tree[id].size;
+            tree[id].tail = tree[id].tail1 = tree[id].size;
             region[id] = sets;
             if (!rootS.empty()) {
-                // vertices next to the root separator last: H(leaf, rootS) is zero above them, which the
-                // root's triangular products exploit (TriMult)
-                int mt = 0;
+                // order: interior | next to the parent's separator only | next to the root separator.
+                // H(leaf, S_root) is zero above the last class and H(leaf, S_parent) above the last two, which the
+                // triangular products of those two nodes exploit (TriMult)
+                int mt = 0, mt1 = 0;
                 for (int p = 0; p < np; ++p) {
+                    if (parentS)
+                        for (int v : (*parentS)[p]) mark[v] = 4;
                     for (int v : rootS[p]) mark[v] = 3;
-                    std::vector<int> in, bd;
+                    std::vector<int> in, bp, br;
                     for (int v : sets[p]) {
-                        bool adj = false;
-                        for (int e = adj_ptr[v]; e < adj_ptr[v + 1] && !adj; ++e) adj = mark[adj_idx[e]] == 3;
-                        (adj ? bd : in).push_back(v);
+                        bool ar = false, ap = false;
+                        for (int e = adj_ptr[v]; e < adj_ptr[v + 1]; ++e) {
+                            ar |= mark[adj_idx[e]] == 3;
+                            ap |= mark[adj_idx[e]] == 4;
+                        }
+                        (ar ? br : ap ? bp : in).push_back(v);
                     }
+                    if (parentS)
+                        for (int v : (*parentS)[p]) mark[v] = -1;
                     for (int v : rootS[p]) mark[v] = -1;
-                    mt = std::max(mt, 3 * (int)bd.size());
-                    in.insert(in.end(), bd.begin(), bd.end());
+                    mt = std::max(mt, 3 * (int)br.size());
+                    mt1 = std::max(mt1, 3 * (int)(br.size() + bp.size()));
+                    in.insert(in.end(), bp.begin(), bp.end());
+                    in.insert(in.end(), br.begin(), br.end());
                     region[id][p] = in;
                 }
                 tree[id].tail = std::min(tree[id].size, (mt + 63) / 64 * 64);
+                tree[id].tail1 = std::min(tree[id].size, (mt1 + 63) / 64 * 64);
             }
             return id;
         };
@@ -235,8 +247,8 @@ struct NdBuilder {
         }
         if (mc == 0) return make_leaf();
         if (depth == 0) rootS = Ss;
-        const int a = build(As, depth + 1);
-        const int c = build(Cs, depth + 1);
+        const int a = build(As, depth + 1, &Ss);
+        const int c = build(Cs, depth + 1, &Ss);
         tree[id].a = a;
         tree[id].c = c;
         tree[id].sizeS = (ms + 63) / 64 * 64;
