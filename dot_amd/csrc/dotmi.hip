@@ -180,6 +180,7 @@ struct dotmi_handle {
     std::vector<hipEvent_t> evPre;  // DOTMI_FLAG_TIME_BACKSOLVE: (start, stop) pairs around each back-solve
     int evUsed = 0;
     int64_t precond_bytes = 0;
+    int splitMin = 512, splitMinTri = 512;  // smallest block whose triangular products are split 2x2
     double flopCount = 0, factorFlops = 0;  // running counter of the recursion; FP64 flop of one factorisation
 };
 
@@ -696,7 +697,7 @@ int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, in
     // profiles/r01_factor_primitives.txt).
     const int a = ((n1 / CHOL_NB) / 2) * CHOL_NB, b = n1 - a;
     const int c = ((n2 / CHOL_NB) / 2) * CHOL_NB, d = n2 - c;
-    const bool split = n1 >= 512 && a > 0 && c > 0;
+    const bool split = n1 >= h->splitMin && a > 0 && c > 0;
     const double *Qaa = Q11, *Qab = Q11 + (size_t)a * lda, *Qbb = Q11 + a + (size_t)a * lda;
     // R12 stays in this level's scratch across the recursion into H22 (which gets the scratch behind it);
     // afterwards Q12 = -Q11 (R12 Q22) lands directly in H12 -- no staging copy.
@@ -791,7 +792,7 @@ struct TriMult {
     int dense(int o, int sz, int rb, int rc, double beta) const
     {
         const int a = ((sz / CHOL_NB) / 2) * CHOL_NB, b = sz - a;
-        if (sz < 512 || a == 0) return gemm(sz, sz, o, o, rb, rc, beta);
+        if (sz < h->splitMinTri || a == 0) return gemm(sz, sz, o, o, rb, rc, beta);
         if (trans) {  // C_a = Qaa^T B_a ; C_b = Qab^T B_a + Qbb^T B_b
             if (int e = dense(o, a, rb, rc, beta)) return e;
             if (int e = gemm(b, a, o, o + a, rb, rc + a, beta)) return e;
@@ -1426,6 +1427,8 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     }
     host_features(h);
     h->targetGRes = host_target_gres(h);
+    if (const char *ev = getenv("DOTMI_SPLIT_MIN")) h->splitMin = std::max(128, atoi(ev));
+    if (const char *ev = getenv("DOTMI_SPLIT_MIN_TRI")) h->splitMinTri = std::max(128, atoi(ev));
     if (int rc = build_device_mesh(h)) return rc;
     {
         const char *ev = getenv("DOTMI_FACTOR_STREAMS");
