@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void elem_energy_grad_kernel(
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nElem; i += stride) {
         const int e = elist ? elist[i] : i;
         const int4 t = T[e];
+        const int4 ps = GRAD ? epos[e] : make_int4(0, 0, 0, 0);  // needed last, requested first
         const double x0[3] = {x[3 * t.x], x[3 * t.x + 1], x[3 * t.x + 2]};
         const double x1[3] = {x[3 * t.y], x[3 * t.y + 1], x[3 * t.y + 2]};
         const double x2[3] = {x[3 * t.z], x[3 * t.z + 1], x[3 * t.z + 2]};
@@ -122,7 +123,6 @@ __global__ __launch_bounds__(256) void elem_energy_grad_kernel(
             for (int c = 0; c < 3; ++c) g[c] = -g[3 + c] - g[6 + c] - g[9 + c];
             // slot k of this tet lands at its position in the vertex's incidence list (vFLoc order), so the
             // vertex gather reads one contiguous run per vertex and needs no index indirection
-            const int4 ps = epos[e];
             const int pk[4] = {ps.x, ps.y, ps.z, ps.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
