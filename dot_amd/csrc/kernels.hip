@@ -1480,15 +1480,16 @@ void launch_loop_control(DevLoop *ctl, const double *partE, int nbE, const doubl
 }
 
 // ------------------------------------------------------------------------------------------------
-// element Hessians.  One 64-lane workgroup handles 64 tets:
-//   phase 1 (lane = tet): F, SVD, projected spectral blocks -> LDS (U, V, A_w, B_w, rest inverse)
-//   phase 2 (wave = tet): the 64 lanes expand  M = K Mh K^T (9x9)  and  H = G M G^T (12x12)
+// element Hessians.  One workgroup of EH_WAVES wavefronts handles 64 tets:
+//   phase 1 (lane of wave 0 = tet): F, SVD, projected spectral blocks -> LDS (U, V, A_w, B_w, rest inverse)
+//   phase 2 (wave = tet, EH_WAVES tets at a time): the 64 lanes expand  M = K Mh K^T (9x9)  and  H = G M G^T (12x12)
 //                         from LDS and write the 144 doubles of H_e as one coalesced 1152-byte row.
 // ------------------------------------------------------------------------------------------------
 constexpr int EH_FIELDS = 9 + 9 + 9 + 12 + 9;  // U V Aw Bw Ainv
+constexpr int EH_WAVES = 2;   // 2 waves: all workgroups of a 86k-tet mesh are resident at once (138 VGPRs)
 
 template <int MAT>
-__global__ __launch_bounds__(64) void elem_hessian_kernel(const int4 *__restrict__ T,
+__global__ __launch_bounds__(64 * EH_WAVES) void elem_hessian_kernel(const int4 *__restrict__ T,
                                                           const double *__restrict__ A, int nTp, int nT,
                                                           const double *__restrict__ mu,
                                                           const double *__restrict__ lam,
@@ -1497,10 +1498,11 @@ __global__ __launch_bounds__(64) void elem_hessian_kernel(const int4 *__restrict
                                                           double *__restrict__ He)
 {
     __shared__ double pack[EH_FIELDS][64];
-    __shared__ double Msh[81];
-    const int lane = threadIdx.x;
+    __shared__ double Msh4[EH_WAVES][81];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double *Msh = Msh4[wv];
     const int e = blockIdx.x * 64 + lane;
-    if (e < nT) {
+    if (wv == 0 && e < nT) {
         const int4 t = T[e];
         double xs[4][3];
         const int vid[4] = {t.x, t.y, t.z, t.w};
@@ -1540,9 +1542,11 @@ __global__ __launch_bounds__(64) void elem_hessian_kernel(const int4 *__restrict
     }
     __syncthreads();
     const int nloc = min(64, nT - blockIdx.x * 64);
-    for (int le = 0; le < nloc; ++le) {
+    for (int it = 0; it < 64 / EH_WAVES; ++it) {
+        const int le = EH_WAVES * it + wv;   // every wave runs all trips (the barriers are workgroup-wide)
+        const bool live = le < nloc;
         // ---- M(ij,rs) = sum_{ab,cd} Mh(ab,cd) U(i,a)V(j,b)U(r,c)V(s,d), 81 entries over 64 lanes
-        for (int idx = lane; idx < 81; idx += 64) {
+        for (int idx = lane; live && idx < 81; idx += 64) {
             const int ij = idx / 9, rs = idx % 9;
             const int i = ij / 3, j = ij % 3, r = rs / 3, s = rs % 3;
             double ui[3], vj[3], ur[3], vs[3];
@@ -1577,7 +1581,7 @@ __global__ __launch_bounds__(64) void elem_hessian_kernel(const int4 *__restrict
         __syncthreads();
         // ---- H(r,q) = sum_{b,b'} coef_r[b] coef_q[b'] M[3c_r+b][3c_q+b'], 144 entries over 64 lanes
         double *out = He + (size_t)144 * (blockIdx.x * 64 + le);
-        for (int idx = lane; idx < 144; idx += 64) {
+        for (int idx = lane; live && idx < 144; idx += 64) {
             const int r = idx / 12, q = idx % 12;
             const int cr = r % 3, cq = q % 3;
             double fr[3], fq[3];
@@ -1604,10 +1608,10 @@ void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *
 {
     const int nb = (M.nT + 63) / 64;
     if (mat == 0)
-        hipLaunchKernelGGL((elem_hessian_kernel<0>), dim3(nb), dim3(64), 0, st, M.T, M.A, M.nTp, M.nT, M.mu,
+        hipLaunchKernelGGL((elem_hessian_kernel<0>), dim3(nb), dim3(64 * EH_WAVES), 0, st, M.T, M.A, M.nTp, M.nT, M.mu,
                            M.lam, M.vol, x, dtSq, He);
     else
-        hipLaunchKernelGGL((elem_hessian_kernel<1>), dim3(nb), dim3(64), 0, st, M.T, M.A, M.nTp, M.nT, M.mu,
+        hipLaunchKernelGGL((elem_hessian_kernel<1>), dim3(nb), dim3(64 * EH_WAVES), 0, st, M.T, M.A, M.nTp, M.nT, M.mu,
                            M.lam, M.vol, x, dtSq, He);
 }
 
