@@ -1634,10 +1634,22 @@ __global__ __launch_bounds__(256) void assemble_kernel(int nnzb, const int *__re
     if (fixed[vr]) {
         acc = (vr == vc && r == c) ? 1.0 : 0.0;  // IglUtils.hpp:148-157
     } else if (!fixed[vc]) {
-        for (int i = blk_ptr[k]; i < blk_ptr[k + 1]; ++i) {
-            const int ent = blk_ent[i];
-            const int e = ent >> 4, a = (ent >> 2) & 3, b = ent & 3;
-            acc += He[(size_t)144 * e + 12 * (3 * a + r) + 3 * b + c];
+        // contributions four at a time: index loads first, then the four value loads, then the adds in list order
+        const int b1 = blk_ptr[k + 1];
+        for (int i = blk_ptr[k]; i < b1; i += 4) {
+            int ent[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ent[u] = (i + u < b1) ? blk_ent[i + u] : -1;
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = ent[u] >> 4, a = (ent[u] >> 2) & 3, b = ent[u] & 3;
+                const double *src = ent[u] >= 0 ? He + (size_t)144 * e + 12 * (3 * a + r) + 3 * b + c : &g_zero_slot;
+                v[u] = *src;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ent[u] >= 0) acc += v[u];
         }
         if (vr == vc && r == c) acc += mass[vr];  // DOTTimeStepper.cpp:598-607
     }
