@@ -1062,19 +1062,46 @@ __global__ __launch_bounds__(256) void merge_kernel(int nV, const int *__restric
     const int stride = gridDim.x * blockDim.x;
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nV; v += stride) {
         double z0 = 0, z1 = 0, z2 = 0;
-        for (int k = vp_ptr[v]; k < vp_ptr[v + 1]; ++k) {
-            const double *ps = psub + vp_off[k];
-            z0 += ps[0];
-            z1 += ps[1];
-            z2 += ps[2];
+        const int k0 = vp_ptr[v], k1 = vp_ptr[v + 1];
+        // everything that does not depend on the slot list is requested before it is walked
+        const int d = divide ? dup[v] : 1;
+        double yv[HIST_MAX][3];
+        if (with_dots) {
+#pragma unroll
+            for (int i = 0; i < HIST_MAX; ++i)
+                if (i < Lr.m) {
+                    const double *yi = Lr.y[i] + 3 * v;
+                    yv[i][0] = yi[0];
+                    yv[i][1] = yi[1];
+                    yv[i][2] = yi[2];
+                }
         }
-        if (divide) {
-            const int d = dup[v];
-            if (d > 1) {
-                z0 /= d;
-                z1 /= d;
-                z2 /= d;
-            }
+        // slots four at a time (a vertex is in 1-3 subdomains, rarely more): offsets first, then the values
+        for (int k = k0; k < k1; k += 4) {
+            int off[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) off[u] = (k + u < k1) ? vp_off[k + u] : -1;
+            double w[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (off[u] >= 0) {
+                    const double *ps = psub + off[u];
+                    w[u][0] = ps[0];
+                    w[u][1] = ps[1];
+                    w[u][2] = ps[2];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (off[u] >= 0) {
+                    z0 += w[u][0];
+                    z1 += w[u][1];
+                    z2 += w[u][2];
+                }
+        }
+        if (d > 1) {
+            z0 /= d;
+            z1 /= d;
+            z2 /= d;
         }
         z[3 * v] = z0;
         z[3 * v + 1] = z1;
@@ -1082,10 +1109,7 @@ __global__ __launch_bounds__(256) void merge_kernel(int nV, const int *__restric
         if (with_dots) {
 #pragma unroll
             for (int i = 0; i < HIST_MAX; ++i)
-                if (i < Lr.m) {
-                    const double *yi = Lr.y[i] + 3 * v;
-                    acc[i] += yi[0] * z0 + yi[1] * z1 + yi[2] * z2;
-                }
+                if (i < Lr.m) acc[i] += yv[i][0] * z0 + yv[i][1] * z1 + yv[i][2] * z2;
         }
     }
     // device-loop mode always stores all HIST_MAX columns: the consumer's m is only known on the device
