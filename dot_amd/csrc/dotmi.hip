@@ -1138,7 +1138,7 @@ int enqueue_loop_slot(dotmi_handle *h)
 
 // The L-BFGS loop of one time step with the control flow on the device (DevLoop).  The host only keeps
 // the queue a few slots ahead of the controller's progress, which it reads from pinned memory.
-int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *failed)
+int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *failed, double *E0, double *g20)
 {
     DevLoop &C = *h->h_ctl;
     memset(&C, 0, sizeof(C));
@@ -1146,8 +1146,6 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     C.hist = h->hist;
     C.tol = h->targetGRes;
     C.dtSq = h->dtSq;
-    C.E_cur = *lastE;
-    C.g2_cur = *g2;
     C.x_cur = h->x;
     C.x_trial = h->x_trial;
     C.g_cur = h->g;
@@ -1170,6 +1168,25 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     C.notifyFrom = std::max(0, std::min(h->prevSlots - 3, h->prevSlots * 3 / 4));  // a shorter step wastes few slots
     const int notifyFrom = C.notifyFrom;
     HIPCHECK(h, hipMemcpyAsync(h->ctl, h->h_ctl, sizeof(DevLoop), hipMemcpyHostToDevice, h->st));
+    {
+        // energy and gradient at the start of the step, reduced by the controller (no host round trip)
+        int nb = 0;
+        launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x, h->xt, nullptr, h->nT, 0, h->nV, h->gcont, h->partE, &nb,
+                                h->st);
+        GatherArgs a;
+        memset(&a, 0, sizeof(a));
+        a.gcont = h->gcont;
+        a.x = h->x;
+        a.xt = h->xt;
+        a.g_new = h->g;
+        a.make_pair = 0;
+        a.iv0 = 0;
+        a.iv1 = h->nV;
+        LbfgsArgs L0;
+        memset(&L0, 0, sizeof(L0));
+        launch_vertex_gather(h->M, a, L0, h->partR, h->st);
+        launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
+    }
     int enq = 0;
     const double tStart = now_ms();
     long spins = 0;
@@ -1200,6 +1217,8 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     *failed = C.status == 3;
     *lastE = C.E_cur;
     *g2 = C.g2_cur;
+    *E0 = C.E0;
+    *g20 = C.g2_0;
     h->x = C.x_cur;
     h->x_trial = C.x_trial;
     h->g = C.g_cur;
@@ -1658,11 +1677,14 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     // initX(2): x += dt v + dt^2 g on free vertices (Optimizer.cpp:442-582)
     launch_init_x(h->nV, h->M.fixed, h->v, h->dt, h->gdtsq, h->x, h->st);
     LbfgsArgs L = lbfgs_args(h);
-    double lastE = 0, R[RED_K];
-    if (int rc = trial(h, h->x, h->g, 0, L, 0, &lastE)) return rc;
-    sum_stats(h, 1, R);
-    double g2 = R[0];
-    const double E0 = lastE, g20 = g2;
+    double lastE = 0, R[RED_K], g2 = 0, E0 = 0, g20 = 0;
+    if (!h->devLoop) {
+        if (int rc = trial(h, h->x, h->g, 0, L, 0, &lastE)) return rc;
+        sum_stats(h, 1, R);
+        g2 = R[0];
+        E0 = lastE;
+        g20 = g2;
+    }
 
     int it = 0, status = 0;
     bool failed = false;
@@ -1670,7 +1692,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     h->slotKind.clear();
     h->slotTimed.clear();
     if (h->devLoop) {
-        if (int rc = run_device_loop(h, &lastE, &g2, &it, &failed)) return rc;
+        if (int rc = run_device_loop(h, &lastE, &g2, &it, &failed, &E0, &g20)) return rc;
     } else
     do {
         // ---- two-loop, first half (host scalars) + q ------------------------------------------------

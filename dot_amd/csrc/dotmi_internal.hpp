@@ -99,6 +99,7 @@ struct DevLoop {
     double tol, dtSq;
     double alpha;          // step of the next retry
     double E_cur, g2_cur;  // at x_cur
+    double E0, g2_0;       // after initX (start of the step)
     double *x_cur, *x_trial, *g_cur, *g_trial;
     int slot;              // free history slot that receives the pair of the running trial
     int order[HIST_MAX + 1];
@@ -154,9 +155,10 @@ void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
                       int v0, int v1, double *partials, hipStream_t st, const DevLoop *ctl = nullptr);
 // one wavefront: sums the partials of the finished trial and advances *ctl (accept / halve / stop);
-// flags_host (pinned, 2 ints) receives {status, slots done}
+// flags_host (pinned, 2 ints) receives {status, slots done}.  init != 0: the partials are those of the evaluation at the
+// start of the step (after initX); the controller only records E and |g|^2
 void launch_loop_control(DevLoop *ctl, const double *partE, int nbE, const double *partR,
-                         const double *alpha_dev, int *flags_host, hipStream_t st);
+                         const double *alpha_dev, int *flags_host, hipStream_t st, int init = 0);
 // element Hessians (12x12 projected), one wavefront per element in the expansion phase
 void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *x, double *He,
                           hipStream_t st);

@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
                                                            const double *__restrict__ partE, int nbE,
                                                            const double *__restrict__ partR,
                                                            const double *__restrict__ alpha_dev,
-                                                           int *__restrict__ flags_host)
+                                                           int *__restrict__ flags_host, int init)
 {
     static_assert(sizeof(DevLoop) % 8 == 0, "DevLoop is copied as 8-byte words");
     static_assert(RED_K <= 32, "two passes of 16 columns");
@@ -1337,9 +1337,15 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
         R[t] = acc;
     }
     __syncthreads();
-    if (t == 0) {
+    if (t == 0 && init) {
+        // evaluation at the start of the step (DOTTimeStepper.cpp:299): nothing to decide yet
+        const double E = C.dtSq * R[RED_K] + R[RED_K + 1];
+        C.evals++;
+        C.E_cur = C.E0 = E;
+        C.g2_cur = C.g2_0 = R[0];
+    } else if (t == 0) {
         double alpha = alpha_in;
-    const double E = C.dtSq * R[RED_K] + R[RED_K + 1];
+        const double E = C.dtSq * R[RED_K] + R[RED_K + 1];
         C.evals++;
         if (C.slots < C.kindCap) C.slot_kind[C.slots] = C.phase == 0 ? 1 : 2;
         C.slots++;
@@ -1490,7 +1496,7 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
     }
     // a store to host memory holds the kernel's end back by several microseconds: only near the expected
     // end of the loop, where the host needs the progress to stop enqueueing
-    if (t == 0 && (C.status != 0 || C.slots >= C.notifyFrom)) {
+    if (t == 0 && !init && (C.status != 0 || C.slots >= C.notifyFrom)) {
         __threadfence_system();
         flags_host[1] = C.slots;
         flags_host[0] = C.status;
@@ -1498,9 +1504,10 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
 }
 
 void launch_loop_control(DevLoop *ctl, const double *partE, int nbE, const double *partR,
-                         const double *alpha_dev, int *flags_host, hipStream_t st)
+                         const double *alpha_dev, int *flags_host, hipStream_t st, int init)
 {
-    hipLaunchKernelGGL(loop_control_kernel, dim3(1), dim3(256), 0, st, ctl, partE, nbE, partR, alpha_dev, flags_host);
+    hipLaunchKernelGGL(loop_control_kernel, dim3(1), dim3(256), 0, st, ctl, partE, nbE, partR, alpha_dev, flags_host,
+                       init);
 }
 
 // ------------------------------------------------------------------------------------------------
