@@ -277,6 +277,7 @@ class AnimScripter:
         self.rot_center = bbox.mean(axis=0)
         self.turn_vert = -1
         self._last = None   # see track()
+        self._rot_cache = None
         self.turn_lo = -math.inf
         self.turn_hi = math.inf
         x0 = V_rest  # result.V == V_rest at init (main.cpp:712 UV = V)
@@ -376,9 +377,11 @@ class AnimScripter:
         xh = np.array(x[idx], dtype=np.float64)
         disp = np.zeros_like(xh)
         if self.ang_vel:
-            for w in np.unique(self._w):
-                sel = self._w == w
-                R = angle_axis_matrix(w * dt, (1.0, 0.0, 0.0))
+            if self._rot_cache is None or self._rot_cache[0] != dt:     # groups and matrices are the same every step
+                groups = [(np.nonzero(self._w == w)[0], angle_axis_matrix(w * dt, (1.0, 0.0, 0.0)))
+                          for w in np.unique(self._w)]
+                self._rot_cache = (dt, groups)
+            for sel, R in self._rot_cache[1]:
                 rel = xh[sel] - self.rot_center
                 disp[sel] = (rel @ R.T + self.rot_center) - xh[sel]
         if self.vel:
