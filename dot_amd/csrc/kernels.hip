@@ -872,10 +872,39 @@ void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipS
     hipLaunchKernelGGL(chol_inv_base_kernel, dim3(count), dim3(256), 0, st, W, nmax, o, info);
 }
 
+// 64 x 64 x 64 product on LDS operands with the FP64 matrix cores: store(i, j, sum_k A(i,k) B(k,j)).
+// Wave w owns rows [16w, 16w+16) (four 16 x 16 tiles).  v_mfma_f64_16x16x4_f64 operands: A(row = lane & 15,
+// k = lane >> 4), B(k = lane >> 4, col = lane & 15); results: col = lane & 15, row = (lane >> 4) + 4 * reg.
+// 80 LDS reads per lane instead of 512 for the 4 x 4 FMA tiling.
+typedef double mfma_v4d __attribute__((ext_vector_type(4)));
+template <class FA, class FB, class FS>
+__device__ __forceinline__ void mfma_gemm64(FA A, FB B, FS store, int tid)
+{
+    const int lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    mfma_v4d acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+        const double a = A(16 * w + lr, 4 * kk + lk);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double b = B(4 * kk + lk, 16 * t + lr);
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) store(16 * w + lk + 4 * r, 16 * t + lr, acc[t][r]);
+    __syncthreads();
+}
+
 // The whole 128 x 128 node of the recursion in one launch (one workgroup per subdomain, LDS resident):
 //   Q11 = R11^-1 ; R12 = Q11^T H12 ; H22 -= R12^T R12 ; Q22 = R22^-1 ; Q12 = -(Q11 R12) Q22 ; H21 = 0
-// The two 64 x 64 factor+invert steps are block_chol_inv<64>(); the four 64^3 products are done by all 256
-// threads from LDS (4 x 4 register tiles).  Replaces 2 base launches +
+// The two 64 x 64 factor+invert steps are block_chol_inv<64>(); the four 64^3 products run on the FP64 matrix
+// cores from LDS (mfma_gemm64).  Replaces 2 base launches +
 // 4 tiny batched GEMMs + 2 block copies, whose launch latencies dominated the bottom of the recursion.
 __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restrict__ W, int nmax, int o,
                                                                int *__restrict__ info)
@@ -901,73 +930,15 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
         Gf[k][j] = Ws[(size_t)(o + NB + j) * nmax + o + NB + k];  // H22(k,j)
     }
     __syncthreads();
-    const int i0 = (tid >> 4) * 4, j0 = (tid & 15) * 4;
-    double acc[4][4];
     // ---- R12(i,j) = sum_k X11(i,k) H12(k,j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
-    for (int k = 0; k < NB; ++k) {
-        double xa[4], hb[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xa[r] = X1[i0 + r][k];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) hb[c] = Bf[k][j0 + c];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fma(xa[r], hb[c], acc[r][c]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Bf[i0 + r][j0 + c] = acc[r][c];
-    __syncthreads();
+    mfma_gemm64([&](int i, int k) { return X1[i][k]; }, [&](int k, int jj) { return Bf[k][jj]; },
+                [&](int i, int jj, double v) { Bf[i][jj] = v; }, tid);
     // ---- H22(c,d) -= sum_k R12(k,c) R12(k,d)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = Gf[i0 + r][j0 + c];
-    for (int k = 0; k < NB; ++k) {
-        double rc[4], rd[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rc[r] = Bf[k][i0 + r];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) rd[c] = Bf[k][j0 + c];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fma(-rc[r], rd[c], acc[r][c]);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Gf[i0 + r][j0 + c] = acc[r][c];
-    __syncthreads();
+    mfma_gemm64([&](int c, int k) { return Bf[k][c]; }, [&](int k, int d) { return Bf[k][d]; },
+                [&](int c, int d, double v) { Gf[c][d] -= v; }, tid);
     // ---- U(i,j) = sum_k Q11(i,k) R12(k,j) = sum_k X11(k,i) R12(k,j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
-    for (int k = 0; k < NB; ++k) {
-        double xa[4], hb[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xa[r] = X1[k][i0 + r];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) hb[c] = Bf[k][j0 + c];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fma(xa[r], hb[c], acc[r][c]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Bf[i0 + r][j0 + c] = acc[r][c];
-    __syncthreads();
+    mfma_gemm64([&](int i, int k) { return X1[k][i]; }, [&](int k, int jj) { return Bf[k][jj]; },
+                [&](int i, int jj, double v) { Bf[i][jj] = v; }, tid);
     // X11 is final: write it out and hand its LDS block to X22 (one 64x65 block less, 108 KB instead of 141 KB
     // per workgroup, so a GEMM workgroup of another branch still fits next to this one on a CU)
     for (int idx = tid; idx < NB * NB; idx += 256) {
@@ -980,27 +951,8 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
     bad = block_chol_inv<64>(Gf, X1, 0, Tq, Tr, tid);
     if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + NB + bad);
     // ---- Q12(i,j) = -sum_c U(i,c) Q22(c,j) = -sum_c U(i,c) X22(j,c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
-    for (int k = 0; k < NB; ++k) {
-        double ua[4], xb[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ua[r] = Bf[i0 + r][k];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) xb[c] = X1[j0 + c][k];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] = __builtin_fma(-ua[r], xb[c], acc[r][c]);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Bf[i0 + r][j0 + c] = acc[r][c];
-    __syncthreads();
+    mfma_gemm64([&](int i, int c) { return Bf[i][c]; }, [&](int c, int jj) { return X1[jj][c]; },
+                [&](int i, int jj, double v) { Bf[i][jj] = -v; }, tid);
     // ---- store: memory row (o+64+j) <- [Q12(:,j) | X22(j,:)]   (rows o+i were written above)
     for (int idx = tid; idx < NB * NB; idx += 256) {
         const int r = idx / NB, c = idx % NB;
