@@ -759,41 +759,37 @@ __device__ __forceinline__ int wave_chol_inv(double (&a)[NB], double (&x)[NB], i
     return bad;
 }
 
-// M x M x M product on LDS operands by all 256 threads (M/16 x M/16 register tiles):
-//   store(i, j, sum_k A(i,k) B(k,j)).  The caller separates reads and writes of shared operands.
+typedef double mfma_v4d __attribute__((ext_vector_type(4)));
+
+// M x M x M product (M = 16 or 32) on LDS operands with v_mfma_f64_16x16x4_f64, one 16 x 16 tile per wavefront
+// (M = 16: wave 0 only): store(i, j, sum_k A(i,k) B(k,j)).  Operand / result layout as in mfma_gemm64 below.
 template <int M, class FA, class FB, class FS>
-__device__ __forceinline__ void lds_gemm(FA A, FB B, FS store, int tid)
+__device__ __forceinline__ void mfma_gemm_small(FA A, FB B, FS store, int tid)
 {
-    constexpr int TS = M / 16;
-    const int i0 = (tid >> 4) * TS, j0 = (tid & 15) * TS;
-    double c[TS][TS];
+    static_assert(M == 16 || M == 32, "one tile per wave");
+    const int lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int ti = (M == 32) ? (w >> 1) : 0, tj = (M == 32) ? (w & 1) : 0;
+    const bool active = (M == 32) || w == 0;
+    mfma_v4d acc = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
+    if (active) {
 #pragma unroll
-    for (int r = 0; r < TS; ++r)
-#pragma unroll
-        for (int q = 0; q < TS; ++q) c[r][q] = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < M; ++k) {
-        double a[TS], b[TS];
-#pragma unroll
-        for (int r = 0; r < TS; ++r) a[r] = A(i0 + r, k);
-#pragma unroll
-        for (int q = 0; q < TS; ++q) b[q] = B(k, j0 + q);
-#pragma unroll
-        for (int r = 0; r < TS; ++r)
-#pragma unroll
-            for (int q = 0; q < TS; ++q) c[r][q] = __builtin_fma(a[r], b[q], c[r][q]);
+        for (int kk = 0; kk < M / 4; ++kk) {
+            const double a = A(16 * ti + lr, 4 * kk + lk);
+            const double b = B(4 * kk + lk, 16 * tj + lr);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
     }
     __syncthreads();
+    if (active) {
 #pragma unroll
-    for (int r = 0; r < TS; ++r)
-#pragma unroll
-        for (int q = 0; q < TS; ++q) store(i0 + r, j0 + q, c[r][q]);
+        for (int r = 0; r < 4; ++r) store(16 * ti + lk + 4 * r, 16 * tj + lr, acc[r]);
+    }
     __syncthreads();
 }
 
 // X = chol(A)^-1 of the N x N diagonal block at [b0, b0+N) of a 64 x 64 matrix held in LDS, by one workgroup
 // of 256 threads: the same 2 x 2 recursion as chol_inv_node(), continued inside LDS -- the 16 x 16 bottom
-// steps run in the registers of wave 0 (wave_chol_inv), every product is done by everybody.
+// steps run in the registers of wave 0 (wave_chol_inv), the products on the FP64 matrix cores (mfma_gemm_small).
 //   G: A on entry (row-major, symmetric), destroyed.   X: X(i,k) on exit, zero above the diagonal.
 //   T32 / T16: 32x33 and 16x17 scratch.   Returns 0 or 1 + index (relative to b0) of the first non-positive
 //   pivot (valid in wave 0).
@@ -825,18 +821,18 @@ __device__ __forceinline__ int block_chol_inv(double (*G)[LD64], double (*X)[LD6
         };
         int bad = block_chol_inv<H>(G, X, b0, T32, T16, tid);
         // R12(i,j) = sum_k X11(i,k) A12(k,j)
-        lds_gemm<H>([&](int i, int k) { return X[b0 + i][b0 + k]; }, [&](int k, int j) { return G[b0 + k][b0 + H + j]; },
+        mfma_gemm_small<H>([&](int i, int k) { return X[b0 + i][b0 + k]; }, [&](int k, int j) { return G[b0 + k][b0 + H + j]; },
                     [&](int i, int j, double v) { T(i, j) = v; }, tid);
         // A22(c,d) -= sum_k R12(k,c) R12(k,d)
-        lds_gemm<H>([&](int c, int k) { return T(k, c); }, [&](int k, int d) { return T(k, d); },
+        mfma_gemm_small<H>([&](int c, int k) { return T(k, c); }, [&](int k, int d) { return T(k, d); },
                     [&](int c, int d, double v) { G[b0 + H + c][b0 + H + d] -= v; }, tid);
         const int b2 = block_chol_inv<H>(G, X, b0 + H, T32, T16, tid);
         if (bad == 0 && b2) bad = H + b2;
         // V(c,j) = sum_k R12(k,c) X11(k,j)  -> the A11 area (free by now)
-        lds_gemm<H>([&](int c, int k) { return T(k, c); }, [&](int k, int j) { return X[b0 + k][b0 + j]; },
+        mfma_gemm_small<H>([&](int c, int k) { return T(k, c); }, [&](int k, int j) { return X[b0 + k][b0 + j]; },
                     [&](int c, int j, double v) { G[b0 + c][b0 + j] = v; }, tid);
         // X21(i,j) = -sum_c X22(i,c) V(c,j) ;  X12 = 0
-        lds_gemm<H>([&](int i, int c) { return X[b0 + H + i][b0 + H + c]; }, [&](int c, int j) { return G[b0 + c][b0 + j]; },
+        mfma_gemm_small<H>([&](int i, int c) { return X[b0 + H + i][b0 + H + c]; }, [&](int c, int j) { return G[b0 + c][b0 + j]; },
                     [&](int i, int j, double v) {
                         X[b0 + H + i][b0 + j] = -v;
                         X[b0 + i][b0 + H + j] = 0.0;
@@ -876,7 +872,6 @@ void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipS
 // Wave w owns rows [16w, 16w+16) (four 16 x 16 tiles).  v_mfma_f64_16x16x4_f64 operands: A(row = lane & 15,
 // k = lane >> 4), B(k = lane >> 4, col = lane & 15); results: col = lane & 15, row = (lane >> 4) + 4 * reg.
 // 80 LDS reads per lane instead of 512 for the 4 x 4 FMA tiling.
-typedef double mfma_v4d __attribute__((ext_vector_type(4)));
 template <class FA, class FB, class FS>
 __device__ __forceinline__ void mfma_gemm64(FA A, FB B, FS store, int tid)
 {
