@@ -172,8 +172,8 @@ struct NdBuilder {
         };
         for (int axis = 0; axis < 3; ++axis) {
             by_axis(axis);
-            for (int k = -8; k <= 8; ++k) {
-                const int t = std::min(n - 1, std::max(1, n / 2 + k * n / 48));
+            for (int k = -16; k <= 16; ++k) {
+                const int t = std::min(n - 1, std::max(1, n / 2 + k * n / 96));
                 for (int i = 0; i < n; ++i) mark[ord[i]] = i < t ? 0 : 1;
                 int nl = 0, nr = 0;
                 min_cover(ord, t, cov, nl, nr);
