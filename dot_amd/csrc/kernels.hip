@@ -269,11 +269,25 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
             }
         }
         if (!fx) {
-            for (int kk = kb + sub; kk < ke; kk += 8) {
-                const double *ge = a.gcont + (size_t)3 * kk;
-                g0 += ge[0];
-                g1 += ge[1];
-                g2 += ge[2];
+            // three incidence entries per lane and trip (24 of the ~20 incident slots per 8-lane group): their loads
+            // are in flight together; the adds keep the order of the one-entry loop
+            for (int kk = kb + sub; kk < ke; kk += 24) {
+                double w[3][3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (kk + 8 * u < ke) {
+                        const double *ge = a.gcont + (size_t)3 * (kk + 8 * u);
+                        w[u][0] = ge[0];
+                        w[u][1] = ge[1];
+                        w[u][2] = ge[2];
+                    }
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    if (kk + 8 * u < ke) {
+                        g0 += w[u][0];
+                        g1 += w[u][1];
+                        g2 += w[u][2];
+                    }
             }
         }
         g0 = group8_sum(g0);
