@@ -110,6 +110,7 @@ struct dotmi_handle {
     int4 *clearSeg = nullptr;                    // row segments (row, first column, columns, -) cleared before a refill
     int nClearSeg = 0;
     bool wDirty = false;                         // W has been through a factorisation (targeted clearing applies)
+    bool poisoned = false;                       // the last factorisation failed: the factors in W are garbage
     size_t tmp_stride = 0;
     int *didx = nullptr;
     double *dpos = nullptr;
@@ -998,8 +999,10 @@ int refactor_finish(dotmi_handle *h, double *ms_hess, double *ms_fact)
         if (h->h_info[i] != 0) {
             h->err = "subdomain " + std::to_string(h->p0 + i) + " Hessian not positive definite (pivot " +
                      std::to_string(h->h_info[i]) + ")";
+            h->poisoned = true;  // every later step / back-solve fails until a factorisation succeeds
             return DOTMI_E_NOTSPD;
         }
+    h->poisoned = false;
     float a = 0, b = 0;
     hipEventElapsedTime(&a, h->ev0, h->ev1);
     hipEventElapsedTime(&b, h->ev1, h->ev2);
@@ -1606,8 +1609,7 @@ int dotmi_set_dirichlet(dotmi_handle *h, int32_t n, const int32_t *idx, const do
     if (h->didxHost.size() != (size_t)n || memcmp(h->didxHost.data(), idx, sizeof(int32_t) * n) != 0) {
         HIPCHECK(h, hipStreamSynchronize(h->st));
         h->didxHost.assign(idx, idx + n);
-        if (h->dposPinned) hipHostFree(h->dposPinned);
-    if (h->evDir) hipEventDestroy(h->evDir);
+        if (h->dposPinned) hipHostFree(h->dposPinned);   // the stream is idle: nothing reads the staging buffer
         h->dposPinned = nullptr;
         HIPCHECK(h, hipHostMalloc((void **)&h->dposPinned, sizeof(double) * 3 * n));
         HIPCHECK(h, hipMemcpyAsync(h->didx, h->didxHost.data(), sizeof(int) * n, hipMemcpyHostToDevice, h->st));
@@ -1661,6 +1663,10 @@ int dotmi_last_iter_log(const dotmi_handle *h, int32_t cap, double *alpha, doubl
 int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
 {
     if (!h) return DOTMI_E_INVALID;
+    if (h->poisoned) {
+        h->err = "the subdomain factors are invalid (the last factorisation failed): " + h->err;
+        return DOTMI_E_NOTSPD;
+    }
     HIPCHECK(h, hipSetDevice(h->device));
     const double T0 = now_ms();
     const int n = h->n;
@@ -1732,7 +1738,13 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
             launch_step_forward(n, h->x, h->p, h->x_trial, nullptr, alpha, 0, h->alphaMin, h->alpha_dev, h->h_alpha, h->st);
             if (int rc = trial(h, h->x_trial, h->g_trial, 1, L, slot, &E)) return rc;
         }
-        if (failed) break;
+        if (failed) {
+            // the reference leaves result.V at the last trial point and lastEnergyVal at its energy
+            // (Optimizer.cpp:819-861); the iteration is not counted (DOTTimeStepper.cpp:311-316)
+            std::swap(h->x, h->x_trial);
+            lastE = E;
+            break;
+        }
         std::swap(h->x, h->x_trial);
         std::swap(h->g, h->g_trial);
         lastE = E;
@@ -1782,8 +1794,9 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     launch_be_update(h->nV, h->M.fixed, h->x, h->xn, h->v, h->xt, h->dt, h->gdtsq, h->st);
     HIPCHECK(h, hipStreamSynchronize(h->st));
     HIPCHECK(h, hipGetLastError());
-    if (!failed)
-        if (int rc = refactor_finish(h, &ms_hess, &ms_fact)) return rc;
+    int rcFactor = 0;
+    if (!failed) rcFactor = refactor_finish(h, &ms_hess, &ms_fact);
+    if (rcFactor == DOTMI_E_DEVICE) return rcFactor;
     if (st) {
         memset(st, 0, sizeof(*st));
         st->iters = it;
@@ -1812,6 +1825,9 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         st->precond_bytes = h->precond_bytes;
         st->factor_flops = h->factorFlops;
     }
+    // a non-SPD subdomain: the step itself is complete (x, v advanced as the reference would have before it
+    // exit(-1)s in the factorisation, Optimizer.cpp:301-313), the handle is poisoned until a refactor succeeds
+    if (rcFactor) return rcFactor;
     return status;
 }
 
@@ -1899,6 +1915,10 @@ int dotmi_refactor(dotmi_handle *h, const double *x)
 int dotmi_apply_precond(dotmi_handle *h, const double *r, double *p)
 {
     if (!h || !r || !p) return DOTMI_E_INVALID;
+    if (h->poisoned) {
+        h->err = "the subdomain factors are invalid (the last factorisation failed)";
+        return DOTMI_E_NOTSPD;
+    }
     HIPCHECK(h, hipSetDevice(h->device));
     if (int rc = upload_tmp(h, r, h->q)) return rc;
     LbfgsArgs L;

@@ -1314,8 +1314,14 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
             // back-tracking (c1 = 0, lower bound 0)
             alpha /= 2.0;
             C.halvings++;
-            if (alpha == 0.0) C.status = 3;
-            else {
+            if (alpha == 0.0) {
+                // the step length underflowed: the reference stops at the last trial point (Optimizer.cpp:819-861)
+                C.status = 3;
+                double *tmp = C.x_cur;
+                C.x_cur = C.x_trial;
+                C.x_trial = tmp;
+                C.E_cur = E;
+            } else {
                 C.phase = 1;
                 C.alpha = alpha;
             }

@@ -118,8 +118,11 @@ public:
                 check(dotmi_get_state(h_, x.data(), nullptr, nullptr), "get_state");
                 idx.clear();
                 pos.clear();
-                if (script_(x, dt_, idx, pos, fixed_)) check(dotmi_refix(h_, fixed_.data()), "refix");
+                // move first, then re-pattern at the moved positions (Optimizer.cpp:333-335: stepAnimScript moves
+                // result.V and only then updatePrecondMtrAndFactorize runs)
+                const bool changed = script_(x, dt_, idx, pos, fixed_);
                 check(dotmi_set_dirichlet(h_, (int32_t)idx.size(), idx.data(), pos.data()), "set_dirichlet");
+                if (changed) check(dotmi_refix(h_, fixed_.data()), "refix");
             }
             if (globalIterNum_ >= frameAmt_) {
                 ++globalIterNum_;

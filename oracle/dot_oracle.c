@@ -442,7 +442,10 @@ struct dor_sim {
     /* logs */
     int log_n, log_cap;
     double *log_alpha, *log_E, *log_g2;
-    long numLineSearch;
+    long numLineSearch, ls0;
+    /* running step (dor_step_begin / _iterate / _end) */
+    int it, failed;
+    double lastE, g2, E0, g2_0;
     double t_energy, t_grad, t_solve, t_hess, t_factor;
     int energy_evals;
 };
@@ -1174,48 +1177,59 @@ static int solve_one_step(dor_sim *s, double *lastE, double *alpha)
 }
 
 /* Optimizer.cpp:327-368 solve(1) without the script move (dor_move) +
- * DOTTimeStepper.cpp:273-346 fullyImplicit */
-int dor_step(dor_sim *s, dor_step_stats *st)
+ * DOTTimeStepper.cpp:273-346 fullyImplicit, split into begin / iterate / end so that a test can stop
+ * between two L-BFGS iterations and look at (x, g, history): teacher forcing, SURVEY.md section 8(c) F4. */
+void dor_step_begin(dor_sim *s)
 {
-    double T0 = now_ms();
     int n = 3 * s->nV;
     s->t_energy = s->t_grad = s->t_solve = s->t_hess = s->t_factor = 0;
     s->energy_evals = 0;
-    long ls0 = s->numLineSearch;
+    s->ls0 = s->numLineSearch;
     s->nh = 0;
     s->log_n = 0;
+    s->it = 0;
+    s->failed = 0;
     /* initX(2), Optimizer.cpp:442-582 */
     for (int v = 0; v < s->nV; ++v)
         for (int d = 0; d < 3; ++d) {
             double pd = s->fixed[v] ? 0.0 : s->dt * s->v[3 * v + d] + s->dtSq * s->gravity[d];
             s->x[3 * v + d] = s->x[3 * v + d] + 1.0 * pd;
         }
-    double lastE = dor_eval_energy(s, s->x);
+    s->lastE = dor_eval_energy(s, s->x);
     dor_eval_gradient(s, s->x, s->g);
-    double g2 = dotn(s->g, s->g, n);
-    if (st) {
-        st->E0 = lastE;
-        st->g2_0 = g2;
+    s->g2 = dotn(s->g, s->g, n);
+    s->E0 = s->lastE;
+    s->g2_0 = s->g2;
+}
+
+/* one pass of the do-while body of fullyImplicit (DOTTimeStepper.cpp:303-337).
+ * returns 0 = go on, 1 = converged, 2 = iteration cap, 3 = line search failed */
+int dor_step_iterate(dor_sim *s)
+{
+    int n = 3 * s->nV;
+    const int iterCap = 10000;
+    double alpha;
+    if (solve_one_step(s, &s->lastE, &alpha)) {
+        s->failed = 1;
+        return 3;
     }
-    int iterCap = 10000, it = 0, status = 0, failed = 0;
-    do {
-        double alpha;
-        if (solve_one_step(s, &lastE, &alpha)) {
-            failed = 1;
-            break;
-        }
-        g2 = dotn(s->g, s->g, n);
-        if (s->log_n < s->log_cap) {
-            s->log_alpha[s->log_n] = alpha;
-            s->log_E[s->log_n] = lastE;
-            s->log_g2[s->log_n] = g2;
-            s->log_n++;
-        }
-        if (++it >= iterCap) break;
-    } while (g2 > s->targetGRes);
-    if (failed) status = 2;
+    s->g2 = dotn(s->g, s->g, n);
+    if (s->log_n < s->log_cap) {
+        s->log_alpha[s->log_n] = alpha;
+        s->log_E[s->log_n] = s->lastE;
+        s->log_g2[s->log_n] = s->g2;
+        s->log_n++;
+    }
+    if (++s->it >= iterCap) return 2;
+    return s->g2 > s->targetGRes ? 0 : 1;
+}
+
+int dor_step_end(dor_sim *s, dor_step_stats *st, double T0)
+{
+    int n = 3 * s->nV, status = 0;
+    if (s->failed) status = 2;
     else {
-        if (it >= iterCap) status = 2;
+        if (s->it >= 10000) status = 2;
         dor_refactor(s, s->x);
     }
     /* BE update, Optimizer.cpp:354-361 */
@@ -1225,13 +1239,15 @@ int dor_step(dor_sim *s, dor_step_stats *st)
     }
     compute_xtilde(s);
     if (st) {
-        st->iters = it;
-        st->ls_halvings = (int)(s->numLineSearch - ls0);
+        st->E0 = s->E0;
+        st->g2_0 = s->g2_0;
+        st->iters = s->it;
+        st->ls_halvings = (int)(s->numLineSearch - s->ls0);
         st->energy_evals = s->energy_evals;
         st->status = status;
-        st->E = lastE;
-        st->g2 = g2;
-        st->ms_total = now_ms() - T0;
+        st->E = s->lastE;
+        st->g2 = s->g2;
+        st->ms_total = T0 > 0 ? now_ms() - T0 : 0.0;
         st->ms_energy = s->t_energy;
         st->ms_gradient = s->t_grad;
         st->ms_backsolve = s->t_solve;
@@ -1239,6 +1255,65 @@ int dor_step(dor_sim *s, dor_step_stats *st)
         st->ms_factor = s->t_factor;
     }
     return status;
+}
+
+int dor_step(dor_sim *s, dor_step_stats *st)
+{
+    double T0 = now_ms();
+    dor_step_begin(s);
+    while (dor_step_iterate(s) == 0) {
+    }
+    return dor_step_end(s, st, T0);
+}
+
+/* state between two iterations of a running step: iterate, gradient, stored pairs (oldest first) */
+int dor_get_lbfgs(const dor_sim *s, double *x, double *g, double *S, double *Y, double *lastE)
+{
+    int n = 3 * s->nV;
+    if (x) memcpy(x, s->x, sizeof(double) * n);
+    if (g) memcpy(g, s->g, sizeof(double) * n);
+    for (int h = 0; h < s->nh; ++h) {
+        if (S) memcpy(S + (size_t)h * n, s->hs[h], sizeof(double) * n);
+        if (Y) memcpy(Y + (size_t)h * n, s->hy[h], sizeof(double) * n);
+    }
+    if (lastE) *lastE = s->lastE;
+    return s->nh;
+}
+
+/* One L-BFGS-H direction + first line-search trial from a GIVEN iterate and history, nothing of the running
+ * state is used or changed except the current factors and x~ (DOTTimeStepper.cpp:386-467, Optimizer.cpp:1076-1093,
+ * :791).  Outputs (any may be NULL): g = gradient at x, q = after the first loop, z = M^-1 q, p = direction,
+ * alpha0 = clamp(-p.g / p.Hp, 0.1, 1), Etrial = E(x + alpha0 p). */
+void dor_probe_direction(dor_sim *s, const double *x, int m, const double *S, const double *Y, double *g_out,
+                         double *q_out, double *z_out, double *p_out, double *alpha0, double *Etrial)
+{
+    int n = 3 * s->nV;
+    double *g = malloc(sizeof(double) * n), *q = malloc(sizeof(double) * n), *p = malloc(sizeof(double) * n);
+    double *Hp = malloc(sizeof(double) * n), *xt = malloc(sizeof(double) * n);
+    double ksi[64], ys[64];
+    dor_eval_gradient(s, x, g);
+    for (int i = 0; i < n; ++i) q[i] = -g[i];
+    for (int h = 0; h < m; ++h) ys[h] = dotn(Y + (size_t)h * n, S + (size_t)h * n, n);
+    for (int h = m - 1; h >= 0; --h) {
+        ksi[h] = dotn(S + (size_t)h * n, q, n) / ys[h];
+        for (int i = 0; i < n; ++i) q[i] -= ksi[h] * Y[(size_t)h * n + i];
+    }
+    dor_apply_precond(s, q, p);
+    if (z_out) memcpy(z_out, p, sizeof(double) * n);
+    for (int h = 0; h < m; ++h) {
+        double c = ksi[h] - dotn(Y + (size_t)h * n, p, n) / ys[h];
+        for (int i = 0; i < n; ++i) p[i] += S[(size_t)h * n + i] * c;
+    }
+    dor_spmv(s, p, Hp);
+    double pg = dotn(p, g, n), pHp = dotn(p, Hp, n);
+    double a = fmax(0.1, fmin(1.0, -pg / pHp));
+    for (int i = 0; i < n; ++i) xt[i] = x[i] + a * p[i];
+    if (Etrial) *Etrial = dor_eval_energy(s, xt);
+    if (alpha0) *alpha0 = a;
+    if (g_out) memcpy(g_out, g, sizeof(double) * n);
+    if (q_out) memcpy(q_out, q, sizeof(double) * n);
+    if (p_out) memcpy(p_out, p, sizeof(double) * n);
+    free(g); free(q); free(p); free(Hp); free(xt);
 }
 
 int dor_last_iter_log(const dor_sim *s, int cap, double *alpha, double *E, double *g2)

@@ -68,6 +68,17 @@ void dor_destroy(dor_sim *s);
 /* scripted Dirichlet motion: x[idx[k]] = pos[3k..] (AnimScripter.cpp:456-466) */
 void dor_move(dor_sim *s, int n, const int *idx, const double *pos);
 int dor_step(dor_sim *s, dor_step_stats *st);
+/* the same step in pieces (teacher forcing: stop between two L-BFGS iterations):
+ * begin = initX + first evaluation; iterate = one solve_oneStep, returns 0 go on / 1 converged / 2 cap /
+ * 3 line search failed; end = refactor + BE update (T0 = 0: no wall time) */
+void dor_step_begin(dor_sim *s);
+int dor_step_iterate(dor_sim *s);
+int dor_step_end(dor_sim *s, dor_step_stats *st, double T0);
+/* iterate, gradient and the stored pairs (oldest first, m*n each) of a running step; returns m */
+int dor_get_lbfgs(const dor_sim *s, double *x, double *g, double *S, double *Y, double *lastE);
+/* one direction + first trial from a given iterate and history (current factors and x~) */
+void dor_probe_direction(dor_sim *s, const double *x, int m, const double *S, const double *Y, double *g_out,
+                         double *q_out, double *z_out, double *p_out, double *alpha0, double *Etrial);
 /* per-iteration log of the last step: alpha, E, g2 (iterStats.txt columns) */
 int dor_last_iter_log(const dor_sim *s, int cap, double *alpha, double *E, double *g2);
 
