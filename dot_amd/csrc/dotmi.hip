@@ -1929,6 +1929,91 @@ int dotmi_apply_precond(dotmi_handle *h, const double *r, double *p)
     return 0;
 }
 
+// One L-BFGS-H direction and its first line-search trial from a caller-supplied iterate and history, with the
+// kernels of the host-driven loop (DOTTimeStepper.cpp:386-467, Optimizer.cpp:1076-1093, :791).  Teacher forcing
+// (SURVEY.md 8(c) F4): a test feeds the oracle's (x, history) of iteration k and compares q, z, p, alpha_0 and
+// E(x + alpha_0 p).  Uses the current factors and x~; the L-BFGS slots it overwrites are reset by the next step.
+int dotmi_probe_direction(dotmi_handle *h, const double *x, int32_t m, const double *S, const double *Y, double *g_out,
+                          double *q_out, double *z_out, double *p_out, double *alpha0, double *E_trial)
+{
+    if (!h || !x || m < 0 || m > h->hist || (m > 0 && (!S || !Y))) return DOTMI_E_INVALID;
+    if (h->poisoned) {
+        h->err = "the subdomain factors are invalid (the last factorisation failed)";
+        return DOTMI_E_NOTSPD;
+    }
+    if (h->dist) {
+        h->err = "dotmi_probe_direction: single-GPU handles only";
+        return DOTMI_E_INVALID;
+    }
+    HIPCHECK(h, hipSetDevice(h->device));
+    const int n = h->n;
+    const size_t bytes = sizeof(double) * n;
+    // the probe works on tmpn (iterate), g_trial (gradient), x_trial (trial point): the handle's own x, g stay
+    HIPCHECK(h, hipMemcpyAsync(h->tmpn, x, bytes, hipMemcpyHostToDevice, h->st));
+    for (int i = 0; i < m; ++i) {
+        HIPCHECK(h, hipMemcpyAsync(h->S[i], S + (size_t)i * n, bytes, hipMemcpyHostToDevice, h->st));
+        HIPCHECK(h, hipMemcpyAsync(h->Y[i], Y + (size_t)i * n, bytes, hipMemcpyHostToDevice, h->st));
+    }
+    int nb = 0;
+    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->tmpn, h->xt, nullptr, h->nT, 0, h->nV, h->gcont, h->partE, &nb,
+                            h->st);
+    GatherArgs a;
+    memset(&a, 0, sizeof(a));
+    a.gcont = h->gcont;
+    a.x = h->tmpn;
+    a.xt = h->xt;
+    a.g_new = h->g_trial;
+    a.iv0 = 0;
+    a.iv1 = h->nV;
+    LbfgsArgs L;
+    memset(&L, 0, sizeof(L));
+    launch_vertex_gather(h->M, a, L, h->partR, h->st);
+    std::vector<double> g(n);
+    HIPCHECK(h, hipMemcpyAsync(g.data(), h->g_trial, bytes, hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    // Gram matrix and the first half of the two-loop on the host (the running loop gets the same numbers from the
+    // gather kernel's partial sums)
+    L.m = m;
+    double b[HIST_MAX] = {0}, xi[HIST_MAX] = {0};
+    auto dot = [&](const double *u, const double *v) {
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc += u[k] * v[k];
+        return acc;
+    };
+    for (int i = 0; i < m; ++i) {
+        L.s[i] = h->S[i];
+        L.y[i] = h->Y[i];
+        b[i] = dot(S + (size_t)i * n, g.data());
+        for (int j = 0; j < m; ++j) L.sy[i][j] = dot(S + (size_t)i * n, Y + (size_t)j * n);
+        L.ys[i] = L.sy[i][i];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+        double sq = -b[i];
+        for (int j = m - 1; j > i; --j) sq -= xi[j] * L.sy[i][j];
+        xi[i] = sq / L.ys[i];
+    }
+    launch_build_q(n, h->g_trial, L, xi, h->q, h->st);
+    if (int rc = apply_precond(h, h->q, h->z, L)) return rc;
+    launch_build_p(n, h->z, L, h->partC, xi, h->p, h->st);
+    launch_spmv_dots(h->M, h->Hval, h->p, h->g_trial, nullptr, 0, h->nV, h->partS, h->st);
+    launch_step_forward(n, h->tmpn, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, h->h_alpha, h->st);
+    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x_trial, h->xt, nullptr, h->nT, 0, h->nV, nullptr, h->partE, &nb,
+                            h->st);
+    HIPCHECK(h, hipMemcpyAsync(h->h_partE, h->partE, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, h->st));
+    if (g_out) memcpy(g_out, g.data(), bytes);
+    if (q_out) HIPCHECK(h, hipMemcpyAsync(q_out, h->q, bytes, hipMemcpyDeviceToHost, h->st));
+    if (z_out) HIPCHECK(h, hipMemcpyAsync(z_out, h->z, bytes, hipMemcpyDeviceToHost, h->st));
+    if (p_out) HIPCHECK(h, hipMemcpyAsync(p_out, h->p, bytes, hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    if (alpha0) *alpha0 = h->h_alpha[0];
+    if (E_trial) {
+        const double se = chunked_sum(nb, [&](int k) { return h->h_partE[2 * k]; });
+        const double si = chunked_sum(nb, [&](int k) { return h->h_partE[2 * k + 1]; });
+        *E_trial = h->dtSq * se + si;
+    }
+    return 0;
+}
+
 int dotmi_spmv(dotmi_handle *h, const double *p, double *Hp)
 {
     if (!h || !p || !Hp) return DOTMI_E_INVALID;

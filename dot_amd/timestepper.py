@@ -181,6 +181,21 @@ class DOTTimeStepper:
         self._check(self._L.dotmi_apply_precond(self._h, dp(r), dp(p)), "apply_precond")
         return p
 
+    def probeDirection(self, x, S=None, Y=None):
+        """one solve_oneStep up to its first trial from a given iterate + history -> dict(g, q, z, p, alpha0, E)"""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        m = 0 if S is None else len(S)
+        Sa = np.ascontiguousarray(S, dtype=np.float64).reshape(m, -1) if m else None
+        Ya = np.ascontiguousarray(Y, dtype=np.float64).reshape(m, -1) if m else None
+        out = {k: np.empty((self.nV, 3)) for k in ("g", "q", "z", "p")}
+        a0, E = C.c_double(), C.c_double()
+        self._check(self._L.dotmi_probe_direction(
+            self._h, dp(x), m, dp(Sa) if m else None, dp(Ya) if m else None, dp(out["g"]), dp(out["q"]),
+            dp(out["z"]), dp(out["p"]), C.cast(C.byref(a0), _lib.c_dp), C.cast(C.byref(E), _lib.c_dp)),
+            "probe_direction")
+        out["alpha0"], out["E"] = a0.value, E.value
+        return out
+
     def multiply(self, p) -> np.ndarray:
         p = np.ascontiguousarray(p, dtype=np.float64)
         out = np.empty((self.nV, 3))

@@ -155,6 +155,13 @@ int dotmi_eval_elem_hessians(dotmi_handle *h, const double *x, double *H); /* En
 int dotmi_refactor(dotmi_handle *h, const double *x /*NULL = current*/);   /* DOTTimeStepper::updateHessianAndFactor, :349 */
 int dotmi_apply_precond(dotmi_handle *h, const double *r, double *p);      /* DOTTimeStepper.cpp:406-450 */
 int dotmi_spmv(dotmi_handle *h, const double *p, double *Hp);              /* LinSysSolver::multiply, CHOLMODSolver.cpp:185 */
+/* One iteration of DOTTimeStepper::solve_oneStep up to its first line-search trial (DOTTimeStepper.cpp:386-467,
+ * Optimizer::initStepSize :1076-1093, the first computeEnergyVal of lineSearch :791) from a caller-supplied
+ * iterate x and m <= history stored pairs (S, Y: m*n each, oldest first): g = gradient at x, q = after the first
+ * loop, z = the domain-decomposed block solve of q, p = search direction, alpha0, E(x + alpha0 p).  Any output may
+ * be NULL.  Uses the handle's current factors and x~ and leaves its state alone (teacher-forced parity). */
+int dotmi_probe_direction(dotmi_handle *h, const double *x, int32_t m, const double *S, const double *Y,
+                          double *g, double *q, double *z, double *p, double *alpha0, double *E_trial);
 /* derived mesh features, any pointer may be NULL: restTriInv nT*9 row-major, triArea nT, mass nV */
 int dotmi_get_features(dotmi_handle *h, double *A, double *vol, double *mass);
 /* dense principal sub-matrix R_s H R_s^T currently on the device (n_s = 3*local verts), row-major.

@@ -54,6 +54,14 @@ def lib():
         L.dor_move.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp]
         L.dor_step.argtypes = [C.c_void_p, C.POINTER(StepStats)]
         L.dor_step.restype = C.c_int
+        L.dor_step_begin.argtypes = [C.c_void_p]
+        L.dor_step_iterate.argtypes = [C.c_void_p]
+        L.dor_step_iterate.restype = C.c_int
+        L.dor_step_end.argtypes = [C.c_void_p, C.POINTER(StepStats), C.c_double]
+        L.dor_step_end.restype = C.c_int
+        L.dor_get_lbfgs.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]
+        L.dor_get_lbfgs.restype = C.c_int
+        L.dor_probe_direction.argtypes = [C.c_void_p, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
         L.dor_last_iter_log.argtypes = [C.c_void_p, C.c_int, c_dp, c_dp, c_dp]
         L.dor_last_iter_log.restype = C.c_int
         L.dor_get_state.argtypes = [C.c_void_p, c_dp, c_dp, c_dp]
@@ -128,6 +136,41 @@ class OracleSim:
         st = StepStats()
         lib().dor_step(self.h, C.byref(st))
         return st
+
+    # ---- a step in pieces (teacher forcing) ----
+    def step_begin(self):
+        lib().dor_step_begin(self.h)
+
+    def step_iterate(self) -> int:
+        """0 go on, 1 converged, 2 iteration cap, 3 line search failed"""
+        return lib().dor_step_iterate(self.h)
+
+    def step_end(self):
+        st = StepStats()
+        lib().dor_step_end(self.h, C.byref(st), 0.0)
+        return st
+
+    def lbfgs_state(self):
+        """(x, g, S[m,nV,3], Y[m,nV,3], lastE) between two iterations of a running step"""
+        n = 3 * self.nV
+        x, g = np.zeros((self.nV, 3)), np.zeros((self.nV, 3))
+        S, Y = np.zeros((5, n)), np.zeros((5, n))
+        E = C.c_double()
+        m = lib().dor_get_lbfgs(self.h, _dp(x), _dp(g), _dp(S), _dp(Y), C.cast(C.byref(E), c_dp))
+        return x, g, S[:m].copy(), Y[:m].copy(), E.value
+
+    def probe_direction(self, x, S=None, Y=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        m = 0 if S is None else len(S)
+        Sa = np.ascontiguousarray(S, dtype=np.float64).reshape(m, -1) if m else None
+        Ya = np.ascontiguousarray(Y, dtype=np.float64).reshape(m, -1) if m else None
+        out = {k: np.zeros((self.nV, 3)) for k in ("g", "q", "z", "p")}
+        a0, E = C.c_double(), C.c_double()
+        lib().dor_probe_direction(self.h, _dp(x), m, _dp(Sa) if m else None, _dp(Ya) if m else None, _dp(out["g"]),
+                                  _dp(out["q"]), _dp(out["z"]), _dp(out["p"]), C.cast(C.byref(a0), c_dp),
+                                  C.cast(C.byref(E), c_dp))
+        out["alpha0"], out["E"] = a0.value, E.value
+        return out
 
     def iter_log(self):
         cap = 10001

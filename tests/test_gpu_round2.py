@@ -60,3 +60,201 @@ def test_failed_factorisation_poisons_the_handle():
     ts.updatePrecondMtrAndFactorize(sc.x0)   # a good factorisation heals it
     assert ts.step().status == 0
     ts.close()
+
+
+def run_both(sc, ts, orc, nsteps):
+    out = []
+    for _ in range(nsteps):
+        x = ts.getResult()
+        idx, pos = sc.scripter.step(x, sc.cfg.dt)
+        ts.setDirichlet(idx, pos)
+        orc.move(idx, pos)
+        out.append((ts.step(), orc.step()))
+    return out
+
+
+# ---- BASELINE.json configs[2]: horse, FixedCoRot, 8 subdomains (horse7K is the stand-in for the missing 136K mesh) --
+def test_horse7K_stretch_fcr_8_steps_match_oracle():
+    """Steps 0-4 of input/tb1_horse_scalab/horse7K_stretch_DOT.txt (FCR, 8 METIS parts): identical L-BFGS iterations
+    and back-tracking halvings on all five; positions to 1e-9 while the line search does not amplify rounding
+    (steps 0-3: measured 2e-16, 3e-16, 1e-14, 7e-12).  Step 4 back-tracks six times and the free runs drift to 4e-6
+    with the same decisions, step 5 takes 8 vs 11 halvings: the teacher-forced tests below show that each single
+    iteration of those steps still agrees to rounding."""
+    sc, ep, n, ts, orc = make_pair("horse7K_stretch")
+    assert sc.cfg.energy == "FCR" and n == 8
+    for k in range(5):
+        (st, so), = run_both(sc, ts, orc, 1)
+        assert (st.status, st.iters, st.ls_halvings) == (so.status, so.iters, so.ls_halvings), k
+        assert st.g2 <= ts.targetGRes
+        dx = np.abs(ts.getResult() - orc.state()[0]).max()
+        if k < 4:
+            assert dx < 1e-9 and abs(st.E - so.E) <= 1e-10 * abs(so.E), (k, dx)
+        else:
+            assert dx < 1e-4 and abs(st.E - so.E) <= 1e-5 * abs(so.E), (k, dx)   # trajectory band (SURVEY 8c F5)
+        if k == 3:
+            x, v, xt = ts.getState()
+            xo, vo, xto = orc.state()
+            assert np.abs(v - vo).max() < 1e-7 and np.abs(xt - xto).max() < 1e-9
+    ts.close(); orc.close()
+
+
+# ---- BASELINE.json configs[4]: synthetic 1M-tet bar twist, StableNH, 256 subdomains -------------------------------
+def test_synbar_256_parts_reduced_size_matches_oracle():
+    """The same generator, script, material and 256-part recursive-coordinate-bisection partition as the 1M-tet
+    configuration on a mesh the oracle finishes in seconds (40x10x10 cubes = 24 000 tets)."""
+    sc, ep, n, ts, orc = make_pair("synbar:40x10x10:256")
+    assert n == 256 and sc.T.shape[0] == 24000 and sc.cfg.energy == "SNH"
+    for k, (st, so) in enumerate(run_both(sc, ts, orc, 3)):
+        assert (st.status, st.iters, st.ls_halvings) == (so.status, so.iters, so.ls_halvings), k
+    assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
+    r = np.random.default_rng(3).standard_normal((sc.V_rest.shape[0], 3))
+    r[sc.fixed.astype(bool)] = 0
+    po = orc.apply_precond(r)
+    assert np.abs(ts.applyPrecond(r) - po).max() <= 1e-9 * np.abs(po).max()
+    ts.close(); orc.close()
+
+
+def test_synbar_1M_tets_256_parts_full_size_properties():
+    """configs[4] at full size (140x35x35 cubes = 1 029 000 tets, 182 736 vertices, 256 parts) through the
+    size-independent properties: the line search never accepts an energy increase, the step ends below the
+    tolerance, X^T X H_s = I on two subdomains, H_s is the principal sub-matrix of the global H (checked through
+    the SpMV), the preconditioner is SPD, and a second handle reproduces the step bit for bit."""
+    sc, ep, n = load_workload("synbar:140x35x35:256")
+    assert sc.T.shape[0] == 1029000 and sc.V_rest.shape[0] == 182736 and n == 256
+    cfg = sc.cfg
+
+    def one(ts):
+        x = ts.getResult()
+        idx, pos = sc.scripter.step(x, cfg.dt)
+        ts.setDirichlet(idx, pos)
+        st = ts.step()
+        return st, ts.getResult(), ts.iterLog()
+
+    ts = DOTTimeStepper(sc, ep, n)
+    st, x1, (alpha, E, g2) = one(ts)
+    assert st.status == 0 and st.iters == len(E) and st.g2 <= ts.targetGRes
+    assert E[0] <= st.E0 and np.all(np.diff(E) <= 0.0)          # E(x + alpha p) > E(x) is never accepted
+    assert np.all((alpha > 0) & (alpha <= 1.0))
+    assert g2[-1] == st.g2 and np.all(g2[:-1] > ts.targetGRes)
+    free = ~sc.fixed.astype(bool)
+    rng = np.random.default_rng(11)
+    for part in (0, 137):
+        Hs, l2g = ts.partMatrix(part)
+        X, _ = ts.partMatrix(part, inverse=True)
+        ns = Hs.shape[0]
+        assert np.abs(X.T @ X @ Hs - np.eye(ns)).max() < 1e-9
+        # rows of the global SpMV restricted to the part's vertices == H_s (free dofs; fixed rows are identity)
+        p = np.zeros((sc.V_rest.shape[0], 3))
+        p[l2g] = rng.standard_normal((l2g.size, 3))
+        Hp = ts.multiply(p)[l2g].reshape(-1)
+        assert np.abs(Hp - Hs @ p[l2g].reshape(-1)).max() <= 1e-10 * np.abs(Hp).max()
+    # the block solve is linear, and on right-hand sides supported on vertices owned by ONE subdomain it is that
+    # subdomain's X^T X (no averaging there: dup = 1)
+    nV = sc.V_rest.shape[0]
+    r = rng.standard_normal((nV, 3)) * free[:, None]
+    r2 = rng.standard_normal((nV, 3)) * free[:, None]
+    Mr, Mr2, Mc = ts.applyPrecond(r), ts.applyPrecond(r2), ts.applyPrecond(0.5 * r - 2.0 * r2)
+    assert np.abs(Mc - (0.5 * Mr - 2.0 * Mr2)).max() <= 1e-11 * np.abs(Mr).max()
+    dup = np.zeros(nV, dtype=np.int32)
+    for p_ in range(n):
+        dup[np.unique(sc.T[ep == p_])] += 1
+    X, l2g = ts.partMatrix(137, inverse=True)
+    own = (dup[l2g] == 1) & free[l2g]
+    assert own.sum() > 10
+    rs = np.zeros((l2g.size, 3))
+    rs[own] = rng.standard_normal((int(own.sum()), 3))
+    rr = np.zeros((nV, 3))
+    rr[l2g] = rs
+    zs = (X.T @ (X @ rs.reshape(-1))).reshape(-1, 3)
+    z = ts.applyPrecond(rr)
+    assert np.abs(z[l2g][own] - zs[own]).max() <= 1e-10 * np.abs(zs).max()
+    ts.close()
+    sc2, ep2, _ = load_workload("synbar:140x35x35:256")     # fresh scripter state
+    ts2 = DOTTimeStepper(sc2, ep2, n)
+    x = ts2.getResult()
+    idx, pos = sc2.scripter.step(x, cfg.dt)
+    ts2.setDirichlet(idx, pos)
+    st2 = ts2.step()
+    assert (st2.iters, st2.ls_halvings, st2.E, st2.g2) == (st.iters, st.ls_halvings, st.E, st.g2)
+    assert np.array_equal(ts2.getResult(), x1)
+    ts2.close()
+
+
+# ---- teacher-forced per-iteration parity (SURVEY.md 8(c) F4; reference rows DOTTimeStepper.cpp:299,304,329) -------
+def teacher_forced(sc, ts, orc, max_iters):
+    """Walk the ORACLE through one time step; before every iteration hand its (x, history) to both probes and compare
+    what the HIP path and the oracle make of the same input.  Returns the per-iteration relative errors."""
+    err = {k: [] for k in ("g", "q", "z", "p", "alpha0", "E")}
+    decisions = 0
+    orc.step_begin()
+    it = 0
+    while it < max_iters:
+        xk, gk, S, Y, lastE = orc.lbfgs_state()
+        po = orc.probe_direction(xk, S, Y)
+        pd = ts.probeDirection(xk, S, Y)
+        for k in ("g", "q", "z", "p"):
+            err[k].append(np.abs(pd[k] - po[k]).max() / np.abs(po[k]).max())
+        err["alpha0"].append(abs(pd["alpha0"] - po["alpha0"]) / po["alpha0"])
+        err["E"].append(abs(pd["E"] - po["E"]) / abs(po["E"]))
+        # the accept / halve decision of the first trial, where it is not a rounding coin flip
+        if abs(po["E"] - lastE) > 1e-9 * abs(lastE):
+            assert (pd["E"] > lastE) == (po["E"] > lastE), it
+            decisions += 1
+        it += 1
+        if orc.step_iterate() != 0:
+            break
+    return {k: np.array(v) for k, v in err.items()}, it, decisions
+
+
+def sync_to_oracle(ts, orc):
+    """start-of-step state of the oracle -> the device: (x, v, x_n), x~ and the factors at x_n"""
+    x, v, _ = orc.state()
+    ts.setState(x, v, x)
+    ts.updatePrecondMtrAndFactorize(x)
+
+
+def test_teacher_forced_stiff_monkey_first_100_iterations():
+    """monkey18K, StableNH, E = 4e5, dt = 0.04, 64 parts (BASELINE.json configs[3]): the regime with > 100 halvings
+    per step, where free-running trajectories part ways inside step 0.  With the oracle's own (x, history) forced in,
+    every iteration's q, block solve z, direction p, alpha_0 and trial energy agree to the bounds below -- so the
+    early divergence of free runs is rounding amplified by the line search, not a different preconditioner."""
+    sc, ep, n, ts, orc = make_pair("monkey18K_stiff")
+    x = ts.getResult()
+    idx, pos = sc.scripter.step(x, sc.cfg.dt)
+    ts.setDirichlet(idx, pos)
+    orc.move(idx, pos)
+    # same start-of-step x (scripted handles moved); x~ and the factors are those of the rest state on both sides
+    err, iters, decisions = teacher_forced(sc, ts, orc, 101)
+    assert iters >= 100
+    print("teacher-forced monkey18K_stiff: max rel err over", iters, "iterations:",
+          {k: float(v.max()) for k, v in err.items()}, "decisions checked:", decisions)
+    assert err["g"].max() < 1e-10 and err["q"].max() < 1e-10
+    assert err["z"].max() < 1e-8, err["z"].max()       # the block solve with the explicit inverse factor
+    assert err["p"].max() < 1e-8
+    assert err["alpha0"].max() < 1e-8 and err["E"].max() < 1e-12
+    ts.close(); orc.close()
+
+
+@pytest.mark.parametrize("step", [4, 5])
+def test_teacher_forced_horse7K_back_tracking_steps(step):
+    """horse7K_stretch free runs drift at step 4 (same decisions, 4e-6 in x) and differ at step 5 (8 vs 11 halvings).
+    Each of those steps teacher-forced from the oracle's start-of-step state: every iteration agrees to rounding."""
+    sc, ep, n, ts, orc = make_pair("horse7K_stretch")
+    for _ in range(step):
+        x = orc.state()[0]
+        idx, pos = sc.scripter.step(x, sc.cfg.dt)
+        orc.move(idx, pos)
+        orc.step()
+    sync_to_oracle(ts, orc)
+    x = orc.state()[0]
+    idx, pos = sc.scripter.step(x, sc.cfg.dt)
+    orc.move(idx, pos)
+    ts.setDirichlet(idx, pos)
+    err, iters, decisions = teacher_forced(sc, ts, orc, 200)
+    print(f"teacher-forced horse7K step {step}: max rel err over", iters, "iterations:",
+          {k: float(v.max()) for k, v in err.items()}, "decisions checked:", decisions)
+    assert iters >= 10 and decisions >= iters // 2
+    assert err["g"].max() < 1e-10 and err["q"].max() < 1e-10
+    assert err["z"].max() < 1e-9 and err["p"].max() < 1e-9
+    assert err["alpha0"].max() < 1e-9 and err["E"].max() < 1e-12
+    ts.close(); orc.close()

@@ -57,3 +57,34 @@ def test_oracle_is_deterministic_and_thread_count_independent():
     O.lib().dor_set_threads(4)
     _, its4, E4, _ = run("bunny5K_LTSS", 2)
     assert its1 == its4 and E1 == E4
+
+
+def test_step_in_pieces_equals_step_and_probe_reproduces_the_running_iteration():
+    """dor_step_begin/_iterate/_end is dor_step; dor_probe_direction fed with the state between two iterations
+    reproduces the next iteration's step length and trial energy (the teacher-forcing harness of the GPU tests)."""
+    sc, ep, nparts = load_workload("synbar:8x3x3:4")
+    cfg = sc.cfg
+    mk = lambda: O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep,
+                             nparts, cfg.with_gravity)
+    a, b = mk(), mk()
+    x = a.state()[0]
+    idx, pos = sc.scripter.step(x, cfg.dt)
+    a.move(idx, pos); b.move(idx, pos)
+    sa = a.step()
+    b.step_begin()
+    probes = []
+    while True:
+        xk, gk, S, Y, lastE = b.lbfgs_state()
+        probes.append(b.probe_direction(xk, S, Y))
+        assert np.array_equal(probes[-1]["g"], gk)
+        if b.step_iterate() != 0:
+            break
+    sb = b.step_end()
+    assert (sa.iters, sa.ls_halvings, sa.E, sa.g2) == (sb.iters, sb.ls_halvings, sb.E, sb.g2)
+    assert np.array_equal(a.state()[0], b.state()[0]) and np.array_equal(a.state()[1], b.state()[1])
+    alpha, E, _ = a.iter_log()
+    assert len(probes) == sa.iters
+    for k, pr in enumerate(probes):
+        if alpha[k] == pr["alpha0"]:          # no back-tracking in this iteration: the probe IS the iteration
+            assert E[k] == pr["E"]
+    assert sum(alpha[k] == probes[k]["alpha0"] for k in range(sa.iters)) >= sa.iters - sa.ls_halvings
