@@ -44,14 +44,25 @@ inline Config parse_script(const std::string &path)
         std::stringstream ss(line);
         std::string tok;
         if (!(ss >> tok)) continue;
-        if (tok == "energy") ss >> c.energy;
-        else if (tok == "timeStepper") {
+        if (tok == "energy") {
+            ss >> c.energy;
+            if (c.energy != "FCR" && c.energy != "SNH") c.energy = "SNH";  // default of getEnergyTypeByStr, Config.cpp:348-357
+        } else if (tok == "timeStepper") {
             ss >> c.timeStepper;
-            int n;
-            if (ss >> n) {
-                int b;
-                if (n == -1 && (ss >> b)) c.blockSize = b;  // "DOT -1 <nodes per block>" (main.cpp:792-798)
-                else c.partitionAmt = n >= 2 ? n : 4;
+            static const char *known[] = {"Newton", "ADMM", "ADMMDD", "LBFGS", "LBFGSH", "LBFGSHI", "LBFGSJH", "DOT", "GSDD"};
+            bool ok = false;
+            for (const char *k : known) ok |= c.timeStepper == k;
+            if (!ok) c.timeStepper = "Newton";  // default of getTimeStepperTypeByStr, Config.cpp:378-387
+            // Config.cpp:62-80: only the domain-decomposed steppers read a partition count; a negative count is
+            // followed by the nodes per block ("DOT -1 1024", main.cpp:792-798), 0 / 1 mean the default 4
+            if (c.timeStepper == "ADMMDD" || c.timeStepper == "DOT" || c.timeStepper == "LBFGSJH" ||
+                c.timeStepper == "GSDD") {
+                int n;
+                if (ss >> n) {
+                    c.partitionAmt = n;
+                    if (n < 0) ss >> c.blockSize;
+                    else if (n < 2) c.partitionAmt = 4;
+                }
             }
         } else if (tok == "size") ss >> c.size;
         else if (tok == "time") ss >> c.duration >> c.dt;
@@ -63,7 +74,7 @@ inline Config parse_script(const std::string &path)
             std::string kind;
             ss >> kind;
             if (kind == "input") ss >> c.shapePath;
-        } else if (tok == "rotateModel") ss >> c.rotDeg >> c.rotAxis[0] >> c.rotAxis[1] >> c.rotAxis[2];
+        } else if (tok == "rotateModel") ss >> c.rotAxis[0] >> c.rotAxis[1] >> c.rotAxis[2] >> c.rotDeg;  // axis first, Config.cpp:173-176
         else if (tok == "handleRatio") ss >> c.handleRatio;
         else if (tok == "warmStart") ss >> c.warmStart;
         else if (tok == "restart") {

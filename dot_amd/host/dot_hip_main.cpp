@@ -13,7 +13,7 @@
 // Script token `restart <status file>` resumes from a saved status (Optimizer.cpp:126-177).
 //
 // usage: dot_hip 100 <script.txt> [--mesh-root DIR] [--parts N] [--energy FCR|SNH] [--epart raw.i32]
-//                [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K]
+//                [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K] [--dump-config]
 #include <chrono>
 #include <cstring>
 #include <iostream>
@@ -33,7 +33,7 @@ int main(int argc, char **argv)
 {
     if (argc < 3) {
         std::fprintf(stderr, "usage: %s 100 <script.txt> [--mesh-root DIR] [--parts N] [--energy FCR|SNH] "
-                             "[--epart raw.i32] [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K]\n", argv[0]);
+                             "[--epart raw.i32] [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K] [--dump-config]\n", argv[0]);
         return 2;
     }
     if (std::string(argv[1]) != "100") {
@@ -43,7 +43,7 @@ int main(int argc, char **argv)
     const std::string scriptPath = argv[2];
     std::string meshRoot = ".", outDir, epartFile, energyOverride;
     int partsOverride = -1, frames = -1, device = 0, dumpScene = -1;
-    bool files = true;
+    bool files = true, dumpConfig = false;
     for (int i = 3; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) throw std::runtime_error("missing value for " + a); return argv[++i]; };
@@ -56,10 +56,26 @@ int main(int argc, char **argv)
         else if (a == "--device") device = std::stoi(next());
         else if (a == "--no-files") files = false;
         else if (a == "--dump-scene") dumpScene = std::stoi(next());
+        else if (a == "--dump-config") dumpConfig = true;
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     try {
         Config cfg = parse_script(scriptPath);
+        if (dumpConfig) {
+            // the parsed fields as "key value" lines, the format of oracle/ref_config.cpp (the reference's own
+            // Config::loadFromFile): tests/test_oracle_pin.py compares the two on every input script of the reference
+            std::printf("energy %s\ntimeStepper %s\npartitionAmt %d\nblockSize %d\n", cfg.energy.c_str(),
+                        cfg.timeStepper.c_str(), cfg.partitionAmt, cfg.blockSize);
+            std::printf("size %.17g\nduration %.17g\ndt %.17g\nrho %.17g\nYM %.17g\nPR %.17g\n", cfg.size, cfg.duration,
+                        cfg.dt, cfg.rho, cfg.YM, cfg.PR);
+            std::printf("withGravity %d\ninputShapePath %s\nwarmStart %d\nhandleRatio %.17g\nrotDeg %.17g\n",
+                        cfg.withGravity ? 1 : 0, cfg.shapePath.c_str(), cfg.warmStart, cfg.handleRatio, cfg.rotDeg);
+            if (cfg.rotDeg != 0.0) std::printf("rotAxis %.17g %.17g %.17g\n", cfg.rotAxis[0], cfg.rotAxis[1], cfg.rotAxis[2]);
+            std::printf("restart %d\nstatusPath %s\ntol %zu", cfg.restart ? 1 : 0, cfg.statusPath.c_str(), cfg.tol.size());
+            for (double t : cfg.tol) std::printf(" %.17g", t);
+            std::printf("\n");
+            return 0;
+        }
         if (!energyOverride.empty()) cfg.energy = energyOverride;
         if (cfg.shapePath.empty()) throw std::runtime_error("script has no `shape input <mesh>` (primitive shapes are 2-D only)");
         TetMesh mesh = load_tet_mesh(cfg.shapePath[0] == '/' ? cfg.shapePath : meshRoot + "/" + cfg.shapePath);

@@ -51,6 +51,10 @@ class Config:
         return ENERGY_SNH if self.energy == "SNH" else ENERGY_FCR
 
 
+ENERGY_NAMES = ("FCR", "SNH")                               # Config.cpp:14-16
+STEPPER_NAMES = ("Newton", "ADMM", "ADMMDD", "LBFGS", "LBFGSH", "LBFGSHI", "LBFGSJH", "DOT", "GSDD")   # :23-28
+
+
 def parse_script(path: str) -> Config:
     """One token per line, order-free, unknown tokens ignored (Config.cpp:43-208)."""
     cfg = Config()
@@ -64,15 +68,22 @@ def parse_script(path: str) -> Config:
             continue
         key = tok[0]
         if key == "energy":
-            cfg.energy = tok[1]
+            # unknown names fall back to the default type, Config::getEnergyTypeByStr (Config.cpp:348-357)
+            cfg.energy = tok[1] if tok[1] in ENERGY_NAMES else "SNH"
         elif key == "timeStepper":
+            # unknown names are Newton, Config::getTimeStepperTypeByStr (Config.cpp:378-387)
+            tok[1] = tok[1] if tok[1] in STEPPER_NAMES else "Newton"
             cfg.time_stepper = tok[1]
-            if len(tok) > 2:
+            # Config.cpp:62-80: only the domain-decomposed steppers read a partition count; a negative count is
+            # followed by the nodes per block ("DOT -1 1024", main.cpp:792-798), 0 / 1 mean the default 4
+            if tok[1] in ("ADMMDD", "DOT", "LBFGSJH", "GSDD") and len(tok) > 2:
                 n = int(tok[2])
-                if n == -1 and len(tok) > 3:          # "DOT -1 <nodes per block>"
-                    cfg.block_size = int(tok[3])
-                else:
-                    cfg.partition_amt = n if n >= 2 else 4
+                cfg.partition_amt = n
+                if n < 0:
+                    if len(tok) > 3:
+                        cfg.block_size = int(tok[3])
+                elif n < 2:
+                    cfg.partition_amt = 4
         elif key == "size":
             cfg.size = float(tok[1])
         elif key == "time":
@@ -88,8 +99,8 @@ def parse_script(path: str) -> Config:
         elif key == "shape" and len(tok) > 2 and tok[1] == "input":
             cfg.shape_path = tok[2]
         elif key == "rotateModel":
-            cfg.rot_deg = float(tok[1])
-            cfg.rot_axis = (float(tok[2]), float(tok[3]), float(tok[4]))
+            cfg.rot_axis = (float(tok[1]), float(tok[2]), float(tok[3]))   # axis first, Config.cpp:173-176
+            cfg.rot_deg = float(tok[4])
         elif key == "handleRatio":
             cfg.handle_ratio = float(tok[1])
         elif key == "warmStart":

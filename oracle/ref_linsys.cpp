@@ -1,0 +1,83 @@
+// ref_linsys.cpp -- TEST INFRASTRUCTURE ONLY.  A driver around the REFERENCE's own linear-system code, compiled where
+// it lies (oracle/Makefile target _ref/librefsolver.so): src/LinSysSolver/LinSysSolver.hpp (pattern + coefficient
+// indexing), src/LinSysSolver/CHOLMODSolver.cpp (analyze / factorize / solve / multiply) on the vendored CHOLMOD
+// 3.0.12 + AMD + COLAMD (plain gcc on their .c files; BLAS/LAPACK = /opt/conda/lib/libmkl_rt.so, a real BLAS that
+// is part of the image), and IglUtils::addBlockToMatrix<3> (src/Utils/IglUtils.hpp:143-220).  Nothing is copied.
+//
+// What it pins (VERDICT r01 "weak 1"): the global assembly a9 (set_pattern index maps, the fixed-vertex unit rows,
+// the mass on the free diagonal -- the statements of DOTTimeStepper::computeHElemAndFillIn, DOTTimeStepper.cpp:588-613,
+// are re-issued here against the reference's solver object because DOTTimeStepper.cpp itself needs <tbb/tbb.h>) and
+// a11 (CHOLMODSolver::factorize / solve / multiply).
+#include "CHOLMODSolver.hpp"
+#include "IglUtils.hpp"
+
+#include <cstring>
+#include <set>
+#include <vector>
+
+using Solver = DOT::CHOLMODSolver<Eigen::VectorXi, Eigen::VectorXd>;
+
+extern "C" {
+
+// T: nT*4, fixed: nV, He: nT*144 row-major element Hessians (already projected, dt^2 vol included), mass: nV
+// rhs, x: n = 3 nV.  Outputs: sol = A^-1 rhs, Ax = A x, and (if dense != NULL) the n*n matrix the solver holds.
+// returns 0, or 1 when the factorisation failed
+int ref_linsys_run(int nV, int nT, const int *T, const unsigned char *fixed, const double *He, const double *mass,
+                   const double *rhs, const double *x, double *sol, double *Ax, double *dense)
+{
+    // Mesh::computeFeatures builds vNeighbor / vFLoc like this (Mesh.cpp:600-614)
+    std::vector<std::set<int>> vNeighbor(nV);
+    std::vector<std::set<std::pair<int, int>>> vFLoc(nV);
+    for (int e = 0; e < nT; ++e)
+        for (int a = 0; a < 4; ++a) {
+            vFLoc[T[4 * e + a]].insert(std::pair<int, int>(e, a));
+            for (int b = 0; b < 4; ++b)
+                if (a != b) vNeighbor[T[4 * e + a]].insert(T[4 * e + b]);
+        }
+    std::set<int> fixedVert;
+    for (int v = 0; v < nV; ++v)
+        if (fixed[v]) fixedVert.insert(v);
+
+    Solver solver;
+    solver.set_type(1, 2);
+    solver.set_pattern(vNeighbor, fixedVert);
+    solver.analyze_pattern();
+
+    // DOTTimeStepper::computeHElemAndFillIn, DOTTimeStepper.cpp:588-613 (vInds: Energy.cpp:771-775)
+    solver.setZero();
+    for (int vI = 0; vI < nV; ++vI) {
+        for (const auto &FLocI : vFLoc[vI]) {
+            const int e = FLocI.first;
+            Eigen::Matrix<double, 12, 12> H;
+            for (int r = 0; r < 12; ++r)
+                for (int c = 0; c < 12; ++c) H(r, c) = He[(size_t)144 * e + 12 * r + c];
+            Eigen::Matrix<int, 1, 4> vInd;
+            for (int k = 0; k < 4; ++k) vInd[k] = fixed[T[4 * e + k]] ? (-T[4 * e + k] - 1) : T[4 * e + k];
+            DOT::IglUtils::addBlockToMatrix<3>(H.block(FLocI.second * 3, 0, 3, 12), vInd, FLocI.second, &solver);
+        }
+        if (!fixed[vI]) {
+            const int ind0 = vI * 3;
+            solver.addCoeff(ind0, ind0, mass[vI]);
+            solver.addCoeff(ind0 + 1, ind0 + 1, mass[vI]);
+            solver.addCoeff(ind0 + 2, ind0 + 2, mass[vI]);
+        }
+    }
+    const int n = 3 * nV;
+    if (dense) {
+        Eigen::SparseMatrix<double> M;
+        solver.getCoeffMtr(M);
+        std::memset(dense, 0, sizeof(double) * (size_t)n * n);
+        for (int k = 0; k < M.outerSize(); ++k)
+            for (Eigen::SparseMatrix<double>::InnerIterator it(M, k); it; ++it) dense[(size_t)it.row() * n + it.col()] = it.value();
+    }
+    if (solver.factorize()) return 1;   // CHOLMODSolver::factorize returns !cholmod_factorize(...)
+    Eigen::VectorXd b = Eigen::Map<const Eigen::VectorXd>(rhs, n), r;
+    solver.solve(b, r);
+    std::memcpy(sol, r.data(), sizeof(double) * n);
+    Eigen::VectorXd xv = Eigen::Map<const Eigen::VectorXd>(x, n), y;
+    solver.multiply(xv, y);
+    std::memcpy(Ax, y.data(), sizeof(double) * n);
+    return 0;
+}
+
+}  // extern "C"

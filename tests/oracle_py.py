@@ -277,6 +277,52 @@ def ref():
     return _ref
 
 
+_refsolver = None
+
+
+def ref_solver_available():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "librefsolver.so")) and os.path.exists(
+        "/opt/conda/lib/libmkl_rt.so.1")
+
+
+def ref_linsys(T, fixed, He, mass, rhs, v, want_dense=False):
+    """The reference's LinSysSolver + CHOLMODSolver (oracle/ref_linsys.cpp): assemble the global matrix from the
+    element Hessians as DOTTimeStepper::computeHElemAndFillIn does, factorize, solve(rhs), multiply(v)."""
+    global _refsolver
+    if _refsolver is None:
+        os.environ.setdefault("MKL_THREADING_LAYER", "SEQUENTIAL")
+        # the BLAS is named by its full path: an rpath to /opt/conda/lib would also pull in that directory's libstdc++
+        C.CDLL("/opt/conda/lib/libmkl_rt.so.1", mode=C.RTLD_GLOBAL)
+        _refsolver = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "librefsolver.so"))
+        _refsolver.ref_linsys_run.argtypes = [C.c_int, C.c_int, c_ip, c_up, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
+        _refsolver.ref_linsys_run.restype = C.c_int
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+    He = np.ascontiguousarray(He, dtype=np.float64)
+    mass = np.ascontiguousarray(mass, dtype=np.float64)
+    rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    nV, nT = mass.size, T.shape[0]
+    n = 3 * nV
+    sol, Av = np.zeros(n), np.zeros(n)
+    dense = np.zeros((n, n)) if want_dense else None
+    rc = _refsolver.ref_linsys_run(nV, nT, _ip(T), fixed.ctypes.data_as(c_up), _dp(He), _dp(mass), _dp(rhs), _dp(v),
+                                   _dp(sol), _dp(Av), _dp(dense) if want_dense else None)
+    if rc != 0:
+        raise RuntimeError("reference CHOLMODSolver::factorize failed")
+    return sol, Av, dense
+
+
+def ref_config_parse(path):
+    """DOT::Config::loadFromFile of the reference (oracle/_ref/ref_config, oracle/ref_config.cpp) -> dict of strings"""
+    txt = subprocess.check_output([os.path.join(ORACLE_DIR, "_ref", "ref_config"), path]).decode()
+    out = {}
+    for line in txt.splitlines():
+        k, _, v = line.partition(" ")
+        out[k] = v
+    return out
+
+
 def metis_partition(T, nV, nparts, tmpdir="/tmp"):
     """Run the reference's vendored METIS (oracle/_ref/metis_part) on a tet list."""
     exe = os.path.join(ORACLE_DIR, "_ref", "metis_part")

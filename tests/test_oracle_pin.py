@@ -1,10 +1,14 @@
 """Pins the oracle (oracle/dot_oracle.c) against the REFERENCE: golden vectors produced by the
 reference's own code (tests/golden/ref_vectors.npz, see make_ref_vectors.py) and, when
 oracle/_ref/librefpin.so is present, the reference pieces called live."""
+import os
+
 import numpy as np
 import pytest
 
 from tests import oracle_py as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 dp = O._dp
 
@@ -111,3 +115,144 @@ def test_autoflip_svd_identity():
     U = np.zeros((3, 3)); S = np.zeros(3); V = np.zeros((3, 3))
     R.ref_autoflip_svd(dp(F), dp(U), dp(S), dp(V))
     assert np.allclose(S, 1.0) and np.allclose(U @ V.T, np.eye(3))
+
+
+# ---- round 2: the reference's LinSysSolver + CHOLMODSolver (a9 global assembly, a11 factorize / solve / multiply) ----
+LINSYS = os.path.join(ROOT, "tests", "golden", "ref_linsys.npz")
+CONFIG = os.path.join(ROOT, "tests", "golden", "ref_config.json")
+
+
+def _linsys_cases():
+    import json
+    G = np.load(LINSYS)
+    meta = json.loads(str(G["meta"]))
+    return G, meta
+
+
+def _oracle_for(meta_k):
+    from dot_amd.configs import load_workload
+    sc, ep, _ = load_workload(meta_k["workload"])
+    sc.cfg.energy = meta_k["energy"]
+    cfg = sc.cfg
+    orc = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, 1,
+                      cfg.with_gravity)
+    return sc, orc
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3])
+def test_oracle_assembly_solve_and_spmv_match_reference_cholmod_solver(k):
+    """Golden vectors made by the reference's own LinSysSolver.hpp + CHOLMODSolver.cpp on the vendored CHOLMOD
+    (tests/golden/make_ref_vectors2.py): the oracle's global assembly (fixed rows, mass on the free diagonal, block
+    indexing), its sparse product and -- with the whole mesh as ONE subdomain -- its factor + solve must agree."""
+    G, meta = _linsys_cases()
+    sc, orc = _oracle_for(meta[k])
+    x, rhs, v = G[f"c{k}_x"], G[f"c{k}_rhs"], G[f"c{k}_v"]
+    orc.refactor(x)
+    Av = orc.spmv(v)
+    assert np.abs(Av - G[f"c{k}_Av"]).max() <= 1e-13 * np.abs(G[f"c{k}_Av"]).max()
+    sol = orc.apply_precond(rhs)
+    assert np.abs(sol - G[f"c{k}_sol"]).max() <= 1e-10 * np.abs(G[f"c{k}_sol"]).max()
+    if f"c{k}_dense" in G:
+        D = G[f"c{k}_dense"]
+        assert np.array_equal(D, D.T)
+        Hs = orc.part_dense(0)
+        assert np.abs(Hs - D).max() <= 1e-14 * np.abs(D).max()
+        fixed = np.repeat(sc.fixed.astype(bool), 3)
+        assert np.array_equal(D[fixed][:, fixed], np.eye(int(fixed.sum())))       # IglUtils.hpp:148-157
+        assert not D[fixed][:, ~fixed].any()
+    orc.close()
+
+
+@pytest.mark.skipif(not O.ref_solver_available(), reason="oracle/_ref/librefsolver.so or the image's MKL not present")
+def test_reference_cholmod_solver_live_against_oracle():
+    """the same comparison with the compiled reference code called live on a fresh random state"""
+    G, meta = _linsys_cases()
+    sc, orc = _oracle_for(dict(workload="synbar:7x3x2:1", energy="SNH"))
+    rng = np.random.default_rng(77)
+    nV = sc.V_rest.shape[0]
+    x = sc.x0 + 0.05 * rng.standard_normal(sc.x0.shape)
+    orc.refactor(x)
+    rhs = rng.standard_normal((nV, 3)) * (1 - sc.fixed[:, None])
+    v = rng.standard_normal((nV, 3))
+    sol, Av, _ = O.ref_linsys(sc.T, sc.fixed, orc.elem_hessians(x), orc.features()[2], rhs, v)
+    assert np.abs(orc.spmv(v).reshape(-1) - Av).max() <= 1e-13 * np.abs(Av).max()
+    assert np.abs(orc.apply_precond(rhs).reshape(-1) - sol).max() <= 1e-10 * np.abs(sol).max()
+    orc.close()
+
+
+# ---- round 2: the reference's Config::loadFromFile (f1 parser) -------------------------------------------------------
+def _cfg_fields(cfg):
+    """dot_amd.scene.Config -> the key/value strings of oracle/ref_config.cpp"""
+    out = dict(energy=cfg.energy, timeStepper=cfg.time_stepper, partitionAmt=str(cfg.partition_amt),
+               blockSize=str(cfg.block_size), size=cfg.size, duration=cfg.duration, dt=cfg.dt, rho=cfg.rho, YM=cfg.YM,
+               PR=cfg.PR, withGravity=str(int(cfg.with_gravity)), inputShapePath=cfg.shape_path,
+               warmStart=str(cfg.warm_start), handleRatio=cfg.handle_ratio, rotDeg=cfg.rot_deg,
+               restart=str(int(cfg.restart)), statusPath=cfg.status_path)
+    if cfg.rot_deg != 0.0:
+        out["rotAxis"] = cfg.rot_axis
+    return out
+
+
+def _same(ours, ref):
+    if isinstance(ours, float):
+        return float(ref) == ours
+    if isinstance(ours, tuple):
+        return tuple(float(t) for t in ref.split()) == ours
+    return ours == ref
+
+
+def test_script_parsers_match_reference_config_on_every_input_script(tmp_path):
+    """Every input/**/*.txt of the reference (62 scripts; `script` line removed, see oracle/ref_config.cpp) parsed by
+    the reference's own Config::loadFromFile (golden) vs dot_amd.scene.parse_script and the C++ parse_script of
+    dot_amd/host/Scene.hpp (through `dot_hip 100 <script> --dump-config`)."""
+    import json
+    import subprocess
+    from dot_amd import scene
+    with open(CONFIG) as f:
+        G = json.load(f)
+    assert len(G) >= 60
+    exe = os.path.join(ROOT, "dot_amd", "dot_hip")
+    nblock = nrot = 0
+    for rel, rec in G.items():
+        p = tmp_path / "s.txt"
+        p.write_text(rec["text"])
+        ref = rec["parsed"]
+        assert ref["rc"] == "0"
+        ours = _cfg_fields(scene.parse_script(str(p)))
+        for key, val in ours.items():
+            assert _same(val, ref[key]), (rel, key, val, ref[key])
+        nblock += ref["blockSize"] != "-1"
+        nrot += "rotAxis" in ref
+        if os.path.exists(exe):
+            txt = subprocess.check_output([exe, "100", str(p), "--dump-config"]).decode()
+            cpp = dict(l.partition(" ")[::2] for l in txt.splitlines())
+            for key in ours:
+                a, b = cpp[key], ref[key]
+                if key in ("size", "duration", "dt", "rho", "YM", "PR", "handleRatio", "rotDeg"):
+                    assert float(a) == float(b), (rel, key, a, b)
+                elif key == "rotAxis":
+                    assert [float(t) for t in a.split()] == [float(t) for t in b.split()], (rel, key)
+                else:
+                    assert a == b, (rel, key, a, b)
+    assert nblock >= 3 and nrot >= 5     # the block-size mode and rotateModel are exercised by the fixture
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_config")),
+                    reason="oracle/_ref/ref_config not built")
+def test_reference_config_live_tokens(tmp_path):
+    """tokens no shipped script uses, parsed live by the reference and by us: tol list, restart, turnOffGravity,
+    partition counts 0 / 1 (-> 4), a negative count with a block size, an unknown energy name (-> SNH); every text
+    names energy and timeStepper because the reference's constructor leaves those two uninitialised"""
+    from dot_amd import scene
+    texts = ["energy SNH\ntimeStepper DOT 1\ntime 3 0.01\nturnOffGravity\ntol 2\n1e-3\n2e-4\n",
+             "energy FCR\ntimeStepper GSDD -7 300\nrestart some/status12\nwarmStart 0\nhandleRatio 0.25\n",
+             "energy NH\ntimeStepper LBFGSH 9\nstiffness 123 0.3\ndensity 7\nsize 2.5\nrotateModel 1 0 0 -30\n"]
+    for t in texts:
+        p = tmp_path / "s.txt"
+        p.write_text(t)
+        ref = O.ref_config_parse(str(p))
+        cfg = scene.parse_script(str(p))
+        for key, val in _cfg_fields(cfg).items():
+            assert _same(val, ref[key]), (t, key, val, ref[key])
+        tol = [float(x) for x in ref["tol"].split()[1:]]
+        assert (cfg.tol or []) == tol
