@@ -418,20 +418,28 @@ int build_device_mesh(dotmi_handle *h)
     DevParts &P = h->P;
     P.nParts = h->p1 - h->p0;
     // ---- nested-dissection layout of the owned subdomains ---------------------------------------
-    int ndLevels = 2, ndMin = 768;
+    int ndLevels = -1, ndMin = 768;
     if (const char *ev = getenv("DOTMI_ND_LEVELS")) ndLevels = std::max(0, atoi(ev));
     if (const char *ev = getenv("DOTMI_ND_MIN")) ndMin = std::max(128, atoi(ev));
     std::vector<std::vector<std::vector<int>>> region;  // [node][owned part] -> vertices of the leaf / separator
     {
         std::vector<std::vector<int>> sets(P.nParts);
         for (int ls = 0; ls < P.nParts; ++ls) sets[ls] = h->partVerts[h->p0 + ls];
+        if (ndLevels < 0) ndLevels = nd_default_levels(sets);
         nd_plan(sets, nV, adj_ptr, adj_idx, h->Xrest.data(), ndLevels, ndMin, h->nd, region);
     }
     P.nmax = h->nd[0].size;
-    if (P.nmax > 4096) {
-        h->err = "a subdomain is too large (padded dense size " + std::to_string(P.nmax) +
-                 " > 4096, about 1300 vertices): use more subdomains";
-        return DOTMI_E_INVALID;
+    {
+        // the dense blocks are the one allocation that grows quadratically: refuse what cannot fit instead of failing
+        // somewhere inside hipMalloc (the reference's sparse CHOLMOD factors have no such limit, CHOLMODSolver.cpp:136-163)
+        size_t freeB = 0, totalB = 0;
+        HIPCHECK(h, hipMemGetInfo(&freeB, &totalB));
+        const double need = 8.0 * P.nParts * (double)P.nmax * P.nmax * 1.25;
+        if (need > 0.9 * (double)freeB) {
+            h->err = "the dense subdomain factors need " + std::to_string((long long)(need / 1e9)) + " GB (" +
+                     std::to_string(P.nParts) + " blocks of " + std::to_string(P.nmax) + "^2), more than the free HBM: use more subdomains";
+            return DOTMI_E_INVALID;
+        }
     }
     // per part: padded position of every local vertex, tiles of the back-solve, structural non-zeros
     h->partPos.assign(P.nParts, {});
@@ -487,7 +495,31 @@ int build_device_mesh(dotmi_handle *h)
     // heavy tiles first: work ~ rows * row length
     auto tile_work = [](const int4 &t) { return (long long)(t.z >> 16) * (t.y + 64 - t.w); };
     std::stable_sort(tiles.begin(), tiles.end(), [&](const int4 &a, const int4 &b) { return tile_work(a) > tile_work(b); });
+    // rows longer than the register tile of the single-pass kernel go through the two-phase kernel, cut into
+    // column chunks of BS_LONG
+    std::vector<int4> ltiles;
+    std::vector<int2> lwork;
+    {
+        std::vector<int4> shortTiles;
+        P.maxTileLen = 0;
+        P.maxChunks = 1;
+        for (const int4 &t : tiles) {
+            const int len = t.y + (t.z >> 16) - t.w;
+            if (len > BS_LONG) {
+                const int nch = (((len + 15) & ~15) + BS_LONG - 1) / BS_LONG;
+                for (int c = 0; c < nch; ++c) lwork.push_back(make_int2((int)ltiles.size(), c));
+                P.maxChunks = std::max(P.maxChunks, nch);
+                ltiles.push_back(t);
+            } else {
+                P.maxTileLen = std::max(P.maxTileLen, len);
+                shortTiles.push_back(t);
+            }
+        }
+        tiles.swap(shortTiles);
+    }
     P.ntiles = (int)tiles.size();
+    P.nltiles = (int)ltiles.size();
+    P.nlwork = (int)lwork.size();
     // merge lists (owned parts only)
     std::vector<int> vp_ptr(nV + 1, 0), vp_off;
     {
@@ -528,6 +560,10 @@ int build_device_mesh(dotmi_handle *h)
     P.npad = (int)pad_dst.size();
     if (int rc = upload(h, &P.dofmap, dofmap)) return rc;
     if (int rc = upload(h, &P.tile, tiles)) return rc;
+    if (int rc = upload(h, &P.ltile, ltiles)) return rc;
+    if (int rc = upload(h, &P.lwork, lwork)) return rc;
+    if (int rc = dalloc(h, &P.tdots, (size_t)std::max(P.nltiles, 1) * P.maxChunks * 64)) return rc;
+    HIPCHECK(h, hipMemset(P.tdots, 0, sizeof(double) * (size_t)std::max(P.nltiles, 1) * P.maxChunks * 64));
     if (int rc = upload(h, &P.trange, trange)) return rc;
     if (int rc = upload(h, &P.vp_ptr, vp_ptr)) return rc;
     if (int rc = upload(h, &P.vp_off, vp_off)) return rc;
@@ -1295,8 +1331,8 @@ int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xr
     }
     std::vector<NdNode> tree;
     std::vector<std::vector<std::vector<int>>> region;
-    *nmax = nd_plan(sets, nV, adj_ptr, adj_idx, Xrest, levels < 0 ? 2 : levels, min_split < 128 ? 768 : min_split, tree,
-                    region);
+    *nmax = nd_plan(sets, nV, adj_ptr, adj_idx, Xrest, levels < 0 ? nd_default_levels(sets) : levels,
+                    min_split < 128 ? 768 : min_split, tree, region);
     *n_nodes = (int32_t)tree.size();
     if (nodes) {
         if ((int)tree.size() > node_cap) return DOTMI_E_INVALID;

@@ -10,6 +10,7 @@ namespace dotmi {
 constexpr int HIST_MAX = 6;     // L-BFGS pairs kept (reference uses 5, DOTTimeStepper.cpp:45)
 constexpr int NB_RED = 256;     // blocks of every reducing kernel (fixed => run-to-run bit-identical sums)
 constexpr int RED_K = 3 * HIST_MAX + 3;  // partial values per block
+constexpr int BS_LONG = 4096;   // longest row (columns) the single-pass back-solve kernel holds in registers
 constexpr int CHOL_NB = 64;     // base block of the recursive inverse-Cholesky (LDS resident)
 
 // ---- mesh + topology resident in HBM ------------------------------------------------------------
@@ -41,6 +42,13 @@ struct DevParts {
     double *Wtmp;           // owned * tmp_stride scratch of the recursion
     int ntiles;             // back-solve jobs, heavy first:
     int4 *tile;             //   (part, first row, tile index within the part | rows << 16, first column)
+    int maxTileLen;         // longest row of a tile in `tile` (<= BS_LONG: longer tiles are in `ltile`)
+    // tiles whose rows exceed BS_LONG columns: two-phase back-solve over column chunks (kernels.hip)
+    int nltiles, nlwork;    // long tiles; (long tile, chunk) work items
+    int4 *ltile;            // same encoding as `tile`
+    int2 *lwork;            // (index into ltile, chunk)
+    int maxChunks;          // chunks of the longest long tile
+    double *tdots;          // nltiles * maxChunks * 64 chunk partials of the row dot products
     int nbmax;              // max row tiles per part
     int2 *trange;           // owned * nbmax: columns [first, end) each tile of a part contributes to
     double *ppart;          // owned * nbmax * nmax partial results of the back-solve tiles

@@ -696,18 +696,140 @@ __global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int2 *__res
     psub[(size_t)s * nmax + k] = acc;
 }
 
+// ---- rows longer than one workgroup's register tile (subdomains beyond ~1300 vertices: `timeStepper DOT 6` on a
+// 17k-vertex mesh gives n_s ~ 9800) -----------------------------------------------------------------------------
+// A long tile (<= 64 rows of one tree region) is cut into column chunks of BSL_CW; the single pass becomes two:
+//   phase 0  tdots[tile][chunk][row] = row[chunk] . r[chunk]                       (streams the tile once)
+//   phase 1  t_row = sum over chunks (fixed order);  ppart[tile][chunk columns] = sum_rows t_row * row[chunk]
+//                                                                                  (streams it a second time)
+// so these rows cost 2x their bytes.  Only the separator rows of the upper tree levels of big subdomains are that
+// long; everything else stays on the single-pass kernel above.
+constexpr int BSL_THREADS = 512, BSL_CH = 4, BSL_CW = 2 * BSL_THREADS * BSL_CH;   // 4096 columns per chunk
+
+template <int PHASE>
+__global__ __launch_bounds__(BSL_THREADS) void backsolve_long_kernel(const int4 *__restrict__ ljob,
+                                                                     const int2 *__restrict__ lwork,
+                                                                     const int *__restrict__ dofmap,
+                                                                     const double *__restrict__ W, int nmax,
+                                                                     const double *__restrict__ q,
+                                                                     double *__restrict__ tdots, int maxChunks,
+                                                                     double *__restrict__ ppart, int nbmax,
+                                                                     const DevLoop *__restrict__ ctl)
+{
+    constexpr int NW = BSL_THREADS / 64;
+    __shared__ double sm[2][NW][8];
+    __shared__ double tsh[BS_ROWS];
+    if (ctl && (ctl->status != 0 || ctl->phase != 0)) return;
+    const int2 wk = lwork[blockIdx.x];          // (long-tile index, chunk)
+    const int4 jb = ljob[wk.x];
+    const int s = jb.x, i0 = jb.y, tileIdx = jb.z & 0xffff, cb = jb.w;
+    const int ns = i0 + (jb.z >> 16);
+    const int ncol = min((ns + 15) & ~15, nmax);
+    const int c0 = cb + wk.y * BSL_CW;           // this workgroup's columns [c0, c0 + BSL_CW) ∩ [cb, ncol)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double *Ws = W + (size_t)s * nmax * nmax;
+    const int *dm = dofmap + (size_t)s * nmax;
+    int cend[BSL_CH];
+    double2 r[BSL_CH], pacc[BSL_CH];
+#pragma unroll
+    for (int m = 0; m < BSL_CH; ++m) {
+        const int c = c0 + 2 * tid + 2 * BSL_THREADS * m;
+        const int d0 = (c < ncol) ? dm[c] : -1, d1 = (c < ncol) ? dm[c + 1] : -1;
+        if (PHASE == 0) {
+            r[m].x = d0 >= 0 ? q[d0] : 0.0;
+            r[m].y = d1 >= 0 ? q[d1] : 0.0;
+        }
+        pacc[m] = make_double2(0.0, 0.0);
+        cend[m] = (d0 >= 0 || d1 >= 0) ? c : 0x7fffffff;
+    }
+    if (PHASE == 1) {
+        // t_row: the chunk partials of phase 0 in chunk order
+        const int nch = (ncol - cb + BSL_CW - 1) / BSL_CW;
+        if (tid < BS_ROWS) {
+            double t = 0.0;
+            for (int c = 0; c < nch; ++c) t += tdots[((size_t)wk.x * maxChunks + c) * BS_ROWS + tid];
+            tsh[tid] = t;
+        }
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int sb = 0; sb < BS_ROWS / 8; ++sb) {
+        const int ib = i0 + sb * 8;
+        if (ib >= ns) break;
+        double2 y[8][BSL_CH];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const double *row = Ws + (size_t)min(ib + rr, ns - 1) * nmax;
+            const int rend = ((ib + rr) < ns) ? min(ncol, (ib + rr + 16) & ~15) : 0;
+#pragma unroll
+            for (int m = 0; m < BSL_CH; ++m) {
+                const int c = c0 + 2 * tid + 2 * BSL_THREADS * m;
+                y[rr][m] = (cend[m] < rend) ? *reinterpret_cast<const double2 *>(row + c) : make_double2(0.0, 0.0);
+            }
+        }
+        if (PHASE == 0) {
+            const int buf = sb & 1;
+            double d[8];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < BSL_CH; ++m) acc += y[rr][m].x * r[m].x + y[rr][m].y * r[m].y;
+                d[rr] = wave_sum(acc);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) sm[buf][wv][rr] = d[rr];
+            }
+            __syncthreads();
+            if (tid < 8) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += sm[buf][w][tid];
+                tdots[((size_t)wk.x * maxChunks + wk.y) * BS_ROWS + 8 * sb + tid] = t;
+            }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const double t = tsh[8 * sb + rr];   // rows past the tile's end were loaded as zeros
+#pragma unroll
+                for (int m = 0; m < BSL_CH; ++m) {
+                    pacc[m].x += t * y[rr][m].x;
+                    pacc[m].y += t * y[rr][m].y;
+                }
+            }
+        }
+    }
+    if (PHASE == 1) {
+        double *out = ppart + ((size_t)s * nbmax + tileIdx) * nmax;
+#pragma unroll
+        for (int m = 0; m < BSL_CH; ++m) {
+            const int c = c0 + 2 * tid + 2 * BSL_THREADS * m;
+            if (c < ncol) *reinterpret_cast<double2 *>(out + c) = pacc[m];
+        }
+    }
+}
+
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1)
 {
-    if (P.ntiles == 0) return;
+    if (P.ntiles == 0 && P.nltiles == 0) return;
     // optional events bracket the streaming kernel alone (the roofline entry of bench.py is about that kernel)
     if (ev0) hipEventRecord(ev0, st);
-    if (P.nmax <= 2560)
-        hipLaunchKernelGGL((backsolve_kernel<256>), dim3(P.ntiles), dim3(256), 0, st, P.tile, P.dofmap, P.W, P.nmax, q,
-                           P.ppart, P.nbmax, ctl);
-    else  // nmax <= 4096, enforced at create time
-        hipLaunchKernelGGL((backsolve_kernel<512>), dim3(P.ntiles), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax, q,
-                           P.ppart, P.nbmax, ctl);
+    if (P.ntiles > 0) {
+        if (P.maxTileLen <= 2560)
+            hipLaunchKernelGGL((backsolve_kernel<256>), dim3(P.ntiles), dim3(256), 0, st, P.tile, P.dofmap, P.W, P.nmax, q,
+                               P.ppart, P.nbmax, ctl);
+        else  // rows of up to 4096 columns; longer ones are in the long-tile list
+            hipLaunchKernelGGL((backsolve_kernel<512>), dim3(P.ntiles), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax, q,
+                               P.ppart, P.nbmax, ctl);
+    }
     if (ev1) hipEventRecord(ev1, st);
+    if (P.nltiles > 0) {
+        hipLaunchKernelGGL((backsolve_long_kernel<0>), dim3(P.nlwork), dim3(BSL_THREADS), 0, st, P.ltile, P.lwork, P.dofmap,
+                           P.W, P.nmax, q, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl);
+        hipLaunchKernelGGL((backsolve_long_kernel<1>), dim3(P.nlwork), dim3(BSL_THREADS), 0, st, P.ltile, P.lwork, P.dofmap,
+                           P.W, P.nmax, q, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl);
+    }
     hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.trange,
                        P.ppart, P.nmax, P.nbmax, P.psub, ctl);
 }

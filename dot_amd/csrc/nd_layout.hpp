@@ -271,6 +271,17 @@ struct NdBuilder {
 };
 
 
+// default depth of the dissection: two levels for the ~2000-dof subdomains of the headline configurations; big
+// subdomains (`timeStepper DOT 6` on a 17k-vertex mesh: ~9800 dofs) go deeper until the leaves are ~1200 dofs
+inline int nd_default_levels(const std::vector<std::vector<int>> &partVerts)
+{
+    int nsmax = 0;
+    for (auto &v : partVerts) nsmax = std::max(nsmax, 3 * (int)v.size());
+    int levels = 2;
+    for (int sz = nsmax; sz > 4800 && levels < 6; sz /= 2) ++levels;
+    return levels;
+}
+
 // layout of the given vertex sets (one per owned subdomain): tree[0] is the root, region[node][part] the
 // vertices of the node's leaf block / separator in layout order; returns the padded size (lda, multiple of 64)
 inline int nd_plan(const std::vector<std::vector<int>> &partVerts, int nV, const std::vector<int> &adj_ptr,

@@ -284,3 +284,47 @@ def test_device_assembly_spmv_and_solve_match_reference_cholmod_solver(k):
         D = G[f"c{k}_dense"]
         assert np.abs(Hs - D).max() <= 1e-13 * np.abs(D).max()
     ts.close()
+
+
+# ---- the reference's shipped scripts use `timeStepper DOT 6`: subdomains of ~3000 vertices ---------------------------
+# iterations per step of the CPU oracle on this configuration (10 steps, ~2.5 s each on 8 threads, recorded from
+# oracle/dot_oracle.c; the first two are re-run live below).  BASELINE.md section 2 lists 9 10 12 14 14 15 15 16 15 16
+# for the reference's own run of the script as shipped: +-1 on four steps.  The 32-part / SNH and bunny5K 8-part lists
+# of the same table are reproduced exactly, so the difference is most likely the 6-way partition of that run (not
+# recorded), not the solver.
+BAR6_ITERS = [8, 10, 12, 14, 14, 14, 15, 15, 16, 15]
+BAR6_PUBLISHED = [9, 10, 12, 14, 14, 15, 15, 16, 15, 16]
+
+
+def test_bar17K_as_shipped_fcr_6_subdomains():
+    """input/bar17K_twist_DOT.txt:2 `timeStepper DOT 6` with the reference's METIS partition (fixture bar17K_6): the
+    largest subdomain has 3271 vertices (n_s = 9813), beyond the 4096-column register tile of the single-pass
+    back-solve -- its separator rows go through the two-phase long-row kernel and the dissection tree is 4 deep.
+    The device path takes the oracle's iterations on all ten steps (within one of the reference's published run) and
+    agrees with the oracle run live on the first two (its envelope Cholesky needs seconds per step at this size)."""
+    sc, ep, n = load_workload("bar17K_twist", 6)
+    sc.cfg.energy = "FCR"
+    cfg = sc.cfg
+    assert n == 6 and max(np.unique(sc.T[ep == p]).size for p in range(6)) == 3271
+    ts = DOTTimeStepper(sc, ep, n)
+    orc = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, n,
+                      cfg.with_gravity)
+    r = np.random.default_rng(5).standard_normal((sc.V_rest.shape[0], 3)) * (1 - sc.fixed[:, None])
+    po = orc.apply_precond(r)
+    assert np.abs(ts.applyPrecond(r) - po).max() <= 1e-9 * np.abs(po).max()
+    iters = []
+    for k in range(10):
+        x = ts.getResult()
+        idx, pos = sc.scripter.step(x, cfg.dt)
+        ts.setDirichlet(idx, pos)
+        st = ts.step()
+        assert st.status == 0 and st.g2 <= ts.targetGRes
+        iters.append(st.iters)
+        if k < 2:
+            orc.move(idx, pos)
+            so = orc.step()
+            assert (st.iters, st.ls_halvings) == (so.iters, so.ls_halvings)
+            assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
+    assert iters == BAR6_ITERS, iters
+    assert all(abs(a - b) <= 1 for a, b in zip(iters, BAR6_PUBLISHED))
+    ts.close(); orc.close()
