@@ -515,6 +515,7 @@ void launch_multidot(int n, const double *v, const double *const *vecs, int m, d
 // of a subdomain are summed in fixed order by reduce_partial_p_kernel (no atomics, deterministic).
 // ------------------------------------------------------------------------------------------------
 constexpr int BS_ROWS = 64;   // memory rows per workgroup
+typedef double nt_double2 __attribute__((ext_vector_type(2)));
 
 // One tile with rows of at most 2*THREADS*MAXCH columns, SUB rows in registers at a time.  Short rows
 // (the leaves of the dissection) take many rows per pass, long rows few, so that every pass has about
@@ -560,7 +561,14 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
 #pragma unroll
             for (int m = 0; m < MAXCH; ++m) {
                 const int c = cb + 2 * tid + 2 * THREADS * m;
-                y[rr][m] = (cend[m] < rend) ? *reinterpret_cast<const double2 *>(row + c) : make_double2(0.0, 0.0);
+                if (cend[m] < rend) {
+                    // streamed once per launch by exactly one workgroup: non-temporal, so the 229 MB of factors do not
+                    // push the small hot arrays of the other loop kernels out of the 256 MB Infinity Cache
+                    const nt_double2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_double2 *>(row + c));
+                    y[rr][m] = make_double2(v.x, v.y);
+                } else {
+                    y[rr][m] = make_double2(0.0, 0.0);
+                }
             }
         }
         const int buf = sb & 1;
