@@ -27,6 +27,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DEFAULT_WORKLOAD = "bar17K_twist"  # BASELINE.json configs[1]
+# also reported (short runs) in the `workloads` array of the JSON line: BASELINE.json configs[0] (north_star names it next to
+# bar17K_twist) and configs[4], the 1 M-tet bar whose 3.4 GB of factors cannot sit in the 256 MB Infinity Cache
+EXTRA_WORKLOADS = "bunny5K_LTSS,synbar:140x35x35:256"
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
@@ -36,6 +39,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD)
+    ap.add_argument("--extra-workloads", default=EXTRA_WORKLOADS,
+                    help="comma list of further workloads reported in the `workloads` array (N=1 only), or `none`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -67,70 +72,111 @@ def main():
         dist.broadcast(buf, 0)
         comm_id = bytes(buf.cpu().numpy().tobytes())
 
-    sc, ep, nparts = load_workload(args.workload)
-    cfg = sc.cfg
-    ts = DOTTimeStepper(sc, ep, nparts, device=local_rank, rank=rank, world=world, comm_id=comm_id,
-                        flags=dl.FLAG_TIME_BACKSOLVE)
-
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # scripted (Dirichlet) vertices are never moved by the solver: the scripter keeps their positions itself, as the
-    # reference's host mesh does, instead of reading all positions back every step
-    cached = cfg.script != "rubberBandPull"
-    if cached:
-        sc.scripter.track(sc.x0)
+    def pmc_traffic(workload):
+        """HBM bytes of one back-solve launch from the PMC counters (FETCH_SIZE / WRITE_SIZE need their own rocprofv3
+        passes, so they are collected separately on the same kernel + workload by tools/pmc_backsolve.sh and committed
+        under profiles/): -> (bytes, file) or (None, None)"""
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_backsolve_pmc*.json")), reverse=True):
+            with open(f) as fh:
+                rec = json.load(fh)
+            if rec.get("workload") == workload:
+                return rec["hbm_bytes_per_backsolve"], os.path.relpath(f, ROOT)
+        return None, None
 
-    def one_step():
-        x = None if cached else ts.getResult()
-        idx, pos = sc.scripter.step(x, cfg.dt)
-        if idx.size:
-            ts.setDirichlet(idx, pos)
-        return ts.step()
+    def run_workload(name, steps, warmup):
+        """-> (record, per-step stats, scene, timestepper is closed)"""
+        sc, ep, nparts = load_workload(name)
+        cfg = sc.cfg
+        ts = DOTTimeStepper(sc, ep, nparts, device=local_rank, rank=rank, world=world, comm_id=comm_id,
+                            flags=dl.FLAG_TIME_BACKSOLVE)
+        # scripted (Dirichlet) vertices are never moved by the solver: the scripter keeps their positions itself, as
+        # the reference's host mesh does, instead of reading all positions back every step
+        cached = cfg.script != "rubberBandPull"
+        if cached:
+            sc.scripter.track(sc.x0)
 
-    for _ in range(args.warmup):
-        one_step()
-    sync()
-    t0 = time.perf_counter()
-    stats = [one_step() for _ in range(args.steps)]
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def one_step():
+            x = None if cached else ts.getResult()
+            idx, pos = sc.scripter.step(x, cfg.dt)
+            if idx.size:
+                ts.setDirichlet(idx, pos)
+            return ts.step()
 
-    ms_per_step = 1e3 * elapsed / args.steps
-    iters = [s.iters for s in stats]
-    # ---- roofline of the dominant hand-written kernel, measured inside the timed region ------------------
-    pre_ms = sum(s.ms_precond for s in stats)
-    pre_n = sum(s.precond_launches for s in stats)
-    bytes_per_launch = stats[0].precond_bytes            # 8 x structural non-zeros of the inverse factors of THIS rank's parts
-    avg_ms = pre_ms / max(pre_n, 1)
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if pre_n else 0.0
-    # HBM traffic of one back-solve from the PMC counters (FETCH_SIZE / WRITE_SIZE need their own rocprofv3
-    # passes, so they are collected separately on the same kernel + workload and committed under profiles/)
-    traffic = None
-    import glob
-    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_backsolve_pmc.json")))
-    pmc = pmcs[-1] if pmcs else ""
-    if world == 1 and pmc:
-        with open(pmc) as f:
-            rec = json.load(f)
-        if rec.get("workload") == args.workload:
-            traffic = rec["hbm_bytes_per_backsolve"]
-    roofline = {
-        "bound": "hbm", "kernel": "backsolve_kernel: subdomain back-solve p_s = X_s^T (X_s r_s), nested-dissection block-sparse inverse factors",
-        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5),
-        # every 8th back-solve of the timed region is bracketed with HIP events (an event record costs ~6 us
-        # of stream time, so bracketing all of them would inflate the metric by ~3%)
-        "launches_timed": int(pre_n), "launches_total": int(sum(iters)),
-        "share_of_step_time": round(avg_ms * sum(iters) / (1e3 * elapsed), 3),
-    }
+        for _ in range(warmup):
+            one_step()
+        sync()
+        t0 = time.perf_counter()
+        stats, walls = [], []
+        for _ in range(steps):
+            c0 = time.perf_counter()
+            stats.append(one_step())            # dotmi_step returns after the stream has drained
+            walls.append(time.perf_counter() - c0)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        iters = [s.iters for s in stats]
+        # ---- roofline of the dominant hand-written kernel, measured inside the timed region -----------------
+        pre_ms = sum(s.ms_precond for s in stats)
+        pre_n = sum(s.precond_launches for s in stats)
+        bytes_per_launch = stats[0].precond_bytes   # 8 x structural non-zeros of the inverse factors of THIS rank's parts
+        avg_ms = pre_ms / max(pre_n, 1)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if pre_n else 0.0
+        # SURVEY.md section 8(d) prices the back-solve as a dense two-pass triangular solve: sum_s n_s^2 * 8 bytes
+        L = dl.load()
+        ns = [L.dotmi_part_size(ts._h, p) for p in range(nparts)]
+        dense_bytes = int(sum(8 * n * n + 16 * n for n in ns))
+        traffic, traffic_src = pmc_traffic(name) if world == 1 else (None, None)
+        roofline = {
+            "bound": "hbm", "kernel": "backsolve_kernel: subdomain back-solve p_s = X_s^T (X_s r_s), nested-dissection "
+            "block-sparse inverse factors, one streaming pass",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5),
+            "bytes_definition": "8 x structural non-zeros of the block-sparse X_s this launch streams (each once)",
+            # the same launch priced with SURVEY 8(d)'s dense formula (what a dense forward + backward substitution
+            # would have to read): > 1 means the dissection layout + single pass read that many times fewer bytes
+            "dense_8d_bytes_per_launch": dense_bytes,
+            "frac_if_priced_as_dense_8d": round(dense_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pre_n else 0.0,
+            # every 8th back-solve of the timed region is bracketed with HIP events (an event record costs ~6 us
+            # of stream time, so bracketing all of them would inflate the metric by ~3%)
+            "launches_timed": int(pre_n), "launches_total": int(sum(iters)),
+            "share_of_step_time": round(avg_ms * sum(iters) / (1e3 * elapsed), 3),
+        }
+        w = np.array(walls) * 1e3
+        rec = {
+            "workload": name, "nV": int(sc.V_rest.shape[0]), "nT": int(sc.T.shape[0]), "energy": cfg.energy,
+            "subdomains": int(nparts), "dt": cfg.dt, "script": cfg.script, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * elapsed / steps, 3), "ms_per_step_p50": round(float(np.percentile(w, 50)), 3),
+            "ms_per_step_p95": round(float(np.percentile(w, 95)), 3),
+            "iters_per_frame": round(float(np.mean(iters)), 2), "iters": iters,
+            "halvings_per_frame": round(float(np.mean([s.ls_halvings for s in stats])), 2),
+            "step_breakdown_ms": {
+                "lbfgs_loop": round(float(np.mean([s.ms_loop for s in stats])), 3),
+                "hessian_assembly": round(float(np.mean([s.ms_hessian for s in stats])), 3),
+                "subdomain_factor": round(float(np.mean([s.ms_factor for s in stats])), 3),
+                "back_solve_kernels": round(avg_ms * float(np.mean(iters)), 3),
+            },
+            "roofline": roofline,
+        }
+        target = ts.targetGRes
+        ts.close()
+        return rec, stats, sc, nparts, target, elapsed
+
+    rec, stats, sc, nparts, target_gres, elapsed = run_workload(args.workload, args.steps, args.warmup)
+    cfg = sc.cfg
+    ms_per_step = rec["ms_per_step"]
+    iters = rec["iters"]
+    roofline = rec["roofline"]
+    avg_ms = roofline["avg_launch_ms"]
 
     # ---- second roofline: the once-per-step factorisation against the dense FP64 matrix-core peak ----------------
     FP64_MFMA_PEAK = 78.6   # TFLOP/s, MI355X FP64 matrix = vector peak (256 CUs x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
@@ -148,27 +194,32 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "ms_per_time_step", "value": round(ms_per_step, 3), "unit": "ms", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "metric": "ms_per_time_step", "value": ms_per_step, "unit": "ms", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "mesh fixture tests/golden/meshes (reference input mesh), scripted handles",
             "config": {
-                "workload": args.workload, "nV": int(sc.V_rest.shape[0]), "nT": int(sc.T.shape[0]),
+                "workload": args.workload, "nV": rec["nV"], "nT": rec["nT"],
                 "energy": cfg.energy, "subdomains": int(nparts), "dt": cfg.dt, "script": cfg.script,
-                "rel_tol": 1e-5, "target_gres": ts.targetGRes,
+                "rel_tol": 1e-5, "target_gres": target_gres,
                 "parallelism": f"{nparts} subdomains sharded over {world} GPU(s), RCCL all-reduce" if world > 1
                                else f"{nparts} subdomains on 1 GPU",
             },
-            "iters_per_frame": round(float(np.mean(iters)), 2), "iters": iters,
-            "step_breakdown_ms": {
-                "lbfgs_loop": round(float(np.mean([s.ms_loop for s in stats])), 3),
-                "hessian_assembly": round(float(np.mean([s.ms_hessian for s in stats])), 3),
-                "subdomain_factor": round(float(np.mean([s.ms_factor for s in stats])), 3),
-                "back_solve_kernels": round(avg_ms * float(np.mean(iters)), 3),
-            },
+            "ms_per_step_p50": rec["ms_per_step_p50"], "ms_per_step_p95": rec["ms_per_step_p95"],
+            "iters_per_frame": rec["iters_per_frame"], "iters": iters,
+            "step_breakdown_ms": rec["step_breakdown_ms"],
             "roofline": roofline,
             "roofline_factor": roofline_factor,
         }
+        # ---- the other single-GPU configurations BASELINE.json / north_star name, short runs ------------------
+        if world == 1 and args.extra_workloads and args.extra_workloads != "none":
+            out["workloads"] = [rec]
+            for name in args.extra_workloads.split(","):
+                if name == args.workload:
+                    continue
+                big = name.startswith("synbar")
+                r2 = run_workload(name, 6 if big else 12, 2)[0]
+                out["workloads"].append(r2)
         # ---- CPU baseline on this box's host cores: bounded sample of the same workload ---------------
         if not args.no_cpu_baseline and world == 1:
             from tests import oracle_py as O
@@ -197,7 +248,6 @@ def main():
                           f"oracle/dot_oracle.c with OpenMP, iters/step {cits}",
             }
         print(json.dumps(out), flush=True)
-    ts.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
