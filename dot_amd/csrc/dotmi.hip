@@ -145,7 +145,14 @@ struct dotmi_handle {
     std::vector<double> log_alpha, log_E, log_g2;
     long long numLineSearch = 0;
     int energy_evals = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, evA = nullptr;
+    // DOTMI_FLAG_TIME_PHASES: boundaries of the phases of one line-search trial (host loop: every trial ends in a
+    // stream synchronisation, after which the brackets recorded since the last one are read and the events reused)
+    bool timePhases = false;
+    hipEvent_t evP[8] = {nullptr};
+    int evPn = 0;              // boundaries recorded since the last synchronisation
+    int evPslot[8] = {0};      // ms_phase slot of the interval that ENDS at boundary k (k >= 1)
+    double phaseMs[DOTMI_T_COUNT] = {0};
     // the subdomain factorisation runs as `groups` independent batches on their own streams so that the
     // latency-bound base blocks / small GEMMs of one batch overlap the large GEMMs of another
     struct FactorGroup {
@@ -1009,6 +1016,7 @@ int refactor_issue(dotmi_handle *h, const double *x)
     HIPCHECK(h, hipEventRecord(h->ev0, h->st));
     launch_elem_hessians(h->M, h->mat, h->dtSq, x, h->He, h->st);
     launch_assemble(h->M, h->He, h->Hval, h->st);
+    HIPCHECK(h, hipEventRecord(h->evA, h->st));
     // only the blocks the factorisation leaves non-zero are cleared before the refill: the leaf squares and
     // the separator panels; the (A,C) blocks and the cleared mirror panels stay zero for the handle's life
     if (h->wDirty) {
@@ -1039,11 +1047,15 @@ int refactor_finish(dotmi_handle *h, double *ms_hess, double *ms_fact)
             return DOTMI_E_NOTSPD;
         }
     h->poisoned = false;
-    float a = 0, b = 0;
+    float a = 0, b = 0, c = 0;
     hipEventElapsedTime(&a, h->ev0, h->ev1);
     hipEventElapsedTime(&b, h->ev1, h->ev2);
+    hipEventElapsedTime(&c, h->ev0, h->evA);
     if (ms_hess) *ms_hess += a;
     if (ms_fact) *ms_fact += b;
+    h->phaseMs[DOTMI_T_MATRIX_COMPUTATION] += c;       // element Hessians + global assembly
+    h->phaseMs[DOTMI_T_MATRIX_ASSEMBLY] += a - c;      // clear + dense sub-matrix fill
+    h->phaseMs[DOTMI_T_NUMERICAL_FACTORIZATION] += b;
     HIPCHECK(h, hipGetLastError());
     return 0;
 }
@@ -1055,6 +1067,26 @@ int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
     if (int rc = refactor_issue(h, x)) return rc;
     HIPCHECK(h, hipStreamSynchronize(h->st));
     return refactor_finish(h, ms_hess, ms_fact);
+}
+
+// DOTMI_FLAG_TIME_PHASES: a phase boundary on the stream; the interval that ends here is booked under `slot`
+// (slot < 0: the boundary only starts an interval)
+inline void phase_mark(dotmi_handle *h, int slot)
+{
+    if (!h->timePhases || h->evPn >= 8) return;
+    hipEventRecord(h->evP[h->evPn], h->st);
+    h->evPslot[h->evPn] = slot;
+    h->evPn++;
+}
+// after a stream synchronisation: read the recorded brackets
+inline void phase_collect(dotmi_handle *h)
+{
+    for (int k = 1; k < h->evPn; ++k) {
+        float ms = 0;
+        if (h->evPslot[k] >= 0 && hipEventElapsedTime(&ms, h->evP[k - 1], h->evP[k]) == hipSuccess)
+            h->phaseMs[h->evPslot[k]] += ms;
+    }
+    h->evPn = 0;
 }
 
 // p = D^-1 sum_s R_s^T W_s R_s q   (DOTTimeStepper.cpp:406-450); leaves y_i.z partials in partC
@@ -1079,7 +1111,7 @@ int apply_precond(dotmi_handle *h, const double *q, double *z, const LbfgsArgs &
 
 // energy + element gradients + vertex gather (+ pair) at `xeval`; results: *E, stats in h_partR
 int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, const LbfgsArgs &L, int slot,
-          double *E)
+          double *E, int evalSlot = DOTMI_T_LINESEARCH_EVAL, int gradSlot = DOTMI_T_UPDATE_HISTORY)
 {
     int nb = 0;
     // single-GPU: the reduction partials go straight to pinned host memory (zero-copy), so one stream
@@ -1089,6 +1121,7 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
     launch_elem_energy_grad(h->M, h->mat, h->dtSq, xeval, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, h->gcont,
                             partE, &nb, h->st);
     h->nbE = nb;
+    phase_mark(h, evalSlot);
     GatherArgs a;
     a.gcont = h->gcont;
     a.x = xeval;
@@ -1121,7 +1154,9 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
         HIPCHECK(h, hipMemcpyAsync(h->h_partR, h->partR, sizeof(double) * NB_RED * RED_K, hipMemcpyDeviceToHost,
                                    h->st));
     }
+    phase_mark(h, gradSlot);
     HIPCHECK(h, hipStreamSynchronize(h->st));
+    phase_collect(h);
     if (!h->shardElems) {
         const double se = chunked_sum(nb, [&](int b) { return h->h_partE[2 * b]; });
         const double si = chunked_sum(nb, [&](int b) { return h->h_partE[2 * b + 1]; });
@@ -1386,6 +1421,9 @@ void dotmi_destroy(dotmi_handle *h)
     if (h->ev0) hipEventDestroy(h->ev0);
     if (h->ev1) hipEventDestroy(h->ev1);
     if (h->ev2) hipEventDestroy(h->ev2);
+    if (h->evA) hipEventDestroy(h->evA);
+    for (hipEvent_t e : h->evP)
+        if (e) hipEventDestroy(e);
     for (hipEvent_t e : h->evPre) hipEventDestroy(e);
     if (h->factorGraph) hipGraphExecDestroy(h->factorGraph);
     for (auto &G : h->groups) {
@@ -1465,6 +1503,10 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     HIPCHECK(h, hipEventCreate(&h->ev0));
     HIPCHECK(h, hipEventCreate(&h->ev1));
     HIPCHECK(h, hipEventCreate(&h->ev2));
+    HIPCHECK(h, hipEventCreate(&h->evA));
+    h->timePhases = (h->flags & DOTMI_FLAG_TIME_PHASES) != 0;
+    if (h->timePhases)
+        for (auto &e : h->evP) HIPCHECK(h, hipEventCreate(&e));
     RBCHECK(h, rocblas_create_handle(&h->blas));
     RBCHECK(h, rocblas_set_stream(h->blas, h->st));
     h->dist = h->world > 1 || (h->flags & DOTMI_FLAG_FORCE_DIST);
@@ -1556,7 +1598,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     HIPCHECK(h, hipHostMalloc((void **)&h->h_alpha, sizeof(double) * 8));
     {
         const char *ev = getenv("DOTMI_DEVICE_LOOP");
-        h->devLoop = !h->dist && !(h->flags & DOTMI_FLAG_HOST_LOOP) && !(ev && atoi(ev) == 0);
+        h->devLoop = !h->dist && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) && !(ev && atoi(ev) == 0);
         h->logCap = std::min(h->iterCap, 10001) + 1;
         h->kindCap = 4096;
         HIPCHECK(h, hipHostMalloc((void **)&h->h_ctl, sizeof(DevLoop)));
@@ -1716,12 +1758,16 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     const long long ls0 = h->numLineSearch;
     double ms_hess = 0, ms_fact = 0;
 
+    for (double &v : h->phaseMs) v = 0.0;
+    h->evPn = 0;
+    phase_mark(h, -1);
     // initX(2): x += dt v + dt^2 g on free vertices (Optimizer.cpp:442-582)
     launch_init_x(h->nV, h->M.fixed, h->v, h->dt, h->gdtsq, h->x, h->st);
     LbfgsArgs L = lbfgs_args(h);
     double lastE = 0, R[RED_K], g2 = 0, E0 = 0, g20 = 0;
     if (!h->devLoop) {
-        if (int rc = trial(h, h->x, h->g, 0, L, 0, &lastE)) return rc;
+        if (int rc = trial(h, h->x, h->g, 0, L, 0, &lastE, DOTMI_T_FULLYIMPLICIT_ECOMP, DOTMI_T_FULLYIMPLICIT_ECOMP))
+            return rc;
         sum_stats(h, 1, R);
         g2 = R[0];
         E0 = lastE;
@@ -1745,10 +1791,14 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
             xi[i] = sq / h->ys[i];
         }
         L = lbfgs_args(h);
+        phase_mark(h, -1);
         launch_build_q(n, h->g, L, xi, h->q, h->st);
+        phase_mark(h, DOTMI_T_MODIFY_GRAD);
         // ---- subdomain back-solve, merge, second half ------------------------------------------------
         if (int rc = apply_precond(h, h->q, h->z, L)) return rc;
+        phase_mark(h, DOTMI_T_BACKSOLVE);
         launch_build_p(n, h->z, L, h->partC, xi, h->p, h->st);
+        phase_mark(h, DOTMI_T_MODIFY_SEARCHDIR);
         // ---- alpha_0 and the first trial ---------------------------------------------------------------
         launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st);
         const double *spart = h->partS;
@@ -1759,6 +1809,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
             spart = h->partG;  // rows >= 1 stay zero
         }
         launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, h->h_alpha, h->st);
+        phase_mark(h, DOTMI_T_LINESEARCH_OTHER);
         const int slot = free_slot(h);
         double E = 0;
         if (int rc = trial(h, h->x_trial, h->g_trial, 1, L, slot, &E)) return rc;
@@ -1771,7 +1822,9 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
                 failed = true;
                 break;
             }
+            phase_mark(h, -1);
             launch_step_forward(n, h->x, h->p, h->x_trial, nullptr, alpha, 0, h->alphaMin, h->alpha_dev, h->h_alpha, h->st);
+            phase_mark(h, DOTMI_T_LINESEARCH_OTHER);
             if (int rc = trial(h, h->x_trial, h->g_trial, 1, L, slot, &E)) return rc;
         }
         if (failed) {
@@ -1827,8 +1880,11 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         if (int rc = refactor_issue(h, h->x)) return rc;
     }
     // BE update (Optimizer.cpp:354-361)
+    phase_mark(h, -1);
     launch_be_update(h->nV, h->M.fixed, h->x, h->xn, h->v, h->xt, h->dt, h->gdtsq, h->st);
+    phase_mark(h, DOTMI_T_SOLVE_EXTRACOMP);
     HIPCHECK(h, hipStreamSynchronize(h->st));
+    phase_collect(h);
     HIPCHECK(h, hipGetLastError());
     int rcFactor = 0;
     if (!failed) rcFactor = refactor_finish(h, &ms_hess, &ms_fact);
@@ -1860,6 +1916,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         }
         st->precond_bytes = h->precond_bytes;
         st->factor_flops = h->factorFlops;
+        for (int k = 0; k < DOTMI_T_COUNT; ++k) st->ms_phase[k] = h->phaseMs[k];
     }
     // a non-SPD subdomain: the step itself is complete (x, v advanced as the reference would have before it
     // exit(-1)s in the factorisation, Optimizer.cpp:301-313), the handle is poisoned until a refactor succeeds

@@ -43,6 +43,7 @@ struct Options {  // the Config fields the DOT stepper reads (src/Config.hpp)
     const int32_t *epart = nullptr;  // METIS::partMesh result (nT)
     int device = 0, rank = 0, world = 1;
     const void *commId = nullptr;
+    int flags = 0;  // DOTMI_FLAG_* (e.g. DOTMI_FLAG_TIME_PHASES to fill the reference's timer_step slots)
 };
 
 class DotHipTimeStepper {
@@ -101,6 +102,7 @@ public:
         p.rank = opt_.rank;
         p.world = opt_.world;
         p.comm_id = opt_.commId;
+        p.flags = opt_.flags;
         if (int rc = dotmi_create(&m, &p, x0_.data(), &h_))
             throw std::runtime_error(std::string("dotmi_create: ") + dotmi_last_error(nullptr) + " (" +
                                      std::to_string(rc) + ")");

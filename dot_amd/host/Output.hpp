@@ -1,0 +1,74 @@
+// Output.hpp -- the on-disk formats of the reference's headless run that carry numbers from the hot path:
+//   info.txt   saveInfoForPresent (main.cpp:338-358): two header lines, then Timer::print (Utils/Timer.hpp:58-68) of
+//              `timer` (1 activity), `timer_step` (14 activities, names main.cpp:867-880) and `timer_temp3` (7
+//              activities, :882-888), then "<distortion> 0"
+//   <n>.obj    igl::writeOBJ(V_surf, F_surf) from Optimizer::saveStatus (Optimizer.cpp:1137-1150): surface vertices
+//              re-indexed, Eigen FullPrecision (15 significant digits), faces 1-based
+// The timer_step slots are filled from dotmi_step_stats.ms_phase (HIP events on the library's stream).
+#pragma once
+#include <array>
+#include <fstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace dot_amd {
+
+static const char *const TIMER_STEP_NAMES[14] = {
+    "matrixComputation", "matrixAssembly", "symbolicFactorization", "numericalFactorization", "backSolve",
+    "lineSearch_other", "modifyGrad", "modifySearchDir", "updateHistory", "lineSearch_eVal", "fullyImplicit_eComp",
+    "solve_extraComp", "compGrad", "CCD"};
+static const char *const TIMER_TEMP3_NAMES[7] = {"init", "initPrimal", "initDual", "initWeights", "initCons", "subdSolve",
+                                                 "consSolve"};
+
+struct RunTimers {
+    double descent = 0;     // seconds inside the stepper's solve (timer activity 0)
+    double step[14] = {0};  // seconds per timer_step activity
+    double temp3[7] = {0};  // ADMM-only activities: always 0 for DOT
+};
+
+// Timer::print (Utils/Timer.hpp:58-68)
+inline void print_timer(std::ostream &os, int n, const double *timings, const char *const *names)
+{
+    double sum = 0.0;
+    os << n << " activities:\n";
+    for (int i = 0; i < n; ++i) {
+        os.width(10);
+        os << std::right << timings[i] << " s: " << names[i] << "\n";
+        sum += timings[i];
+    }
+    os.width(10);
+    os << std::right << sum << " s: Total\n";
+}
+
+inline void write_info_txt(const std::string &path, int vertAmtInput, int nT, int iterNum, int innerIterAmt,
+                           const RunTimers &t)
+{
+    std::ofstream file(path);
+    if (!file) throw std::runtime_error("cannot write " + path);
+    file << vertAmtInput << " " << nT << std::endl;
+    // energyParams[0] = 1.0 for the DOT run (main.cpp:891), so the last field is 0
+    file << iterNum << " " << innerIterAmt << " 0 0 " << 1.0 - 1.0 << std::endl;
+    static const char *const descentName[1] = {"descent"};
+    print_timer(file, 1, &t.descent, descentName);
+    print_timer(file, 14, t.step, TIMER_STEP_NAMES);
+    print_timer(file, 7, t.temp3, TIMER_TEMP3_NAMES);
+    file << 0.0 << " " << 0.0 << std::endl;
+}
+
+// igl::writeOBJ(str, V, F) (libigl writeOBJ.cpp:100-120): IOFormat(FullPrecision, DontAlignCols, " ", "\n", "v ", "",
+// "", "\n") for V and the same with "f " for F + 1
+inline void write_surface_obj(const std::string &path, const std::vector<double> &x, const std::vector<int> &surfIndToTet,
+                              const std::vector<std::array<int, 3>> &F_surf)
+{
+    std::ofstream s(path);
+    if (!s) throw std::runtime_error("cannot write " + path);
+    s.precision(15);   // Eigen::FullPrecision for double
+    for (size_t i = 0; i < surfIndToTet.size(); ++i) {
+        const double *p = &x[3 * (size_t)surfIndToTet[i]];
+        s << "v " << p[0] << " " << p[1] << " " << p[2] << "\n";
+    }
+    for (auto &f : F_surf) s << "f " << f[0] + 1 << " " << f[1] + 1 << " " << f[2] + 1 << "\n";
+}
+
+}  // namespace dot_amd

@@ -93,6 +93,7 @@ inline Config parse_script(const std::string &path)
 struct TetMesh {
     std::vector<double> V;   // nV*3
     std::vector<int32_t> T;  // nT*4
+    std::vector<int32_t> SF; // nSF*3: the `$Surface` section of the .msh when the file has one (IglUtils.cpp:722-736)
     int nV() const { return (int)V.size() / 3; }
     int nT() const { return (int)T.size() / 4; }
 };
@@ -125,6 +126,19 @@ inline TetMesh read_tet_msh(const std::string &path)
         m.T[4 * e] = a - 1; m.T[4 * e + 1] = b - 1; m.T[4 * e + 2] = c - 1; m.T[4 * e + 3] = d - 1;
     }
     if (!in) throw std::runtime_error("malformed mesh " + path);
+    // optional `$Surface` section: "<count>" then "a b c" rows, 1-based (IglUtils.cpp:722-736)
+    while (std::getline(in, line))
+        if (line.rfind("$Surface", 0) == 0) {
+            int nS = 0;
+            in >> nS;
+            m.SF.resize(3 * (size_t)nS);
+            for (int i = 0; i < 3 * nS; ++i) {
+                in >> m.SF[i];
+                m.SF[i] -= 1;
+            }
+            if (!in) throw std::runtime_error("malformed $Surface section in " + path);
+            break;
+        }
     return m;
 }
 
@@ -198,31 +212,59 @@ inline void read_status(const std::string &path, int nV, int &timestep, std::vec
     if (x.empty() || v.empty() || !in.eof()) throw std::runtime_error("malformed status file " + path);
 }
 
-// boundary faces = faces that belong to exactly one tet, outward orientation
+// The surface triangles SF the reference works with: the mesh file's `$Surface` section when it has one, else
+// IglUtils::findSurfaceTris (IglUtils.cpp:558-590): the four faces of every tet, outward oriented, in a map keyed
+// by the ORIENTED triple (lexicographic, Triplet.h:29-45); a face is on the surface when none of the three
+// rotations of its reversal is present; output in map order.  tri2tet = IglUtils::buildSTri2Tet (:591-625).
 inline std::vector<std::array<int, 3>> find_surface_tris(const TetMesh &m, std::vector<int> *tri2tet = nullptr)
 {
     static const int FACE[4][3] = {{0, 2, 1}, {0, 3, 2}, {0, 1, 3}, {1, 2, 3}};
-    struct Hit {
-        int count, tet;
-        std::array<int, 3> tri;
-    };
-    std::map<std::array<int, 3>, Hit> seen;
+    std::map<std::array<int, 3>, int> tri;
     for (int e = 0; e < m.nT(); ++e)
-        for (auto &f : FACE) {
-            std::array<int, 3> t = {m.T[4 * e + f[0]], m.T[4 * e + f[1]], m.T[4 * e + f[2]]}, key = t;
-            std::sort(key.begin(), key.end());
-            auto it = seen.find(key);
-            if (it == seen.end()) seen[key] = Hit{1, e, t};
-            else it->second.count++;
-        }
+        for (auto &f : FACE) tri[{m.T[4 * e + f[0]], m.T[4 * e + f[1]], m.T[4 * e + f[2]]}] = e;
     std::vector<std::array<int, 3>> out;
-    if (tri2tet) tri2tet->clear();
-    for (auto &kv : seen)
-        if (kv.second.count == 1) {
-            out.push_back(kv.second.tri);
-            if (tri2tet) tri2tet->push_back(kv.second.tet);
+    if (!m.SF.empty()) {
+        for (size_t i = 0; i < m.SF.size() / 3; ++i) out.push_back({m.SF[3 * i], m.SF[3 * i + 1], m.SF[3 * i + 2]});
+    } else {
+        for (auto &kv : tri) {
+            const auto &t = kv.first;
+            if (tri.count({t[2], t[1], t[0]}) || tri.count({t[1], t[0], t[2]}) || tri.count({t[0], t[2], t[1]})) continue;
+            out.push_back(t);
         }
+    }
+    if (tri2tet) {
+        tri2tet->clear();
+        for (auto &t : out) {
+            auto it = tri.find(t);
+            if (it == tri.end()) it = tri.find({t[1], t[2], t[0]});
+            if (it == tri.end()) it = tri.find({t[2], t[0], t[1]});
+            tri2tet->push_back(it == tri.end() ? -1 : it->second);
+        }
+    }
     return out;
+}
+
+// surface vertices re-indexed in ascending tet-vertex order and the surface triangles in that numbering: the
+// V_surf / F_surf of main.cpp:800-830 that Optimizer::saveStatus writes as <n>.obj (Optimizer.cpp:1137-1150)
+struct SurfaceMesh {
+    std::vector<int> surfIndToTet;             // surface vertex -> tet vertex
+    std::vector<std::array<int, 3>> F_surf;    // in surface numbering
+};
+inline SurfaceMesh build_surface_mesh(const TetMesh &m)
+{
+    const auto SF = find_surface_tris(m);
+    std::vector<int> tetIndToSurf(m.nV(), -1);
+    std::vector<char> on(m.nV(), 0);
+    for (auto &t : SF)
+        for (int k = 0; k < 3; ++k) on[t[k]] = 1;
+    SurfaceMesh S;
+    for (int v = 0; v < m.nV(); ++v)
+        if (on[v]) {
+            tetIndToSurf[v] = (int)S.surfIndToTet.size();
+            S.surfIndToTet.push_back(v);
+        }
+    for (auto &t : SF) S.F_surf.push_back({tetIndToSurf[t[0]], tetIndToSurf[t[1]], tetIndToSurf[t[2]]});
+    return S;
 }
 
 // label.obj (one "v <subdomain> 0 0" line per surface triangle) and wire.poly (surface wire frame), the two

@@ -13,13 +13,14 @@
 // Script token `restart <status file>` resumes from a saved status (Optimizer.cpp:126-177).
 //
 // usage: dot_hip 100 <script.txt> [--mesh-root DIR] [--parts N] [--energy FCR|SNH] [--epart raw.i32]
-//                [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K] [--dump-config]
+//                [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K] [--dump-config] [--dump-formats DIR] [--fast]
 #include <chrono>
 #include <cstring>
 #include <iostream>
 #include <sys/stat.h>
 
 #include "DotHipTimeStepper.hpp"
+#include "Output.hpp"
 #include "Scene.hpp"
 
 using namespace dot_amd;
@@ -33,7 +34,7 @@ int main(int argc, char **argv)
 {
     if (argc < 3) {
         std::fprintf(stderr, "usage: %s 100 <script.txt> [--mesh-root DIR] [--parts N] [--energy FCR|SNH] "
-                             "[--epart raw.i32] [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K] [--dump-config]\n", argv[0]);
+                             "[--epart raw.i32] [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K] [--dump-config] [--dump-formats DIR] [--fast]\n", argv[0]);
         return 2;
     }
     if (std::string(argv[1]) != "100") {
@@ -43,7 +44,8 @@ int main(int argc, char **argv)
     const std::string scriptPath = argv[2];
     std::string meshRoot = ".", outDir, epartFile, energyOverride;
     int partsOverride = -1, frames = -1, device = 0, dumpScene = -1;
-    bool files = true, dumpConfig = false;
+    bool files = true, dumpConfig = false, fast = false;
+    std::string dumpFormats;
     for (int i = 3; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) throw std::runtime_error("missing value for " + a); return argv[++i]; };
@@ -57,6 +59,8 @@ int main(int argc, char **argv)
         else if (a == "--no-files") files = false;
         else if (a == "--dump-scene") dumpScene = std::stoi(next());
         else if (a == "--dump-config") dumpConfig = true;
+        else if (a == "--dump-formats") dumpFormats = next();   // write 0.obj + info.txt of the initial scene into DIR (no GPU)
+        else if (a == "--fast") fast = true;   // device-resident loop: the loop slots of info.txt stay 0
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     try {
@@ -102,6 +106,17 @@ int main(int argc, char **argv)
         const bool outGiven = !outDir.empty();
         if (outDir.empty()) outDir = "output/" + name;
 
+        if (!dumpFormats.empty()) {
+            mkdir(dumpFormats.c_str(), 0755);
+            const SurfaceMesh S = build_surface_mesh(mesh);
+            write_surface_obj(dumpFormats + "/0.obj", x0, S.surfIndToTet, S.F_surf);
+            RunTimers rt;   // a fixed pattern so a reader can check which value sits under which name
+            rt.descent = 12.5;
+            for (int k = 0; k < 14; ++k) rt.step[k] = 0.001 * (k + 1);
+            write_info_txt(dumpFormats + "/info.txt", mesh.nV(), mesh.nT(), 7, 123, rt);
+            write_partition_files(dumpFormats, mesh, x0, epart);
+            return 0;
+        }
         // --dump-scene K: print the scene the hot path would receive and K scripted moves (no GPU needed);
         // with --out also the partition files
         if (dumpScene >= 0) {
@@ -142,6 +157,9 @@ int main(int argc, char **argv)
         Options opt;
         opt.energyType = cfg.energy == "SNH" ? DOTMI_ENERGY_SNH : DOTMI_ENERGY_FCR;
         opt.withGravity = cfg.withGravity; opt.partitionAmt = nParts; opt.epart = epart.data(); opt.device = device;
+        // the reference keeps its timer_step running all the time; here the per-phase HIP-event brackets cost a
+        // host-driven loop, so they are on whenever files are written unless --fast asks for the device-resident loop
+        if (files && !fast) opt.flags |= DOTMI_FLAG_TIME_PHASES;
 
         FILE *fIter = nullptr, *fLog = nullptr;
         if (files) {
@@ -152,7 +170,8 @@ int main(int argc, char **argv)
             if (!fIter || !fLog) throw std::runtime_error("cannot write into " + outDir);
             write_partition_files(outDir, mesh, x0, epart);
         }
-        const auto surf = files ? find_surface_tris(mesh) : std::vector<std::array<int, 3>>();
+        const SurfaceMesh surf = files ? build_surface_mesh(mesh) : SurfaceMesh();
+        RunTimers timers;
 
         const double tSetup = now_s();
         DotHipTimeStepper ts(mv, opt, x0.data());
@@ -165,6 +184,7 @@ int main(int argc, char **argv)
             return changed;
         });
         ts.precompute();
+        timers.step[DOTMI_T_SYMBOLIC_FACTORIZATION] = now_s() - tSetup;   // pattern + layout work of the setup (analyze_pattern's role)
         int firstFrame = 0;
         if (cfg.restart) {
             std::vector<double> xs, vs;
@@ -184,12 +204,7 @@ int main(int argc, char **argv)
                 std::snprintf(buf, sizeof(buf), "%s/status%d", outDir.c_str(), n);
                 ts.saveStatus(buf);
                 std::snprintf(buf, sizeof(buf), "%s/%d.obj", outDir.c_str(), n);
-                const auto x = ts.getResult();
-                if (FILE *fo = std::fopen(buf, "w")) {
-                    for (int v = 0; v < mesh.nV(); ++v) std::fprintf(fo, "v %.10g %.10g %.10g\n", x[3 * v], x[3 * v + 1], x[3 * v + 2]);
-                    for (auto &t : surf) std::fprintf(fo, "f %d %d %d\n", t[0] + 1, t[1] + 1, t[2] + 1);
-                    std::fclose(fo);
-                }
+                write_surface_obj(buf, ts.getResult(), surf.surfIndToTet, surf.F_surf);
                 std::fprintf(fLog, "%dth tol: %g\n", n, ts.getTargetGRes());
             }
             const double t0 = now_s();
@@ -198,6 +213,7 @@ int main(int argc, char **argv)
             if (rc == 1) break;
             const auto &st = ts.lastStats();
             lineSearch += st.ls_halvings;
+            for (int k = 0; k < DOTMI_T_COUNT; ++k) timers.step[k] += 1e-3 * st.ms_phase[k];
             if (files) {
                 const int k = dotmi_last_iter_log(ts.handle(), 10001, al.data(), En.data(), g2.data());
                 std::fprintf(fIter, "%d 0 %g %g\n", n, st.E0, st.g2_0);
@@ -208,10 +224,8 @@ int main(int argc, char **argv)
             std::printf("FRAME %d ms %.3f iters %d halvings %d E %.17g status %d\n", n, st.ms_total, st.iters, st.ls_halvings, st.E, rc);
         }
         if (files) {
-            if (FILE *fi = std::fopen((outDir + "/info.txt").c_str(), "w")) {
-                std::fprintf(fi, "%d %d\n%d %d 0 0 0\nstepping %.6f s\n", mesh.nV(), mesh.nT(), ts.getIterNum(), ts.getInnerIterAmt(), tStep);
-                std::fclose(fi);
-            }
+            timers.descent = tStep;
+            write_info_txt(outDir + "/info.txt", mesh.nV(), mesh.nT(), ts.getIterNum(), ts.getInnerIterAmt(), timers);
             std::fclose(fIter);
             std::fclose(fLog);
         }

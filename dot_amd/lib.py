@@ -21,6 +21,7 @@ ENERGY_SNH = 1
 FLAG_TIME_BACKSOLVE = 2
 FLAG_FORCE_DIST = 4
 FLAG_HOST_LOOP = 8
+FLAG_TIME_PHASES = 16
 
 
 class Mesh(C.Structure):
@@ -42,7 +43,7 @@ class StepStats(C.Structure):
                 ("g2", C.c_double), ("ms_total", C.c_double), ("ms_loop", C.c_double),
                 ("ms_hessian", C.c_double), ("ms_factor", C.c_double), ("ms_precond", C.c_double),
                 ("precond_launches", C.c_int64), ("precond_bytes", C.c_int64),
-                ("factor_flops", C.c_double)]
+                ("factor_flops", C.c_double), ("ms_phase", C.c_double * 14)]
 
 
 EXPORTS = [

@@ -207,14 +207,34 @@ def read_status(path: str, nV: int) -> Tuple[int, np.ndarray, np.ndarray]:
 
 
 def surface_triangles(T: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """Boundary faces (those of exactly one tet) and the tet each belongs to (IglUtils::findSurfaceTris)."""
-    FACE = np.array([[0, 2, 1], [0, 3, 2], [0, 1, 3], [1, 2, 3]])
-    tris = T[:, FACE].reshape(-1, 3)
-    tet = np.repeat(np.arange(T.shape[0]), 4)
-    key = np.sort(tris, axis=1)
-    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
-    keep = cnt[inv.reshape(-1)] == 1
-    return tris[keep], tet[keep]
+    """Surface triangles in the ORDER of IglUtils::findSurfaceTris (IglUtils.cpp:558-590) and the tet each belongs to
+    (buildSTri2Tet, :591-625): the four outward faces of every tet go into a map keyed by the oriented vertex triple
+    (lexicographic, Triplet.h:29-45); a face is on the surface when none of the three rotations of its reversal is a
+    key; output in key order."""
+    FACE = ((0, 2, 1), (0, 3, 2), (0, 1, 3), (1, 2, 3))
+    tri = {}
+    for e, t in enumerate(np.asarray(T).tolist()):
+        for f in FACE:
+            tri[(t[f[0]], t[f[1]], t[f[2]])] = e
+    out, tet = [], []
+    for k in sorted(tri):
+        if (k[2], k[1], k[0]) in tri or (k[1], k[0], k[2]) in tri or (k[0], k[2], k[1]) in tri:
+            continue
+        out.append(k)
+        tet.append(tri[k])
+    return np.array(out, dtype=np.int32).reshape(-1, 3), np.array(tet, dtype=np.int32)
+
+
+def surface_mesh(T: np.ndarray, SF: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray]:
+    """(surfIndToTet, F_surf): surface vertices in ascending tet-vertex order and the surface triangles re-indexed to
+    them -- V_surf / F_surf of main.cpp:800-830, written as <n>.obj by Optimizer::saveStatus (Optimizer.cpp:1137-1150).
+    SF: the `$Surface` rows of the mesh file when it has them, else findSurfaceTris."""
+    if SF is None:
+        SF, _ = surface_triangles(T)
+    s2t = np.unique(SF)
+    t2s = np.full(int(np.asarray(T).max()) + 1, -1, dtype=np.int64)
+    t2s[s2t] = np.arange(s2t.size)
+    return s2t.astype(np.int32), t2s[SF].astype(np.int32)
 
 
 def load_mesh_npz(path: str) -> Tuple[np.ndarray, np.ndarray]:

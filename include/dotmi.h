@@ -79,6 +79,30 @@ typedef struct {
                                      * two produce identical iterates -- kept for A/B tests and always used
                                      * on the sharded multi-GPU path */
 
+#define DOTMI_FLAG_TIME_PHASES 16    /* drive the loop from the host and bracket every phase of an iteration with HIP
+                                     * events on the handle's stream; the device times land in
+                                     * dotmi_step_stats.ms_phase under the reference's timer_step slots.  Costs
+                                     * ~8 event records per iteration: for info.txt, not for benchmarks */
+
+/* indices of dotmi_step_stats.ms_phase = the reference's timer_step activities (src/main.cpp:867-880) */
+enum {
+    DOTMI_T_MATRIX_COMPUTATION = 0,  /* element Hessians + global assembly (slot started at DOTTimeStepper.cpp:576) */
+    DOTMI_T_MATRIX_ASSEMBLY = 1,     /* subdomain matrices (fillInDecomposedHessians, :623) */
+    DOTMI_T_SYMBOLIC_FACTORIZATION = 2,
+    DOTMI_T_NUMERICAL_FACTORIZATION = 3,
+    DOTMI_T_BACKSOLVE = 4,           /* subdomain solves + merge (:404-452) */
+    DOTMI_T_LINESEARCH_OTHER = 5,    /* alpha_0 SpMV, stepForward (Optimizer.cpp:756-881) */
+    DOTMI_T_MODIFY_GRAD = 6,         /* two-loop, first half (:386-400) */
+    DOTMI_T_MODIFY_SEARCHDIR = 7,    /* two-loop, second half (:455-467) */
+    DOTMI_T_UPDATE_HISTORY = 8,      /* gradient + (s, y) update (:475-494) */
+    DOTMI_T_LINESEARCH_EVAL = 9,     /* energy evaluations of the line search (Optimizer.cpp:791,830) */
+    DOTMI_T_FULLYIMPLICIT_ECOMP = 10, /* initX + first energy / gradient (DOTTimeStepper.cpp:288-293) */
+    DOTMI_T_SOLVE_EXTRACOMP = 11,    /* BE update, x~ (Optimizer.cpp:353-365) */
+    DOTMI_T_COMPGRAD = 12,
+    DOTMI_T_CCD = 13,
+    DOTMI_T_COUNT = 14
+};
+
 typedef struct {
     int32_t iters;        /* L-BFGS iterations (innerIterAmt delta, DOTTimeStepper.cpp:338) */
     int32_t ls_halvings;  /* numOfLineSearch delta (Optimizer.cpp:816) */
@@ -96,6 +120,10 @@ typedef struct {
                               block-sparse inverse factors X_s of this rank (each is streamed once) */
     double factor_flops;  /* FP64 flop of one factorisation of this rank's subdomains as executed (GEMMs incl. the
                              identity padding + diagonal blocks): ms_factor's MFMA roofline */
+    double ms_phase[DOTMI_T_COUNT]; /* device milliseconds of this step under the reference's timer_step slots.  Always
+                             filled: MATRIX_COMPUTATION, MATRIX_ASSEMBLY, NUMERICAL_FACTORIZATION (HIP events of the
+                             refresh at the end of the step).  The loop slots (BACKSOLVE ... FULLYIMPLICIT_ECOMP,
+                             SOLVE_EXTRACOMP) only with DOTMI_FLAG_TIME_PHASES. */
 } dotmi_step_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

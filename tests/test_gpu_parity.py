@@ -442,6 +442,28 @@ def test_cpp_headless_runner_end_to_end(tmp_path):
     st = (o / "status2").read_text().splitlines()
     assert st[0] == "timestep 2" and st[2] == "position 4670 3" and any(l.startswith("velocity 14010") for l in st)
     assert "Timestep2 innerIterAmt" in (o / "log.txt").read_text()
+    # info.txt in the reference's layout (main.cpp:338-358), the timer_step slots filled from HIP events
+    # (dotmi_step_stats.ms_phase, DOTMI_FLAG_TIME_PHASES): every slot the DOT path exercises is non-zero
+    from tests.test_host_logic import TIMER_STEP, read_info_txt, read_obj
+    info = read_info_txt(o / "info.txt")
+    assert (info["nV"], info["nT"], info["iterNum"]) == (4670, 19379, 3)
+    assert info["innerIterAmt"] == sum(int(f[5]) for f in frames)
+    tstep = dict(info["timer_step"])
+    assert list(tstep) == TIMER_STEP
+    for name in ("matrixComputation", "matrixAssembly", "symbolicFactorization", "numericalFactorization", "backSolve",
+                 "lineSearch_other", "modifyGrad", "modifySearchDir", "updateHistory", "lineSearch_eVal",
+                 "fullyImplicit_eComp", "solve_extraComp"):
+        assert tstep[name] > 0.0, name
+    assert tstep["compGrad"] == 0.0 and tstep["CCD"] == 0.0
+    loop = sum(tstep[k] for k in TIMER_STEP if k != "symbolicFactorization")
+    assert loop <= info["timer"][0][1]                 # device time of the phases <= wall time inside solve()
+    # <n>.obj: the surface mesh only, re-indexed; frame 0 = the initial positions of the surface vertices
+    s2t, Fs = scene.surface_mesh(sc.T)
+    Vo, Fo = read_obj(o / "0.obj")
+    assert Vo.shape == (s2t.size, 3) and s2t.size < 4670 and np.array_equal(Fo, Fs)
+    assert np.abs(Vo - sc.x0[s2t]).max() < 1e-13
+    V2, _ = read_obj(o / "2.obj")
+    assert V2.shape == Vo.shape and np.abs(V2 - Vo).max() > 1e-4      # it moved
     # `restart <status>`: resume at time step 2 from the saved status (7 significant digits in the file)
     (tmp_path / "bunny_r.txt").write_text((tmp_path / "bunny.txt").read_text() + f"restart {o / 'status2'}\n")
     out2 = subprocess.check_output([exe, "100", str(tmp_path / "bunny_r.txt"), "--mesh-root", str(tmp_path), "--epart",

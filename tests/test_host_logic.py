@@ -2,6 +2,7 @@
 motion, partitioners, workload table.  No GPU, no oracle."""
 import math
 import os
+import subprocess
 
 import numpy as np
 import pytest
@@ -9,6 +10,8 @@ import pytest
 from dot_amd import scene
 from dot_amd.configs import WORKLOADS, load_workload
 from dot_amd.sharding import owned_elements, part_scalar_sizes, plan_shards, vertex_slice
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_parse_script_tokens(tmp_path):
@@ -318,3 +321,101 @@ def test_scripter_tracking_equals_reading_positions_back(workload):
         x[i1] = p1
         i2, p2 = sc2.scripter.step(None, sc2.cfg.dt)
         assert np.array_equal(i1, i2) and np.array_equal(p1, p2)
+
+
+# ---- f2: the reference's output formats, read back by a restated reader of those formats ----------------------------
+def _read_timer_tables(lines):
+    """Timer::print blocks (Utils/Timer.hpp:58-68): '<n> activities:' then n lines '%10g s: <name>' and the Total"""
+    import re
+    tables, i = [], 0
+    while i < len(lines):
+        m = re.fullmatch(r"(\d+) activities:", lines[i])
+        if not m:
+            break
+        n = int(m.group(1))
+        rows = []
+        for l in lines[i + 1:i + 2 + n]:
+            mm = re.fullmatch(r"\s*(\S+) s: (\S+)", l)
+            assert mm and len(l.split(" s: ")[0]) >= 10, l       # os.width(10), right aligned
+            rows.append((mm.group(2), float(mm.group(1))))
+        assert rows[-1][0] == "Total" and abs(rows[-1][1] - sum(v for _, v in rows[:-1])) <= 1e-5 * max(1.0, rows[-1][1])
+        tables.append(rows[:-1])
+        i += n + 2
+    return tables, lines[i:]
+
+
+def read_info_txt(path):
+    """saveInfoForPresent (main.cpp:338-358)"""
+    lines = open(path).read().splitlines()
+    nV, nT = (int(t) for t in lines[0].split())
+    f = lines[1].split()
+    assert len(f) == 5 and f[2:] == ["0", "0", "0"]
+    tables, rest = _read_timer_tables(lines[2:])
+    assert rest == ["0 0"]
+    return dict(nV=nV, nT=nT, iterNum=int(f[0]), innerIterAmt=int(f[1]), timer=tables[0], timer_step=tables[1],
+                timer_temp3=tables[2])
+
+
+def read_obj(path):
+    """igl::writeOBJ(V, F) (libigl writeOBJ.cpp:100-120): 'v x y z' rows then 'f a b c' rows, 1-based"""
+    V, F = [], []
+    for l in open(path).read().splitlines():
+        t = l.split(" ")
+        if t[0] == "v":
+            assert not F and len(t) == 4
+            V.append([float(u) for u in t[1:]])
+        else:
+            assert t[0] == "f" and len(t) == 4
+            F.append([int(u) - 1 for u in t[1:]])
+    return np.array(V), np.array(F)
+
+
+TIMER_STEP = ["matrixComputation", "matrixAssembly", "symbolicFactorization", "numericalFactorization", "backSolve",
+              "lineSearch_other", "modifyGrad", "modifySearchDir", "updateHistory", "lineSearch_eVal",
+              "fullyImplicit_eComp", "solve_extraComp", "compGrad", "CCD"]                      # main.cpp:867-880
+TIMER_TEMP3 = ["init", "initPrimal", "initDual", "initWeights", "initCons", "subdSolve", "consSolve"]   # :882-888
+
+
+@pytest.mark.parametrize("with_surface_section", [False, True])
+def test_info_txt_and_surface_obj_formats(tmp_path, with_surface_section):
+    """VERDICT r01 f2: info.txt = two header lines + the three Timer tables with the reference's 14 + 7 slot names;
+    <n>.obj = the re-indexed SURFACE mesh (not all tet vertices), 15 significant digits.  `dot_hip --dump-formats`
+    writes both from the initial scene without a GPU."""
+    exe = os.path.join(ROOT, "dot_amd", "dot_hip")
+    if not os.path.exists(exe):
+        pytest.skip("dot_hip not built")
+    V, T = scene.synthetic_bar(5, 2, 2)
+    rng = np.random.default_rng(9)
+    V = V + 0.01 * rng.standard_normal(V.shape)
+    nV, nT = V.shape[0], T.shape[0]
+    SF = None
+    msh = "$MeshFormat\n4 0 8\n$EndMeshFormat\n$Nodes\n1 %d\n0 3 0 %d\n" % (nV, nV)
+    msh += "".join("%d %r %r %r\n" % (i + 1, p[0], p[1], p[2]) for i, p in enumerate(V.tolist()))
+    msh += "$EndNodes\n$Elements\n1 %d\n0 3 4 %d\n" % (nT, nT)
+    msh += "".join("%d %d %d %d %d\n" % (i + 1, t[0] + 1, t[1] + 1, t[2] + 1, t[3] + 1) for i, t in enumerate(T.tolist()))
+    msh += "$EndElements\n"
+    if with_surface_section:
+        SF = scene.surface_triangles(T)[0][::-1].copy()          # any order the file chooses must be kept
+        msh += "$Surface\n%d\n" % SF.shape[0] + "".join("%d %d %d\n" % (a + 1, b + 1, c + 1) for a, b, c in SF.tolist())
+        msh += "$EndSurface\n"
+    (tmp_path / "m.msh").write_text(msh)
+    (tmp_path / "s.txt").write_text("energy FCR\ntimeStepper DOT 2\nsize 1\ntime 1 0.02\ndensity 1000\n"
+                                    "stiffness 100000 0.4\nscript twist\nshape input m.msh\nhandleRatio 0.1\n")
+    subprocess.check_call([exe, "100", str(tmp_path / "s.txt"), "--mesh-root", str(tmp_path), "--dump-formats",
+                           str(tmp_path / "o")])
+    info = read_info_txt(tmp_path / "o" / "info.txt")
+    assert (info["nV"], info["nT"], info["iterNum"], info["innerIterAmt"]) == (nV, nT, 7, 123)
+    assert info["timer"] == [("descent", 12.5)]
+    assert [n for n, _ in info["timer_step"]] == TIMER_STEP and [n for n, _ in info["timer_temp3"]] == TIMER_TEMP3
+    assert [v for _, v in info["timer_step"]] == [round(0.001 * (k + 1), 3) for k in range(14)]
+    assert all(v == 0.0 for _, v in info["timer_temp3"])
+    # surface mesh: the scene normalises the positions, the Python mirror does the same
+    sc = scene.load_scene(str(tmp_path / "s.txt"), mesh_dir=str(tmp_path))
+    s2t, Fs = scene.surface_mesh(T, SF)
+    Vo, Fo = read_obj(tmp_path / "o" / "0.obj")
+    assert Vo.shape == (s2t.size, 3) and s2t.size < nV             # interior vertices are not written
+    assert np.array_equal(Fo, Fs)                                   # same triangles, same order, re-indexed
+    assert np.abs(Vo - sc.x0[s2t]).max() <= 1e-14 * np.abs(sc.x0).max()
+    # label.obj follows the same triangle order (one subdomain label per surface triangle)
+    labels = (tmp_path / "o" / "label.obj").read_text().splitlines()
+    assert len(labels) == Fs.shape[0]
