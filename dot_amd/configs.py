@@ -28,12 +28,21 @@ WORKLOADS = {
     "monkey18K_stiff": ("monkey18K", dict(energy="SNH", size=1.0, duration=10.0, dt=0.04, rho=1000.0, YM=4e5,
                                           PR=0.4, script="twistnsns_old", rot_deg=40.0, rot_axis=(0.0, 1.0, 0.0),
                                           handle_ratio=0.02), 64),
+    # input/tb5_ablation/kingkong18K_SS_DOT-1K.txt: `timeStepper DOT -1 1024` -> nV / 1024 + 1 = 18 subdomains
+    # (main.cpp:792-798)
+    "kingkong18K_SS_1K": ("kingkong18K", dict(energy="FCR", size=1.0, duration=10.0, dt=0.025, rho=1000.0, YM=1e5,
+                                              PR=0.4, script="stretchnsquash", block_size=1024), -1),
+    # input/tb5_ablation/monkey18K_TSS_DOT-1K.txt
+    "monkey18K_TSS_1K": ("monkey18K", dict(energy="FCR", size=1.0, duration=10.0, dt=0.025, rho=1000.0, YM=1e5,
+                                           PR=0.4, script="twistnsns_old", rot_deg=40.0, rot_axis=(0.0, 1.0, 0.0),
+                                           handle_ratio=0.02, block_size=1024), -1),
 }
 
 
 def load_workload(name: str, nparts: int | None = None):
-    """-> (Scene, epart, nparts).  Partition = committed METIS fixture when it exists for this
-    (mesh, nparts), else the package's own recursive-coordinate-bisection partitioner."""
+    """-> (Scene, epart, nparts).  Partition = committed METIS fixture when it exists for this (mesh, nparts), else the
+    library's own partitioner (dotmi_partition); the synthetic bars keep the seedless coordinate bisection SURVEY.md
+    section 8(d) M5 specifies for them.  Block-size scripts (`DOT -1 <b>`) get nV / b + 1 subdomains."""
     if name.startswith("synbar"):
         # synbar:<nx>x<ny>x<nz>:<nparts>  e.g. the 1M-tet bar = synbar:140x35x35:256
         _, dims, npart_s = name.split(":")
@@ -44,14 +53,17 @@ def load_workload(name: str, nparts: int | None = None):
         np_ = int(npart_s) if nparts is None else nparts
         return sc, partition_rcb(sc.V_rest, sc.T, np_), np_
     mesh, kw, np_default = WORKLOADS[name]
-    np_ = np_default if nparts is None else nparts
     V, T = load_mesh_npz(os.path.join(MESH_DIR, mesh + ".npz"))
     cfg = Config(**kw)
+    if cfg.block_size > 0 and nparts is None:
+        np_default = V.shape[0] // cfg.block_size + 1      # main.cpp:792-798
+    np_ = np_default if nparts is None else nparts
     cfg.partition_amt = np_
     sc = build_scene(cfg, V, T)
     f = os.path.join(PART_DIR, f"{mesh}_{np_}.npy")
     if os.path.exists(f):
         epart = np.load(f).astype(np.int32)
     else:
-        epart = partition_rcb(sc.V_rest, sc.T, np_)
+        from .scene import partition_dual
+        epart = partition_dual(sc.V_rest, sc.T, np_)
     return sc, epart, np_

@@ -28,6 +28,7 @@
 #include "../../include/dotmi.h"
 #include "dotmi_internal.hpp"
 #include "elem_math.hpp"
+#include "partition.hpp"
 
 using namespace dotmi;
 
@@ -1393,6 +1394,16 @@ int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xr
     return 0;
 }
 
+// host-only: the built-in element partitioner (partition.hpp)
+int dotmi_partition(int32_t nV, int32_t nT, const int32_t *T, const double *X, int32_t nParts, int32_t *epart)
+{
+    if (nV < 1 || nT < 1 || !T || !X || nParts < 1 || !epart) return DOTMI_E_INVALID;
+    for (int i = 0; i < 4 * nT; ++i)
+        if (T[i] < 0 || T[i] >= nV) return DOTMI_E_INVALID;
+    partition_elements(nV, nT, T, X, nParts, epart);
+    return 0;
+}
+
 int dotmi_comm_unique_id(void *out128)
 {
     ncclUniqueId id;
@@ -1453,7 +1464,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         return DOTMI_E_NOGPU;
     }
     if (!mesh || !prm || !x_init || mesh->nV <= 0 || mesh->nT <= 0 || !mesh->X_rest || !mesh->T || !mesh->mu ||
-        !mesh->lambda || !mesh->fixed || !mesh->epart || mesh->nParts < 1 || prm->dt <= 0 ||
+        !mesh->lambda || !mesh->fixed || mesh->nParts < 1 || prm->dt <= 0 ||
         prm->history < 1 || prm->history > HIST_MAX || prm->world < 1 || prm->rank < 0 ||
         prm->rank >= prm->world || (prm->world > 1 && !prm->comm_id) ||
         (prm->energy != DOTMI_ENERGY_FCR && prm->energy != DOTMI_ENERGY_SNH)) {
@@ -1461,7 +1472,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         return DOTMI_E_INVALID;
     }
     for (int e = 0; e < mesh->nT; ++e) {
-        if (mesh->epart[e] < 0 || mesh->epart[e] >= mesh->nParts) {
+        if (mesh->epart && (mesh->epart[e] < 0 || mesh->epart[e] >= mesh->nParts)) {
             h->err = "epart out of range";
             return DOTMI_E_INVALID;
         }
@@ -1492,7 +1503,12 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     h->density = mesh->density;
     h->nPartsAll = mesh->nParts;
     h->T.assign(mesh->T, mesh->T + 4 * (size_t)h->nT);
-    h->epart.assign(mesh->epart, mesh->epart + h->nT);
+    if (mesh->epart) {
+        h->epart.assign(mesh->epart, mesh->epart + h->nT);
+    } else {   // no partition given: the built-in partitioner (the reference calls METIS here, METIS.hpp:109-140)
+        h->epart.resize(h->nT);
+        partition_elements(mesh->nV, mesh->nT, mesh->T, mesh->X_rest, mesh->nParts, h->epart.data());
+    }
     h->fixed.assign(mesh->fixed, mesh->fixed + h->nV);
     h->Xrest.assign(mesh->X_rest, mesh->X_rest + h->n);
     h->mu.assign(mesh->mu, mesh->mu + h->nT);

@@ -99,7 +99,10 @@ int main(int argc, char **argv)
             f.read((char *)epart.data(), sizeof(int32_t) * epart.size());
             if (!f) throw std::runtime_error("cannot read " + epartFile);
         } else {
-            epart = partition_rcb(mesh, nParts);  // METIS is third-party; pass --epart for the reference's partition
+            // METIS is third-party: pass --epart for the reference's partition; otherwise the library's own partitioner
+            epart.resize(mesh.nT());
+            if (dotmi_partition(mesh.nV(), mesh.nT(), mesh.T.data(), mesh.V.data(), nParts, epart.data()) != 0)
+                throw std::runtime_error("dotmi_partition failed");
         }
         std::string name = scriptPath.substr(scriptPath.find_last_of('/') + 1);
         name = name.substr(0, name.find_last_of('.'));

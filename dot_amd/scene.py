@@ -507,6 +507,20 @@ def synthetic_bar(nx: int, ny: int, nz: int, lx: float = 4.0, ly: float = 1.0, l
     return V, T
 
 
+def partition_dual(V: np.ndarray, T: np.ndarray, nparts: int) -> np.ndarray:
+    """The library's built-in partitioner (dotmi_partition, host only: recursive bisection of the tets' face-adjacency
+    graph with Fiduccia-Mattheyses refinement) -- what stands in for METIS::partMesh on meshes without a fixture."""
+    from . import lib as _lib
+    L = _lib.load()
+    V = np.ascontiguousarray(V, dtype=np.float64)
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    ep = np.zeros(T.shape[0], dtype=np.int32)
+    rc = L.dotmi_partition(V.shape[0], T.shape[0], _lib.ip(T), _lib.dp(V), int(nparts), _lib.ip(ep))
+    if rc != 0:
+        raise ValueError(f"dotmi_partition failed ({rc})")
+    return ep
+
+
 def partition_rcb(V: np.ndarray, T: np.ndarray, nparts: int) -> np.ndarray:
     """Seedless recursive coordinate bisection of element centroids (own partitioner for meshes
     without a METIS fixture; results then differ from the reference only within solver tolerance)."""

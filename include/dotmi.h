@@ -49,7 +49,7 @@ typedef struct {
     const double *lambda;  /* nT */
     double density;
     const uint8_t *fixed;  /* nV, 1 = Dirichlet */
-    const int32_t *epart;  /* nT, values in [0,nParts) */
+    const int32_t *epart;  /* nT, values in [0,nParts); NULL = partition with dotmi_partition() */
     int32_t nParts;
 } dotmi_mesh;
 
@@ -152,6 +152,12 @@ int dotmi_plan_shards(int32_t nParts, const int32_t *part_scalar_size, int32_t w
 int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xrest, const int32_t *epart,
                       int32_t nParts, int32_t p0, int32_t p1, int32_t levels, int32_t min_split,
                       int32_t node_cap, int32_t *nodes, int32_t *n_nodes, int32_t *nmax, int32_t *pos);
+
+/* Host-only (touches no device): the built-in element partitioner, for meshes that come without the partition METIS
+ * gives the reference (METIS::partMesh, src/Utils/METIS.hpp:109-140; block-size runs `DOT -1 <nodes/block>`,
+ * src/main.cpp:792-798).  Recursive bisection of the face-adjacency graph of the tets, coordinate split + Fiduccia-
+ * Mattheyses refinement of the face cut; seedless and deterministic.  epart: nT values in [0,nParts). */
+int dotmi_partition(int32_t nV, int32_t nT, const int32_t *T, const double *X, int32_t nParts, int32_t *epart);
 
 /* world>1: rank 0 calls this and ships the 128 bytes to every rank (e.g. torch.distributed
  * broadcast); all ranks pass it as params.comm_id.  */

@@ -14,7 +14,7 @@ from tests import oracle_py as O  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 os.makedirs(os.path.join(HERE, "parts"), exist_ok=True)
 for mesh, nparts in (("bunny5K", 8), ("bunny5K", 6), ("bar17K", 32), ("bar17K", 6), ("horse7K", 8),
-                     ("monkey18K", 64)):
+                     ("monkey18K", 64), ("kingkong18K", 18), ("monkey18K", 18)):   # 18 = nV / 1024 + 1 (`DOT -1 1024`)
     V, T = load_mesh_npz(os.path.join(HERE, "meshes", mesh + ".npz"))
     ep = O.metis_partition(T, V.shape[0], nparts)
     assert ep.min() == 0 and ep.max() == nparts - 1

@@ -150,6 +150,8 @@ def test_rcb_partition_is_balanced_and_complete():
 def test_workload_table_and_fixtures():
     for name, (mesh, kw, nparts) in WORKLOADS.items():
         sc, ep, n = load_workload(name)
+        if nparts < 0:                                   # block-size mode: nV / block + 1 (main.cpp:792-798)
+            nparts = sc.V_rest.shape[0] // sc.cfg.block_size + 1
         assert n == nparts and ep.shape == (sc.T.shape[0],) and ep.min() == 0 and ep.max() == nparts - 1
         assert sc.fixed.sum() > 0 and sc.V_rest.max() <= 1.0 + 1e-12
         d = sc.V_rest[sc.T[:, 1:]] - sc.V_rest[sc.T[:, :1]]
