@@ -97,6 +97,12 @@ struct dotmi_handle {
     hipStream_t st = nullptr;
     rocblas_handle blas = nullptr;
     ncclComm_t comm = nullptr;
+    void (*arCb)(void *, double *, int64_t) = nullptr;   // host all-reduce hook (dotmi_params::allreduce) instead of RCCL
+    void *arCtx = nullptr;
+    double *arStage = nullptr;                          // pinned staging of the hook's payload
+    size_t arCap = 0;
+    double *ctrlDev = nullptr;                          // RED_K + 2 doubles: control scalars of a trial (rank 0's are used)
+    double ctrl[RED_K + 2] = {0};                       // world > 1: [E, alpha, R[0..RED_K)] of the last trial as adopted from rank 0
     DevMesh M{};
     DevParts P{};
     int *elist = nullptr;
@@ -136,6 +142,7 @@ struct dotmi_handle {
     int timeStride = 8;                        // DOTMI_FLAG_TIME_BACKSOLVE brackets every timeStride-th back-solve
     int timeCount = 0;
     int nbE = 0;
+    int M_nbR() const { return NB_RED; }   // rows of the statistics partials
 
     // L-BFGS host state (chronological)
     int m = 0;
@@ -219,6 +226,9 @@ struct dotmi_handle {
     } while (0)
 
 namespace {
+
+int allreduce_sum(dotmi_handle *h, double *dev, size_t n);
+int adopt_rank0(dotmi_handle *h, double *vals, int n);
 
 template <class T>
 int dalloc(dotmi_handle *h, T **ptr, size_t count)
@@ -1040,13 +1050,28 @@ int refactor_issue(dotmi_handle *h, const double *x)
 // after the stream has been synchronised: SPD check of every owned subdomain and the two timings
 int refactor_finish(dotmi_handle *h, double *ms_hess, double *ms_fact)
 {
-    for (int i = 0; i < h->P.nParts; ++i)
-        if (h->h_info[i] != 0) {
-            h->err = "subdomain " + std::to_string(h->p0 + i) + " Hessian not positive definite (pivot " +
-                     std::to_string(h->h_info[i]) + ")";
-            h->poisoned = true;  // every later step / back-solve fails until a factorisation succeeds
+    int bad = -1;
+    for (int i = 0; i < h->P.nParts && bad < 0; ++i)
+        if (h->h_info[i] != 0) bad = i;
+    if (h->world > 1) {
+        // all ranks fail together: a rank that returned alone would leave the others blocked in the next collective
+        double f = bad >= 0 ? 1.0 : 0.0;
+        HIPCHECK(h, hipMemcpyAsync(h->ctrlDev, &f, sizeof(double), hipMemcpyHostToDevice, h->st));
+        if (int rc = allreduce_sum(h, h->ctrlDev, 1)) return rc;
+        HIPCHECK(h, hipMemcpyAsync(&f, h->ctrlDev, sizeof(double), hipMemcpyDeviceToHost, h->st));
+        HIPCHECK(h, hipStreamSynchronize(h->st));
+        if (f > 0.0 && bad < 0) {
+            h->err = "a subdomain Hessian on another rank is not positive definite";
+            h->poisoned = true;
             return DOTMI_E_NOTSPD;
         }
+    }
+    if (bad >= 0) {
+        h->err = "subdomain " + std::to_string(h->p0 + bad) + " Hessian not positive definite (pivot " +
+                 std::to_string(h->h_info[bad]) + ")";
+        h->poisoned = true;  // every later step / back-solve fails until a factorisation succeeds
+        return DOTMI_E_NOTSPD;
+    }
     h->poisoned = false;
     float a = 0, b = 0, c = 0;
     hipEventElapsedTime(&a, h->ev0, h->ev1);
@@ -1068,6 +1093,42 @@ int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
     if (int rc = refactor_issue(h, x)) return rc;
     HIPCHECK(h, hipStreamSynchronize(h->st));
     return refactor_finish(h, ms_hess, ms_fact);
+}
+
+// sum over the ranks of n doubles at `dev`, in place, ordered on the handle's stream: RCCL, or the host hook
+int allreduce_sum(dotmi_handle *h, double *dev, size_t n)
+{
+    if (h->comm) {
+        NCCLCHECK(h, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, h->comm, h->st));
+        return 0;
+    }
+    if (!h->arCb) return 0;   // single rank without a communicator (cannot happen on the sharded path)
+    if (n > h->arCap) {
+        if (h->arStage) hipHostFree(h->arStage);
+        h->arStage = nullptr;
+        HIPCHECK(h, hipHostMalloc((void **)&h->arStage, sizeof(double) * n));
+        h->arCap = n;
+    }
+    HIPCHECK(h, hipMemcpyAsync(h->arStage, dev, sizeof(double) * n, hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    h->arCb(h->arCtx, h->arStage, (int64_t)n);
+    HIPCHECK(h, hipMemcpyAsync(dev, h->arStage, sizeof(double) * n, hipMemcpyHostToDevice, h->st));
+    return 0;
+}
+
+// Every rank takes its accept / halve / converged decisions from RANK 0's control scalars (the ranks
+// compute them redundantly on replicated data, but a single differing bit would make them branch apart and dead-lock
+// in the next collective).  vals: host array, replaced by rank 0's on every rank.  One small collective per trial.
+int adopt_rank0(dotmi_handle *h, double *vals, int n)
+{
+    if (h->world <= 1) return 0;
+    if (h->rank != 0)
+        for (int i = 0; i < n; ++i) vals[i] = 0.0;
+    HIPCHECK(h, hipMemcpyAsync(h->ctrlDev, vals, sizeof(double) * n, hipMemcpyHostToDevice, h->st));
+    if (int rc = allreduce_sum(h, h->ctrlDev, n)) return rc;   // x + 0 + ... + 0 is exact: a broadcast
+    HIPCHECK(h, hipMemcpyAsync(vals, h->ctrlDev, sizeof(double) * n, hipMemcpyDeviceToHost, h->st));
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    return 0;
 }
 
 // DOTMI_FLAG_TIME_PHASES: a phase boundary on the stream; the interval that ends here is booked under `slot`
@@ -1101,7 +1162,7 @@ int apply_precond(dotmi_handle *h, const double *q, double *z, const LbfgsArgs &
         launch_merge(h->M, h->P, L, z, h->partC, 1 | 2, h->st);
     } else {
         launch_merge(h->M, h->P, L, z, h->partC, 0, h->st);
-        NCCLCHECK(h, ncclAllReduce(z, z, h->n, ncclDouble, ncclSum, h->comm, h->st));
+        if (int rc = allreduce_sum(h, z, h->n)) return rc;
         launch_div_dup(h->nV, h->P.dup, z, h->st);
         const double *ys_[HIST_MAX];
         for (int i = 0; i < L.m; ++i) ys_[i] = L.y[i];
@@ -1144,7 +1205,7 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
         // pack E_local behind the gradient and reduce both in one collective
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
                            gout + h->n);
-        NCCLCHECK(h, ncclAllReduce(gout, gout, h->n + 1, ncclDouble, ncclSum, h->comm, h->st));
+        if (int rc = allreduce_sum(h, gout, (size_t)h->n + 1)) return rc;
         if (make_pair) launch_pair_stats(h->n, a, L, h->partR, h->st);
         else {
             // |g|^2 only
@@ -1165,12 +1226,26 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
     } else {
         *E = h->h_partE[0];
     }
+    if (h->world > 1) {
+        // one set of control scalars for all ranks: rank 0's (energy, step length, every column of the statistics)
+        h->ctrl[0] = *E;
+        h->ctrl[1] = h->h_alpha[0];
+        for (int j = 0; j < RED_K; ++j)
+            h->ctrl[2 + j] = chunked_sum(h->M_nbR(), [&](int b) { return h->h_partR[(size_t)b * RED_K + j]; });
+        if (int rc = adopt_rank0(h, h->ctrl, RED_K + 2)) return rc;
+        *E = h->ctrl[0];
+        h->h_alpha[0] = h->ctrl[1];
+    }
     h->energy_evals++;
     return 0;
 }
 
 void sum_stats(const dotmi_handle *h, int nvals, double *R)
 {
+    if (h->world > 1) {   // what trial() adopted from rank 0
+        for (int j = 0; j < nvals; ++j) R[j] = h->ctrl[2 + j];
+        return;
+    }
     for (int j = 0; j < nvals; ++j) R[j] = chunked_sum(NB_RED, [&](int b) { return h->h_partR[(size_t)b * RED_K + j]; });
 }
 
@@ -1394,6 +1469,43 @@ int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xr
     return 0;
 }
 
+// host-only: what one rank owns under dotmi_create's plan
+int dotmi_plan_rank(int32_t nV, int32_t nT, const int32_t *T, const int32_t *epart, int32_t nParts, int32_t rank,
+                    int32_t world, int32_t *p0, int32_t *p1, int32_t *elems, int32_t *n_elems, int32_t *v0, int32_t *v1,
+                    int32_t *part_size)
+{
+    if (nV < 1 || nT < 1 || !T || !epart || nParts < 1 || world < 1 || rank < 0 || rank >= world) return DOTMI_E_INVALID;
+    std::vector<int32_t> ps(nParts, 0), first(world + 1);
+    {
+        std::vector<int> mark(nV, -1);
+        for (int pI = 0; pI < nParts; ++pI)
+            for (int e = 0; e < nT; ++e)
+                if (epart[e] == pI)
+                    for (int k = 0; k < 4; ++k) {
+                        const int v = T[4 * e + k];
+                        if (v < 0 || v >= nV) return DOTMI_E_INVALID;
+                        if (mark[v] != pI) {
+                            mark[v] = pI;
+                            ps[pI] += 3;
+                        }
+                    }
+    }
+    dotmi_plan_shards(nParts, ps.data(), world, first.data());
+    if (p0) *p0 = first[rank];
+    if (p1) *p1 = first[rank + 1];
+    int ne = 0;
+    for (int e = 0; e < nT; ++e)
+        if (epart[e] >= first[rank] && epart[e] < first[rank + 1]) {
+            if (elems) elems[ne] = e;
+            ++ne;
+        }
+    if (n_elems) *n_elems = ne;
+    if (v0) *v0 = (int32_t)((long long)nV * rank / world);
+    if (v1) *v1 = (int32_t)((long long)nV * (rank + 1) / world);
+    if (part_size) std::copy(ps.begin(), ps.end(), part_size);
+    return 0;
+}
+
 // host-only: the built-in element partitioner (partition.hpp)
 int dotmi_partition(int32_t nV, int32_t nT, const int32_t *T, const double *X, int32_t nParts, int32_t *epart)
 {
@@ -1421,6 +1533,7 @@ void dotmi_destroy(dotmi_handle *h)
     if (h->comm) ncclCommDestroy(h->comm);
     if (h->blas) rocblas_destroy_handle(h->blas);
     for (void *p : h->allocs) hipFree(p);
+    if (h->arStage) hipHostFree(h->arStage);
     if (h->h_partE) hipHostFree(h->h_partE);
     if (h->h_partR) hipHostFree(h->h_partR);
     if (h->h_alpha) hipHostFree(h->h_alpha);
@@ -1466,7 +1579,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     if (!mesh || !prm || !x_init || mesh->nV <= 0 || mesh->nT <= 0 || !mesh->X_rest || !mesh->T || !mesh->mu ||
         !mesh->lambda || !mesh->fixed || mesh->nParts < 1 || prm->dt <= 0 ||
         prm->history < 1 || prm->history > HIST_MAX || prm->world < 1 || prm->rank < 0 ||
-        prm->rank >= prm->world || (prm->world > 1 && !prm->comm_id) ||
+        prm->rank >= prm->world || (prm->world > 1 && !prm->comm_id && !prm->allreduce) ||
         (prm->energy != DOTMI_ENERGY_FCR && prm->energy != DOTMI_ENERGY_SNH)) {
         h->err = "invalid argument";
         return DOTMI_E_INVALID;
@@ -1530,11 +1643,19 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         const char *ev = getenv("DOTMI_SHARD_ELEMS");  // override for testing: 0 / 1
         h->shardElems = h->dist && (ev ? atoi(ev) != 0 : h->nT >= 400000);
     }
-    if (h->dist) {
+    h->arCb = prm->allreduce;
+    h->arCtx = prm->allreduce_ctx;
+    if (h->dist && !h->arCb) {
         ncclUniqueId id;
         if (h->world > 1) memcpy(&id, prm->comm_id, 128);
         else NCCLCHECK(h, ncclGetUniqueId(&id));
         NCCLCHECK(h, ncclCommInitRank(&h->comm, h->world, id, h->rank));
+    }
+    {
+        void *cd = nullptr;
+        HIPCHECK(h, hipMalloc(&cd, sizeof(double) * (RED_K + 8)));
+        h->allocs.push_back(cd);
+        h->ctrlDev = (double *)cd;
     }
 
     if (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) {
@@ -1821,7 +1942,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         if (h->shardElems) {
             hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partS, NB_RED, RED_K, 2, 0.0,
                                0.0, 0, h->partG);
-            NCCLCHECK(h, ncclAllReduce(h->partG, h->partG, 2, ncclDouble, ncclSum, h->comm, h->st));
+            if (int rc = allreduce_sum(h, h->partG, 2)) return rc;
             spart = h->partG;  // rows >= 1 stay zero
         }
         launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, h->h_alpha, h->st);

@@ -34,7 +34,11 @@ class Params(C.Structure):
     _fields_ = [("energy", C.c_int32), ("dt", C.c_double), ("gravity", C.c_double * 3),
                 ("relTol", C.c_double), ("history", C.c_int32), ("iterCap", C.c_int32),
                 ("alphaMin", C.c_double), ("device", C.c_int32), ("rank", C.c_int32),
-                ("world", C.c_int32), ("comm_id", C.c_void_p), ("flags", C.c_int32)]
+                ("world", C.c_int32), ("comm_id", C.c_void_p), ("flags", C.c_int32),
+                ("allreduce", C.c_void_p), ("allreduce_ctx", C.c_void_p)]
+
+
+ALLREDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
 
 
 class StepStats(C.Structure):
@@ -51,7 +55,7 @@ EXPORTS = [
     "dotmi_get_state", "dotmi_set_dirichlet", "dotmi_refix", "dotmi_step", "dotmi_last_iter_log",
     "dotmi_target_gres", "dotmi_eval_energy", "dotmi_eval_gradient", "dotmi_eval_elem_hessians",
     "dotmi_refactor", "dotmi_apply_precond", "dotmi_spmv", "dotmi_get_features", "dotmi_part_size",
-    "dotmi_part_matrix", "dotmi_probe_direction", "dotmi_bench_precond", "dotmi_bench_energy", "dotmi_plan_shards", "dotmi_plan_layout", "dotmi_partition",
+    "dotmi_part_matrix", "dotmi_probe_direction", "dotmi_bench_precond", "dotmi_bench_energy", "dotmi_plan_shards", "dotmi_plan_layout", "dotmi_plan_rank", "dotmi_partition",
 ]
 
 _lib = None
@@ -99,6 +103,8 @@ def load() -> C.CDLL:
     L.dotmi_bench_precond.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]
     L.dotmi_bench_energy.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]
     L.dotmi_plan_shards.argtypes = [C.c_int32, c_ip, C.c_int32, c_ip]
+    L.dotmi_plan_rank.argtypes = [C.c_int32, C.c_int32, c_ip, c_ip, C.c_int32, C.c_int32, C.c_int32, c_ip, c_ip, c_ip, c_ip,
+                                  c_ip, c_ip, c_ip]
     L.dotmi_partition.argtypes = [C.c_int32, C.c_int32, c_ip, c_dp, C.c_int32, c_ip]
     L.dotmi_plan_layout.argtypes = [C.c_int32, C.c_int32, c_ip, c_dp, c_ip, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, c_ip, c_ip, c_ip, c_ip]

@@ -20,7 +20,10 @@ from .scene import Scene, lame
 class DOTTimeStepper:
     def __init__(self, scene: Scene, epart: np.ndarray, nparts: int, energy: Optional[int] = None,
                  device: int = 0, rank: int = 0, world: int = 1, comm_id: Optional[bytes] = None,
-                 history: int = 5, rel_tol: float = 1e-5, iter_cap: int = 10000, flags: int = 0):
+                 history: int = 5, rel_tol: float = 1e-5, iter_cap: int = 10000, flags: int = 0, allreduce=None):
+        """allreduce: optional callable(np.ndarray) that sums the array over the ranks IN PLACE (world > 1): the
+        library then stages its collectives through host memory and calls it instead of RCCL
+        (dotmi_params::allreduce) -- e.g. a torch.distributed gloo all_reduce."""
         L = _lib.load()
         cfg = scene.cfg
         self.scene = scene
@@ -53,6 +56,12 @@ class DOTTimeStepper:
         self._comm = C.create_string_buffer(comm_id, 128) if comm_id is not None else None
         p.comm_id = C.cast(self._comm, C.c_void_p) if self._comm is not None else None
         p.flags = flags
+        self._arcb = None
+        if allreduce is not None:
+            def _cb(ctx, buf, n, _f=allreduce):
+                _f(np.ctypeslib.as_array(buf, shape=(n,)))
+            self._arcb = _lib.ALLREDUCE_CB(_cb)          # kept alive with the handle
+            p.allreduce = C.cast(self._arcb, C.c_void_p)
         x0 = np.ascontiguousarray(scene.x0, dtype=np.float64)
         h = C.c_void_p()
         rc = L.dotmi_create(C.byref(m), C.byref(p), dp(x0), C.byref(h))

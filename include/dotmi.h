@@ -67,6 +67,12 @@ typedef struct {
     int32_t world;     /* 1 = single GPU */
     const void *comm_id; /* world>1: the 128-byte id from dotmi_comm_unique_id (same on all ranks) */
     int32_t flags;     /* DOTMI_FLAG_* */
+    /* world>1, optional: a host sum-all-reduce the library calls INSTEAD of RCCL (comm_id may then be NULL): buf holds
+     * n doubles in host memory, to be replaced on every rank by the sum over the ranks; every rank calls it with the
+     * same n in the same order.  The library stages the payload through pinned host memory.  This is how a
+     * deployment without RCCL (or a test: two processes on one GPU over gloo) runs the sharded path. */
+    void (*allreduce)(void *ctx, double *buf, int64_t n);
+    void *allreduce_ctx;
 } dotmi_params;
 
 #define DOTMI_FLAG_FORCE_DIST 4     /* take the sharded code path (element lists, partial sums, RCCL
@@ -140,6 +146,15 @@ const char *dotmi_last_error(const dotmi_handle *h); /* h may be NULL: last crea
  * first_part has world+1 entries; rank r owns parts [first_part[r], first_part[r+1]).  This is the
  * split dotmi_create applies; elements follow their part (ADMMDDTimeStepper.cpp:161). */
 int dotmi_plan_shards(int32_t nParts, const int32_t *part_scalar_size, int32_t world, int32_t *first_part);
+
+/* Host-only planning helper (touches no device): everything rank `rank` of `world` owns under dotmi_create's plan --
+ * parts [*p0, *p1) (dotmi_plan_shards on the parts' scalar sizes), the elements of those parts (elems: up to nT
+ * ids ascending, *n_elems of them; elemList_subdomain of the owned parts, ADMMDDTimeStepper.cpp:161), the vertex slice
+ * [*v0, *v1) whose inertia terms / SpMV rows it adds, and part_size[nParts] = 3 x vertices of every part.  Any output
+ * pointer may be NULL. */
+int dotmi_plan_rank(int32_t nV, int32_t nT, const int32_t *T, const int32_t *epart, int32_t nParts, int32_t rank,
+                    int32_t world, int32_t *p0, int32_t *p1, int32_t *elems, int32_t *n_elems, int32_t *v0, int32_t *v1,
+                    int32_t *part_size);
 
 /* Host-only planning helper (touches no device): the nested-dissection layout dotmi_create gives the
  * dense blocks of parts [p0,p1).  The reference leaves the ordering of each subdomain matrix to CHOLMOD's

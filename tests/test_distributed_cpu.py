@@ -34,14 +34,32 @@ def _worker(rank, world, initfile, outdir):
     x = np.ascontiguousarray(sc.x0 + 0.01 * rng.standard_normal(sc.x0.shape))
     xt = sim.state()[2]
     fx = sc.fixed.astype(bool)
+    # what this rank owns comes from the LIBRARY's own plan (dotmi_plan_rank, host only: the code dotmi_create
+    # runs), not from a re-derivation; the Python mirror in dot_amd/sharding.py must agree with it
+    import ctypes as C
+    from dot_amd import lib as dl
+    Ld = dl.load()
+    T32 = np.ascontiguousarray(sc.T, dtype=np.int32)
+    ep32 = np.ascontiguousarray(ep, dtype=np.int32)
+    own = np.zeros(T32.shape[0], dtype=np.int32)
+    psz = np.zeros(nparts, dtype=np.int32)
+    p0, p1, ne, v0c, v1c = (C.c_int32() for _ in range(5))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    assert Ld.dotmi_plan_rank(sc.V_rest.shape[0], T32.shape[0], ip(T32), ip(ep32), nparts, rank, world, C.byref(p0),
+                              C.byref(p1), ip(own), C.byref(ne), C.byref(v0c), C.byref(v1c), ip(psz)) == 0
+    own = own[:ne.value]
+    v0, v1 = v0c.value, v1c.value
     first = plan_shards(part_scalar_sizes(sc.T, ep, nparts), world)
-    own = owned_elements(ep, first, rank)
-    v0, v1 = vertex_slice(sc.V_rest.shape[0], rank, world)
+    assert (first[rank], first[rank + 1]) == (p0.value, p1.value)
+    assert np.array_equal(own, owned_elements(ep, first, rank))
+    assert (v0, v1) == vertex_slice(sc.V_rest.shape[0], rank, world)
+    assert np.array_equal(psz, part_scalar_sizes(sc.T, ep, nparts))
+    for s_ in range(nparts):
+        assert psz[s_] == 3 * sim.part_verts(s_).size
 
     # ---- [g ; E]: element contributions of the owned parts + inertia of the vertex slice ---------
     buf = np.zeros(3 * len(x) + 1)
     g = buf[:-1].reshape(-1, 3)
-    import ctypes as C
     for e in own:
         ge = np.zeros(12); pe = C.c_double()
         x4 = np.ascontiguousarray(x[sc.T[e]])
