@@ -92,6 +92,7 @@ struct dotmi_handle {
     std::vector<int> dup;
     std::vector<NdNode> nd;                 // nested-dissection layout shared by the owned parts (root = 0)
     std::vector<std::vector<int>> partPos;  // owned parts: padded scalar position of partVerts[p][i]
+    std::vector<int> partTilePtr;           // owned parts: range of each part's tiles in DevParts::tileByPart
 
     // device
     hipStream_t st = nullptr;
@@ -129,6 +130,7 @@ struct dotmi_handle {
     // pinned host
     double *h_partE = nullptr, *h_partR = nullptr, *h_alpha = nullptr;
     // device-resident loop control (single-GPU path)
+    bool gsdd = false;   // DOTMI_FLAG_GSDD
     bool devLoop = false;
     DevLoop *ctl = nullptr, *h_ctl = nullptr;  // device / pinned staging
     int *h_flags = nullptr;                    // pinned: {status, slots done}, written by the controller
@@ -510,6 +512,10 @@ int build_device_mesh(dotmi_handle *h)
     for (auto &r : ranges) P.nbmax = std::max(P.nbmax, (int)r.size());
     std::vector<int2> trange((size_t)std::max(P.nParts, 1) * P.nbmax, make_int2(0, 0));
     for (int ls = 0; ls < P.nParts; ++ls) std::copy(ranges[ls].begin(), ranges[ls].end(), trange.begin() + (size_t)ls * P.nbmax);
+    const std::vector<int4> tilesByPart(tiles);   // generated part after part
+    h->partTilePtr.assign(P.nParts + 1, 0);
+    for (const int4 &t : tilesByPart) h->partTilePtr[t.x + 1]++;
+    for (int ls = 0; ls < P.nParts; ++ls) h->partTilePtr[ls + 1] += h->partTilePtr[ls];
     // heavy tiles first: work ~ rows * row length
     auto tile_work = [](const int4 &t) { return (long long)(t.z >> 16) * (t.y + 64 - t.w); };
     std::stable_sort(tiles.begin(), tiles.end(), [&](const int4 &a, const int4 &b) { return tile_work(a) > tile_work(b); });
@@ -578,6 +584,7 @@ int build_device_mesh(dotmi_handle *h)
     P.npad = (int)pad_dst.size();
     if (int rc = upload(h, &P.dofmap, dofmap)) return rc;
     if (int rc = upload(h, &P.tile, tiles)) return rc;
+    if (int rc = upload(h, &P.tileByPart, tilesByPart)) return rc;
     if (int rc = upload(h, &P.ltile, ltiles)) return rc;
     if (int rc = upload(h, &P.lwork, lwork)) return rc;
     if (int rc = dalloc(h, &P.tdots, (size_t)std::max(P.nltiles, 1) * P.maxChunks * 64)) return rc;
@@ -1385,6 +1392,53 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     return 0;
 }
 
+// The reference's Gauss-Seidel domain-decomposition iteration (`timeStepper GSDD`, DOTTimeStepper::solve_oneStep_GSDD,
+// DOTTimeStepper.cpp:507-565, driven by fullyImplicit :299-337) on this path's factors and kernels: one sweep over the
+// subdomains per iteration; for subdomain s  p_s = H_s^-1 (-g restricted to s)  (:521-527), the search direction is p_s
+// on the subdomain's vertices and zero elsewhere (:529-532), the line search starts from step 1 (initStepSize,
+// Optimizer.cpp:1076-1093: only TST_DOT estimates it) and halves while the energy increases, and the gradient is
+// brought up to date before the next subdomain (:541-551).  Host-driven: every trial needs its energy on the host.
+int run_gsdd_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *failed)
+{
+    const int n = h->n;
+    LbfgsArgs L0;
+    memset(&L0, 0, sizeof(L0));
+    double R[RED_K];
+    do {
+        for (int ls = 0; ls < h->P.nParts && !*failed; ++ls) {
+            launch_build_q(n, h->g, L0, nullptr, h->q, h->st);                     // q = -g
+            launch_gemv_part(h->P, ls, h->P.tileByPart + h->partTilePtr[ls], h->partTilePtr[ls + 1] - h->partTilePtr[ls],
+                             h->q, n, h->p, h->st);
+            double alpha = 1.0, E = 0;
+            launch_step_forward(n, h->x, h->p, h->x_trial, nullptr, alpha, 0, h->alphaMin, h->alpha_dev, h->h_alpha, h->st);
+            if (int rc = trial(h, h->x_trial, h->g_trial, 0, L0, 0, &E)) return rc;
+            while (E > *lastE && alpha > 0.0) {   // Optimizer.cpp:806-833
+                alpha /= 2.0;
+                h->numLineSearch++;
+                if (alpha == 0.0) {
+                    *failed = true;
+                    break;
+                }
+                launch_step_forward(n, h->x, h->p, h->x_trial, nullptr, alpha, 0, h->alphaMin, h->alpha_dev, h->h_alpha,
+                                    h->st);
+                if (int rc = trial(h, h->x_trial, h->g_trial, 0, L0, 0, &E)) return rc;
+            }
+            std::swap(h->x, h->x_trial);   // also on failure: the reference stays at the last trial point
+            std::swap(h->g, h->g_trial);   // the gradient of the accepted point came with its energy
+            *lastE = E;
+            h->log_alpha.push_back(alpha);
+            h->log_E.push_back(E);
+            sum_stats(h, 1, R);
+            h->log_g2.push_back(R[0]);
+        }
+        if (*failed) break;
+        sum_stats(h, 1, R);
+        *g2 = R[0];
+        if (++*it >= h->iterCap) break;
+    } while (*g2 > h->targetGRes);
+    return 0;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1735,7 +1789,13 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     HIPCHECK(h, hipHostMalloc((void **)&h->h_alpha, sizeof(double) * 8));
     {
         const char *ev = getenv("DOTMI_DEVICE_LOOP");
-        h->devLoop = !h->dist && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) && !(ev && atoi(ev) == 0);
+        h->gsdd = (h->flags & DOTMI_FLAG_GSDD) != 0;
+        if (h->gsdd && (h->dist || h->P.nltiles > 0)) {
+            h->err = "DOTMI_FLAG_GSDD: single GPU and subdomains without long-row tiles only";
+            return DOTMI_E_INVALID;
+        }
+        h->devLoop = !h->dist && !h->gsdd && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) &&
+                     !(ev && atoi(ev) == 0);
         h->logCap = std::min(h->iterCap, 10001) + 1;
         h->kindCap = 4096;
         HIPCHECK(h, hipHostMalloc((void **)&h->h_ctl, sizeof(DevLoop)));
@@ -1916,7 +1976,9 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     const double Tloop = now_ms();
     h->slotKind.clear();
     h->slotTimed.clear();
-    if (h->devLoop) {
+    if (h->gsdd) {
+        if (int rc = run_gsdd_loop(h, &lastE, &g2, &it, &failed)) return rc;
+    } else if (h->devLoop) {
         if (int rc = run_device_loop(h, &lastE, &g2, &it, &failed, &E0, &g20)) return rc;
     } else
     do {

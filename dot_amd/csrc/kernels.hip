@@ -663,10 +663,10 @@ __device__ const double g_zero_slot = 0.0;
 __global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int2 *__restrict__ trange,
                                                                const double *__restrict__ ppart, int nmax,
                                                                int nbmax, double *__restrict__ psub,
-                                                               const DevLoop *__restrict__ ctl)
+                                                               const DevLoop *__restrict__ ctl, int s0)
 {
     if (ctl && (ctl->status != 0 || ctl->phase != 0)) return;
-    const int s = blockIdx.y;
+    const int s = blockIdx.y + s0;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= nmax) return;
     const int2 *tr = trange + (size_t)s * nbmax;
@@ -839,7 +839,33 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
                            P.W, P.nmax, q, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl);
     }
     hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.trange,
-                       P.ppart, P.nmax, P.nbmax, P.psub, ctl);
+                       P.ppart, P.nmax, P.nbmax, P.psub, ctl, 0);
+}
+
+// p[dofmap_s[k]] = psub_s[k] on the live positions of part s (p was cleared by the caller)
+__global__ __launch_bounds__(256) void fill_part_kernel(const int *__restrict__ dofmap, const double *__restrict__ psub,
+                                                        int nmax, int s, double *__restrict__ p)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= nmax) return;
+    const int d = dofmap[(size_t)s * nmax + k];
+    if (d >= 0) p[d] = psub[(size_t)s * nmax + k];
+}
+
+void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, const double *q, int n, double *p,
+                      hipStream_t st)
+{
+    hipMemsetAsync(p, 0, sizeof(double) * n, st);
+    if (njobs <= 0) return;
+    if (P.maxTileLen <= 2560)
+        hipLaunchKernelGGL((backsolve_kernel<256>), dim3(njobs), dim3(256), 0, st, job, P.dofmap, P.W, P.nmax, q, P.ppart,
+                           P.nbmax, (const DevLoop *)nullptr);
+    else
+        hipLaunchKernelGGL((backsolve_kernel<512>), dim3(njobs), dim3(512), 0, st, job, P.dofmap, P.W, P.nmax, q, P.ppart,
+                           P.nbmax, (const DevLoop *)nullptr);
+    hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, 1), dim3(256), 0, st, P.trange, P.ppart, P.nmax,
+                       P.nbmax, P.psub, (const DevLoop *)nullptr, ls);
+    hipLaunchKernelGGL(fill_part_kernel, dim3((P.nmax + 255) / 256), dim3(256), 0, st, P.dofmap, P.psub, P.nmax, ls, p);
 }
 
 // ------------------------------------------------------------------------------------------------

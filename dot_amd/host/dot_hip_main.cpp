@@ -163,6 +163,7 @@ int main(int argc, char **argv)
         // the reference keeps its timer_step running all the time; here the per-phase HIP-event brackets cost a
         // host-driven loop, so they are on whenever files are written unless --fast asks for the device-resident loop
         if (files && !fast) opt.flags |= DOTMI_FLAG_TIME_PHASES;
+        if (cfg.timeStepper == "GSDD") opt.flags |= DOTMI_FLAG_GSDD;   // `timeStepper GSDD <n>`: the Gauss-Seidel sibling
 
         FILE *fIter = nullptr, *fLog = nullptr;
         if (files) {

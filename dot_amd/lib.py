@@ -22,6 +22,7 @@ FLAG_TIME_BACKSOLVE = 2
 FLAG_FORCE_DIST = 4
 FLAG_HOST_LOOP = 8
 FLAG_TIME_PHASES = 16
+FLAG_GSDD = 32
 
 
 class Mesh(C.Structure):

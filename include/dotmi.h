@@ -109,6 +109,13 @@ enum {
     DOTMI_T_COUNT = 14
 };
 
+#define DOTMI_FLAG_GSDD 32           /* dotmi_step runs the reference's Gauss-Seidel domain-decomposition iteration
+                                     * (`timeStepper GSDD <n>`, DOTTimeStepper::solve_oneStep_GSDD,
+                                     * DOTTimeStepper.cpp:507-565) on the same factors and kernels instead of
+                                     * L-BFGS-H: per iteration one sweep over the subdomains -- solve H_s p_s = -g_s,
+                                     * line search from step 1 along p_s, refresh the gradient.  stats.iters = sweeps.
+                                     * Single GPU; subdomains whose rows exceed 4096 columns are not supported here. */
+
 typedef struct {
     int32_t iters;        /* L-BFGS iterations (innerIterAmt delta, DOTTimeStepper.cpp:338) */
     int32_t ls_halvings;  /* numOfLineSearch delta (Optimizer.cpp:816) */

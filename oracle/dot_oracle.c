@@ -1257,6 +1257,62 @@ int dor_step_end(dor_sim *s, dor_step_stats *st, double T0)
     return status;
 }
 
+/* `timeStepper GSDD`: DOTTimeStepper::solve_oneStep_GSDD (DOTTimeStepper.cpp:507-565) inside fullyImplicit's loop
+ * (:299-337).  One iteration = one Gauss-Seidel sweep over the subdomains: for subdomain sI the right-hand side is minus
+ * the CURRENT gradient on its vertices (:509-511 for the first, computeGradient_extract :546-550 afterwards), the
+ * search direction is the subdomain solve filled into a zero vector (:521-532, ADMMDDTimeStepper::fill :1646-1665), the
+ * line search starts at step 1 (Optimizer::initStepSize :1076-1093 -- only TST_DOT estimates the step) and halves while
+ * the energy increases (:806-833). */
+int dor_step_gsdd(dor_sim *s, dor_step_stats *st)
+{
+    double T0 = now_ms();
+    int n = 3 * s->nV;
+    dor_step_begin(s);
+    do {
+        for (int sI = 0; sI < s->nParts && !s->failed; ++sI) {
+            const dor_part *P = &s->parts[sI];
+            double *b = malloc(sizeof(double) * 3 * (P->nv > 0 ? P->nv : 1));
+            for (int pi = 0; pi < P->nv; ++pi) {
+                int v = P->l2g[P->ord[pi]];
+                for (int d = 0; d < 3; ++d) b[3 * pi + d] = -s->g[3 * v + d];
+            }
+            solve_part(P, b);
+            memset(s->p, 0, sizeof(double) * n);
+            for (int i = 0; i < P->nv; ++i) {
+                int v = P->l2g[i], pi = P->pos[i];
+                for (int d = 0; d < 3; ++d) s->p[3 * v + d] = b[3 * pi + d];
+            }
+            free(b);
+            double alpha = 1.0;
+            memcpy(s->x0, s->x, sizeof(double) * n);
+            for (int i = 0; i < n; ++i) s->x[i] = s->x0[i] + alpha * s->p[i];
+            double E = dor_eval_energy(s, s->x);
+            while (E > s->lastE && alpha > 0.0) {
+                alpha /= 2.0;
+                s->numLineSearch++;
+                if (alpha == 0.0) {
+                    s->failed = 1;
+                    break;
+                }
+                for (int i = 0; i < n; ++i) s->x[i] = s->x0[i] + alpha * s->p[i];
+                E = dor_eval_energy(s, s->x);
+            }
+            s->lastE = E;
+            dor_eval_gradient(s, s->x, s->g);
+        }
+        if (s->failed) break;
+        s->g2 = dotn(s->g, s->g, n);
+        if (s->log_n < s->log_cap) {
+            s->log_alpha[s->log_n] = 0.0;
+            s->log_E[s->log_n] = s->lastE;
+            s->log_g2[s->log_n] = s->g2;
+            s->log_n++;
+        }
+        if (++s->it >= 10000) break;
+    } while (s->g2 > s->targetGRes);
+    return dor_step_end(s, st, T0);
+}
+
 int dor_step(dor_sim *s, dor_step_stats *st)
 {
     double T0 = now_ms();

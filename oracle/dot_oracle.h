@@ -68,6 +68,8 @@ void dor_destroy(dor_sim *s);
 /* scripted Dirichlet motion: x[idx[k]] = pos[3k..] (AnimScripter.cpp:456-466) */
 void dor_move(dor_sim *s, int n, const int *idx, const double *pos);
 int dor_step(dor_sim *s, dor_step_stats *st);
+/* the same step with the reference's GSDD iteration (DOTTimeStepper::solve_oneStep_GSDD, DOTTimeStepper.cpp:507-565) */
+int dor_step_gsdd(dor_sim *s, dor_step_stats *st);
 /* the same step in pieces (teacher forcing: stop between two L-BFGS iterations):
  * begin = initX + first evaluation; iterate = one solve_oneStep, returns 0 go on / 1 converged / 2 cap /
  * 3 line search failed; end = refactor + BE update (T0 = 0: no wall time) */

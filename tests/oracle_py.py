@@ -54,6 +54,8 @@ def lib():
         L.dor_move.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp]
         L.dor_step.argtypes = [C.c_void_p, C.POINTER(StepStats)]
         L.dor_step.restype = C.c_int
+        L.dor_step_gsdd.argtypes = [C.c_void_p, C.POINTER(StepStats)]
+        L.dor_step_gsdd.restype = C.c_int
         L.dor_step_begin.argtypes = [C.c_void_p]
         L.dor_step_iterate.argtypes = [C.c_void_p]
         L.dor_step_iterate.restype = C.c_int
@@ -135,6 +137,11 @@ class OracleSim:
     def step(self):
         st = StepStats()
         lib().dor_step(self.h, C.byref(st))
+        return st
+
+    def step_gsdd(self):
+        st = StepStats()
+        lib().dor_step_gsdd(self.h, C.byref(st))
         return st
 
     # ---- a step in pieces (teacher forcing) ----

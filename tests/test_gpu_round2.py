@@ -401,3 +401,24 @@ def test_builtin_partitioner_through_the_abi():
     assert np.array_equal(x1, ts0.getResult()) and np.abs(x1 - orc.state()[0]).max() < 1e-9
     L.dotmi_destroy(h)
     ts0.close(); orc.close()
+
+
+# ---- f4, first slice: the reference's GSDD iteration on the same factors and kernels --------------------------------
+@pytest.mark.parametrize("name,energy,steps", [("bunny5K_LTSS", "FCR", 2), ("synbar:12x4x4:6", "SNH", 3)])
+def test_gsdd_steps_match_oracle(name, energy, steps):
+    """`timeStepper GSDD <n>` (DOTTimeStepper::solve_oneStep_GSDD, DOTTimeStepper.cpp:507-565): Gauss-Seidel sweeps over
+    the subdomains, each with its own solve + line search from step 1.  DOTMI_FLAG_GSDD vs dor_step_gsdd: identical
+    sweep counts and halvings, positions to 1e-9; and it converges to the same tolerance as L-BFGS-H."""
+    sc, ep, n, ts, orc = make_pair(name, energy=energy, flags=dl.FLAG_GSDD)
+    for k in range(steps):
+        x = ts.getResult()
+        idx, pos = sc.scripter.step(x, sc.cfg.dt)
+        ts.setDirichlet(idx, pos)
+        orc.move(idx, pos)
+        st, so = ts.step(), orc.step_gsdd()
+        print(name, "GSDD step", k, "sweeps", st.iters, so.iters, "halvings", st.ls_halvings, so.ls_halvings)
+        assert (st.status, st.iters, st.ls_halvings) == (so.status, so.iters, so.ls_halvings), k
+        assert st.g2 <= ts.targetGRes and abs(st.E - so.E) <= 1e-10 * abs(so.E)
+        assert st.energy_evals == so.energy_evals
+    assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
+    ts.close(); orc.close()
