@@ -43,6 +43,7 @@ struct Options {  // the Config fields the DOT stepper reads (src/Config.hpp)
     const int32_t *epart = nullptr;  // METIS::partMesh result (nT)
     int device = 0, rank = 0, world = 1;
     const void *commId = nullptr;
+    double alphaMin = 0.1;  // lower clamp of alpha_0 (Optimizer.cpp:1085); 1.0 = unit first step (LBFGS-H, :1088)
     int flags = 0;  // DOTMI_FLAG_* (e.g. DOTMI_FLAG_TIME_PHASES to fill the reference's timer_step slots)
 };
 
@@ -97,7 +98,7 @@ public:
         p.relTol = relTol_;
         p.history = 5;        // DOTTimeStepper.cpp:45
         p.iterCap = 10000;    // DOTTimeStepper.cpp:302
-        p.alphaMin = 0.1;     // Optimizer.cpp:1085
+        p.alphaMin = opt_.alphaMin;
         p.device = opt_.device;
         p.rank = opt_.rank;
         p.world = opt_.world;

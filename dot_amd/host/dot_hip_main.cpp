@@ -89,11 +89,18 @@ int main(int argc, char **argv)
         AnimScripter scripter(cfg.script, mesh.V, border);
         std::vector<double> x0 = scripter.initial_positions(mesh.V);
 
+        // `timeStepper LBFGSH` (LBFGSTimeStepper with D0T_H, LBFGSTimeStepper.cpp:196-262, :338-420): L-BFGS whose initial
+        // inverse Hessian is the factored GLOBAL projected Hessian and whose line search starts from step 1 -- this
+        // path with the whole mesh as ONE subdomain (no averaging: dup = 1) and the alpha_0 clamp at 1
+        const bool lbfgsH = cfg.timeStepper == "LBFGSH";
         int nParts = partsOverride > 0 ? partsOverride : cfg.partitionAmt;
+        if (lbfgsH) nParts = 1;
         if (cfg.blockSize > 0 && partsOverride <= 0) nParts = mesh.nV() / cfg.blockSize + 1;  // main.cpp:792-798
-        if (nParts < 2) nParts = 4;
+        if (nParts < 2 && !lbfgsH) nParts = 4;
         std::vector<int32_t> epart;
-        if (!epartFile.empty()) {
+        if (lbfgsH) {
+            epart.assign(mesh.nT(), 0);
+        } else if (!epartFile.empty()) {
             std::ifstream f(epartFile, std::ios::binary);
             epart.resize(mesh.nT());
             f.read((char *)epart.data(), sizeof(int32_t) * epart.size());
@@ -163,7 +170,8 @@ int main(int argc, char **argv)
         // the reference keeps its timer_step running all the time; here the per-phase HIP-event brackets cost a
         // host-driven loop, so they are on whenever files are written unless --fast asks for the device-resident loop
         if (files && !fast) opt.flags |= DOTMI_FLAG_TIME_PHASES;
-        if (cfg.timeStepper == "GSDD") opt.flags |= DOTMI_FLAG_GSDD;   // `timeStepper GSDD <n>`: the Gauss-Seidel sibling
+        if (cfg.timeStepper == "GSDD") opt.flags |= DOTMI_FLAG_GSDD;
+        if (lbfgsH) opt.alphaMin = 1.0;   // `timeStepper GSDD <n>`: the Gauss-Seidel sibling
 
         FILE *fIter = nullptr, *fLog = nullptr;
         if (files) {

@@ -20,7 +20,8 @@ from .scene import Scene, lame
 class DOTTimeStepper:
     def __init__(self, scene: Scene, epart: np.ndarray, nparts: int, energy: Optional[int] = None,
                  device: int = 0, rank: int = 0, world: int = 1, comm_id: Optional[bytes] = None,
-                 history: int = 5, rel_tol: float = 1e-5, iter_cap: int = 10000, flags: int = 0, allreduce=None):
+                 history: int = 5, rel_tol: float = 1e-5, iter_cap: int = 10000, flags: int = 0, allreduce=None,
+                 alpha_min: float = 0.1):
         """allreduce: optional callable(np.ndarray) that sums the array over the ranks IN PLACE (world > 1): the
         library then stages its collectives through host memory and calls it instead of RCCL
         (dotmi_params::allreduce) -- e.g. a torch.distributed gloo all_reduce."""
@@ -50,7 +51,7 @@ class DOTTimeStepper:
         p.relTol = rel_tol
         p.history = history
         p.iterCap = iter_cap
-        p.alphaMin = 0.1
+        p.alphaMin = alpha_min   # 0.1 = DOT's clamp (Optimizer.cpp:1085); 1.0 = the unit first step of LBFGS-H (:1088)
         p.device = device
         p.rank, p.world = rank, world
         self._comm = C.create_string_buffer(comm_id, 128) if comm_id is not None else None

@@ -422,6 +422,8 @@ typedef struct {
 struct dor_sim {
     int nV, nT, mat, nParts;
     double dt, dtSq, gravity[3], relTol, targetGRes;
+    double alphaMin; /* lower clamp of the initial step length: 0.1 for DOT (Optimizer.cpp:1085); 1 = the fixed unit step of
+                        the other steppers (initStepSize's else branch, :1088) */
     int *T;
     double *Xrest, *A, *vol, *mu, *lam, *mass;
     unsigned char *fixed;
@@ -1031,6 +1033,7 @@ dor_sim *dor_create(int nV, int nT, const double *Xrest, const int *T, double YM
     s->dtSq = dt * dt;
     s->gravity[1] = withGravity ? -9.80665 : 0.0; /* Optimizer.cpp:107-110 */
     s->relTol = relTol;
+    s->alphaMin = 0.1;
     int n = 3 * nV;
     s->T = malloc(sizeof(int) * 4 * (size_t)nT);
     memcpy(s->T, T, sizeof(int) * 4 * (size_t)nT);
@@ -1112,7 +1115,7 @@ static int line_search(dor_sim *s, double *alpha_out, double *lastE)
     int n = 3 * s->nV;
     dor_spmv(s, s->p, s->Hp);
     double pg = dotn(s->p, s->g, n), pHp = dotn(s->p, s->Hp, n);
-    double alpha = fmax(0.1, fmin(1.0, -pg / pHp));
+    double alpha = fmax(s->alphaMin, fmin(1.0, -pg / pHp));
     memcpy(s->x0, s->x, sizeof(double) * n);
     for (int i = 0; i < n; ++i) s->x[i] = s->x0[i] + alpha * s->p[i];
     double E = dor_eval_energy(s, s->x);
@@ -1362,7 +1365,7 @@ void dor_probe_direction(dor_sim *s, const double *x, int m, const double *S, co
     }
     dor_spmv(s, p, Hp);
     double pg = dotn(p, g, n), pHp = dotn(p, Hp, n);
-    double a = fmax(0.1, fmin(1.0, -pg / pHp));
+    double a = fmax(s->alphaMin, fmin(1.0, -pg / pHp));
     for (int i = 0; i < n; ++i) xt[i] = x[i] + a * p[i];
     if (Etrial) *Etrial = dor_eval_energy(s, xt);
     if (alpha0) *alpha0 = a;
@@ -1401,6 +1404,7 @@ void dor_set_state(dor_sim *s, const double *x, const double *v, const double *x
 }
 
 double dor_target_gres(const dor_sim *s) { return s->targetGRes; }
+void dor_set_alpha_min(dor_sim *s, double a) { s->alphaMin = a; }
 
 /* fixed set changed by the script (rubberBandPull release, AnimScripter.cpp:404-417):
  * Optimizer::solve -> updatePrecondMtrAndFactorize (DOTTimeStepper.cpp:185-270) re-patterns and

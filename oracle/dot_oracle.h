@@ -87,6 +87,8 @@ int dor_last_iter_log(const dor_sim *s, int cap, double *alpha, double *E, doubl
 void dor_get_state(const dor_sim *s, double *x, double *v, double *xtilde);
 void dor_set_state(dor_sim *s, const double *x, const double *v, const double *xn);
 double dor_target_gres(const dor_sim *s);
+/* lower clamp of the initial step length: 0.1 = DOT (Optimizer.cpp:1085), 1.0 = unit step of the other steppers (:1088) */
+void dor_set_alpha_min(dor_sim *s, double a);
 void dor_set_fixed(dor_sim *s, const unsigned char *fixed);
 
 /* features / structure getters */

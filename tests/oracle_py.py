@@ -70,6 +70,7 @@ def lib():
         L.dor_set_state.argtypes = [C.c_void_p, c_dp, c_dp, c_dp]
         L.dor_target_gres.argtypes = [C.c_void_p]
         L.dor_target_gres.restype = C.c_double
+        L.dor_set_alpha_min.argtypes = [C.c_void_p, C.c_double]
         L.dor_set_fixed.argtypes = [C.c_void_p, c_up]
         L.dor_get_features.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_dp, c_dp]
         L.dor_get_dup.argtypes = [C.c_void_p, c_ip]
@@ -195,6 +196,9 @@ class OracleSim:
         v = np.ascontiguousarray(v, dtype=np.float64)
         xn_p = _dp(np.ascontiguousarray(xn, dtype=np.float64)) if xn is not None else None
         lib().dor_set_state(self.h, _dp(x), _dp(v), xn_p)
+
+    def set_alpha_min(self, a):
+        lib().dor_set_alpha_min(self.h, float(a))
 
     def set_fixed(self, fixed):
         fixed = np.ascontiguousarray(fixed, dtype=np.uint8)

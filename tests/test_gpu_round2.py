@@ -422,3 +422,33 @@ def test_gsdd_steps_match_oracle(name, energy, steps):
         assert st.energy_evals == so.energy_evals
     assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
     ts.close(); orc.close()
+
+
+# ---- f4: LBFGS-H (`timeStepper LBFGSH`) = this path with the whole mesh as ONE subdomain and a unit first step --------
+def test_lbfgs_h_is_the_one_subdomain_case_with_unit_first_step():
+    """LBFGSTimeStepper with D0T_H (LBFGSTimeStepper.cpp:196-262 precompute, :338-420 solve_oneStep, :300-307 refresh):
+    the same two-loop recursion with the factored GLOBAL projected Hessian as initial inverse Hessian, refreshed at the
+    end of every step, and a line search that starts from step 1 (Optimizer::initStepSize only estimates alpha_0 for
+    TST_DOT, Optimizer.cpp:1076-1093).  Here: nParts = 1 (no interface, dup = 1) and alphaMin = 1, which makes
+    clamp(-p.g / p.Hp, alphaMin, 1) the constant 1.  Against the oracle configured the same way; and the first
+    direction of a step is the Newton direction of the projected Hessian: H p = -g."""
+    sc, _, _ = load_workload("synbar:16x5x5:1")
+    cfg = sc.cfg
+    ep = np.zeros(sc.T.shape[0], dtype=np.int32)
+    ts = DOTTimeStepper(sc, ep, 1, alpha_min=1.0)
+    orc = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, 1,
+                      cfg.with_gravity)
+    orc.set_alpha_min(1.0)
+    for k in range(4):
+        (st, so), = run_both(sc, ts, orc, 1)
+        assert (st.status, st.iters, st.ls_halvings) == (so.status, so.iters, so.ls_halvings), k
+        a, _, _ = ts.iterLog()
+        assert np.all(a == 2.0 ** -np.round(-np.log2(a)))        # every accepted step is 1, 1/2, 1/4, ...
+        assert a[0] == 1.0 or st.ls_halvings > 0
+    assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
+    x = ts.getResult()
+    pr = ts.probeDirection(x)
+    Hp = ts.multiply(pr["p"])
+    assert np.abs(Hp + pr["g"]).max() <= 1e-9 * np.abs(pr["g"]).max()
+    assert pr["alpha0"] == 1.0
+    ts.close(); orc.close()
