@@ -131,6 +131,7 @@ struct dotmi_handle {
     double *h_partE = nullptr, *h_partR = nullptr, *h_alpha = nullptr;
     // device-resident loop control (single-GPU path)
     bool gsdd = false;   // DOTMI_FLAG_GSDD
+    bool newton = false; // DOTMI_FLAG_NEWTON
     bool devLoop = false;
     DevLoop *ctl = nullptr, *h_ctl = nullptr;  // device / pinned staging
     int *h_flags = nullptr;                    // pinned: {status, slots done}, written by the controller
@@ -1439,6 +1440,47 @@ int run_gsdd_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *fai
     return 0;
 }
 
+// The reference's projected Newton (`timeStepper Newton`: the base Optimizer::fullyImplicit, Optimizer.cpp:654-700, with
+// Optimizer::solve_oneStep :703-749 and needRefactorize set): per iteration the projected Hessian at the current iterate
+// is assembled and factorised (:705-729), p = H^-1 (-g) (:735-737), the line search starts from step 1 (initStepSize
+// :1088) and the gradient is refreshed (:745).  Uses the same refresh / back-solve kernels as the DOT path.
+int run_newton_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *failed, double *ms_hess, double *ms_fact)
+{
+    const int n = h->n;
+    LbfgsArgs L0;
+    memset(&L0, 0, sizeof(L0));
+    double R[RED_K];
+    do {
+        if (int rc = refactor(h, h->x, ms_hess, ms_fact)) return rc;
+        launch_build_q(n, h->g, L0, nullptr, h->q, h->st);                     // q = -g
+        if (int rc = apply_precond(h, h->q, h->p, L0)) return rc;               // p = H^-1 q (one subdomain: no averaging)
+        double alpha = 1.0, E = 0;
+        launch_step_forward(n, h->x, h->p, h->x_trial, nullptr, alpha, 0, h->alphaMin, h->alpha_dev, h->h_alpha, h->st);
+        if (int rc = trial(h, h->x_trial, h->g_trial, 0, L0, 0, &E)) return rc;
+        while (E > *lastE && alpha > 0.0) {   // Optimizer.cpp:806-833
+            alpha /= 2.0;
+            h->numLineSearch++;
+            if (alpha == 0.0) {
+                *failed = true;
+                break;
+            }
+            launch_step_forward(n, h->x, h->p, h->x_trial, nullptr, alpha, 0, h->alphaMin, h->alpha_dev, h->h_alpha, h->st);
+            if (int rc = trial(h, h->x_trial, h->g_trial, 0, L0, 0, &E)) return rc;
+        }
+        std::swap(h->x, h->x_trial);
+        std::swap(h->g, h->g_trial);
+        *lastE = E;
+        if (*failed) break;
+        sum_stats(h, 1, R);
+        *g2 = R[0];
+        h->log_alpha.push_back(alpha);
+        h->log_E.push_back(E);
+        h->log_g2.push_back(*g2);
+        if (++*it >= h->iterCap) break;
+    } while (*g2 > h->targetGRes);
+    return 0;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1790,11 +1832,16 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     {
         const char *ev = getenv("DOTMI_DEVICE_LOOP");
         h->gsdd = (h->flags & DOTMI_FLAG_GSDD) != 0;
+        h->newton = (h->flags & DOTMI_FLAG_NEWTON) != 0;
+        if (h->newton && (h->dist || h->gsdd)) {
+            h->err = "DOTMI_FLAG_NEWTON: single GPU, not together with DOTMI_FLAG_GSDD";
+            return DOTMI_E_INVALID;
+        }
         if (h->gsdd && (h->dist || h->P.nltiles > 0)) {
             h->err = "DOTMI_FLAG_GSDD: single GPU and subdomains without long-row tiles only";
             return DOTMI_E_INVALID;
         }
-        h->devLoop = !h->dist && !h->gsdd && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) &&
+        h->devLoop = !h->dist && !h->gsdd && !h->newton && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) &&
                      !(ev && atoi(ev) == 0);
         h->logCap = std::min(h->iterCap, 10001) + 1;
         h->kindCap = 4096;
@@ -1976,7 +2023,9 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     const double Tloop = now_ms();
     h->slotKind.clear();
     h->slotTimed.clear();
-    if (h->gsdd) {
+    if (h->newton) {
+        if (int rc = run_newton_loop(h, &lastE, &g2, &it, &failed, &ms_hess, &ms_fact)) return rc;
+    } else if (h->gsdd) {
         if (int rc = run_gsdd_loop(h, &lastE, &g2, &it, &failed)) return rc;
     } else if (h->devLoop) {
         if (int rc = run_device_loop(h, &lastE, &g2, &it, &failed, &E0, &g20)) return rc;
@@ -2073,10 +2122,12 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     } while (g2 > h->targetGRes);
     const double Tloop1 = now_ms();
 
+    const bool refreshAtEnd = !failed && !h->newton;   // Newton refreshes at the START of every iteration instead
     if (failed) status = 2;
     else {
         if (it >= h->iterCap) status = 2;
-        if (int rc = refactor_issue(h, h->x)) return rc;
+        if (refreshAtEnd)
+            if (int rc = refactor_issue(h, h->x)) return rc;
     }
     // BE update (Optimizer.cpp:354-361)
     phase_mark(h, -1);
@@ -2086,7 +2137,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     phase_collect(h);
     HIPCHECK(h, hipGetLastError());
     int rcFactor = 0;
-    if (!failed) rcFactor = refactor_finish(h, &ms_hess, &ms_fact);
+    if (refreshAtEnd) rcFactor = refactor_finish(h, &ms_hess, &ms_fact);
     if (rcFactor == DOTMI_E_DEVICE) return rcFactor;
     if (st) {
         memset(st, 0, sizeof(*st));

@@ -92,7 +92,8 @@ int main(int argc, char **argv)
         // `timeStepper LBFGSH` (LBFGSTimeStepper with D0T_H, LBFGSTimeStepper.cpp:196-262, :338-420): L-BFGS whose initial
         // inverse Hessian is the factored GLOBAL projected Hessian and whose line search starts from step 1 -- this
         // path with the whole mesh as ONE subdomain (no averaging: dup = 1) and the alpha_0 clamp at 1
-        const bool lbfgsH = cfg.timeStepper == "LBFGSH";
+        const bool newton = cfg.timeStepper == "Newton";   // projected Newton: one subdomain, DOTMI_FLAG_NEWTON
+        const bool lbfgsH = cfg.timeStepper == "LBFGSH" || newton;
         int nParts = partsOverride > 0 ? partsOverride : cfg.partitionAmt;
         if (lbfgsH) nParts = 1;
         if (cfg.blockSize > 0 && partsOverride <= 0) nParts = mesh.nV() / cfg.blockSize + 1;  // main.cpp:792-798
@@ -171,7 +172,8 @@ int main(int argc, char **argv)
         // host-driven loop, so they are on whenever files are written unless --fast asks for the device-resident loop
         if (files && !fast) opt.flags |= DOTMI_FLAG_TIME_PHASES;
         if (cfg.timeStepper == "GSDD") opt.flags |= DOTMI_FLAG_GSDD;
-        if (lbfgsH) opt.alphaMin = 1.0;   // `timeStepper GSDD <n>`: the Gauss-Seidel sibling
+        if (lbfgsH) opt.alphaMin = 1.0;
+        if (newton) opt.flags |= DOTMI_FLAG_NEWTON;   // `timeStepper GSDD <n>`: the Gauss-Seidel sibling
 
         FILE *fIter = nullptr, *fLog = nullptr;
         if (files) {

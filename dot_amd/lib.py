@@ -23,6 +23,7 @@ FLAG_FORCE_DIST = 4
 FLAG_HOST_LOOP = 8
 FLAG_TIME_PHASES = 16
 FLAG_GSDD = 32
+FLAG_NEWTON = 64
 
 
 class Mesh(C.Structure):

@@ -116,6 +116,14 @@ enum {
                                      * line search from step 1 along p_s, refresh the gradient.  stats.iters = sweeps.
                                      * Single GPU; subdomains whose rows exceed 4096 columns are not supported here. */
 
+#define DOTMI_FLAG_NEWTON 64         /* dotmi_step runs the reference's projected Newton (`timeStepper Newton`, the base
+                                     * Optimizer::fullyImplicit / solve_oneStep, Optimizer.cpp:654-749): every iteration
+                                     * re-evaluates the projected Hessian at the current iterate, factorises, solves
+                                     * H p = -g and line-searches from step 1; no refresh at the end of the step.  It is
+                                     * the reference's method when the mesh is ONE subdomain (nParts = 1); with more
+                                     * subdomains the solve is the domain-decomposed block solve instead of H^-1.
+                                     * stats.iters = Newton iterations.  Single GPU. */
+
 typedef struct {
     int32_t iters;        /* L-BFGS iterations (innerIterAmt delta, DOTTimeStepper.cpp:338) */
     int32_t ls_halvings;  /* numOfLineSearch delta (Optimizer.cpp:816) */

@@ -1316,6 +1316,49 @@ int dor_step_gsdd(dor_sim *s, dor_step_stats *st)
     return dor_step_end(s, st, T0);
 }
 
+/* `timeStepper Newton`: the base Optimizer::fullyImplicit (Optimizer.cpp:654-700) with Optimizer::solve_oneStep
+ * (:703-749, needRefactorize): per iteration assemble + factorise the projected Hessian at the current iterate, solve
+ * H p = -g, line search from step 1 (:1088), refresh the gradient.  The reference's method for nParts = 1 (the block
+ * solve is then the global solve). */
+int dor_step_newton(dor_sim *s, dor_step_stats *st)
+{
+    double T0 = now_ms();
+    int n = 3 * s->nV;
+    dor_step_begin(s);
+    do {
+        dor_refactor(s, s->x);
+        for (int i = 0; i < n; ++i) s->q[i] = -s->g[i];
+        dor_apply_precond(s, s->q, s->p);
+        double alpha = 1.0;
+        memcpy(s->x0, s->x, sizeof(double) * n);
+        for (int i = 0; i < n; ++i) s->x[i] = s->x0[i] + alpha * s->p[i];
+        double E = dor_eval_energy(s, s->x);
+        while (E > s->lastE && alpha > 0.0) {
+            alpha /= 2.0;
+            s->numLineSearch++;
+            if (alpha == 0.0) {
+                s->failed = 1;
+                break;
+            }
+            for (int i = 0; i < n; ++i) s->x[i] = s->x0[i] + alpha * s->p[i];
+            E = dor_eval_energy(s, s->x);
+        }
+        s->lastE = E;
+        dor_eval_gradient(s, s->x, s->g);
+        if (s->failed) break;
+        s->g2 = dotn(s->g, s->g, n);
+        if (s->log_n < s->log_cap) {
+            s->log_alpha[s->log_n] = alpha;
+            s->log_E[s->log_n] = s->lastE;
+            s->log_g2[s->log_n] = s->g2;
+            s->log_n++;
+        }
+        if (++s->it >= 10000) break;
+    } while (s->g2 > s->targetGRes);
+    /* dor_step_end refreshes the factors once more; harmless: the next step's first iteration does it again */
+    return dor_step_end(s, st, T0);
+}
+
 int dor_step(dor_sim *s, dor_step_stats *st)
 {
     double T0 = now_ms();

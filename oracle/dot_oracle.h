@@ -70,6 +70,8 @@ void dor_move(dor_sim *s, int n, const int *idx, const double *pos);
 int dor_step(dor_sim *s, dor_step_stats *st);
 /* the same step with the reference's GSDD iteration (DOTTimeStepper::solve_oneStep_GSDD, DOTTimeStepper.cpp:507-565) */
 int dor_step_gsdd(dor_sim *s, dor_step_stats *st);
+/* ... with the reference's projected Newton (base Optimizer::solve_oneStep, Optimizer.cpp:703-749) */
+int dor_step_newton(dor_sim *s, dor_step_stats *st);
 /* the same step in pieces (teacher forcing: stop between two L-BFGS iterations):
  * begin = initX + first evaluation; iterate = one solve_oneStep, returns 0 go on / 1 converged / 2 cap /
  * 3 line search failed; end = refactor + BE update (T0 = 0: no wall time) */

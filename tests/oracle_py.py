@@ -56,6 +56,8 @@ def lib():
         L.dor_step.restype = C.c_int
         L.dor_step_gsdd.argtypes = [C.c_void_p, C.POINTER(StepStats)]
         L.dor_step_gsdd.restype = C.c_int
+        L.dor_step_newton.argtypes = [C.c_void_p, C.POINTER(StepStats)]
+        L.dor_step_newton.restype = C.c_int
         L.dor_step_begin.argtypes = [C.c_void_p]
         L.dor_step_iterate.argtypes = [C.c_void_p]
         L.dor_step_iterate.restype = C.c_int
@@ -143,6 +145,11 @@ class OracleSim:
     def step_gsdd(self):
         st = StepStats()
         lib().dor_step_gsdd(self.h, C.byref(st))
+        return st
+
+    def step_newton(self):
+        st = StepStats()
+        lib().dor_step_newton(self.h, C.byref(st))
         return st
 
     # ---- a step in pieces (teacher forcing) ----

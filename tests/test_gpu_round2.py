@@ -452,3 +452,26 @@ def test_lbfgs_h_is_the_one_subdomain_case_with_unit_first_step():
     assert np.abs(Hp + pr["g"]).max() <= 1e-9 * np.abs(pr["g"]).max()
     assert pr["alpha0"] == 1.0
     ts.close(); orc.close()
+
+
+def test_projected_newton_matches_oracle():
+    """`timeStepper Newton` (base Optimizer::fullyImplicit + solve_oneStep, Optimizer.cpp:654-749): per iteration a
+    fresh projected Hessian, factorisation, H p = -g, line search from 1.  DOTMI_FLAG_NEWTON with the mesh as one
+    subdomain vs dor_step_newton; Newton converges in a handful of iterations where L-BFGS-H takes more."""
+    sc, _, _ = load_workload("synbar:16x5x5:1")
+    cfg = sc.cfg
+    ep = np.zeros(sc.T.shape[0], dtype=np.int32)
+    ts = DOTTimeStepper(sc, ep, 1, flags=dl.FLAG_NEWTON)
+    orc = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, 1,
+                      cfg.with_gravity)
+    for k in range(3):
+        x = ts.getResult()
+        idx, pos = sc.scripter.step(x, cfg.dt)
+        ts.setDirichlet(idx, pos)
+        orc.move(idx, pos)
+        st, so = ts.step(), orc.step_newton()
+        print("Newton step", k, "iterations", st.iters, so.iters, "halvings", st.ls_halvings, so.ls_halvings)
+        assert (st.status, st.iters, st.ls_halvings) == (so.status, so.iters, so.ls_halvings), k
+        assert st.g2 <= ts.targetGRes and st.iters <= 8
+    assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
+    ts.close(); orc.close()
