@@ -84,7 +84,7 @@ struct dotmi_handle {
     std::string err;
 
     // host copies
-    std::vector<int> T, epart;
+    std::vector<int> T, epart, vpart;
     std::vector<uint8_t> fixed;
     std::vector<double> Xrest, A, vol, mass, mu, lam;
     int nPartsAll = 0, p0 = 0, p1 = 0;  // owned global parts [p0,p1)
@@ -409,6 +409,9 @@ int build_device_mesh(dotmi_handle *h)
     h->partVerts.assign(nP, {});
     {
         std::vector<int> mark(nV, -1);
+        if (!h->vpart.empty()) {   // vertex partition given: disjoint vertex sets (block-Jacobi, LBFGS-JH)
+            for (int v = 0; v < nV; ++v) h->partVerts[h->vpart[v]].push_back(v);
+        } else
         for (int pI = 0; pI < nP; ++pI) {
             for (int e = 0; e < nT; ++e)
                 if (h->epart[e] == pI)
@@ -1681,7 +1684,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         return DOTMI_E_INVALID;
     }
     for (int e = 0; e < mesh->nT; ++e) {
-        if (mesh->epart && (mesh->epart[e] < 0 || mesh->epart[e] >= mesh->nParts)) {
+        if (mesh->epart && !mesh->vpart && (mesh->epart[e] < 0 || mesh->epart[e] >= mesh->nParts)) {
             h->err = "epart out of range";
             return DOTMI_E_INVALID;
         }
@@ -1712,7 +1715,19 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     h->density = mesh->density;
     h->nPartsAll = mesh->nParts;
     h->T.assign(mesh->T, mesh->T + 4 * (size_t)h->nT);
-    if (mesh->epart) {
+    if (mesh->vpart) {
+        if (prm->world > 1 || (prm->flags & DOTMI_FLAG_FORCE_DIST)) {
+            h->err = "a vertex partition (vpart) is single-GPU only";
+            return DOTMI_E_INVALID;
+        }
+        for (int v = 0; v < mesh->nV; ++v)
+            if (mesh->vpart[v] < 0 || mesh->vpart[v] >= mesh->nParts) {
+                h->err = "vpart out of range";
+                return DOTMI_E_INVALID;
+            }
+        h->vpart.assign(mesh->vpart, mesh->vpart + h->nV);
+        h->epart.assign(h->nT, 0);   // unused: the subdomains are vertex sets
+    } else if (mesh->epart) {
         h->epart.assign(mesh->epart, mesh->epart + h->nT);
     } else {   // no partition given: the built-in partitioner (the reference calls METIS here, METIS.hpp:109-140)
         h->epart.resize(h->nT);

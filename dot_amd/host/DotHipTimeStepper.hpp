@@ -41,6 +41,7 @@ struct Options {  // the Config fields the DOT stepper reads (src/Config.hpp)
     bool withGravity = true;
     int partitionAmt = 4;
     const int32_t *epart = nullptr;  // METIS::partMesh result (nT)
+    const int32_t *vpart = nullptr;  // optional METIS::partMesh_nodes result (nV): block-Jacobi subdomains (LBFGS-JH)
     int device = 0, rank = 0, world = 1;
     const void *commId = nullptr;
     double alphaMin = 0.1;  // lower clamp of alpha_0 (Optimizer.cpp:1085); 1.0 = unit first step (LBFGS-H, :1088)
@@ -91,6 +92,7 @@ public:
         m.fixed = fixed_.data();
         m.epart = opt_.epart;
         m.nParts = opt_.partitionAmt;
+        m.vpart = opt_.vpart;
         dotmi_params p{};
         p.energy = opt_.energyType;
         p.dt = dt_;

@@ -173,7 +173,17 @@ int main(int argc, char **argv)
         if (files && !fast) opt.flags |= DOTMI_FLAG_TIME_PHASES;
         if (cfg.timeStepper == "GSDD") opt.flags |= DOTMI_FLAG_GSDD;
         if (lbfgsH) opt.alphaMin = 1.0;
-        if (newton) opt.flags |= DOTMI_FLAG_NEWTON;   // `timeStepper GSDD <n>`: the Gauss-Seidel sibling
+        if (newton) opt.flags |= DOTMI_FLAG_NEWTON;
+        // `timeStepper LBFGSJH <n>`: block-Jacobi on a vertex partition (the reference takes METIS::partMesh_nodes;
+        // without METIS a vertex goes to the lowest-numbered subdomain among its elements) and a unit first step
+        std::vector<int32_t> vpart;
+        if (cfg.timeStepper == "LBFGSJH") {
+            vpart.assign(mesh.nV(), nParts);
+            for (int e = 0; e < mesh.nT(); ++e)
+                for (int k = 0; k < 4; ++k) vpart[mesh.T[4 * e + k]] = std::min(vpart[mesh.T[4 * e + k]], epart[e]);
+            opt.vpart = vpart.data();
+            opt.alphaMin = 1.0;
+        }   // `timeStepper GSDD <n>`: the Gauss-Seidel sibling
 
         FILE *fIter = nullptr, *fLog = nullptr;
         if (files) {

@@ -29,7 +29,7 @@ FLAG_NEWTON = 64
 class Mesh(C.Structure):
     _fields_ = [("nV", C.c_int32), ("nT", C.c_int32), ("X_rest", c_dp), ("T", c_ip), ("mu", c_dp),
                 ("lam", c_dp), ("density", C.c_double), ("fixed", c_up), ("epart", c_ip),
-                ("nParts", C.c_int32)]
+                ("nParts", C.c_int32), ("vpart", c_ip)]
 
 
 class Params(C.Structure):

@@ -21,7 +21,7 @@ class DOTTimeStepper:
     def __init__(self, scene: Scene, epart: np.ndarray, nparts: int, energy: Optional[int] = None,
                  device: int = 0, rank: int = 0, world: int = 1, comm_id: Optional[bytes] = None,
                  history: int = 5, rel_tol: float = 1e-5, iter_cap: int = 10000, flags: int = 0, allreduce=None,
-                 alpha_min: float = 0.1):
+                 alpha_min: float = 0.1, vpart: Optional[np.ndarray] = None):
         """allreduce: optional callable(np.ndarray) that sums the array over the ranks IN PLACE (world > 1): the
         library then stages its collectives through host memory and calls it instead of RCCL
         (dotmi_params::allreduce) -- e.g. a torch.distributed gloo all_reduce."""
@@ -42,8 +42,9 @@ class DOTTimeStepper:
         self._fixed = np.ascontiguousarray(scene.fixed, dtype=np.uint8)
         self._epart = np.ascontiguousarray(epart, dtype=np.int32)
         self.nparts = int(nparts)
+        self._vpart = np.ascontiguousarray(vpart, dtype=np.int32) if vpart is not None else None
         m = Mesh(self.nV, self.nT, dp(self._X), ip(self._T), dp(self._mu), dp(self._lam), cfg.rho,
-                 up(self._fixed), ip(self._epart), self.nparts)
+                 up(self._fixed), ip(self._epart), self.nparts, ip(self._vpart) if vpart is not None else None)
         p = Params()
         p.energy = cfg.energy_id if energy is None else energy
         p.dt = cfg.dt

@@ -51,6 +51,11 @@ typedef struct {
     const uint8_t *fixed;  /* nV, 1 = Dirichlet */
     const int32_t *epart;  /* nT, values in [0,nParts); NULL = partition with dotmi_partition() */
     int32_t nParts;
+    const int32_t *vpart;  /* optional, nV values in [0,nParts): a VERTEX partition (METIS::partMesh_nodes,
+                              METIS.hpp:161-193).  When given, subdomain s is the vertex set {v : vpart[v] == s} --
+                              disjoint blocks of the global Hessian, no interface, no averaging: the block-Jacobi
+                              initialiser of LBFGS-JH (LBFGSTimeStepper.cpp:70-90, :240-262, :381-393); epart is then
+                              ignored.  Single GPU. */
 } dotmi_mesh;
 
 /* Config / Optimizer constants (src/Config.hpp, Optimizer.cpp:98-111, DOTTimeStepper.cpp:45) */

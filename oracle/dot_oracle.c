@@ -433,6 +433,7 @@ struct dor_sim {
     double *Hval;                          /* nnzb*9 */
     double *He;                            /* nT*144 */
     int *epart, *dup;
+    int *vpart; /* optional vertex partition: subdomains = vertex sets (block Jacobi) */
     dor_part *parts;
     /* state */
     double *x, *xn, *v, *xt, *g, *p;
@@ -581,6 +582,13 @@ static void build_parts(dor_sim *s)
         dor_part *P = &s->parts[pI];
         memset(mark, 0, sizeof(int) * nV);
         int n = 0;
+        if (s->vpart) {   /* vertex partition (LBFGS-JH, LBFGSTimeStepper.cpp:70-90): disjoint vertex sets */
+            for (int v = 0; v < nV; ++v)
+                if (s->vpart[v] == pI) {
+                    mark[v] = 1;
+                    n++;
+                }
+        } else
         for (int e = 0; e < nT; ++e)
             if (s->epart[e] == pI)
                 for (int k = 0; k < 4; ++k) {
@@ -1024,6 +1032,16 @@ dor_sim *dor_create(int nV, int nT, const double *Xrest, const int *T, double YM
                     const unsigned char *fixed, const double *x_init, const int *epart,
                     int nParts, double relTol)
 {
+    return dor_create_v(nV, nT, Xrest, T, YM, PR, rho, material, dt, withGravity, fixed, x_init, epart, NULL, nParts,
+                        relTol);
+}
+
+/* vpart != NULL: the subdomains are the vertex sets of a VERTEX partition (LBFGS-JH), epart is ignored */
+dor_sim *dor_create_v(int nV, int nT, const double *Xrest, const int *T, double YM, double PR,
+                      double rho, int material, double dt, int withGravity,
+                      const unsigned char *fixed, const double *x_init, const int *epart, const int *vpart,
+                      int nParts, double relTol)
+{
     dor_sim *s = calloc(1, sizeof(dor_sim));
     s->nV = nV;
     s->nT = nT;
@@ -1046,8 +1064,12 @@ dor_sim *dor_create(int nV, int nT, const double *Xrest, const int *T, double YM
     s->mass = malloc(sizeof(double) * nV);
     s->fixed = malloc(nV);
     memcpy(s->fixed, fixed, nV);
-    s->epart = malloc(sizeof(int) * nT);
-    memcpy(s->epart, epart, sizeof(int) * nT);
+    s->epart = calloc(nT, sizeof(int));
+    if (epart) memcpy(s->epart, epart, sizeof(int) * nT);
+    if (vpart) {
+        s->vpart = malloc(sizeof(int) * nV);
+        memcpy(s->vpart, vpart, sizeof(int) * nV);
+    }
     build_features(s, YM, PR, rho);
     build_topology(s);
     build_parts(s);
@@ -1095,7 +1117,7 @@ void dor_destroy(dor_sim *s)
     for (int i = 0; i < HIST; ++i) { free(s->hs[i]); free(s->hy[i]); }
     free(s->T); free(s->Xrest); free(s->A); free(s->vol); free(s->mu); free(s->lam); free(s->mass);
     free(s->fixed); free(s->vf_ptr); free(s->vf_elem); free(s->vf_slot); free(s->adj_ptr);
-    free(s->adj_idx); free(s->eblk); free(s->Hval); free(s->He); free(s->epart); free(s->dup);
+    free(s->adj_idx); free(s->eblk); free(s->Hval); free(s->He); free(s->epart); free(s->vpart); free(s->dup);
     free(s->x); free(s->xn); free(s->v); free(s->xt); free(s->g); free(s->p);
     free(s->ework); free(s->gcont); free(s->x0); free(s->q); free(s->gold); free(s->Hp); free(s->tmp_s); free(s->tmp_y);
     free(s->log_alpha); free(s->log_E); free(s->log_g2);

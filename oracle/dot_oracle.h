@@ -63,6 +63,12 @@ dor_sim *dor_create(int nV, int nT, const double *Xrest, const int *T, double YM
                     double rho, int material, double dt, int withGravity,
                     const unsigned char *fixed, const double *x_init, const int *epart,
                     int nParts, double relTol);
+/* the same with an optional VERTEX partition vpart[nV] (METIS::partMesh_nodes): subdomains = disjoint vertex sets, the
+ * block-Jacobi initialiser of LBFGS-JH (LBFGSTimeStepper.cpp:70-90, :240-262, :381-393); epart may then be NULL */
+dor_sim *dor_create_v(int nV, int nT, const double *Xrest, const int *T, double YM, double PR,
+                      double rho, int material, double dt, int withGravity,
+                      const unsigned char *fixed, const double *x_init, const int *epart, const int *vpart,
+                      int nParts, double relTol);
 void dor_destroy(dor_sim *s);
 
 /* scripted Dirichlet motion: x[idx[k]] = pos[3k..] (AnimScripter.cpp:456-466) */

@@ -6,7 +6,9 @@
  * minconn=1, contig=1, ncuts=3, nseps=3, niter=10, ncommon=3, seed=-1, ufactor=30, dbglvl 511
  * -- dbglvl only prints, we pass 0).
  *
- * usage: metis_part <tets.i32 (nT*4 raw int32)> <nV> <nParts> <out epart.i32>
+ * usage: metis_part <tets.i32 (nT*4 raw int32)> <nV> <nParts> <out epart.i32> [nodal]
+ * nodal: METIS::partMesh_nodes (src/Utils/METIS.hpp:161-193, METIS_PartMeshNodal, unit vertex weights) -- the VERTEX
+ *        partition LBFGS-JH works on (LBFGSTimeStepper.cpp:70-90); the output is then npart (nV raw int32)
  */
 #include <metis.h>
 #include <stdint.h>
@@ -58,16 +60,25 @@ int main(int argc, char **argv)
     for (idx_t e = 0; e < ne; ++e) ewgt[e] = 1;
     for (idx_t p = 0; p < nparts; ++p) tpwgts[p] = 1.0 / nparts;
     idx_t ncommon = 3, objval = 0;
-    int status = METIS_PartMeshDual(&ne, &nn, eptr, eind, ewgt, NULL, &ncommon, &nparts, tpwgts,
-                                    options, &objval, epart, npart);
+    const int nodal = argc > 5 && argv[5][0] == 'n';
+    int status;
+    if (nodal) {
+        idx_t *vwgt = malloc(sizeof(idx_t) * nn);
+        for (idx_t v = 0; v < nn; ++v) vwgt[v] = 1;
+        status = METIS_PartMeshNodal(&ne, &nn, eptr, eind, vwgt, NULL, &nparts, tpwgts, options, &objval, epart, npart);
+    } else {
+        status = METIS_PartMeshDual(&ne, &nn, eptr, eind, ewgt, NULL, &ncommon, &nparts, tpwgts, options, &objval, epart,
+                                    npart);
+    }
     if (status != METIS_OK) {
         fprintf(stderr, "METIS status %d\n", status);
         return 4;
     }
-    int32_t *out = malloc(sizeof(int32_t) * ne);
-    for (idx_t e = 0; e < ne; ++e) out[e] = (int32_t)epart[e];
+    const idx_t nout = nodal ? nn : ne;
+    int32_t *out = malloc(sizeof(int32_t) * nout);
+    for (idx_t e = 0; e < nout; ++e) out[e] = (int32_t)(nodal ? npart[e] : epart[e]);
     f = fopen(argv[4], "wb");
-    fwrite(out, sizeof(int32_t), ne, f);
+    fwrite(out, sizeof(int32_t), nout, f);
     fclose(f);
     fprintf(stderr, "metis_part: ne=%ld nn=%ld nparts=%ld edgecut=%ld\n", (long)ne, (long)nn,
             (long)nparts, (long)objval);

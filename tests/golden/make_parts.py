@@ -20,3 +20,11 @@ for mesh, nparts in (("bunny5K", 8), ("bunny5K", 6), ("bar17K", 32), ("bar17K", 
     assert ep.min() == 0 and ep.max() == nparts - 1
     np.save(os.path.join(HERE, "parts", f"{mesh}_{nparts}.npy"), ep.astype(np.uint8))
     print(mesh, nparts, np.bincount(ep))
+
+# vertex partitions (METIS::partMesh_nodes, METIS.hpp:161-193) for LBFGS-JH
+for mesh, nparts in (("bunny5K", 8),):
+    V, T = load_mesh_npz(os.path.join(HERE, "meshes", mesh + ".npz"))
+    vp = O.metis_partition(T, V.shape[0], nparts, nodal=True)
+    assert vp.size == V.shape[0] and vp.min() == 0 and vp.max() == nparts - 1
+    np.save(os.path.join(HERE, "parts", f"{mesh}_{nparts}_nodes.npy"), vp.astype(np.uint8))
+    print(mesh, nparts, "nodes", np.bincount(vp))

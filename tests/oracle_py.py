@@ -50,6 +50,9 @@ def lib():
         L.dor_create.restype = C.c_void_p
         L.dor_create.argtypes = [C.c_int, C.c_int, c_dp, c_ip, C.c_double, C.c_double, C.c_double,
                                  C.c_int, C.c_double, C.c_int, c_up, c_dp, c_ip, C.c_int, C.c_double]
+        L.dor_create_v.restype = C.c_void_p
+        L.dor_create_v.argtypes = [C.c_int, C.c_int, c_dp, c_ip, C.c_double, C.c_double, C.c_double,
+                                   C.c_int, C.c_double, C.c_int, c_up, c_dp, c_ip, c_ip, C.c_int, C.c_double]
         L.dor_destroy.argtypes = [C.c_void_p]
         L.dor_move.argtypes = [C.c_void_p, C.c_int, c_ip, c_dp]
         L.dor_step.argtypes = [C.c_void_p, C.POINTER(StepStats)]
@@ -108,7 +111,7 @@ class OracleSim:
     """Thin object wrapper over dor_sim."""
 
     def __init__(self, V_rest, T, YM, PR, rho, material, dt, fixed, x_init, epart, nparts,
-                 with_gravity=True, rel_tol=1e-5):
+                 with_gravity=True, rel_tol=1e-5, vpart=None):
         L = lib()
         self.nV, self.nT = V_rest.shape[0], T.shape[0]
         self.nparts = int(nparts)
@@ -117,9 +120,15 @@ class OracleSim:
         fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
         x_init = np.ascontiguousarray(x_init, dtype=np.float64)
         epart = np.ascontiguousarray(epart, dtype=np.int32)
-        self.h = L.dor_create(self.nV, self.nT, _dp(V_rest), _ip(T), YM, PR, rho, material, dt,
-                              int(with_gravity), fixed.ctypes.data_as(c_up), _dp(x_init),
-                              _ip(epart), self.nparts, rel_tol)
+        if vpart is not None:
+            vpart = np.ascontiguousarray(vpart, dtype=np.int32)
+            self.h = L.dor_create_v(self.nV, self.nT, _dp(V_rest), _ip(T), YM, PR, rho, material, dt,
+                                    int(with_gravity), fixed.ctypes.data_as(c_up), _dp(x_init),
+                                    _ip(epart), _ip(vpart), self.nparts, rel_tol)
+        else:
+            self.h = L.dor_create(self.nV, self.nT, _dp(V_rest), _ip(T), YM, PR, rho, material, dt,
+                                  int(with_gravity), fixed.ctypes.data_as(c_up), _dp(x_init),
+                                  _ip(epart), self.nparts, rel_tol)
 
     def close(self):
         if self.h:
@@ -341,13 +350,15 @@ def ref_config_parse(path):
     return out
 
 
-def metis_partition(T, nV, nparts, tmpdir="/tmp"):
-    """Run the reference's vendored METIS (oracle/_ref/metis_part) on a tet list."""
+def metis_partition(T, nV, nparts, tmpdir="/tmp", nodal=False):
+    """Run the reference's vendored METIS (oracle/_ref/metis_part) on a tet list: the element partition of
+    METIS::partMesh, or (nodal) the vertex partition of METIS::partMesh_nodes."""
     exe = os.path.join(ORACLE_DIR, "_ref", "metis_part")
     tin = os.path.join(tmpdir, f"_tets_{os.getpid()}.i32")
     tout = os.path.join(tmpdir, f"_epart_{os.getpid()}.i32")
     np.ascontiguousarray(T, dtype=np.int32).tofile(tin)
-    subprocess.check_call([exe, tin, str(nV), str(nparts), tout], stderr=subprocess.DEVNULL)
+    subprocess.check_call([exe, tin, str(nV), str(nparts), tout] + (["nodal"] if nodal else []),
+                          stderr=subprocess.DEVNULL)
     ep = np.fromfile(tout, dtype=np.int32)
     os.remove(tin)
     os.remove(tout)

@@ -475,3 +475,38 @@ def test_projected_newton_matches_oracle():
         assert st.g2 <= ts.targetGRes and st.iters <= 8
     assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
     ts.close(); orc.close()
+
+
+def test_lbfgs_jh_block_jacobi_on_a_vertex_partition():
+    """LBFGS-JH (`timeStepper LBFGSJH <n>`, LBFGSTimeStepper with D0T_JH: node lists from METIS::partMesh_nodes
+    LBFGSTimeStepper.cpp:70-90, per-block factors of the global Hessian's principal sub-matrices :240-262 / :309-331,
+    block-Jacobi solve :381-393, unit first step): dotmi_mesh.vpart = the reference's METIS vertex partition (fixture
+    bunny5K_8_nodes) + alphaMin = 1.  Subdomains are disjoint (dup = 1 everywhere), so the block solve of a vector
+    supported on one block is that block's solve and zero elsewhere.  Against the oracle configured the same way."""
+    import os
+    from dot_amd.configs import PART_DIR
+    sc, ep, n = load_workload("bunny5K_LTSS")
+    cfg = sc.cfg
+    vp = np.load(os.path.join(PART_DIR, "bunny5K_8_nodes.npy")).astype(np.int32)
+    assert vp.size == sc.V_rest.shape[0] and np.bincount(vp).min() > 500
+    ts = DOTTimeStepper(sc, ep, n, alpha_min=1.0, vpart=vp)
+    orc = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, n,
+                      cfg.with_gravity, vpart=vp)
+    orc.set_alpha_min(1.0)
+    assert np.all(orc.dup() == 1)
+    for s_ in range(n):
+        Hs, l2g = ts.partMatrix(s_)
+        assert np.array_equal(l2g, np.nonzero(vp == s_)[0])
+    r = np.zeros_like(sc.x0)
+    blk = np.nonzero((vp == 3) & ~sc.fixed.astype(bool))[0]
+    r[blk] = np.random.default_rng(2).standard_normal((blk.size, 3))
+    z = ts.applyPrecond(r)
+    assert not z[vp != 3].any()
+    zo = orc.apply_precond(r)
+    assert np.abs(z - zo).max() <= 1e-9 * np.abs(zo).max()
+    for k in range(3):
+        (st, so), = run_both(sc, ts, orc, 1)
+        print("LBFGS-JH step", k, "iterations", st.iters, so.iters, "halvings", st.ls_halvings, so.ls_halvings)
+        assert (st.status, st.iters, st.ls_halvings) == (so.status, so.iters, so.ls_halvings), k
+    assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
+    ts.close(); orc.close()
