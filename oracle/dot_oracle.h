@@ -14,10 +14,13 @@
  *   - METIS partition: produced by the reference's vendored METIS 5.1.0 compiled into oracle/_ref.
  *   - step level: tolerance constant and L-BFGS iteration counts per step published in
  *     BASELINE.md section 2 (bunny5K FCR/8 parts, bar17K SNH/32 parts).
- *   - d2Psi/dsigma2, B-coefficients, dP/dF assembly, Hessian scatter, preconditioner, two-loop,
- *     line search: restated from source, validated by finite differences / algebraic identities
- *     (the reference's own test strategy, Energy.cpp:1279-1521); the reference's .cpp files for
- *     these need TBB headers, which this image lacks, so they are NOT compiled here.
+ *   - global Hessian scatter (LinSysSolver::set_pattern indexing, addBlockToMatrix, fixed rows, mass), factor, solve,
+ *     SpMV: checked against the reference's LinSysSolver.hpp + CHOLMODSolver.cpp compiled unmodified on the vendored
+ *     CHOLMOD (oracle/_ref/librefsolver.so, tests/golden/ref_linsys.npz) -- round 2.
+ *   - d2Psi/dsigma2, B-coefficients, dP/dF assembly, subdomain-matrix fix-up, two-loop, line search: restated from
+ *     source, validated by finite differences / algebraic identities (the reference's own test strategy,
+ *     Energy.cpp:1279-1521); the reference's .cpp files for these need TBB headers, which this image lacks, so they
+ *     are NOT compiled here.
  */
 #ifndef DOT_ORACLE_H
 #define DOT_ORACLE_H
