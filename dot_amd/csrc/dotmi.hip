@@ -667,6 +667,8 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = dalloc(h, &P.Wtmp, (size_t)P.nParts * h->tmp_stride)) return rc;
     if (int rc = dalloc(h, &P.ppart, (size_t)P.nParts * P.nbmax * P.nmax)) return rc;
     if (int rc = dalloc(h, &P.psub, (size_t)P.nParts * P.nmax)) return rc;
+    if (int rc = dalloc(h, &P.rpad, (size_t)P.nParts * P.nmax + 8)) return rc;
+    HIPCHECK(h, hipMemset(P.rpad, 0, sizeof(double) * ((size_t)P.nParts * P.nmax + 8)));
     if (int rc = dalloc(h, &h->info_dev, (size_t)std::max(P.nParts, 1))) return rc;
     HIPCHECK(h, hipHostMalloc((void **)&h->h_info, sizeof(int) * std::max(P.nParts, 1)));
     memset(h->h_info, 0, sizeof(int) * std::max(P.nParts, 1));
@@ -1267,12 +1269,12 @@ int enqueue_loop_slot(dotmi_handle *h)
     const int n = h->n;
     LbfgsArgs L0;
     memset(&L0, 0, sizeof(L0));
-    launch_build_q(n, h->g, L0, nullptr, h->q, h->st, h->ctl);
+    launch_build_qpad(h->P, h->g, L0, nullptr, h->st, h->ctl);   // q, straight into the padded right-hand sides
     // an event record costs ~6 us of stream time: sample, do not bracket every launch
     const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size() &&
                        (h->timeCount++ % h->timeStride) == 0;
     h->slotTimed.push_back(timed ? h->evUsed : -1);
-    launch_gemv(h->P, h->q, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr,
+    launch_gemv(h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr,
                 timed ? h->evPre[h->evUsed + 1] : nullptr);
     if (timed) h->evUsed += 2;
     launch_merge(h->M, h->P, L0, h->z, h->partC, 1 | 2, h->st, h->ctl);
@@ -2055,10 +2057,10 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         }
         L = lbfgs_args(h);
         phase_mark(h, -1);
-        launch_build_q(n, h->g, L, xi, h->q, h->st);
+        launch_build_qpad(h->P, h->g, L, xi, h->st);   // q, straight into the padded right-hand sides
         phase_mark(h, DOTMI_T_MODIFY_GRAD);
         // ---- subdomain back-solve, merge, second half ------------------------------------------------
-        if (int rc = apply_precond(h, h->q, h->z, L)) return rc;
+        if (int rc = apply_precond(h, nullptr, h->z, L)) return rc;
         phase_mark(h, DOTMI_T_BACKSOLVE);
         launch_build_p(n, h->z, L, h->partC, xi, h->p, h->st);
         phase_mark(h, DOTMI_T_MODIFY_SEARCHDIR);

@@ -54,6 +54,8 @@ struct DevParts {
     int2 *trange;           // owned * nbmax: columns [first, end) each tile of a part contributes to
     double *ppart;          // owned * nbmax * nmax partial results of the back-solve tiles
     double *psub;           // owned * nmax per-part results (padded positions)
+    double *rpad;           // owned * nmax right-hand sides in padded order (zeros on the padding): what the back-solve
+                            // tiles read, contiguous -- filled by build_qpad (loop) or gathered from q (launch_gemv)
     // merge: per vertex list of positions in psub (all parts on this rank), CSR over vertices
     int *vp_ptr, *vp_off;
     int *dup;               // nV (global multiplicity, DOTTimeStepper.cpp:47-56)
@@ -151,8 +153,12 @@ void launch_multidot(int n, const double *v, const double *const *vecs, int m, d
 void launch_build_q(int n, const double *g, const LbfgsArgs &L, const double *xi_host, double *q,
                     hipStream_t st, const DevLoop *ctl = nullptr);
 // subdomain back-solve: psub_s = X_s^T (X_s q[dofmap_s])
+// q == nullptr: P.rpad already holds the right-hand sides (launch_build_qpad); else they are gathered from q first
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
                  hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// rpad_s[k] = q[dofmap_s[k]] with q = -g - sum_j xi_j y_j formed on the fly (same operations as build_q), 0 on padding
+void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, const double *xi_host, hipStream_t st,
+                       const DevLoop *ctl = nullptr);
 // one subdomain only (GSDD, DOTTimeStepper.cpp:507-565): psub_s = X_s^T (X_s q[dofmap_s]) for owned part `ls`, whose
 // tiles are job[0..njobs); then p = 0 except p[dofs of part ls] = psub_s  (ADMMDDTimeStepper::fill, :1646-1665)
 void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, const double *q, int n, double *p,
