@@ -1075,6 +1075,32 @@ __device__ __forceinline__ int block_chol_inv(double (*G)[LD64], double (*X)[LD6
     }
 }
 
+// A 64 x 64 column-major block (leading dimension ld, 16-byte aligned) into the registers of a 256-thread workgroup:
+// eight independent 16-byte loads per thread, all in flight together (the element-by-element loop this replaces took
+// ~8 us per block: its loads were issued one iteration at a time).  blk64_to_lds stores element (k, j) to G[k][j].
+struct Blk64 {
+    double2 v[8];
+};
+__device__ __forceinline__ Blk64 blk64_load(const double *__restrict__ src, size_t ld, int tid)
+{
+    Blk64 b;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int idx2 = tid + 256 * u;          // 2048 pairs: column j = idx2 / 32, rows 2 k2, 2 k2 + 1
+        b.v[u] = *reinterpret_cast<const double2 *>(src + (size_t)(idx2 >> 5) * ld + 2 * (idx2 & 31));
+    }
+    return b;
+}
+__device__ __forceinline__ void blk64_to_lds(const Blk64 &b, double (*G)[CHOL_NB + 1], int tid)
+{
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int idx2 = tid + 256 * u, j = idx2 >> 5, k = 2 * (idx2 & 31);
+        G[k][j] = b.v[u].x;
+        G[k + 1][j] = b.v[u].y;
+    }
+}
+
 __global__ __launch_bounds__(256) void chol_inv_base_kernel(double *__restrict__ W, int nmax, int o,
                                                             int *__restrict__ info)
 {
@@ -1082,10 +1108,7 @@ __global__ __launch_bounds__(256) void chol_inv_base_kernel(double *__restrict__
     __shared__ double G[NB][LD64], X[NB][LD64], T32[32][33], T16[16][17];
     double *Ws = W + (size_t)blockIdx.x * nmax * nmax + (size_t)o * nmax + o;
     const int tid = threadIdx.x;
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int j = idx / NB, i = idx % NB;
-        G[i][j] = Ws[(size_t)j * nmax + i];  // A(i,j): column-major upper block, symmetric
-    }
+    blk64_to_lds(blk64_load(Ws, nmax, tid), G, tid);   // A(i,j): column-major upper block, symmetric
     __syncthreads();
     const int bad = block_chol_inv<64>(G, X, 0, T32, T16, tid);
     // store Q = X^T column-major, i.e. memory row i, position k <- X(i,k) (zero for k > i)
@@ -1134,6 +1157,16 @@ __device__ __forceinline__ void mfma_gemm64(FA A, FB B, FS store, int tid)
 // The two 64 x 64 factor+invert steps are block_chol_inv<64>(); the four 64^3 products run on the FP64 matrix
 // cores from LDS (mfma_gemm64).  Replaces 2 base launches +
 // 4 tiny batched GEMMs + 2 block copies, whose launch latencies dominated the bottom of the recursion.
+#ifdef NODE128_PROFILE
+__device__ long long g_node128_prof[32];
+#define N128_MARK(i)                                                                      \
+    do {                                                                                  \
+        __syncthreads();                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x == 0) g_node128_prof[i] = wall_clock64();      \
+    } while (0)
+#else
+#define N128_MARK(i)
+#endif
 __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restrict__ W, int nmax, int o,
                                                                int *__restrict__ info)
 {
@@ -1144,20 +1177,24 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
     __shared__ double Tq[32][33], Tr[16][17];
     double *Ws = W + (size_t)blockIdx.x * nmax * nmax;
     const int tid = threadIdx.x;
+    N128_MARK(0);
     // column-major element (r, c) of the block matrix lives at Ws[(size_t)c * nmax + r]
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int j = idx / NB, k = idx % NB;
-        Gf[k][j] = Ws[(size_t)(o + j) * nmax + o + k];            // H11(k,j)
-        Bf[k][j] = Ws[(size_t)(o + NB + j) * nmax + o + k];       // H12(k,j)
+    {
+        const Blk64 h11 = blk64_load(Ws + (size_t)o * nmax + o, nmax, tid);          // H11(k,j)
+        const Blk64 h12 = blk64_load(Ws + (size_t)(o + NB) * nmax + o, nmax, tid);   // H12(k,j)
+        blk64_to_lds(h11, Gf, tid);
+        blk64_to_lds(h12, Bf, tid);
     }
+    // H22 is not needed before the first diagonal block is done: its loads stay in flight across that phase
+    const Blk64 h22 = blk64_load(Ws + (size_t)(o + NB) * nmax + o + NB, nmax, tid);
     __syncthreads();
+    N128_MARK(1);
     int bad = block_chol_inv<64>(Gf, X1, 0, Tq, Tr, tid);
+    N128_MARK(2);
     if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + bad);
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int j = idx / NB, k = idx % NB;
-        Gf[k][j] = Ws[(size_t)(o + NB + j) * nmax + o + NB + k];  // H22(k,j)
-    }
+    blk64_to_lds(h22, Gf, tid);                                   // H22(k,j)
     __syncthreads();
+    N128_MARK(3);
     // ---- R12(i,j) = sum_k X11(i,k) H12(k,j)
     mfma_gemm64([&](int i, int k) { return X1[i][k]; }, [&](int k, int jj) { return Bf[k][jj]; },
                 [&](int i, int jj, double v) { Bf[i][jj] = v; }, tid);
@@ -1167,6 +1204,7 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
     // ---- U(i,j) = sum_k Q11(i,k) R12(k,j) = sum_k X11(k,i) R12(k,j)
     mfma_gemm64([&](int i, int k) { return X1[k][i]; }, [&](int k, int jj) { return Bf[k][jj]; },
                 [&](int i, int jj, double v) { Bf[i][jj] = v; }, tid);
+    N128_MARK(4);
     // X11 is final: write it out and hand its LDS block to X22 (one 64x65 block less, 108 KB instead of 141 KB
     // per workgroup, so a GEMM workgroup of another branch still fits next to this one on a CU)
     for (int idx = tid; idx < NB * NB; idx += 256) {
@@ -1175,18 +1213,22 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
         Ws[(size_t)(o + r) * nmax + o + NB + c] = 0.0;               // H21 block: strictly lower -> zero
     }
     __syncthreads();
+    N128_MARK(5);
     // ---- X22 = chol(H22)^-1
     bad = block_chol_inv<64>(Gf, X1, 0, Tq, Tr, tid);
+    N128_MARK(6);
     if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + NB + bad);
     // ---- Q12(i,j) = -sum_c U(i,c) Q22(c,j) = -sum_c U(i,c) X22(j,c)
     mfma_gemm64([&](int i, int c) { return Bf[i][c]; }, [&](int c, int jj) { return X1[jj][c]; },
                 [&](int i, int jj, double v) { Bf[i][jj] = -v; }, tid);
+    N128_MARK(7);
     // ---- store: memory row (o+64+j) <- [Q12(:,j) | X22(j,:)]   (rows o+i were written above)
     for (int idx = tid; idx < NB * NB; idx += 256) {
         const int r = idx / NB, c = idx % NB;
         Ws[(size_t)(o + NB + r) * nmax + o + c] = Bf[c][r];          // Q12(c,r)
         Ws[(size_t)(o + NB + r) * nmax + o + NB + c] = X1[r][c];     // Q22(c,r) = X22(r,c)
     }
+    N128_MARK(8);
 }
 
 void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, hipStream_t st)
