@@ -1771,6 +1771,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         h->ctrlDev = (double *)cd;
     }
 
+    if (const char *ev = getenv("DOTMI_TIME_STRIDE")) h->timeStride = std::max(1, atoi(ev));
     if (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) {
         h->evPre.resize(2 * 512);
         for (auto &e : h->evPre) HIPCHECK(h, hipEventCreate(&e));
