@@ -51,7 +51,7 @@ def main():
     import torch.distributed as dist
 
     from dot_amd import lib as dl
-    from dot_amd.configs import WORKLOADS, load_workload
+    from tests.workloads import WORKLOADS, load_workload
     from dot_amd.timestepper import DOTTimeStepper, comm_unique_id
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -25,7 +25,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", ".."))
-from dot_amd.configs import load_workload  # noqa: E402
+from tests.workloads import load_workload  # noqa: E402
 from tests import oracle_py as O  # noqa: E402
 
 REF = os.environ.get("DOT_REFERENCE", "/root/reference")

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from dot_amd import lib as dl
-from dot_amd.configs import load_workload
+from tests.workloads import load_workload
 from dot_amd.sharding import part_scalar_sizes, plan_shards
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, initfile, outdir):
     sys.path.insert(0, ROOT)
     os.environ["OMP_NUM_THREADS"] = "2"
-    from dot_amd.configs import load_workload
+    from tests.workloads import load_workload
     from dot_amd.sharding import owned_elements, part_scalar_sizes, plan_shards, vertex_slice
     from tests import oracle_py as O
 

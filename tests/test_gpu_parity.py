@@ -9,7 +9,7 @@ import pytest
 
 from dot_amd import lib as dl
 from dot_amd import scene
-from dot_amd.configs import load_workload
+from tests.workloads import load_workload
 from dot_amd.timestepper import DOTTimeStepper
 from tests import oracle_py as O
 
@@ -414,7 +414,7 @@ def test_cpp_headless_runner_end_to_end(tmp_path):
     reference's output files (iterStats.txt / log.txt / status<n> / <n>.obj / info.txt)."""
     import os, subprocess
     from tests.test_host_logic import _write_msh
-    from dot_amd.configs import MESH_DIR
+    from tests.workloads import MESH_DIR
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "dot_amd", "dot_hip")
     if not os.path.exists(exe):

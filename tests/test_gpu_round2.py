@@ -5,7 +5,7 @@ import pytest
 
 from dot_amd import lib as dl
 from dot_amd import scene
-from dot_amd.configs import load_workload
+from tests.workloads import load_workload
 from dot_amd.timestepper import DOTTimeStepper
 from tests import oracle_py as O
 
@@ -484,7 +484,7 @@ def test_lbfgs_jh_block_jacobi_on_a_vertex_partition():
     bunny5K_8_nodes) + alphaMin = 1.  Subdomains are disjoint (dup = 1 everywhere), so the block solve of a vector
     supported on one block is that block's solve and zero elsewhere.  Against the oracle configured the same way."""
     import os
-    from dot_amd.configs import PART_DIR
+    from tests.workloads import PART_DIR
     sc, ep, n = load_workload("bunny5K_LTSS")
     cfg = sc.cfg
     vp = np.load(os.path.join(PART_DIR, "bunny5K_8_nodes.npy")).astype(np.int32)

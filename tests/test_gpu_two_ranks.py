@@ -21,7 +21,7 @@ def _worker(rank, world, initfile, outdir, workload, shard_elems, steps):
     os.environ["OMP_NUM_THREADS"] = "2"
     import torch
     import torch.distributed as dist
-    from dot_amd.configs import load_workload
+    from tests.workloads import load_workload
     from dot_amd.timestepper import DOTTimeStepper
 
     dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
@@ -53,7 +53,7 @@ def _worker(rank, world, initfile, outdir, workload, shard_elems, steps):
 @pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 4), ("horse7K_stretch", 4)])
 def test_two_ranks_on_one_gpu_reproduce_the_single_gpu_run(workload, steps, shard_elems):
     import torch.multiprocessing as mp
-    from dot_amd.configs import load_workload
+    from tests.workloads import load_workload
     from dot_amd.timestepper import DOTTimeStepper
 
     world = 2

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from dot_amd import scene
-from dot_amd.configs import WORKLOADS, load_workload
+from tests.workloads import WORKLOADS, load_workload
 from dot_amd.sharding import owned_elements, part_scalar_sizes, plan_shards, vertex_slice
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

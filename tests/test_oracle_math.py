@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from dot_amd.configs import load_workload
+from tests.workloads import load_workload
 from tests import oracle_py as O
 
 dp = O._dp

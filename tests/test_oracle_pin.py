@@ -130,7 +130,7 @@ def _linsys_cases():
 
 
 def _oracle_for(meta_k):
-    from dot_amd.configs import load_workload
+    from tests.workloads import load_workload
     sc, ep, _ = load_workload(meta_k["workload"])
     sc.cfg.energy = meta_k["energy"]
     cfg = sc.cfg

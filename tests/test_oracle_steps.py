@@ -5,7 +5,7 @@ fact 4), so exact counts are asserted only where the reference itself is roundin
 import numpy as np
 import pytest
 
-from dot_amd.configs import load_workload
+from tests.workloads import load_workload
 from tests import oracle_py as O
 
 # BASELINE.md section 2

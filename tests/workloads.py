@@ -1,4 +1,5 @@
-"""Named workloads (BASELINE.json `configs`).  Each mirrors one of the
+"""TEST / BENCH HARNESS (not part of the dot_amd package: the product reads no fixture).
+Named workloads (BASELINE.json `configs`).  Each mirrors one of the
 reference's input scripts with the overrides BASELINE.json names; the script *values* are restated
 here so nothing needs /root/reference at run time (meshes come from tests/golden/meshes)."""
 from __future__ import annotations
@@ -7,9 +8,9 @@ import os
 
 import numpy as np
 
-from .scene import Config, Scene, build_scene, load_mesh_npz, partition_rcb, synthetic_bar
+from dot_amd.scene import Config, Scene, build_scene, load_mesh_npz, partition_rcb, synthetic_bar
 
-_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 MESH_DIR = os.path.join(_ROOT, "tests", "golden", "meshes")
 PART_DIR = os.path.join(_ROOT, "tests", "golden", "parts")
 
@@ -64,6 +65,6 @@ def load_workload(name: str, nparts: int | None = None):
     if os.path.exists(f):
         epart = np.load(f).astype(np.int32)
     else:
-        from .scene import partition_dual
+        from dot_amd.scene import partition_dual
         epart = partition_dual(sc.V_rest, sc.T, np_)
     return sc, epart, np_
