@@ -81,7 +81,8 @@ struct Bisector {
         return false;
     }
 
-    void refine(const std::vector<int> &ids, int targetLeft)
+    // minLeft / minRight: every side keeps at least as many elements as it will be split into parts
+    void refine(const std::vector<int> &ids, int targetLeft, int minLeft, int minRight)
     {
         const int n = (int)ids.size();
         const int tol = std::max(2, n / 64);   // sizes within ~1.5 % of the target
@@ -104,6 +105,7 @@ struct Bisector {
                         const int e = bucket[b][head[b]++];
                         if (locked[e] || gain(e) + 4 != b || !on_boundary(e)) continue;   // stale entry
                         const int nl = left + (side[e] == 0 ? -1 : 1);
+                        if (nl < minLeft || n - nl < minRight) continue;
                         if (std::abs(nl - targetLeft) > tol && std::abs(nl - targetLeft) >= std::abs(left - targetLeft)) continue;
                         pick = e;
                         break;
@@ -194,7 +196,7 @@ struct Bisector {
                 ord.swap(bfs);
             }
             for (size_t i = 0; i < ord.size(); ++i) side[ord[i]] = (int)i < cut ? 0 : 1;
-            refine(ids, cut);
+            refine(ids, cut, nl, nparts - nl);
             const long c = cut_faces();
             if (bestCut < 0 || c < bestCut) {
                 bestCut = c;

@@ -510,3 +510,43 @@ def test_lbfgs_jh_block_jacobi_on_a_vertex_partition():
         assert (st.status, st.iters, st.ls_halvings) == (so.status, so.iters, so.ls_halvings), k
     assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
     ts.close(); orc.close()
+
+
+def test_random_layout_sweep_matches_oracle():
+    """tools/fuzz_layouts.py in the suite: random jittered bars x partitions (some ragged) x dissection depths x materials x
+    scripts, two steps each: identical iterations and halvings, positions to 1e-9."""
+    import os
+    rng = np.random.default_rng(20260929)
+    keep = {k: os.environ.get(k) for k in ("DOTMI_ND_LEVELS", "DOTMI_ND_MIN")}
+    try:
+        for trial in range(8):
+            nx, ny, nz = int(rng.integers(4, 14)), int(rng.integers(2, 6)), int(rng.integers(2, 6))
+            nparts = int(rng.integers(2, 9))
+            levels, ndmin = int(rng.integers(0, 4)), int(rng.choice([128, 192, 256, 512, 768]))
+            energy = str(rng.choice(["FCR", "SNH"]))
+            script = str(rng.choice(["stretch", "twist", "squash", "hang"]))
+            os.environ["DOTMI_ND_LEVELS"], os.environ["DOTMI_ND_MIN"] = str(levels), str(ndmin)
+            V, T = scene.synthetic_bar(nx, ny, nz, jitter=0.08)
+            cfg = scene.Config(energy=energy, script=script, dt=0.02, rho=1000.0, YM=1e5, PR=0.4, handle_ratio=0.05)
+            sc = scene.build_scene(cfg, V, T)
+            ep = scene.partition_dual(sc.V_rest, sc.T, nparts) if trial % 2 else scene.partition_rcb(sc.V_rest, sc.T, nparts)
+            if rng.random() < 0.3:                      # ragged: move a random tenth of the elements into part 0
+                ep = ep.copy(); ep[rng.random(ep.size) < 0.1] = 0
+            ts = DOTTimeStepper(sc, ep, nparts)
+            orc = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, nparts)
+            for k in range(2):
+                x = ts.getResult()
+                idx, pos = sc.scripter.step(x, cfg.dt)
+                if idx.size:
+                    ts.setDirichlet(idx, pos); orc.move(idx, pos)
+                st, so = ts.step(), orc.step()
+                what = (trial, nx, ny, nz, nparts, levels, ndmin, energy, script, k)
+                assert (st.iters, st.ls_halvings) == (so.iters, so.ls_halvings), what
+                assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9, what
+            ts.close(); orc.close()
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -421,3 +421,36 @@ def test_info_txt_and_surface_obj_formats(tmp_path, with_surface_section):
     # label.obj follows the same triangle order (one subdomain label per surface triangle)
     labels = (tmp_path / "o" / "label.obj").read_text().splitlines()
     assert len(labels) == Fs.shape[0]
+
+
+# ---- the built-in partitioner (dotmi_partition, host only) ----------------------------------------------------------
+@pytest.mark.parametrize("workload,nparts,metis_iface", [("bunny5K_LTSS", 8, 1031), ("bar17K_twist", 32, 8099),
+                                                         ("horse7K_stretch", 8, 1197)])
+def test_builtin_partitioner_quality_balance_and_determinism(workload, nparts, metis_iface):
+    """dotmi_partition (recursive dual-graph bisection + FM refinement) stands in for METIS::partMesh on meshes without
+    a fixture: every part non-empty and within 6 % of the mean size, deterministic, element ids untouched, and an
+    interface size (sum over subdomains of vertices shared with another subdomain) within 20 % of the reference's
+    METIS partition of the same mesh -- coordinate bisection is 20-70 % above it."""
+    sc, ep_metis, n = load_workload(workload)
+    assert n == nparts
+    a = scene.partition_dual(sc.V_rest, sc.T, nparts)
+    b = scene.partition_dual(sc.V_rest, sc.T, nparts)
+    assert np.array_equal(a, b) and a.shape == (sc.T.shape[0],) and a.min() == 0 and a.max() == nparts - 1
+    cnt = np.bincount(a, minlength=nparts)
+    assert cnt.min() > 0 and np.abs(cnt - cnt.mean()).max() <= 0.06 * cnt.mean()
+
+    def interface(e):
+        vs = [np.unique(sc.T[e == p]) for p in range(nparts)]
+        dup = np.zeros(sc.V_rest.shape[0], dtype=int)
+        for v in vs:
+            dup[v] += 1
+        return int(sum((dup[v] > 1).sum() for v in vs))
+
+    assert interface(ep_metis) == metis_iface                       # SURVEY.md section 8: C2 sum of interface = 8 099
+    own, rcb = interface(a), interface(scene.partition_rcb(sc.V_rest, sc.T, nparts))
+    assert own <= 1.20 * metis_iface and own < 0.9 * rcb, (own, metis_iface, rcb)
+    # degenerate requests
+    one = scene.partition_dual(sc.V_rest, sc.T, 1)
+    assert not one.any()
+    many = scene.partition_dual(sc.V_rest[:], sc.T[:50], 50)
+    assert sorted(many.tolist()) == list(range(50))
