@@ -1749,16 +1749,26 @@ void launch_loop_control(DevLoop *ctl, const double *partE, int nbE, const doubl
 }
 
 // ------------------------------------------------------------------------------------------------
-// element Hessians.  One workgroup of EH_WAVES wavefronts handles 64 tets:
-//   phase 1 (lane of wave 0 = tet): F, SVD, projected spectral blocks -> LDS (U, V, A_w, B_w, rest inverse)
-//   phase 2 (wave = tet, EH_WAVES tets at a time): the 64 lanes expand  M = K Mh K^T (9x9)  and  H = G M G^T (12x12)
-//                         from LDS and write the 144 doubles of H_e as one coalesced 1152-byte row.
+// element Hessians  H_e = (dF/dx)^T [w U^(A (+) B)U^^T]_PSD (dF/dx)   (Energy.cpp:738-777, :1129-1270, IglUtils.hpp:466-479)
+// One wavefront = 64 tets.
+//   phase 1 (lane = tet): F, SVD, projected spectral blocks A_w (3x3), B_w (three 2x2) -> LDS, together with U and,
+//           for each of the 4 vertices, y_v = V^T c_v  (c_v = that vertex' row of dF/dx: c_0 = -(sum of the rest-inverse
+//           rows), c_k = row k-1)
+//   phase 2 (16 lanes per tet, lane = vertex pair (v, v')): the 3x3 block
+//               H_vv' = U N_vv' U^T,    N_vv'[a][c] = sum_{b,d} Mh[(a,b),(c,d)] y_v[b] y_v'[d]
+//           with Mh the 21 spectral entries (A_w on ((a,a),(c,c)); B_w of the pair (p,q) on ((p,q),(q,p)) x itself), i.e.
+//               N[a][c]  = A_w[a][c] y_v[a] y_v'[c]                                   for all a, c
+//               N[p][p] += b00 y_v[q] y_v'[q] ;  N[p][q] += b01 y_v[q] y_v'[p]
+//               N[q][p] += b10 y_v[p] y_v'[q] ;  N[q][q] += b11 y_v[p] y_v'[p]       for (p,q) = (0,1),(1,2),(2,0)
+//           For (2,0) the pair order (p,q),(q,p) is index 6 then 2: the reference's "transposed" fill M(6,6)=B(0,0),
+//           M(6,2)=B(0,1), M(2,6)=B(1,0), M(2,2)=B(1,1)  (Energy.cpp:1203-1207).
+//   Same contraction as expanding the 9x9 dP/dF and applying dF/dx twice, in ~2.4 kflop per tet instead of ~11 kflop
+//   (round 1 expanded all 81 + 144 entries with 64 lanes per tet and was instruction-bound: 131 us on 86k tets).
 // ------------------------------------------------------------------------------------------------
-constexpr int EH_FIELDS = 9 + 9 + 9 + 12 + 9;  // U V Aw Bw Ainv
-constexpr int EH_WAVES = 2;   // 2 waves: all workgroups of a 86k-tet mesh are resident at once (138 VGPRs)
+constexpr int EH_FIELDS = 9 + 12 + 9 + 12;  // U, y_0..y_3, Aw, Bw
 
 template <int MAT>
-__global__ __launch_bounds__(64 * EH_WAVES) void elem_hessian_kernel(const int4 *__restrict__ T,
+__global__ __launch_bounds__(64) void elem_hessian_kernel(const int4 *__restrict__ T,
                                                           const double *__restrict__ A, int nTp, int nT,
                                                           const double *__restrict__ mu,
                                                           const double *__restrict__ lam,
@@ -1766,12 +1776,11 @@ __global__ __launch_bounds__(64 * EH_WAVES) void elem_hessian_kernel(const int4 
                                                           const double *__restrict__ x, double dtSq,
                                                           double *__restrict__ He)
 {
-    __shared__ double pack[EH_FIELDS][64];
-    __shared__ double Msh4[EH_WAVES][81];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double *Msh = Msh4[wv];
+    // tet-major, odd row length: the 16 lanes of a tet read different fields of one row (distinct banks)
+    __shared__ double pack[64][EH_FIELDS + 1];
+    const int lane = threadIdx.x;
     const int e = blockIdx.x * 64 + lane;
-    if (wv == 0 && e < nT) {
+    if (e < nT) {
         const int4 t = T[e];
         double xs[4][3];
         const int vid[4] = {t.x, t.y, t.z, t.w};
@@ -1795,80 +1804,74 @@ __global__ __launch_bounds__(64 * EH_WAVES) void elem_hessian_kernel(const int4 
         double S[3], Bw[3][4];
         svd3(F, U, S, V);
         spectral_blocks<MAT>(S, mu[e], lam[e], dtSq * vol[e], true, Aw, Bw);
+        double *row = pack[lane];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                pack[3 * r + c][lane] = U.m[r][c];
-                pack[9 + 3 * r + c][lane] = V.m[r][c];
-                pack[18 + 3 * r + c][lane] = Aw.m[r][c];
-                pack[39 + 3 * r + c][lane] = Ai[r][c];
+                row[3 * r + c] = U.m[r][c];
+                row[21 + 3 * r + c] = Aw.m[r][c];
             }
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pack[27 + 4 * c + k][lane] = Bw[c][k];
+            for (int k = 0; k < 4; ++k) row[30 + 4 * c + k] = Bw[c][k];
+        // y_v[b] = sum_j V[j][b] c_v[j]
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            double cv[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) cv[j] = (v == 0) ? (-Ai[0][j] - Ai[1][j] - Ai[2][j]) : Ai[v - 1][j];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) row[9 + 3 * v + b] = V.m[0][b] * cv[0] + V.m[1][b] * cv[1] + V.m[2][b] * cv[2];
+        }
     }
     __syncthreads();
     const int nloc = min(64, nT - blockIdx.x * 64);
-    for (int it = 0; it < 64 / EH_WAVES; ++it) {
-        const int le = EH_WAVES * it + wv;   // every wave runs all trips (the barriers are workgroup-wide)
-        const bool live = le < nloc;
-        // ---- M(ij,rs) = sum_{ab,cd} Mh(ab,cd) U(i,a)V(j,b)U(r,c)V(s,d), 81 entries over 64 lanes
-        for (int idx = lane; live && idx < 81; idx += 64) {
-            const int ij = idx / 9, rs = idx % 9;
-            const int i = ij / 3, j = ij % 3, r = rs / 3, s = rs % 3;
-            double ui[3], vj[3], ur[3], vs[3];
+    const int pr = lane & 15, v = pr >> 2, w = pr & 3;
+#pragma unroll 2
+    for (int trip = 0; trip < 16; ++trip) {
+        const int le = 4 * trip + (lane >> 4);
+        if (le >= nloc) continue;
+        const double *row = pack[le];
+        double Um[3][3], Aw[3][3], yv[3], yw[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                ui[k] = pack[3 * i + k][le];
-                vj[k] = pack[9 + 3 * j + k][le];
-                ur[k] = pack[3 * r + k][le];
-                vs[k] = pack[9 + 3 * s + k][le];
-            }
-            double acc = 0.0;
-            // A block: (aa, cc)
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    acc += pack[18 + 3 * a + c][le] * ui[a] * vj[a] * ur[c] * vs[c];
-            // B blocks for pairs (p,q) = (0,1),(1,2),(2,0), basis order (ab) = (p,q),(q,p).  For (2,0)
-            // that is index 6 then 2, which is exactly the reference's "transposed" fill
-            // M(6,6)=B(0,0), M(6,2)=B(0,1), M(2,6)=B(1,0), M(2,2)=B(1,1)  (Energy.cpp:1203-1207).
+        for (int r = 0; r < 3; ++r) {
+            yv[r] = row[9 + 3 * v + r];
+            yw[r] = row[9 + 3 * w + r];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const int p_ = c, q_ = (c + 1) % 3;
-                const double b00 = pack[27 + 4 * c + 0][le], b01 = pack[27 + 4 * c + 1][le];
-                const double b10 = pack[27 + 4 * c + 2][le], b11 = pack[27 + 4 * c + 3][le];
-                const double k_pq = ui[p_] * vj[q_], k_qp = ui[q_] * vj[p_];
-                const double l_pq = ur[p_] * vs[q_], l_qp = ur[q_] * vs[p_];
-                acc += b00 * k_pq * l_pq + b01 * k_pq * l_qp + b10 * k_qp * l_pq + b11 * k_qp * l_qp;
+                Um[r][c] = row[3 * r + c];
+                Aw[r][c] = row[21 + 3 * r + c];
             }
-            Msh[idx] = acc;
         }
-        __syncthreads();
-        // ---- H(r,q) = sum_{b,b'} coef_r[b] coef_q[b'] M[3c_r+b][3c_q+b'], 144 entries over 64 lanes
-        double *out = He + (size_t)144 * (blockIdx.x * 64 + le);
-        for (int idx = lane; live && idx < 144; idx += 64) {
-            const int r = idx / 12, q = idx % 12;
-            const int cr = r % 3, cq = q % 3;
-            double fr[3], fq[3];
+        double N[3][3];
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const double a0 = pack[39 + b][le], a1 = pack[39 + 3 + b][le], a2 = pack[39 + 6 + b][le];
-                const double neg = -a0 - a1 - a2;
-                fr[b] = (r < 3) ? neg : ((r < 6) ? a0 : ((r < 9) ? a1 : a2));
-                fq[b] = (q < 3) ? neg : ((q < 6) ? a0 : ((q < 9) ? a1 : a2));
-            }
-            double acc = 0.0;
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b)
+            for (int c = 0; c < 3; ++c) N[a][c] = Aw[a][c] * yv[a] * yw[c];
 #pragma unroll
-                for (int b2 = 0; b2 < 3; ++b2) acc += fr[b] * fq[b2] * Msh[9 * (3 * cr + b) + 3 * cq + b2];
-            out[idx] = acc;
+        for (int c = 0; c < 3; ++c) {
+            const int p_ = c, q_ = (c + 1) % 3;
+            const double b00 = row[30 + 4 * c], b01 = row[30 + 4 * c + 1], b10 = row[30 + 4 * c + 2],
+                         b11 = row[30 + 4 * c + 3];
+            N[p_][p_] += b00 * yv[q_] * yw[q_];
+            N[p_][q_] += b01 * yv[q_] * yw[p_];
+            N[q_][p_] += b10 * yv[p_] * yw[q_];
+            N[q_][q_] += b11 * yv[p_] * yw[p_];
         }
-        __syncthreads();
+        // H_vw = U N U^T
+        double UN[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) UN[r][c] = Um[r][0] * N[0][c] + Um[r][1] * N[1][c] + Um[r][2] * N[2][c];
+        double *out = He + (size_t)144 * (blockIdx.x * 64 + le) + 36 * v + 3 * w;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                out[12 * r + c] = UN[r][0] * Um[c][0] + UN[r][1] * Um[c][1] + UN[r][2] * Um[c][2];
     }
 }
 
@@ -1877,11 +1880,11 @@ void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *
 {
     const int nb = (M.nT + 63) / 64;
     if (mat == 0)
-        hipLaunchKernelGGL((elem_hessian_kernel<0>), dim3(nb), dim3(64 * EH_WAVES), 0, st, M.T, M.A, M.nTp, M.nT, M.mu,
-                           M.lam, M.vol, x, dtSq, He);
+        hipLaunchKernelGGL((elem_hessian_kernel<0>), dim3(nb), dim3(64), 0, st, M.T, M.A, M.nTp, M.nT, M.mu, M.lam, M.vol,
+                           x, dtSq, He);
     else
-        hipLaunchKernelGGL((elem_hessian_kernel<1>), dim3(nb), dim3(64 * EH_WAVES), 0, st, M.T, M.A, M.nTp, M.nT, M.mu,
-                           M.lam, M.vol, x, dtSq, He);
+        hipLaunchKernelGGL((elem_hessian_kernel<1>), dim3(nb), dim3(64), 0, st, M.T, M.A, M.nTp, M.nT, M.mu, M.lam, M.vol,
+                           x, dtSq, He);
 }
 
 // global block-CSR assembly in gather form: thread = (block k, entry rc)

@@ -3,7 +3,7 @@
 tag=${1:-x}; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python /root/repo/bench.py --no-cpu-baseline "$@" > /tmp/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python /root/repo/bench.py --no-cpu-baseline --extra-workloads none "$@" > /tmp/prof_$tag.log 2>&1
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
 mkdir -p /root/repo/gpurun_out
 cp $f /root/repo/gpurun_out/${tag}_kernel_stats.csv
