@@ -468,6 +468,10 @@ int build_device_mesh(dotmi_handle *h)
     // per part: padded position of every local vertex, tiles of the back-solve, structural non-zeros
     h->partPos.assign(P.nParts, {});
     std::vector<int> dofmap((size_t)P.nParts * P.nmax, -1);
+    // rows per back-solve tile: 64, or 32 when 64-row tiles would not give every CU two workgroups (few subdomains:
+    // the launch is then bound by the pass chain of a workgroup, which halves)
+    int tileRows = ((long long)P.nParts * P.nmax / 64 < 2 * 256) ? 32 : 64;
+    if (const char *ev = getenv("DOTMI_TILE_ROWS")) tileRows = std::min(64, std::max(8, atoi(ev) / 8 * 8));
     std::vector<int4> tiles;
     std::vector<std::vector<int2>> ranges(P.nParts);
     h->precond_bytes = 0;
@@ -501,8 +505,8 @@ int build_device_mesh(dotmi_handle *h)
             // the rows of a region start at their node's first column (a leaf's padding sits in front of its
             // live rows and is skipped; 16-column granularity keeps the 128-byte lines whole)
             const int cb = N.a < 0 ? (ro & ~15) : N.off;
-            for (int r0 = ro; r0 < ro + used; r0 += 64) {
-                const int rows = std::min(64, ro + used - r0);
+            for (int r0 = ro; r0 < ro + used; r0 += tileRows) {
+                const int rows = std::min(tileRows, ro + used - r0);
                 tiles.push_back(make_int4(ls, r0, b | (rows << 16), cb));
                 ranges[ls].push_back(make_int2(cb, r0 + rows));
                 ++b;
