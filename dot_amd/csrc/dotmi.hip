@@ -549,6 +549,13 @@ int build_device_mesh(dotmi_handle *h)
         }
         tiles.swap(shortTiles);
     }
+    // tiles whose rows need the 512-thread variant (more than 2560 columns) first: when both kinds exist they are
+    // launched separately, so that the short ones run on the 256-thread kernel (two workgroups per CU instead of one)
+    std::stable_partition(tiles.begin(), tiles.end(), [](const int4 &t) { return t.y + (t.z >> 16) - t.w > 2560; });
+    P.ntilesWide = 0;
+    for (const int4 &t : tiles) P.ntilesWide += (t.y + (t.z >> 16) - t.w > 2560);
+    if (const char *ev = getenv("DOTMI_SPLIT_BS"))
+        if (atoi(ev) == 0) P.ntilesWide = (P.maxTileLen > 2560) ? (int)tiles.size() : 0;   // one launch, as before
     P.ntiles = (int)tiles.size();
     P.nltiles = (int)ltiles.size();
     P.nlwork = (int)lwork.size();

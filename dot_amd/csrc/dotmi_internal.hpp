@@ -42,6 +42,7 @@ struct DevParts {
     double *Wtmp;           // owned * tmp_stride scratch of the recursion
     int ntiles;             // back-solve jobs, heavy first:
     int4 *tile;             //   (part, first row, tile index within the part | rows << 16, first column)
+    int ntilesWide;         // the first ntilesWide tiles have rows of more than 2560 columns (512-thread kernel)
     int maxTileLen;         // longest row of a tile in `tile` (<= BS_LONG: longer tiles are in `ltile`)
     // tiles whose rows exceed BS_LONG columns: two-phase back-solve over column chunks (kernels.hip)
     int nltiles, nlwork;    // long tiles; (long tile, chunk) work items

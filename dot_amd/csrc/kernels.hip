@@ -886,22 +886,25 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
     // optional events time the streaming kernel alone (the roofline entry of bench.py is about that kernel): they are
     // attached to the dispatch itself (hipExtLaunchKernelGGL: the packet's own begin / end time stamps, what rocprofv3
     // reports as the kernel's duration) -- two hipEventRecord calls around the launch add ~5 us of barrier packets
-    if (P.ntiles > 0) {
-        if (P.maxTileLen <= 2560) {
-            if (ev0 && ev1)
-                hipExtLaunchKernelGGL((backsolve_kernel<256>), dim3(P.ntiles), dim3(256), 0, st, ev0, ev1, 0, P.tile, P.dofmap,
-                                      P.W, P.nmax, (const double *)P.rpad, P.ppart, P.nbmax, ctl);
-            else
-                hipLaunchKernelGGL((backsolve_kernel<256>), dim3(P.ntiles), dim3(256), 0, st, P.tile, P.dofmap, P.W, P.nmax,
-                                   P.rpad, P.ppart, P.nbmax, ctl);
-        } else {  // rows of up to 4096 columns; longer ones are in the long-tile list
-            if (ev0 && ev1)
-                hipExtLaunchKernelGGL((backsolve_kernel<512>), dim3(P.ntiles), dim3(512), 0, st, ev0, ev1, 0, P.tile, P.dofmap,
-                                      P.W, P.nmax, (const double *)P.rpad, P.ppart, P.nbmax, ctl);
-            else
-                hipLaunchKernelGGL((backsolve_kernel<512>), dim3(P.ntiles), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax,
-                                   P.rpad, P.ppart, P.nbmax, ctl);
-        }
+    // wide tiles (rows of 2561..4096 columns) on the 512-thread kernel, the rest on the 256-thread one (two workgroups per
+    // CU instead of one); the events (if any) span both launches: start of the first, stop of the last
+    const int nW = P.ntilesWide, nN = P.ntiles - P.ntilesWide;
+    const bool timed = ev0 && ev1;
+    if (nW > 0) {
+        if (timed)
+            hipExtLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, ev0, nN > 0 ? (hipEvent_t) nullptr : ev1, 0,
+                                  P.tile, P.dofmap, P.W, P.nmax, (const double *)P.rpad, P.ppart, P.nbmax, ctl);
+        else
+            hipLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax, P.rpad,
+                               P.ppart, P.nbmax, ctl);
+    }
+    if (nN > 0) {
+        if (timed)
+            hipExtLaunchKernelGGL((backsolve_kernel<256>), dim3(nN), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
+                                  P.tile + nW, P.dofmap, P.W, P.nmax, (const double *)P.rpad, P.ppart, P.nbmax, ctl);
+        else
+            hipLaunchKernelGGL((backsolve_kernel<256>), dim3(nN), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax,
+                               P.rpad, P.ppart, P.nbmax, ctl);
     }
     if (P.nltiles > 0) {
         hipLaunchKernelGGL((backsolve_long_kernel<0>), dim3(P.nlwork), dim3(BSL_THREADS), 0, st, P.ltile, P.lwork, P.dofmap,
