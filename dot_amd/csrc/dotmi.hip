@@ -1187,10 +1187,7 @@ int apply_precond(dotmi_handle *h, const double *q, double *z, const LbfgsArgs &
     } else {
         launch_merge(h->M, h->P, L, z, h->partC, 0, h->st);
         if (int rc = allreduce_sum(h, z, h->n)) return rc;
-        launch_div_dup(h->nV, h->P.dup, z, h->st);
-        const double *ys_[HIST_MAX];
-        for (int i = 0; i < L.m; ++i) ys_[i] = L.y[i];
-        if (L.m > 0) launch_multidot(h->n, z, ys_, L.m, h->partC, h->st);
+        launch_zfinish(h->nV, h->P.dup, L, z, h->partC, h->st);
     }
     return 0;
 }
@@ -1288,7 +1285,16 @@ int enqueue_loop_slot(dotmi_handle *h)
     launch_gemv(h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr,
                 timed ? h->evPre[h->evUsed + 1] : nullptr);
     if (timed) h->evUsed += 2;
-    launch_merge(h->M, h->P, L0, h->z, h->partC, 1 | 2, h->st, h->ctl);
+    if (!h->dist) {
+        launch_merge(h->M, h->P, L0, h->z, h->partC, 1 | 2, h->st, h->ctl);
+    } else {
+        // sharded subdomains: the one collective of an iteration, enqueued like a kernel.  It runs in every slot (also
+        // in retries and past the end, where the kernels around it return at once), so every rank issues the same
+        // sequence of collectives whatever the controller decides
+        launch_merge(h->M, h->P, L0, h->z, h->partC, 0, h->st, h->ctl);
+        if (int rc = allreduce_sum(h, h->z, n)) return rc;
+        launch_zfinish(h->nV, h->P.dup, L0, h->z, h->partC, h->st, h->ctl);
+    }
     launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
     launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, 0, h->nV, h->partS, h->st, h->ctl);
     launch_step_forward(n, h->x, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st,
@@ -1364,6 +1370,37 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     int enq = 0;
     const double tStart = now_ms();
     long spins = 0;
+    if (h->dist) {
+        // Sharded subdomains: every slot carries a collective, so every rank must enqueue the SAME number of slots.
+        // Deterministic batches instead of following the posted progress: one slot more than the last step used, then
+        // (rarely) short batches; after a batch the ranks check against rank 0 that they stopped in the same state.
+        int target = std::max(h->prevSlots + 1, 4);
+        for (;;) {
+            while (enq < target) {
+                if (int rc = enqueue_loop_slot(h)) return rc;
+                ++enq;
+            }
+            HIPCHECK(h, hipMemcpyAsync(h->h_ctl, h->ctl, sizeof(DevLoop), hipMemcpyDeviceToHost, h->st));
+            HIPCHECK(h, hipStreamSynchronize(h->st));
+            HIPCHECK(h, hipGetLastError());
+            double mine[4] = {(double)C.status, (double)C.slots, (double)C.iter, (double)C.halvings}, r0[4];
+            memcpy(r0, mine, sizeof(mine));
+            if (int rc = adopt_rank0(h, r0, 4)) return rc;
+            if (memcmp(r0, mine, sizeof(mine)) != 0) {
+                h->err = "the ranks left the L-BFGS loop in different states (rank 0: status " + std::to_string((int)r0[0]) +
+                         " after " + std::to_string((int)r0[1]) + " slots; this rank: status " + std::to_string(C.status) +
+                         " after " + std::to_string(C.slots) + ")";
+                h->poisoned = true;
+                return DOTMI_E_DEVICE;
+            }
+            if (C.status != 0) break;
+            target = enq + std::max(2, std::min(8, enq / 4));
+            if (now_ms() - tStart > 600000.0) {
+                h->err = "device loop timed out";
+                return DOTMI_E_DEVICE;
+            }
+        }
+    } else
     while (flags[0] == 0) {
         if (enq < std::max(notifyFrom, (int)flags[1]) + AHEAD) {
             if (int rc = enqueue_loop_slot(h)) return rc;
@@ -1870,8 +1907,10 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
             h->err = "DOTMI_FLAG_GSDD: single GPU and subdomains without long-row tiles only";
             return DOTMI_E_INVALID;
         }
-        h->devLoop = !h->dist && !h->gsdd && !h->newton && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) &&
-                     !(ev && atoi(ev) == 0);
+        // sharded subdomains keep the loop on the device as long as the element pass is replicated (shardElems: the
+        // gradient all-reduce and the alpha_0 scalars still go through the host loop)
+        h->devLoop = !(h->dist && h->shardElems) && !h->gsdd && !h->newton &&
+                     !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) && !(ev && atoi(ev) == 0);
         h->logCap = std::min(h->iterCap, 10001) + 1;
         h->kindCap = 4096;
         HIPCHECK(h, hipHostMalloc((void **)&h->h_ctl, sizeof(DevLoop)));

@@ -1363,6 +1363,53 @@ void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, doubl
                            L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl);
 }
 
+// Sharded subdomains: z holds the all-reduced SUM over every subdomain; z_v /= dup_v and the partial dots c_i = y_i . z,
+// i.e. the second half of merge_kernel after the collective (same vertex loop and partial layout).
+template <bool DEV>
+__global__ __launch_bounds__(256) void zfinish_kernel(int nV, const int *__restrict__ dup, LbfgsArgs L,
+                                                      double *__restrict__ z, double *__restrict__ partials,
+                                                      const DevLoop *__restrict__ ctl)
+{
+    __shared__ double sm[4 * RED_K];
+    if constexpr (DEV) {
+        if (ctl->status != 0 || ctl->phase != 0) return;
+    }
+    const LbfgsArgs &Lr = [&]() -> const LbfgsArgs & {
+        if constexpr (DEV) return ctl->L;
+        else return L;
+    }();
+    double acc[RED_K];
+#pragma unroll
+    for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
+    const int stride = gridDim.x * blockDim.x;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nV; v += stride) {
+        const int d = dup[v];
+        double z0 = z[3 * v], z1 = z[3 * v + 1], z2 = z[3 * v + 2];
+        if (d > 1) {
+            z0 /= d;
+            z1 /= d;
+            z2 /= d;
+            z[3 * v] = z0;
+            z[3 * v + 1] = z1;
+            z[3 * v + 2] = z2;
+        }
+#pragma unroll
+        for (int i = 0; i < HIST_MAX; ++i)
+            if (i < Lr.m) {
+                const double *yi = Lr.y[i] + 3 * v;
+                acc[i] += yi[0] * z0 + yi[1] * z1 + yi[2] * z2;
+            }
+    }
+    write_partials(acc, DEV ? HIST_MAX : Lr.m, partials, sm);
+}
+
+void launch_zfinish(int nV, const int *dup, const LbfgsArgs &L, double *z, double *partials, hipStream_t st,
+                    const DevLoop *ctl)
+{
+    if (ctl) hipLaunchKernelGGL(zfinish_kernel<true>, dim3(NB_RED), dim3(256), 0, st, nV, dup, L, z, partials, ctl);
+    else hipLaunchKernelGGL(zfinish_kernel<false>, dim3(NB_RED), dim3(256), 0, st, nV, dup, L, z, partials, ctl);
+}
+
 __global__ void div_dup_kernel(int nV, const int *__restrict__ dup, double *__restrict__ z)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;

@@ -207,6 +207,26 @@ def test_sharded_code_path_with_one_rank_rccl(shard_elems, monkeypatch):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 5), ("monkey18K_stiff", 1)])
+def test_sharded_device_loop_is_bit_identical_to_sharded_host_loop(workload, steps, monkeypatch):
+    """Sharded subdomains with a replicated element pass keep the loop control on the device: the z all-reduce is
+    enqueued inside every slot and the slots go out in deterministic batches (same count on every rank).  With the 1-rank
+    RCCL communicator of DOTMI_FLAG_FORCE_DIST it must take exactly the decisions of the sharded host loop."""
+    monkeypatch.setenv("DOTMI_SHARD_ELEMS", "0")
+    sc, ep, n = load_workload(workload)
+    a = DOTTimeStepper(sc, ep, n, flags=dl.FLAG_FORCE_DIST)
+    sc2, _, _ = load_workload(workload)
+    b = DOTTimeStepper(sc2, ep, n, flags=dl.FLAG_FORCE_DIST | dl.FLAG_HOST_LOOP)
+    for k in range(steps):
+        ra, rb = a.solve(1), b.solve(1)
+        assert ra == rb
+        sa, sb = a.last_stats, b.last_stats
+        assert (sa.iters, sa.ls_halvings, sa.energy_evals) == (sb.iters, sb.ls_halvings, sb.energy_evals)
+        assert sa.E == sb.E and sa.g2 == sb.g2
+        assert np.array_equal(a.getResult(), b.getResult())
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 6), ("monkey18K_stiff", 2)])
 def test_device_loop_control_is_bit_identical_to_host_loop(workload, steps):
     """The device-resident loop control (DevLoop + loop_control_kernel) replaces one host round trip per

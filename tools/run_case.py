@@ -1,5 +1,6 @@
-"""per-step stats of a workload on the GPU:  python tools/run_case.py <workload> [nparts] [steps] [energy]"""
-import sys, time
+"""per-step stats of a workload on the GPU:  python tools/run_case.py <workload> [nparts] [steps] [energy]
+(env RUN_CASE_FLAGS = dotmi flag bits, e.g. 4 = DOTMI_FLAG_FORCE_DIST: the sharded sequencing on a 1-rank communicator)"""
+import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 from tests.workloads import load_workload
@@ -8,7 +9,7 @@ name = sys.argv[1]; nparts = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 sc, ep, n = load_workload(name, nparts)
 if len(sys.argv) > 4: sc.cfg.energy = sys.argv[4]
-t = time.time(); ts = DOTTimeStepper(sc, ep, n); print("create %.2f s" % (time.time() - t))
+t = time.time(); ts = DOTTimeStepper(sc, ep, n, flags=int(os.environ.get('RUN_CASE_FLAGS', '0'))); print("create %.2f s" % (time.time() - t))
 for k in range(steps):
     x = ts.getResult(); idx, pos = sc.scripter.step(x, sc.cfg.dt); ts.setDirichlet(idx, pos)
     st = ts.step()
