@@ -113,6 +113,7 @@ struct dotmi_handle {
     double *gcont = nullptr, *He = nullptr, *Hval = nullptr, *tmpn = nullptr;
     double *S[HIST_MAX + 1] = {nullptr}, *Y[HIST_MAX + 1] = {nullptr};
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
+    double *gstage = nullptr;   // sharded element pass, device loop: [g (n) ; 0 ; E] staging buffer of the gradient all-reduce
     double *alpha_dev = nullptr;
     int *info_dev = nullptr, *h_info = nullptr;  // per owned part: failing pivot (device / pinned copy)
     int4 *clearSeg = nullptr;                    // row segments (row, first column, columns, -) cleared before a refill
@@ -1217,6 +1218,7 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
     a.y_new = h->Y[slot];
     a.iv0 = h->v0;
     a.iv1 = h->v1;
+    a.stage = 0;
     if (!h->shardElems) {
         a.make_pair = make_pair;
         launch_vertex_gather(h->M, a, L, partR, h->st);
@@ -1296,23 +1298,47 @@ int enqueue_loop_slot(dotmi_handle *h)
         launch_zfinish(h->nV, h->P.dup, L0, h->z, h->partC, h->st, h->ctl);
     }
     launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
-    launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, 0, h->nV, h->partS, h->st, h->ctl);
-    launch_step_forward(n, h->x, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st,
-                        h->ctl);
+    launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st, h->ctl);
+    const double *spart = h->partS;
+    if (h->shardElems) {
+        // this rank's rows of p.g and p.Hp -> two scalars -> summed over the ranks (row 0 of partG; rows >= 1 stay zero)
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partS, NB_RED, RED_K, 2, 0.0, 0.0, 0,
+                           h->partG);
+        if (int rc = allreduce_sum(h, h->partG, 2)) return rc;
+        spart = h->partG;
+    }
+    launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st, h->ctl);
     int nb = 0;
-    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x_trial, h->xt, nullptr, h->nT, 0, h->nV, h->gcont, h->partE,
-                            &nb, h->st, h->ctl);
+    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x_trial, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, h->gcont,
+                            h->partE, &nb, h->st, h->ctl);
     GatherArgs a;
     memset(&a, 0, sizeof(a));
     a.gcont = h->gcont;
     a.xt = h->xt;
     a.p = h->p;
     a.alpha_dev = h->alpha_dev;
-    a.make_pair = 1;
-    a.iv0 = 0;
-    a.iv1 = h->nV;
+    a.iv0 = h->v0;
+    a.iv1 = h->v1;
+    if (!h->shardElems) {
+        a.make_pair = 1;
+        launch_vertex_gather(h->M, a, L0, h->partR, h->st, h->ctl);
+        launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st);
+        return 0;
+    }
+    // sharded element pass: the partial gradient of this rank's elements and its energy go to the staging buffer
+    // [g (n) ; 0 ; E_local], one all-reduce, then the pair + statistics from the summed gradient (which is copied to
+    // the trial gradient, whose address only the controller knows).  The controller reads the energy as one "block"
+    // (0, E): dtSq * 0 + E.
+    a.make_pair = 0;
+    a.stage = 1;
+    a.g_new = h->gstage;
     launch_vertex_gather(h->M, a, L0, h->partR, h->st, h->ctl);
-    launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
+                       h->gstage + n + 1);
+    if (int rc = allreduce_sum(h, h->gstage, (size_t)n + 2)) return rc;
+    a.make_pair = 1;
+    launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
+    launch_loop_control(h->ctl, h->gstage + n, 1, h->partR, h->alpha_dev, h->h_flags, h->st);
     return 0;
 }
 
@@ -1341,6 +1367,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     C.logCap = h->logCap;
     C.kindCap = h->kindCap;
     volatile int *flags = h->h_flags;
+    const int n_ = h->n;
     flags[0] = 0;
     flags[1] = 0;
     // blind up to a little before last step's slot count, then two slots ahead of the posted progress
@@ -1351,21 +1378,31 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     {
         // energy and gradient at the start of the step, reduced by the controller (no host round trip)
         int nb = 0;
-        launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x, h->xt, nullptr, h->nT, 0, h->nV, h->gcont, h->partE, &nb,
-                                h->st);
+        launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, h->gcont,
+                                h->partE, &nb, h->st);
         GatherArgs a;
         memset(&a, 0, sizeof(a));
         a.gcont = h->gcont;
         a.x = h->x;
         a.xt = h->xt;
-        a.g_new = h->g;
+        a.g_new = h->shardElems ? h->gstage : h->g;
         a.make_pair = 0;
-        a.iv0 = 0;
-        a.iv1 = h->nV;
+        a.iv0 = h->v0;
+        a.iv1 = h->v1;
         LbfgsArgs L0;
         memset(&L0, 0, sizeof(L0));
         launch_vertex_gather(h->M, a, L0, h->partR, h->st);
-        launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
+        if (!h->shardElems) {
+            launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
+        } else {
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
+                               h->gstage + n_ + 1);
+            if (int rc = allreduce_sum(h, h->gstage, (size_t)n_ + 2)) return rc;
+            HIPCHECK(h, hipMemcpyAsync(h->g, h->gstage, sizeof(double) * n_, hipMemcpyDeviceToDevice, h->st));
+            const double *vecs[1] = {h->g};
+            launch_multidot(n_, h->g, vecs, 1, h->partR, h->st);   // |g|^2
+            launch_loop_control(h->ctl, h->gstage + n_, 1, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
+        }
     }
     int enq = 0;
     const double tStart = now_ms();
@@ -1892,6 +1929,8 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         HIPCHECK(h, hipMemsetAsync(*pp, 0, sizeof(double) * NB_RED * RED_K, h->st));
     }
     if (int rc = dalloc(h, &h->alpha_dev, 8)) return rc;
+    if (int rc = dalloc(h, &h->gstage, (size_t)n + 2)) return rc;
+    HIPCHECK(h, hipMemsetAsync(h->gstage, 0, sizeof(double) * ((size_t)n + 2), h->st));
     HIPCHECK(h, hipHostMalloc((void **)&h->h_partE, sizeof(double) * 2 * 2048));
     HIPCHECK(h, hipHostMalloc((void **)&h->h_partR, sizeof(double) * NB_RED * RED_K));
     HIPCHECK(h, hipHostMalloc((void **)&h->h_alpha, sizeof(double) * 8));
@@ -1907,10 +1946,8 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
             h->err = "DOTMI_FLAG_GSDD: single GPU and subdomains without long-row tiles only";
             return DOTMI_E_INVALID;
         }
-        // sharded subdomains keep the loop on the device as long as the element pass is replicated (shardElems: the
-        // gradient all-reduce and the alpha_0 scalars still go through the host loop)
-        h->devLoop = !(h->dist && h->shardElems) && !h->gsdd && !h->newton &&
-                     !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) && !(ev && atoi(ev) == 0);
+        h->devLoop = !h->gsdd && !h->newton && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) &&
+                     !(ev && atoi(ev) == 0);
         h->logCap = std::min(h->iterCap, 10001) + 1;
         h->kindCap = 4096;
         HIPCHECK(h, hipHostMalloc((void **)&h->h_ctl, sizeof(DevLoop)));

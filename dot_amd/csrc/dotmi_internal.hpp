@@ -142,11 +142,13 @@ struct GatherArgs {
     double *g_new, *s_new, *y_new;
     int make_pair;
     int iv0, iv1;  // vertex range whose inertia term m_v (x_v - x~_v) this rank adds
+    int stage;     // device loop, sharded element pass: g_new is a staging buffer (kept as passed), no pair
 };
 void launch_vertex_gather(const DevMesh &M, const GatherArgs &a, const LbfgsArgs &L, double *partials,
                           hipStream_t st, const DevLoop *ctl = nullptr);
 // pair + statistics from already summed gradients (multi-GPU: after the all-reduce of g)
-void launch_pair_stats(int n, const GatherArgs &a, const LbfgsArgs &L, double *partials, hipStream_t st);
+void launch_pair_stats(int n, const GatherArgs &a, const LbfgsArgs &L, double *partials, hipStream_t st,
+                       const double *gsrc = nullptr, const DevLoop *ctl = nullptr);
 // two-loop, first half:  b_i = s_i . g  partials
 void launch_multidot(int n, const double *v, const double *const *vecs, int m, double *partials,
                      hipStream_t st);

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
         if (ctl->status != 0) return;
         a.x = ctl->x_trial;
         a.g_old = ctl->g_cur;
-        a.g_new = ctl->g_trial;
+        if (!a.stage) a.g_new = ctl->g_trial;   // stage: this rank's partial gradient goes to the buffer the host named
         a.s_new = ctl->S[ctl->slot];
         a.y_new = ctl->Y[ctl->slot];
     }
@@ -332,29 +332,46 @@ void launch_vertex_gather(const DevMesh &M, const GatherArgs &a, const LbfgsArgs
                            M.fixed, M.mass, a, L, partials, ctl);
 }
 
-__global__ __launch_bounds__(256) void pair_stats_kernel(int n, GatherArgs a, LbfgsArgs L,
-                                                         double *__restrict__ partials)
+// gsrc != nullptr: the summed gradient is read from gsrc and copied to g_new on the way (device loop: the all-reduce
+// runs on a staging buffer because the trial gradient's address is only known on the device)
+template <bool DEV>
+__global__ __launch_bounds__(256) void pair_stats_kernel(int n, GatherArgs a, LbfgsArgs L, const double *__restrict__ gsrc,
+                                                         double *__restrict__ partials, const DevLoop *__restrict__ ctl)
 {
     __shared__ double sm[4 * RED_K];
+    if constexpr (DEV) {
+        if (ctl->status != 0) return;
+        a.g_old = ctl->g_cur;
+        a.g_new = ctl->g_trial;
+        a.s_new = ctl->S[ctl->slot];
+        a.y_new = ctl->Y[ctl->slot];
+    }
+    const LbfgsArgs &Lr = [&]() -> const LbfgsArgs & {
+        if constexpr (DEV) return ctl->L;
+        else return L;
+    }();
     double acc[RED_K];
 #pragma unroll
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
     const double alpha = *a.alpha_dev;
     const int stride = gridDim.x * blockDim.x;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        const double gn = a.g_new[k];
+        const double gn = gsrc ? gsrc[k] : a.g_new[k];
+        if (gsrc) a.g_new[k] = gn;
         const double sn = alpha * a.p[k];
         const double yn = gn - a.g_old[k];
         a.s_new[k] = sn;
         a.y_new[k] = yn;
-        pair_stats_accum(k, gn, sn, yn, L, acc);
+        pair_stats_accum(k, gn, sn, yn, Lr, acc);
     }
     write_partials(acc, RED_K, partials, sm);
 }
 
-void launch_pair_stats(int n, const GatherArgs &a, const LbfgsArgs &L, double *partials, hipStream_t st)
+void launch_pair_stats(int n, const GatherArgs &a, const LbfgsArgs &L, double *partials, hipStream_t st,
+                       const double *gsrc, const DevLoop *ctl)
 {
-    hipLaunchKernelGGL(pair_stats_kernel, dim3(NB_RED), dim3(256), 0, st, n, a, L, partials);
+    if (ctl) hipLaunchKernelGGL(pair_stats_kernel<true>, dim3(NB_RED), dim3(256), 0, st, n, a, L, gsrc, partials, ctl);
+    else hipLaunchKernelGGL(pair_stats_kernel<false>, dim3(NB_RED), dim3(256), 0, st, n, a, L, gsrc, partials, ctl);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -207,12 +207,14 @@ def test_sharded_code_path_with_one_rank_rccl(shard_elems, monkeypatch):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("shard_elems", ["0", "1"])
 @pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 5), ("monkey18K_stiff", 1)])
-def test_sharded_device_loop_is_bit_identical_to_sharded_host_loop(workload, steps, monkeypatch):
-    """Sharded subdomains with a replicated element pass keep the loop control on the device: the z all-reduce is
-    enqueued inside every slot and the slots go out in deterministic batches (same count on every rank).  With the 1-rank
-    RCCL communicator of DOTMI_FLAG_FORCE_DIST it must take exactly the decisions of the sharded host loop."""
-    monkeypatch.setenv("DOTMI_SHARD_ELEMS", "0")
+def test_sharded_device_loop_is_bit_identical_to_sharded_host_loop(workload, steps, shard_elems, monkeypatch):
+    """Sharded subdomains keep the loop control on the device: the collectives (z; with a sharded element pass also the
+    alpha_0 scalars and the staged [g ; 0 ; E]) are enqueued inside every slot and the slots go out in deterministic
+    batches (same count on every rank).  With the 1-rank RCCL communicator of DOTMI_FLAG_FORCE_DIST it must take exactly
+    the decisions of the sharded host loop."""
+    monkeypatch.setenv("DOTMI_SHARD_ELEMS", shard_elems)
     sc, ep, n = load_workload(workload)
     a = DOTTimeStepper(sc, ep, n, flags=dl.FLAG_FORCE_DIST)
     sc2, _, _ = load_workload(workload)
