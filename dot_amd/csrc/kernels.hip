@@ -708,6 +708,9 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
     }
 }
 
+#ifdef BS_PROFILE
+__device__ long long g_bs_prof[8192][5];
+#endif
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restrict__ job,
                                                             const int *__restrict__ dofmap,
@@ -720,6 +723,18 @@ __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restri
     if (ctl && (ctl->status != 0 || ctl->phase != 0)) return;
     const int4 jb = job[blockIdx.x];
     const int len = jb.y + (jb.z >> 16) - jb.w;   // longest row of the tile
+#ifdef BS_PROFILE
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_bs_prof[blockIdx.x][0] = wall_clock64();
+        g_bs_prof[blockIdx.x][2] = len;
+        g_bs_prof[blockIdx.x][3] = jb.z >> 16;
+        g_bs_prof[blockIdx.x][4] = (long long)hw | ((long long)(xcc & 15) << 32);
+    }
+#endif
     if constexpr (THREADS == 256) {
         if (len <= 512) backsolve_tile<256, 1, 32>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
         else if (len <= 1024) backsolve_tile<256, 2, 16>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
@@ -730,7 +745,17 @@ __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restri
         else if (len <= 2048) backsolve_tile<512, 2, 16>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
         else backsolve_tile<512, 4, 8>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
     }
+#ifdef BS_PROFILE
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_bs_prof[blockIdx.x][1] = wall_clock64();
+#endif
 }
+#ifdef BS_PROFILE
+extern "C" int dotmi_debug_bs_prof(long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bs_prof), sizeof(long long) * 5 * (size_t)n);
+}
+#endif
 
 __device__ const double g_zero_slot = 0.0;
 
