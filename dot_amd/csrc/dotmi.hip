@@ -93,6 +93,7 @@ struct dotmi_handle {
     std::vector<NdNode> nd;                 // nested-dissection layout shared by the owned parts (root = 0)
     std::vector<std::vector<int>> partPos;  // owned parts: padded scalar position of partVerts[p][i]
     std::vector<int> partTilePtr;           // owned parts: range of each part's tiles in DevParts::tileByPart
+    std::vector<int> partLworkPtr;          //   and of its long-row work items in DevParts::lworkByPart
 
     // device
     hipStream_t st = nullptr;
@@ -521,10 +522,28 @@ int build_device_mesh(dotmi_handle *h)
     for (auto &r : ranges) P.nbmax = std::max(P.nbmax, (int)r.size());
     std::vector<int2> trange((size_t)std::max(P.nParts, 1) * P.nbmax, make_int2(0, 0));
     for (int ls = 0; ls < P.nParts; ++ls) std::copy(ranges[ls].begin(), ranges[ls].end(), trange.begin() + (size_t)ls * P.nbmax);
-    const std::vector<int4> tilesByPart(tiles);   // generated part after part
+    // the same tiles grouped by part (GSDD solves one subdomain at a time): register-kernel tiles, and the long-row tiles
+    // with their (tile, column chunk) work items
+    auto tile_len = [](const int4 &t) { return t.y + (t.z >> 16) - t.w; };
+    std::vector<int4> tilesByPart, ltilesByPart;
+    std::vector<int2> lworkByPart;
     h->partTilePtr.assign(P.nParts + 1, 0);
-    for (const int4 &t : tilesByPart) h->partTilePtr[t.x + 1]++;
-    for (int ls = 0; ls < P.nParts; ++ls) h->partTilePtr[ls + 1] += h->partTilePtr[ls];
+    h->partLworkPtr.assign(P.nParts + 1, 0);
+    for (const int4 &t : tiles) {   // generated part after part
+        if (tile_len(t) > BS_LONG) {
+            const int nch = (((tile_len(t) + 15) & ~15) + BS_LONG - 1) / BS_LONG;
+            for (int c = 0; c < nch; ++c) lworkByPart.push_back(make_int2((int)ltilesByPart.size(), c));
+            ltilesByPart.push_back(t);
+            h->partLworkPtr[t.x + 1] += nch;
+        } else {
+            tilesByPart.push_back(t);
+            h->partTilePtr[t.x + 1]++;
+        }
+    }
+    for (int ls = 0; ls < P.nParts; ++ls) {
+        h->partTilePtr[ls + 1] += h->partTilePtr[ls];
+        h->partLworkPtr[ls + 1] += h->partLworkPtr[ls];
+    }
     // heavy tiles first: work ~ rows * row length
     auto tile_work = [](const int4 &t) { return (long long)(t.z >> 16) * (t.y + 64 - t.w); };
     std::stable_sort(tiles.begin(), tiles.end(), [&](const int4 &a, const int4 &b) { return tile_work(a) > tile_work(b); });
@@ -601,6 +620,8 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = upload(h, &P.dofmap, dofmap)) return rc;
     if (int rc = upload(h, &P.tile, tiles)) return rc;
     if (int rc = upload(h, &P.tileByPart, tilesByPart)) return rc;
+    if (int rc = upload(h, &P.ltileByPart, ltilesByPart)) return rc;
+    if (int rc = upload(h, &P.lworkByPart, lworkByPart)) return rc;
     if (int rc = upload(h, &P.ltile, ltiles)) return rc;
     if (int rc = upload(h, &P.lwork, lwork)) return rc;
     if (int rc = dalloc(h, &P.tdots, (size_t)std::max(P.nltiles, 1) * P.maxChunks * 64)) return rc;
@@ -1499,6 +1520,7 @@ int run_gsdd_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *fai
         for (int ls = 0; ls < h->P.nParts && !*failed; ++ls) {
             launch_build_q(n, h->g, L0, nullptr, h->q, h->st);                     // q = -g
             launch_gemv_part(h->P, ls, h->P.tileByPart + h->partTilePtr[ls], h->partTilePtr[ls + 1] - h->partTilePtr[ls],
+                             h->P.lworkByPart + h->partLworkPtr[ls], h->partLworkPtr[ls + 1] - h->partLworkPtr[ls],
                              h->q, n, h->p, h->st);
             double alpha = 1.0, E = 0;
             launch_step_forward(n, h->x, h->p, h->x_trial, nullptr, alpha, 0, h->alphaMin, h->alpha_dev, h->h_alpha, h->st);
@@ -1942,8 +1964,8 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
             h->err = "DOTMI_FLAG_NEWTON: single GPU, not together with DOTMI_FLAG_GSDD";
             return DOTMI_E_INVALID;
         }
-        if (h->gsdd && (h->dist || h->P.nltiles > 0)) {
-            h->err = "DOTMI_FLAG_GSDD: single GPU and subdomains without long-row tiles only";
+        if (h->gsdd && h->dist) {
+            h->err = "DOTMI_FLAG_GSDD: single GPU only";
             return DOTMI_E_INVALID;
         }
         h->devLoop = !h->gsdd && !h->newton && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) &&

@@ -50,7 +50,9 @@ struct DevParts {
     int2 *lwork;            // (index into ltile, chunk)
     int maxChunks;          // chunks of the longest long tile
     double *tdots;          // nltiles * maxChunks * 64 chunk partials of the row dot products
-    int4 *tileByPart;       // the same tiles grouped by part (GSDD solves one subdomain at a time)
+    int4 *tileByPart;       // the register-kernel tiles grouped by part (GSDD solves one subdomain at a time)
+    int4 *ltileByPart;      // the long-row tiles grouped by part, and their work items (x = index into ltileByPart)
+    int2 *lworkByPart;
     int nbmax;              // max row tiles per part
     int2 *trange;           // owned * nbmax: columns [first, end) each tile of a part contributes to
     double *ppart;          // owned * nbmax * nmax partial results of the back-solve tiles
@@ -164,8 +166,8 @@ void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, c
                        const DevLoop *ctl = nullptr);
 // one subdomain only (GSDD, DOTTimeStepper.cpp:507-565): psub_s = X_s^T (X_s q[dofmap_s]) for owned part `ls`, whose
 // tiles are job[0..njobs); then p = 0 except p[dofs of part ls] = psub_s  (ADMMDDTimeStepper::fill, :1646-1665)
-void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, const double *q, int n, double *p,
-                      hipStream_t st);
+void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, const int2 *lwork, int nlwork, const double *q,
+                      int n, double *p, hipStream_t st);
 // z = merge(psub) / dup  (+ partial dots y_i . z)
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
                   int with_dots, hipStream_t st, const DevLoop *ctl = nullptr);

@@ -968,19 +968,27 @@ __global__ __launch_bounds__(256) void fill_part_kernel(const int *__restrict__ 
     if (d >= 0) p[d] = psub[(size_t)s * nmax + k];
 }
 
-void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, const double *q, int n, double *p,
-                      hipStream_t st)
+void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, const int2 *lwork, int nlwork, const double *q,
+                      int n, double *p, hipStream_t st)
 {
     hipMemsetAsync(p, 0, sizeof(double) * n, st);
-    if (njobs <= 0) return;
+    if (njobs <= 0 && nlwork <= 0) return;
     hipLaunchKernelGGL(gather_pad_kernel, dim3((P.nmax + 255) / 256), dim3(256), 0, st, P.nmax, P.dofmap + (size_t)ls * P.nmax,
                        q, P.rpad + (size_t)ls * P.nmax);
-    if (P.maxTileLen <= 2560)
-        hipLaunchKernelGGL((backsolve_kernel<256>), dim3(njobs), dim3(256), 0, st, job, P.dofmap, P.W, P.nmax, P.rpad,
-                           P.ppart, P.nbmax, (const DevLoop *)nullptr);
-    else
-        hipLaunchKernelGGL((backsolve_kernel<512>), dim3(njobs), dim3(512), 0, st, job, P.dofmap, P.W, P.nmax, P.rpad,
-                           P.ppart, P.nbmax, (const DevLoop *)nullptr);
+    if (njobs > 0) {
+        if (P.maxTileLen <= 2560)
+            hipLaunchKernelGGL((backsolve_kernel<256>), dim3(njobs), dim3(256), 0, st, job, P.dofmap, P.W, P.nmax, P.rpad,
+                               P.ppart, P.nbmax, (const DevLoop *)nullptr);
+        else
+            hipLaunchKernelGGL((backsolve_kernel<512>), dim3(njobs), dim3(512), 0, st, job, P.dofmap, P.W, P.nmax, P.rpad,
+                               P.ppart, P.nbmax, (const DevLoop *)nullptr);
+    }
+    if (nlwork > 0) {   // rows beyond the register tile: the two-phase kernel on this part's work items
+        hipLaunchKernelGGL((backsolve_long_kernel<0>), dim3(nlwork), dim3(BSL_THREADS), 0, st, P.ltileByPart, lwork, P.dofmap,
+                           P.W, P.nmax, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, (const DevLoop *)nullptr);
+        hipLaunchKernelGGL((backsolve_long_kernel<1>), dim3(nlwork), dim3(BSL_THREADS), 0, st, P.ltileByPart, lwork, P.dofmap,
+                           P.W, P.nmax, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, (const DevLoop *)nullptr);
+    }
     hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, 1), dim3(256), 0, st, P.trange, P.ppart, P.nmax,
                        P.nbmax, P.psub, (const DevLoop *)nullptr, ls);
     hipLaunchKernelGGL(fill_part_kernel, dim3((P.nmax + 255) / 256), dim3(256), 0, st, P.dofmap, P.psub, P.nmax, ls, p);

@@ -119,7 +119,7 @@ enum {
                                      * DOTTimeStepper.cpp:507-565) on the same factors and kernels instead of
                                      * L-BFGS-H: per iteration one sweep over the subdomains -- solve H_s p_s = -g_s,
                                      * line search from step 1 along p_s, refresh the gradient.  stats.iters = sweeps.
-                                     * Single GPU; subdomains whose rows exceed 4096 columns are not supported here. */
+                                     * Single GPU. */
 
 #define DOTMI_FLAG_NEWTON 64         /* dotmi_step runs the reference's projected Newton (`timeStepper Newton`, the base
                                      * Optimizer::fullyImplicit / solve_oneStep, Optimizer.cpp:654-749): every iteration

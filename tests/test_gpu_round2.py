@@ -424,6 +424,24 @@ def test_gsdd_steps_match_oracle(name, energy, steps):
     ts.close(); orc.close()
 
 
+def test_gsdd_with_long_row_subdomains():
+    """`timeStepper GSDD 6` is what the reference ships (input/otherMethods/monkey18K_TSS_GSDD_E2.5e4.txt:2): six
+    subdomains of ~10 k DOFs, whose separator rows are longer than the register tile of the single-pass back-solve.  The
+    per-subdomain solve of the GSDD sweep then runs the part's long-row work items through the two-phase kernel.  On
+    bar17K / 6 (METIS fixture bar17K_6, n_s up to 9813): one step against the oracle."""
+    sc, ep, n, ts, orc = make_pair("bar17K_twist", energy="FCR", nparts=6, flags=dl.FLAG_GSDD)
+    x = ts.getResult()
+    idx, pos = sc.scripter.step(x, sc.cfg.dt)
+    ts.setDirichlet(idx, pos)
+    orc.move(idx, pos)
+    st, so = ts.step(), orc.step_gsdd()
+    print("bar17K/6 GSDD sweeps", st.iters, so.iters, "halvings", st.ls_halvings, so.ls_halvings)
+    assert (st.status, st.iters, st.ls_halvings, st.energy_evals) == (so.status, so.iters, so.ls_halvings, so.energy_evals)
+    assert st.g2 <= ts.targetGRes and abs(st.E - so.E) <= 1e-10 * abs(so.E)
+    assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
+    ts.close(); orc.close()
+
+
 # ---- f4: LBFGS-H (`timeStepper LBFGSH`) = this path with the whole mesh as ONE subdomain and a unit first step --------
 def test_lbfgs_h_is_the_one_subdomain_case_with_unit_first_step():
     """LBFGSTimeStepper with D0T_H (LBFGSTimeStepper.cpp:196-262 precompute, :338-420 solve_oneStep, :300-307 refresh):
