@@ -134,6 +134,7 @@ def main():
         L = dl.load()
         ns = [L.dotmi_part_size(ts._h, p) for p in range(nparts)]
         dense_bytes = int(sum(8 * n * n + 16 * n for n in ns))
+        nmax = int(L.dotmi_padded_size(ts._h))
         traffic, traffic_src = pmc_traffic(name) if world == 1 else (None, None)
         roofline = {
             "bound": "hbm", "kernel": "backsolve_kernel: subdomain back-solve p_s = X_s^T (X_s r_s), nested-dissection "
@@ -166,6 +167,9 @@ def main():
                 "back_solve_kernels": round(avg_ms * float(np.mean(iters)), 3),
             },
             "roofline": roofline,
+            "_ns": [int(v) for v in ns],
+            "part_sizes": {"live_min": int(min(ns)), "live_mean": round(float(np.mean(ns)), 1), "live_max": int(max(ns)),
+                           "padded": nmax},
         }
         target = ts.targetGRes
         ts.close()
@@ -190,6 +194,19 @@ def main():
         "note": "flop as executed (identity padding included); the phase is bound by chains of small dependent kernels, "
                 "see profiles/r01_factor_experiments.txt",
     }
+    # how much of that is padding: every subdomain is factorised in the shared layout of `padded` rows while it has
+    # n_s live ones; cubic work => live share ~ mean((n_s / padded)^3).  For scale: a dense potrf + trtri on the live
+    # sizes would be (2/3) sum n_s^3 flop -- the dissection executes a fraction of that even with its padding.
+    ps = rec["part_sizes"]
+    live_share = float(np.mean([(n / ps["padded"]) ** 3 for n in rec["_ns"]]))
+    dense_flop = float(sum(2.0 / 3.0 * n ** 3 for n in rec["_ns"]))
+    roofline_factor.update({
+        "live_flop_share_estimate": round(live_share, 3),
+        "achieved_on_live_flop_estimate": round(fact_tf * live_share, 2),
+        "frac_on_live_flop_estimate": round(fact_tf * live_share / FP64_MFMA_PEAK, 4),
+        "dense_potrf_trtri_flop_on_live_sizes": dense_flop,
+    })
+    del rec["_ns"]
 
     out = None
     if rank == 0:
@@ -219,6 +236,7 @@ def main():
                     continue
                 big = name.startswith("synbar")
                 r2 = run_workload(name, 6 if big else 12, 2)[0]
+                r2.pop("_ns", None)
                 out["workloads"].append(r2)
         # ---- CPU baseline on this box's host cores: bounded sample of the same workload ---------------
         if not args.no_cpu_baseline and world == 1:

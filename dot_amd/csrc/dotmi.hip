@@ -2510,6 +2510,8 @@ int32_t dotmi_part_size(const dotmi_handle *h, int32_t part)
     return 3 * (int32_t)h->partVerts[part].size();
 }
 
+int32_t dotmi_padded_size(const dotmi_handle *h) { return h ? h->P.nmax : DOTMI_E_INVALID; }
+
 int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *Mout, int32_t *l2g)
 {
     if (!h || part < h->p0 || part >= h->p1 || !Mout) return DOTMI_E_INVALID;

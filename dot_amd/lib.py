@@ -56,7 +56,7 @@ EXPORTS = [
     "dotmi_create", "dotmi_destroy", "dotmi_last_error", "dotmi_comm_unique_id", "dotmi_set_state",
     "dotmi_get_state", "dotmi_set_dirichlet", "dotmi_refix", "dotmi_step", "dotmi_last_iter_log",
     "dotmi_target_gres", "dotmi_eval_energy", "dotmi_eval_gradient", "dotmi_eval_elem_hessians",
-    "dotmi_refactor", "dotmi_apply_precond", "dotmi_spmv", "dotmi_get_features", "dotmi_part_size",
+    "dotmi_refactor", "dotmi_apply_precond", "dotmi_spmv", "dotmi_get_features", "dotmi_part_size", "dotmi_padded_size",
     "dotmi_part_matrix", "dotmi_probe_direction", "dotmi_bench_precond", "dotmi_bench_energy", "dotmi_plan_shards", "dotmi_plan_layout", "dotmi_plan_rank", "dotmi_partition",
 ]
 
@@ -100,6 +100,8 @@ def load() -> C.CDLL:
     L.dotmi_get_features.argtypes = [H, c_dp, c_dp, c_dp]
     L.dotmi_part_size.argtypes = [H, C.c_int32]
     L.dotmi_part_size.restype = C.c_int32
+    L.dotmi_padded_size.argtypes = [H]
+    L.dotmi_padded_size.restype = C.c_int32
     L.dotmi_part_matrix.argtypes = [H, C.c_int32, C.c_int, c_dp, c_ip]
     L.dotmi_probe_direction.argtypes = [H, c_dp, C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.dotmi_bench_precond.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]

@@ -239,6 +239,9 @@ int dotmi_get_features(dotmi_handle *h, double *A, double *vol, double *mass);
  * block-sparse); both matrices are returned in ascending-vertex order (l2g), i.e. X comes back as
  * P^T X_nd P.  l2g (local vertex -> global) may be NULL. */
 int32_t dotmi_part_size(const dotmi_handle *h, int32_t part);
+/* padded scalar size of the dense block every subdomain of this rank is stored in (the shared dissection layout: node
+ * sizes are the maximum over the subdomains, rounded up to 64) -- what the factorisation's flop count is executed on */
+int32_t dotmi_padded_size(const dotmi_handle *h);
 int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *M, int32_t *l2g);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
