@@ -1394,6 +1394,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     // blind up to a little before last step's slot count, then two slots ahead of the posted progress
     const int AHEAD = 2;
     C.notifyFrom = std::max(0, std::min(h->prevSlots - 3, h->prevSlots * 3 / 4));  // a shorter step wastes few slots
+    if (h->dist) C.notifyFrom = 1 << 30;   // deterministic batches: nobody reads the progress (a host store costs ~18 us)
     const int notifyFrom = C.notifyFrom;
     HIPCHECK(h, hipMemcpyAsync(h->ctl, h->h_ctl, sizeof(DevLoop), hipMemcpyHostToDevice, h->st));
     {
