@@ -99,21 +99,50 @@ __global__ __launch_bounds__(256) void elem_energy_grad_kernel(
 #pragma unroll
             for (int c = 0; c < 3; ++c) F.m[r][c] = d0 * Ai[0][c] + d1 * Ai[1][c] + d2 * Ai[2][c];
         }
-        Mat3 U, V;
-        double S[3];
-        svd3(F, U, S, V);
         const double m = mu[e], l = lam[e], w = dtSq * vol[e];
-        acc += psi<MAT>(S, m, l) * vol[e];
+        double P[3][3];
+        if constexpr (MAT == 1) {
+            // Stable Neo-Hookean: Psi(sigma) = (mu (|sigma|^2 - 3) + lam (J - a)^2) / 2, a = 1 + mu / lam
+            // (StableNHEnergy.cpp:91-130), is a function of |F|_F^2 = |sigma|^2 and det F = J only (the reference's SVD has
+            // U, V in SO(3) and the sign of det F on sigma_3), and U diag(dPsi/dsigma) V^T = mu F + lam (J - a) cof F.
+            // Energy and first Piola stress therefore need no SVD here -- the Jacobi sweeps were 40 % of this kernel,
+            // which runs in every line-search trial; the Hessian (once per step) keeps the SVD.  Same values to rounding.
+            const double J = det3(F);
+            const double ic = F.m[0][0] * F.m[0][0] + F.m[0][1] * F.m[0][1] + F.m[0][2] * F.m[0][2] + F.m[1][0] * F.m[1][0] +
+                              F.m[1][1] * F.m[1][1] + F.m[1][2] * F.m[1][2] + F.m[2][0] * F.m[2][0] + F.m[2][1] * F.m[2][1] +
+                              F.m[2][2] * F.m[2][2];
+            const double JmA = J - (1.0 + m / l);
+            acc += (m * (ic - 3.0) + l * JmA * JmA) / 2.0 * vol[e];
+            if (GRAD) {
+                const double t = l * JmA;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int r1 = (r + 1) % 3, r2 = (r + 2) % 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                        const double cof = F.m[r1][c1] * F.m[r2][c2] - F.m[r1][c2] * F.m[r2][c1];
+                        P[r][c] = w * (m * F.m[r][c] + t * cof);
+                    }
+                }
+            }
+        } else {
+            Mat3 U, V;
+            double S[3];
+            svd3(F, U, S, V);
+            acc += psi<MAT>(S, m, l) * vol[e];
+            if (GRAD) {
+                double d[3];
+                dpsi<MAT>(S, m, l, d);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        P[r][c] = w * (U.m[r][0] * d[0] * V.m[c][0] + U.m[r][1] * d[1] * V.m[c][1] +
+                                       U.m[r][2] * d[2] * V.m[c][2]);
+            }
+        }
         if (GRAD) {
-            double d[3];
-            dpsi<MAT>(S, m, l, d);
-            double P[3][3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    P[r][c] = w * (U.m[r][0] * d[0] * V.m[c][0] + U.m[r][1] * d[1] * V.m[c][1] +
-                                   U.m[r][2] * d[2] * V.m[c][2]);
             double g[12];
 #pragma unroll
             for (int a = 0; a < 3; ++a)

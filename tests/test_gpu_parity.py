@@ -38,6 +38,38 @@ def bunny(request):
     ts.close(); orc.close()
 
 
+def snh_gradient_extended(sc, ts, x):
+    """Gradient of the incremental potential for Stable Neo-Hookean in numpy longdouble (64-bit mantissa), closed form:
+    per tet F = Ds A, P = dt^2 vol (mu F + lam (det F - 1 - mu/lam) cof F), nodal forces P A^T; plus m_v (x_v - x~_v)."""
+    LD = np.longdouble
+    cfg = sc.cfg
+    A, vol, mass = ts.features()
+    mu = LD(cfg.YM) / (2 * (1 + LD(cfg.PR)))
+    lam = LD(cfg.YM) * LD(cfg.PR) / ((1 + LD(cfg.PR)) * (1 - 2 * LD(cfg.PR)))
+    xt = ts.getState()[2].astype(LD)
+    X = x.astype(LD)
+    T = sc.T
+    Ds = np.stack([X[T[:, 1]] - X[T[:, 0]], X[T[:, 2]] - X[T[:, 0]], X[T[:, 3]] - X[T[:, 0]]], axis=2)   # [e, r, k]
+    Ai = A.astype(LD).reshape(-1, 3, 3)                                                                     # [e, k, c]
+    F = np.einsum("erk,ekc->erc", Ds, Ai)
+    cof = np.empty_like(F)
+    for r in range(3):
+        for c in range(3):
+            r1, r2, c1, c2 = (r + 1) % 3, (r + 2) % 3, (c + 1) % 3, (c + 2) % 3
+            cof[:, r, c] = F[:, r1, c1] * F[:, r2, c2] - F[:, r1, c2] * F[:, r2, c1]
+    J = (F[:, 0, :] * cof[:, 0, :]).sum(axis=1)
+    w = LD(cfg.dt) ** 2 * vol.astype(LD)
+    P = w[:, None, None] * (mu * F + (lam * (J - (1 + mu / lam)))[:, None, None] * cof)
+    gk = np.einsum("ecj,eaj->eac", P, Ai)            # node a+1, component c
+    g = np.zeros_like(X)
+    for a in range(3):
+        np.add.at(g, T[:, a + 1], gk[:, a, :])
+    np.add.at(g, T[:, 0], -gk.sum(axis=1))
+    g += mass.astype(LD)[:, None] * (X - xt)
+    g[sc.fixed.astype(bool)] = 0
+    return g.astype(np.float64)
+
+
 def test_native_library_is_loaded():
     L = dl.load()
     with open("/proc/self/maps") as f:
@@ -63,7 +95,17 @@ def test_energy_gradient_hessian_match_oracle(bunny, amp):
     E, Eo = ts.computeEnergyVal(x), orc.energy(x)
     assert abs(E - Eo) <= 1e-12 * abs(Eo)
     g, go = ts.computeGradient(x), orc.gradient(x)
-    assert rel(g, go) < 1e-12
+    if sc.cfg.energy == "SNH":
+        # The device evaluates Stable Neo-Hookean energy and stress in closed form (Psi depends on |F|^2 and det F only:
+        # P = mu F + lam (J - a) cof F), the oracle -- like the reference -- through the SVD of F.  Same function; on
+        # badly inverted tets the SVD route (eigen-decomposition of F^T F) carries the larger rounding error.  Both are
+        # compared with the closed form in extended precision: the device within 1e-12 (measured 1.5e-13 at amp 0.05), the
+        # oracle within 1e-11 (measured 2.9e-12).
+        gx = snh_gradient_extended(sc, ts, x)
+        assert rel(g, gx) < 1e-12 and rel(go, gx) < 1e-11 and rel(g, gx) < rel(go, gx) + 1e-15
+        assert rel(g, go) < 1e-11
+    else:
+        assert rel(g, go) < 1e-12
     assert np.abs(g[sc.fixed.astype(bool)]).max() == 0.0
     H, Ho = ts.computeElemHessians(x), orc.elem_hessians(x)
     per_elem = np.abs(H - Ho).reshape(len(H), -1).max(axis=1) / np.abs(Ho).reshape(len(H), -1).max(axis=1)
