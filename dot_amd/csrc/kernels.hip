@@ -225,16 +225,54 @@ __device__ __forceinline__ void pair_stats_accum(int k, double gn, double sn, do
     }
 }
 
-// block-sum every accumulator and store the first nvals of them as this block's partial row.
+// Wave totals of 8 values per lane with a transposed butterfly (10 cross-lane steps instead of 48): afterwards every
+// lane holds the total of value number lane >> 3 (lane bits 5,4,3 select the value, bits 2,1,0 were summed last).
+__device__ __forceinline__ double wave_sum8_transposed(const double (&d)[8], int lane)
+{
+    double e4[4], e2[2], e1;
+    {
+        const bool hi = lane & 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double keep = hi ? d[k + 4] : d[k], send = hi ? d[k] : d[k + 4];
+            e4[k] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    {
+        const bool hi = lane & 16;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double keep = hi ? e4[k + 2] : e4[k], send = hi ? e4[k] : e4[k + 2];
+            e2[k] = keep + __shfl_xor(send, 16, 64);
+        }
+    }
+    {
+        const bool hi = lane & 8;
+        const double keep = hi ? e2[1] : e2[0], send = hi ? e2[0] : e2[1];
+        e1 = keep + __shfl_xor(send, 8, 64);
+    }
+    e1 += __shfl_xor(e1, 4, 64);
+    e1 += __shfl_xor(e1, 2, 64);
+    e1 += __shfl_xor(e1, 1, 64);
+    return e1;
+}
+
+// block-sum the first nvals accumulators (nvals uniform over the block) and store them as this block's partial row.
 // sm: 4*RED_K doubles.
 __device__ __forceinline__ void write_partials(double (&acc)[RED_K], int nvals, double *partials, double *sm)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
+    constexpr int NG = (RED_K + 7) / 8;
 #pragma unroll
-    for (int j = 0; j < RED_K; ++j) {
-        const double s = wave_sum(acc[j]);
-        if (lane == 0) sm[w * RED_K + j] = s;
+    for (int g = 0; g < NG; ++g) {
+        if (8 * g >= nvals) break;   // groups of 8 values; the ones nobody asked for are not reduced
+        double d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = (8 * g + k < RED_K) ? acc[8 * g + k < RED_K ? 8 * g + k : 0] : 0.0;
+        const double s = wave_sum8_transposed(d, lane);
+        const int j = 8 * g + (lane >> 3);
+        if ((lane & 7) == 0 && j < RED_K) sm[w * RED_K + j] = s;
     }
     __syncthreads();
     const int t = threadIdx.x;
@@ -525,38 +563,54 @@ __global__ __launch_bounds__(256) void build_p_kernel(int n, const double *__res
         if constexpr (DEV) return ctl->X;
         else return X;
     }();
+    // the body's operands do not depend on the coefficients: they are requested before the prologue below (partial sums
+    // and the short recurrence), so their latency is hidden behind it.  The grid covers n in one trip (launch_build_p).
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = Lr.m;
+    double zv = 0.0, sv[HIST_MAX];
+    if (k < n) {
+        zv = z[k];
+#pragma unroll
+        for (int j = 0; j < HIST_MAX; ++j) sv[j] = (j < m) ? Lr.s[j][k] : 0.0;
+    }
     if (threadIdx.x < 64) {
         // all partial columns first (independent loads in flight together), then the short recurrence
-        double c[HIST_MAX];
+        double c[8];
 #pragma unroll
-        for (int i = 0; i < HIST_MAX; ++i) c[i] = 0.0;
+        for (int i = 0; i < 8; ++i) c[i] = 0.0;
+        static_assert(HIST_MAX <= 8, "one transposed butterfly");
         for (int b = threadIdx.x; b < c_blocks; b += 64) {
 #pragma unroll
             for (int i = 0; i < HIST_MAX; ++i) c[i] += c_partials[(size_t)b * RED_K + i];  // columns >= m: unused
         }
+        // wave totals of the (up to 8) columns in 10 cross-lane steps; lane 8 i holds column i
+        const double tot = wave_sum8_transposed(c, threadIdx.x);
+        double ct[HIST_MAX], rys[HIST_MAX];
 #pragma unroll
-        for (int i = 0; i < HIST_MAX; ++i) c[i] = __shfl(wave_sum(c[i]), 0, 64);
+        for (int i = 0; i < HIST_MAX; ++i) {
+            ct[i] = __shfl(tot, 8 * i, 64);
+            rys[i] = (i < m) ? 1.0 / Lr.ys[i] : 0.0;   // independent divisions, off the recurrence's dependent chain
+        }
         double d[HIST_MAX];
 #pragma unroll
         for (int i = 0; i < HIST_MAX; ++i) {
             d[i] = 0.0;
-            if (i < Lr.m) {
-                double yp = c[i];
+            if (i < m) {
+                double yp = ct[i];
 #pragma unroll
                 for (int j = 0; j < HIST_MAX; ++j)
                     if (j < i) yp += d[j] * Lr.sy[j][i];
-                d[i] = Xr.xi[i] - yp / Lr.ys[i];
+                d[i] = Xr.xi[i] - yp * rys[i];
             }
             if (threadIdx.x == 0) delta[i] = d[i];
         }
     }
     __syncthreads();
-    const int stride = gridDim.x * blockDim.x;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
-        double v = z[k];
+    if (k < n) {
+        double v = zv;
 #pragma unroll
         for (int j = 0; j < HIST_MAX; ++j)
-            if (j < Lr.m) v += Lr.s[j][k] * delta[j];
+            if (j < m) v += sv[j] * delta[j];
         p[k] = v;
     }
 }
@@ -566,8 +620,7 @@ void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_
 {
     XiArgs X;
     for (int i = 0; i < HIST_MAX; ++i) X.xi[i] = (xi_host && i < L.m) ? xi_host[i] : 0.0;
-    int nb = (n + 255) / 256;
-    if (nb > 1024) nb = 1024;
+    const int nb = (n + 255) / 256;   // one element per thread (the kernel has no grid-stride loop)
     if (ctl) hipLaunchKernelGGL(build_p_kernel<true>, dim3(nb), dim3(256), 0, st, n, z, L, X, c_partials, NB_RED, p, ctl);
     else hipLaunchKernelGGL(build_p_kernel<false>, dim3(nb), dim3(256), 0, st, n, z, L, X, c_partials, NB_RED, p, ctl);
 }
