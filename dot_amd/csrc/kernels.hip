@@ -291,6 +291,7 @@ __device__ __forceinline__ double group8_sum(double v)
 
 // 8 lanes cooperate on one vertex: each sums every 8th incident (element, slot) contribution, the
 // butterfly combines them, then lanes 0..2 of the group own the x, y, z degree of freedom.
+constexpr int GATHER_R = 3;   // vertices a lane group works on at a time
 template <bool DEV>
 __global__ __launch_bounds__(256) void vertex_gather_kernel(
     int nV, const int *__restrict__ vf_ptr, const int *__restrict__ vf_ent,
@@ -316,72 +317,97 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
     const double alpha = a.make_pair ? *a.alpha_dev : 0.0;
     const int sub = threadIdx.x & 7;
     const int ngroups = gridDim.x * 32;
-    for (int v = blockIdx.x * 32 + (threadIdx.x >> 3); v < nV; v += ngroups) {
-        double g0 = 0, g1 = 0, g2 = 0;
-        const bool fx = fixed[v];
-        const int kb = vf_ptr[v], ke = vf_ptr[v + 1];
-        // everything the pair needs that does not depend on the gathered gradient is requested up front, so
-        // the dependent chain of a pass is two memory round trips (incidence range -> contributions)
-        const int k = 3 * v + (sub < 3 ? sub : 0);
-        double ine = 0.0, gold = 0.0, pk = 0.0, si[HIST_MAX], yi[HIST_MAX];
-        if (sub < 3) {
-            if (!fx && v >= a.iv0 && v < a.iv1) ine = mass[v] * (a.x[k] - a.xt[k]);
-            if (a.make_pair) {
-                gold = a.g_old[k];
-                pk = a.p[k];
+    // GATHER_R vertices per lane group and trip, interleaved (see spmv_dots_kernel): the dependent chain of a trip
+    // (incidence range -> contributions) is paid once for all of them; the statistics are accumulated vertex by vertex
+    // in the order of the one-vertex loop
+    constexpr int R = GATHER_R;
+    for (int vbase = blockIdx.x * 32 + (threadIdx.x >> 3); vbase < nV; vbase += R * ngroups) {
+        double g0[R], g1[R], g2[R], ine[R], gold[R], pk[R], si[R][HIST_MAX], yi[R][HIST_MAX];
+        int kb[R], ke[R];
+        bool live[R], fx[R];
 #pragma unroll
-                for (int i = 0; i < HIST_MAX; ++i) {
-                    si[i] = (i < Lr.m) ? Lr.s[i][k] : 0.0;
-                    yi[i] = (i < Lr.m) ? Lr.y[i][k] : 0.0;
+        for (int u = 0; u < R; ++u) {
+            const int v = vbase + u * ngroups;
+            live[u] = v < nV;
+            g0[u] = g1[u] = g2[u] = ine[u] = gold[u] = pk[u] = 0.0;
+            kb[u] = ke[u] = 0;
+            fx[u] = true;
+            if (live[u]) {
+                fx[u] = fixed[v];
+                kb[u] = vf_ptr[v];
+                ke[u] = vf_ptr[v + 1];
+                // everything the pair needs that does not depend on the gathered gradient is requested up front, so
+                // the dependent chain of a pass is two memory round trips (incidence range -> contributions)
+                const int k = 3 * v + (sub < 3 ? sub : 0);
+                if (sub < 3) {
+                    if (!fx[u] && v >= a.iv0 && v < a.iv1) ine[u] = mass[v] * (a.x[k] - a.xt[k]);
+                    if (a.make_pair) {
+                        gold[u] = a.g_old[k];
+                        pk[u] = a.p[k];
+#pragma unroll
+                        for (int i = 0; i < HIST_MAX; ++i) {
+                            si[u][i] = (i < Lr.m) ? Lr.s[i][k] : 0.0;
+                            yi[u][i] = (i < Lr.m) ? Lr.y[i][k] : 0.0;
+                        }
+                    }
                 }
             }
         }
-        if (!fx) {
-            // three incidence entries per lane and trip (24 of the ~20 incident slots per 8-lane group): their loads
-            // are in flight together; the adds keep the order of the one-entry loop
-            for (int kk = kb + sub; kk < ke; kk += 24) {
-                double w[3][3];
+        // three incidence entries per lane, vertex and trip (24 of the ~20 incident slots per 8-lane group): their loads
+        // are in flight together; the adds keep the order of the one-entry loop
+        int nkmax = 0;
 #pragma unroll
-                for (int u = 0; u < 3; ++u)
-                    if (kk + 8 * u < ke) {
-                        const double *ge = a.gcont + (size_t)3 * (kk + 8 * u);
-                        w[u][0] = ge[0];
-                        w[u][1] = ge[1];
-                        w[u][2] = ge[2];
+        for (int u = 0; u < R; ++u) nkmax = max(nkmax, fx[u] ? 0 : ke[u] - kb[u]);
+        for (int t = sub; t < nkmax; t += 24) {
+            double w[R][3][3];
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (!fx[u] && kb[u] + t + 8 * j < ke[u]) {
+                        const double *ge = a.gcont + (size_t)3 * (kb[u] + t + 8 * j);
+                        w[u][j][0] = ge[0];
+                        w[u][j][1] = ge[1];
+                        w[u][j][2] = ge[2];
                     }
 #pragma unroll
-                for (int u = 0; u < 3; ++u)
-                    if (kk + 8 * u < ke) {
-                        g0 += w[u][0];
-                        g1 += w[u][1];
-                        g2 += w[u][2];
+            for (int u = 0; u < R; ++u)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (!fx[u] && kb[u] + t + 8 * j < ke[u]) {
+                        g0[u] += w[u][j][0];
+                        g1[u] += w[u][j][1];
+                        g2[u] += w[u][j][2];
                     }
-            }
         }
-        g0 = group8_sum(g0);
-        g1 = group8_sum(g1);
-        g2 = group8_sum(g2);
-        if (sub < 3) {
-            double gn = (sub == 0) ? g0 : ((sub == 1) ? g1 : g2);
-            gn += ine;
-            a.g_new[k] = gn;
-            if (a.make_pair) {
-                const double sn = alpha * pk;
-                const double yn = gn - gold;
-                a.s_new[k] = sn;
-                a.y_new[k] = yn;
-                acc[0] += gn * gn;
-                acc[1] += yn * sn;
-                acc[2] += sn * gn;
 #pragma unroll
-                for (int i = 0; i < HIST_MAX; ++i)
-                    if (i < Lr.m) {
-                        acc[3 + i] += si[i] * yn;
-                        acc[3 + HIST_MAX + i] += sn * yi[i];
-                        acc[3 + 2 * HIST_MAX + i] += si[i] * gn;
-                    }
-            } else {
-                acc[0] += gn * gn;
+        for (int u = 0; u < R; ++u) {
+            if (!live[u]) continue;   // uniform over the lane group
+            const int v = vbase + u * ngroups;
+            const double t0 = group8_sum(g0[u]), t1 = group8_sum(g1[u]), t2 = group8_sum(g2[u]);
+            if (sub < 3) {
+                const int k = 3 * v + sub;
+                double gn = (sub == 0) ? t0 : ((sub == 1) ? t1 : t2);
+                gn += ine[u];
+                a.g_new[k] = gn;
+                if (a.make_pair) {
+                    const double sn = alpha * pk[u];
+                    const double yn = gn - gold[u];
+                    a.s_new[k] = sn;
+                    a.y_new[k] = yn;
+                    acc[0] += gn * gn;
+                    acc[1] += yn * sn;
+                    acc[2] += sn * gn;
+#pragma unroll
+                    for (int i = 0; i < HIST_MAX; ++i)
+                        if (i < Lr.m) {
+                            acc[3 + i] += si[u][i] * yn;
+                            acc[3 + HIST_MAX + i] += sn * yi[u][i];
+                            acc[3 + 2 * HIST_MAX + i] += si[u][i] * gn;
+                        }
+                } else {
+                    acc[0] += gn * gn;
+                }
             }
         }
     }
@@ -1561,6 +1587,7 @@ void launch_div_dup(int nV, const int *dup, double *z, hipStream_t st)
 // ------------------------------------------------------------------------------------------------
 // alpha_0 = clamp(-p.g / p.Hp, alphaMin, 1): block-CSR SpMV fused with the two dot products
 // ------------------------------------------------------------------------------------------------
+constexpr int SPMV_R = 3;   // block rows a lane group works on at a time
 __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const int *__restrict__ adj_ptr,
                                                         const int *__restrict__ adj_idx,
                                                         const double *__restrict__ Hval,
@@ -1578,34 +1605,70 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const in
     double pg = 0, pHp = 0;
     const int sub = threadIdx.x & 7;
     const int ngroups = gridDim.x * 32;
-    for (int v = v0 + blockIdx.x * 32 + (threadIdx.x >> 3); v < v1; v += ngroups) {
-        double a0 = 0, a1 = 0, a2 = 0;
-        const int kb = adj_ptr[v], e = adj_ptr[v + 1];
-        // the row's own p and g do not depend on the column loop: request them first
-        double q0 = 0, q1 = 0, q2 = 0, gg0 = 0, gg1 = 0, gg2 = 0;
-        if (sub == 0) {
-            q0 = p[3 * v]; q1 = p[3 * v + 1]; q2 = p[3 * v + 2];
-            if (g) { gg0 = g[3 * v]; gg1 = g[3 * v + 1]; gg2 = g[3 * v + 2]; }
-        }
-        for (int k = kb + sub; k < e; k += 8) {
-            const double *b = Hval + (size_t)9 * k;
-            const double *pu = p + 3 * adj_idx[k];
-            const double p0 = pu[0], p1 = pu[1], p2 = pu[2];
-            a0 += b[0] * p0 + b[1] * p1 + b[2] * p2;
-            a1 += b[3] * p0 + b[4] * p1 + b[5] * p2;
-            a2 += b[6] * p0 + b[7] * p1 + b[8] * p2;
-        }
-        a0 = group8_sum(a0);
-        a1 = group8_sum(a1);
-        a2 = group8_sum(a2);
-        if (sub == 0) {
-            if (Hp) {
-                Hp[3 * v] = a0;
-                Hp[3 * v + 1] = a1;
-                Hp[3 * v + 2] = a2;
+    // SPMV_R block rows per lane group and trip, their column loops interleaved: a trip is a chain of three dependent
+    // memory round trips (row range -> column indices -> entries of p, ~1 us each) whatever the number of rows in it, so
+    // a 17 k-vertex mesh takes one trip instead of three.  The sums keep a fixed order (row by row, as before).
+    constexpr int R = SPMV_R;
+    for (int vbase = v0 + blockIdx.x * 32 + (threadIdx.x >> 3); vbase < v1; vbase += R * ngroups) {
+        double a[R][3], q[R][3], gg[R][3];
+        int kb[R], nk[R], nkmax = 0;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int v = vbase + u * ngroups;
+            kb[u] = nk[u] = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) a[u][d] = q[u][d] = gg[u][d] = 0.0;
+            if (v < v1) {
+                kb[u] = adj_ptr[v];
+                nk[u] = adj_ptr[v + 1] - kb[u];
+                // the row's own p and g do not depend on the column loop: request them first
+                if (sub == 0) {
+                    q[u][0] = p[3 * v]; q[u][1] = p[3 * v + 1]; q[u][2] = p[3 * v + 2];
+                    if (g) { gg[u][0] = g[3 * v]; gg[u][1] = g[3 * v + 1]; gg[u][2] = g[3 * v + 2]; }
+                }
             }
-            pHp += q0 * a0 + q1 * a1 + q2 * a2;
-            if (g) pg += q0 * gg0 + q1 * gg1 + q2 * gg2;
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) nkmax = max(nkmax, nk[u]);
+        for (int t = sub; t < nkmax; t += 8) {
+            int col[R];
+            double h[R][9], pc[R][3];
+#pragma unroll
+            for (int u = 0; u < R; ++u) col[u] = (t < nk[u]) ? adj_idx[kb[u] + t] : -1;
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+                if (t < nk[u]) {
+                    const double *b = Hval + (size_t)9 * (kb[u] + t);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) h[u][i] = b[i];
+                }
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+                if (col[u] >= 0) {
+                    const double *pu = p + 3 * col[u];
+                    pc[u][0] = pu[0]; pc[u][1] = pu[1]; pc[u][2] = pu[2];
+                }
+#pragma unroll
+            for (int u = 0; u < R; ++u)
+                if (col[u] >= 0) {
+                    a[u][0] += h[u][0] * pc[u][0] + h[u][1] * pc[u][1] + h[u][2] * pc[u][2];
+                    a[u][1] += h[u][3] * pc[u][0] + h[u][4] * pc[u][1] + h[u][5] * pc[u][2];
+                    a[u][2] += h[u][6] * pc[u][0] + h[u][7] * pc[u][1] + h[u][8] * pc[u][2];
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int v = vbase + u * ngroups;
+            const double a0 = group8_sum(a[u][0]), a1 = group8_sum(a[u][1]), a2 = group8_sum(a[u][2]);
+            if (sub == 0 && v < v1) {
+                if (Hp) {
+                    Hp[3 * v] = a0;
+                    Hp[3 * v + 1] = a1;
+                    Hp[3 * v + 2] = a2;
+                }
+                pHp += q[u][0] * a0 + q[u][1] * a1 + q[u][2] * a2;
+                if (g) pg += q[u][0] * gg[u][0] + q[u][1] * gg[u][1] + q[u][2] * gg[u][2];
+            }
         }
     }
     const double s0 = block_sum256(pg, sm);
