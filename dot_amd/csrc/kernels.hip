@@ -72,13 +72,24 @@ __global__ __launch_bounds__(256) void elem_energy_grad_kernel(
     int nElem, int v0, int v1, double dtSq, const int4 *__restrict__ epos, double *__restrict__ gcont,
     double *__restrict__ partials, const DevLoop *__restrict__ ctl)
 {
-    __shared__ double sm[4];
+    __shared__ double sm[8];
     if (ctl) {
         if (ctl->status != 0) return;
         x = ctl->x_trial;
     }
     double acc = 0.0;  // dtSq * vol * Psi
     const int stride = gridDim.x * blockDim.x;
+    // inertia operands of this thread's first vertex: independent of the element work, requested ahead of it
+    const int vfirst = v0 + blockIdx.x * blockDim.x + threadIdx.x;
+    double ix[3] = {0, 0, 0}, ixt[3] = {0, 0, 0}, im = 0.0;
+    if (vfirst < v1) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            ix[d] = x[3 * vfirst + d];
+            ixt[d] = xt[3 * vfirst + d];
+        }
+        im = mass[vfirst];
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nElem; i += stride) {
         const int e = elist ? elist[i] : i;
         const int4 t = T[e];
@@ -165,16 +176,26 @@ __global__ __launch_bounds__(256) void elem_energy_grad_kernel(
     }
     // inertia: sum_v 1/2 m_v |x_v - x~_v|^2 over this rank's vertex slice
     double ine = 0.0;
-    for (int v = v0 + blockIdx.x * blockDim.x + threadIdx.x; v < v1; v += stride) {
+    if (vfirst < v1) {
+        const double dx = ix[0] - ixt[0], dy = ix[1] - ixt[1], dz = ix[2] - ixt[2];
+        ine += (dx * dx + dy * dy + dz * dz) * im / 2.0;
+    }
+    for (int v = vfirst + stride; v < v1; v += stride) {
         const double dx = x[3 * v] - xt[3 * v], dy = x[3 * v + 1] - xt[3 * v + 1],
                      dz = x[3 * v + 2] - xt[3 * v + 2];
         ine += (dx * dx + dy * dy + dz * dz) * mass[v] / 2.0;
     }
-    const double se = block_sum256(acc, sm);
-    const double si = block_sum256(ine, sm);
+    // both block sums through one exchange (same per-wave and cross-wave order as two block_sum256 calls)
+    const double we = wave_sum(acc), wi = wave_sum(ine);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        sm[w] = we;
+        sm[4 + w] = wi;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        partials[2 * blockIdx.x] = se;      // to be scaled by dtSq on the host
-        partials[2 * blockIdx.x + 1] = si;
+        partials[2 * blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);      // to be scaled by dtSq on the host
+        partials[2 * blockIdx.x + 1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
     }
 }
 
@@ -1597,7 +1618,7 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const in
                                                         double *__restrict__ partials,
                                                         const DevLoop *__restrict__ ctl)
 {
-    __shared__ double sm[4];
+    __shared__ double sm[8];
     if (ctl) {
         if (ctl->status != 0 || ctl->phase != 0) return;
         g = ctl->g_cur;
@@ -1671,11 +1692,17 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const in
             }
         }
     }
-    const double s0 = block_sum256(pg, sm);
-    const double s1 = block_sum256(pHp, sm);
+    // both block sums through one exchange
+    const double w0 = wave_sum(pg), w1 = wave_sum(pHp);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        sm[w] = w0;
+        sm[4 + w] = w1;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        partials[(size_t)blockIdx.x * RED_K] = s0;
-        partials[(size_t)blockIdx.x * RED_K + 1] = s1;
+        partials[(size_t)blockIdx.x * RED_K] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+        partials[(size_t)blockIdx.x * RED_K + 1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
     }
 }
 
