@@ -1791,27 +1791,32 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
         for (int i = t; i < NW8; i += 256) dst[i] = src[i];
     }
     const double alpha_in = *alpha_dev;
-    // chunked_sum() order (dotmi_internal.hpp), one thread per (column, chunk): every load of the kernel is
-    // in flight at once and the dependent add chains are 16 long instead of NB_RED long
+    // chunked_sum() order (dotmi_internal.hpp), one thread per (column, chunk): every load of the kernel is in flight at
+    // once and the dependent add chains are 16 long instead of NB_RED long.  The column index runs fastest over the
+    // lanes, so a load instruction touches a few 168-byte partial rows instead of 64 different ones.
     {
-        const int ch = t & (SUM_CHUNKS - 1);
-        const int colA = t >> 4;          // 0..15
-        const int colB = 16 + (t >> 4);   // 16..RED_K-1 for t < 16*(RED_K-16)
         constexpr int LR = (NB_RED + SUM_CHUNKS - 1) / SUM_CHUNKS;
         static_assert(LR * SUM_CHUNKS == NB_RED, "chunks of equal length");
-        double a = 0.0, b = 0.0, e = 0.0;
-        // all loads of a chunk first (independent), then the adds in order
+        constexpr int NPAIR = RED_K * SUM_CHUNKS;            // (statistic column, chunk) pairs
+        static_assert(NPAIR + 2 * SUM_CHUNKS <= 512, "two passes of 256 threads");
+        const int qa = t, qb = t + 256;
+        const int colA = qa % RED_K, chA = qa / RED_K;
+        const int colB = qb % RED_K, chB = qb / RED_K;
+        const bool hasA = qa < NPAIR, hasB = qb < NPAIR;
         double va[LR], vb[LR];
+        if (hasA) {
 #pragma unroll
-        for (int k = 0; k < LR; ++k) va[k] = partR[(size_t)(ch * LR + k) * RED_K + colA];
-        if (colB < RED_K) {
-#pragma unroll
-            for (int k = 0; k < LR; ++k) vb[k] = partR[(size_t)(ch * LR + k) * RED_K + colB];
+            for (int k = 0; k < LR; ++k) va[k] = partR[(size_t)(chA * LR + k) * RED_K + colA];
         }
-        const int te = t - 16 * (RED_K - 16);  // the next 32 threads: the two energy columns
+        if (hasB) {
+#pragma unroll
+            for (int k = 0; k < LR; ++k) vb[k] = partR[(size_t)(chB * LR + k) * RED_K + colB];
+        }
+        const int te = qb - NPAIR;  // the next 2 * SUM_CHUNKS slots: the two energy columns
         if (te >= 0 && te < 2 * SUM_CHUNKS) {
-            const int LE = (nbE + SUM_CHUNKS - 1) / SUM_CHUNKS, c = te >> 4;
+            const int LE = (nbE + SUM_CHUNKS - 1) / SUM_CHUNKS, c = te / SUM_CHUNKS, ch = te % SUM_CHUNKS;
             const int k0 = ch * LE, k1 = min(nbE, (ch + 1) * LE);
+            double e = 0.0;
             int k = k0;
             for (; k + 8 <= k1; k += 8) {
                 double ve[8];
@@ -1823,14 +1828,18 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
             for (; k < k1; ++k) e += partE[2 * k + c];
             chunk[RED_K + c][ch] = e;
         }
+        if (hasA) {
+            double a = 0.0;
 #pragma unroll
-        for (int k = 0; k < LR; ++k) a += va[k];
-        if (colB < RED_K) {
+            for (int k = 0; k < LR; ++k) a += va[k];
+            chunk[colA][chA] = a;
+        }
+        if (hasB) {
+            double b = 0.0;
 #pragma unroll
             for (int k = 0; k < LR; ++k) b += vb[k];
+            chunk[colB][chB] = b;
         }
-        chunk[colA][ch] = a;
-        if (colB < RED_K) chunk[colB][ch] = b;
     }
     __syncthreads();
     if (C.status != 0) return;
