@@ -1442,13 +1442,24 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
             HIPCHECK(h, hipMemcpyAsync(h->h_ctl, h->ctl, sizeof(DevLoop), hipMemcpyDeviceToHost, h->st));
             HIPCHECK(h, hipStreamSynchronize(h->st));
             HIPCHECK(h, hipGetLastError());
-            double mine[4] = {(double)C.status, (double)C.slots, (double)C.iter, (double)C.halvings}, r0[4];
-            memcpy(r0, mine, sizeof(mine));
-            if (int rc = adopt_rank0(h, r0, 4)) return rc;
-            if (memcmp(r0, mine, sizeof(mine)) != 0) {
-                h->err = "the ranks left the L-BFGS loop in different states (rank 0: status " + std::to_string((int)r0[0]) +
-                         " after " + std::to_string((int)r0[1]) + " slots; this rank: status " + std::to_string(C.status) +
-                         " after " + std::to_string(C.slots) + ")";
+            // every rank contributes its (status, slots, iterations, halvings); the sums equal world x own values exactly
+            // when all ranks agree (small integers in FP64), and every rank sees a disagreement from the same collective,
+            // so they fail together instead of one of them waiting in the next all-reduce
+            double mine[4] = {(double)C.status, (double)C.slots, (double)C.iter, (double)C.halvings}, sum[4];
+            memcpy(sum, mine, sizeof(mine));
+            if (h->world > 1) {
+                HIPCHECK(h, hipMemcpyAsync(h->ctrlDev, sum, sizeof(sum), hipMemcpyHostToDevice, h->st));
+                if (int rc = allreduce_sum(h, h->ctrlDev, 4)) return rc;
+                HIPCHECK(h, hipMemcpyAsync(sum, h->ctrlDev, sizeof(sum), hipMemcpyDeviceToHost, h->st));
+                HIPCHECK(h, hipStreamSynchronize(h->st));
+            }
+            bool agree = true;
+            for (int i = 0; i < 4; ++i) agree = agree && sum[i] == (h->world > 1 ? h->world : 1) * mine[i];
+            if (!agree) {
+                h->err = "the ranks left the L-BFGS loop in different states (this rank: status " + std::to_string(C.status) +
+                         " after " + std::to_string(C.slots) + " slots, " + std::to_string(C.iter) + " iterations; sum over " +
+                         std::to_string(h->world) + " ranks: " + std::to_string((long long)sum[0]) + " / " +
+                         std::to_string((long long)sum[1]) + " / " + std::to_string((long long)sum[2]) + ")";
                 h->poisoned = true;
                 return DOTMI_E_DEVICE;
             }
