@@ -174,8 +174,15 @@ struct dotmi_handle {
         rocblas_handle blas = nullptr;
         hipEvent_t done = nullptr;
         size_t tmpOff = 0;  // offset of this branch's scratch inside a part's Wtmp slice
+        // leaves of equal padded size factorised together (chol_inv_node): displacement of leaf l's diagonal block in W
+        // and of its scratch in Wtmp from the first leaf's
+        LeafOffs lw, lt;
     };
     std::vector<FactorGroup> groups;
+    // device pointer arrays of the fused-leaf batched GEMMs, in call order (built during the first, un-captured pass of
+    // issue_factor; every later pass -- the graph capture included -- finds them by position)
+    std::vector<double **> ptrPool;
+    size_t ptrNext = 0;
     // the two children of a dissection node are independent: the C child runs on its own stream (a
     // parallel branch of the captured graph), so the latency-bound diagonal-block kernels of sibling
     // sub-trees overlap
@@ -191,6 +198,7 @@ struct dotmi_handle {
         int part = 0;       // see chol_inv_tree()
         size_t tmpOff = 0;  // disjoint scratch of concurrently running units
         hipEvent_t fork = nullptr, join = nullptr;
+        LeafOffs lw, lt;    // leaf unit: the other leaves of the same size fused into it (n > 1)
     };
     std::vector<std::vector<FactorUnit>> phases;
     hipEvent_t evFill = nullptr;
@@ -667,6 +675,32 @@ int build_device_mesh(dotmi_handle *h)
             }
             h->tmp_stride = std::max(h->tmp_stride, off);
         }
+        // leaves of the same padded size are factorised together (one batched launch covers them in every subdomain):
+        // the first of a size class leads, the others become displacements of its operands
+        {
+            const char *fv = getenv("DOTMI_FUSE_LEAVES");
+            if (!(fv && atoi(fv) == 0)) {
+                std::vector<dotmi_handle::FactorUnit> fused;
+                for (const auto &U : h->phases[0]) {
+                    const NdNode &N = h->nd[U.node];
+                    bool merged = false;
+                    if (N.a < 0)
+                        for (auto &F : fused) {
+                            const NdNode &N0 = h->nd[F.node];
+                            if (N0.a < 0 && N0.size == N.size && F.lw.n < MAX_FUSED_LEAVES) {
+                                F.lw.d[F.lw.n] = (long long)(N.off - N0.off) * (P.nmax + 1);
+                                F.lt.d[F.lt.n] = (long long)U.tmpOff - (long long)F.tmpOff;
+                                F.lw.n++;
+                                F.lt.n++;
+                                merged = true;
+                                break;
+                            }
+                        }
+                    if (!merged) fused.push_back(U);
+                }
+                h->phases[0] = fused;
+            }
+        }
         // the root is alone in the last phase: its two triangular products split into their child-A and child-C
         // halves (disjoint rows of the same scratch), which run on two branches
         const char *sr = getenv("DOTMI_ND_SPLIT_ROOT");
@@ -763,14 +797,15 @@ int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, in
     const int lda = P.nmax, batch = G.count;
     const rocblas_stride sA = (rocblas_stride)lda * lda;
     double *Wg = P.W + (size_t)G.first * sA;
+    const int nleaf = G.lw.n;   // > 1: this call factorises the same node of several equal leaves at once
     if (sz <= CHOL_NB) {
-        h->flopCount += 2.0 / 3.0 * 64.0 * 64.0 * 64.0 * batch;  // factor + triangular inverse
-        launch_chol_inv_base(Wg, lda, batch, o, h->info_dev + G.first, G.st);
+        h->flopCount += 2.0 / 3.0 * 64.0 * 64.0 * 64.0 * batch * nleaf;  // factor + triangular inverse
+        launch_chol_inv_base(Wg, lda, batch, o, h->info_dev + G.first, G.st, G.lw);
         return 0;
     }
     if (sz == 2 * CHOL_NB) {  // the whole two-block node in one LDS-resident launch
-        h->flopCount += 2.0 / 3.0 * 128.0 * 128.0 * 128.0 * batch;
-        launch_chol_inv_node128(Wg, lda, batch, o, h->info_dev + G.first, G.st);
+        h->flopCount += 2.0 / 3.0 * 128.0 * 128.0 * 128.0 * batch * nleaf;
+        launch_chol_inv_node128(Wg, lda, batch, o, h->info_dev + G.first, G.st, G.lw);
         return 0;
     }
     const int n1 = ((sz / CHOL_NB) / 2) * CHOL_NB, n2 = sz - n1;
@@ -788,9 +823,32 @@ int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, in
     auto gemm = [&](rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double *alpha,
                     const double *A, int la, rocblas_stride sa, const double *B, int lb, rocblas_stride sb,
                     const double *beta, double *C, int lc, rocblas_stride sc) {
-        h->flopCount += 2.0 * m * n * k * batch;
-        return rocblas_dgemm_strided_batched(G.blas, ta, tb, m, n, k, alpha, A, la, sa, B, lb, sb, beta, C, lc, sc,
-                                             batch);
+        h->flopCount += 2.0 * m * n * k * batch * nleaf;
+        if (nleaf == 1)
+            return rocblas_dgemm_strided_batched(G.blas, ta, tb, m, n, k, alpha, A, la, sa, B, lb, sb, beta, C, lc, sc,
+                                                 batch);
+        // fused leaves: pointer-array batch over (leaf, subdomain); an operand lives either in W or in the scratch
+        const size_t wN = (size_t)P.nParts * lda * lda;
+        auto delta = [&](const double *p, int l) { return (p >= P.W && p < P.W + wN) ? G.lw.d[l] : G.lt.d[l]; };
+        const int nb = batch * nleaf;
+        double **dev = nullptr;
+        if (h->ptrNext < h->ptrPool.size()) dev = h->ptrPool[h->ptrNext];
+        else {
+            std::vector<double *> host((size_t)3 * nb);
+            for (int l = 0; l < nleaf; ++l)
+                for (int b2 = 0; b2 < batch; ++b2) {
+                    host[(size_t)l * batch + b2] = const_cast<double *>(A) + delta(A, l) + (size_t)b2 * sa;
+                    host[(size_t)nb + l * batch + b2] = const_cast<double *>(B) + delta(B, l) + (size_t)b2 * sb;
+                    host[(size_t)2 * nb + l * batch + b2] = C + delta(C, l) + (size_t)b2 * sc;
+                }
+            if (hipMalloc((void **)&dev, sizeof(double *) * host.size()) != hipSuccess) return rocblas_status_memory_error;
+            h->allocs.push_back(dev);
+            if (hipMemcpy(dev, host.data(), sizeof(double *) * host.size(), hipMemcpyHostToDevice) != hipSuccess)
+                return rocblas_status_memory_error;
+            h->ptrPool.push_back(dev);
+        }
+        h->ptrNext++;
+        return rocblas_dgemm_batched(G.blas, ta, tb, m, n, k, alpha, dev, la, dev + nb, lb, beta, dev + 2 * nb, lc, nb);
     };
     // Q11 and Q22 are upper triangular and only the upper triangle of H22 is needed: on the big nodes
     // each product is split 2x2 and the structurally-zero / unused quarter is skipped (3 GEMMs
@@ -837,7 +895,7 @@ int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, in
     }
     // the strictly lower block must read as zero when Q is used as a dense GEMM operand one level up
     // and when the back-solve kernel streams whole memory rows
-    launch_block_copy(H21, lda, (size_t)sA, nullptr, 0, 0, n2, n1, batch, G.st);
+    launch_block_copy(H21, lda, (size_t)sA, nullptr, 0, 0, n2, n1, batch, G.st, G.lw);
     return 0;
 }
 
@@ -1002,6 +1060,7 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id, i
 // issue (or replay) the inverse-Cholesky recursion of every owned subdomain on h->st
 int issue_factor(dotmi_handle *h)
 {
+    h->ptrNext = 0;
     HIPCHECK(h, hipEventRecord(h->evFill, h->st));
     for (auto &G : h->groups) {
         if (G.st != h->st) HIPCHECK(h, hipStreamWaitEvent(G.st, h->evFill, 0));
@@ -1012,6 +1071,8 @@ int issue_factor(dotmi_handle *h)
                 const auto &U = phase[k];
                 dotmi_handle::FactorGroup Gk = G;
                 Gk.tmpOff = U.tmpOff;
+                Gk.lw = U.lw;
+                Gk.lt = U.lt;
                 if (par && k > 0) {
                     Gk.st = h->branches[k - 1].st;
                     Gk.blas = h->branches[k - 1].blas;

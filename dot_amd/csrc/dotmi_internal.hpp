@@ -189,10 +189,19 @@ void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *
 void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st);
 void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st);
 void launch_clear_segments(const DevParts &P, const int4 *seg, int nseg, hipStream_t st);
-void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipStream_t st);
-void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, hipStream_t st);
+// Leaves of the dissection tree that have the same padded size are factorised together: one launch / one batched GEMM
+// per step of the dense recursion covers `n` leaves of every subdomain.  d[l] = displacement (in doubles) of leaf l's
+// diagonal block from the first leaf's inside a subdomain's dense block.
+constexpr int MAX_FUSED_LEAVES = 8;
+struct LeafOffs {
+    int n = 1;
+    long long d[MAX_FUSED_LEAVES] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipStream_t st, const LeafOffs &LO = LeafOffs());
+void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, hipStream_t st,
+                             const LeafOffs &LO = LeafOffs());
 void launch_block_copy(double *dst, int ldd, size_t sd, const double *src, int lds_, size_t ss, int rows,
-                       int cols, int batch, hipStream_t st);
+                       int cols, int batch, hipStream_t st, const LeafOffs &LO = LeafOffs());
 // small helpers
 void launch_init_x(int nV, const uint8_t *fixed, const double *v, double dt, const double *gdtsq,
                    double *x, hipStream_t st);

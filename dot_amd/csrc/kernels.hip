@@ -1294,8 +1294,9 @@ __device__ __forceinline__ void blk64_to_lds(const Blk64 &b, double (*G)[CHOL_NB
 }
 
 __global__ __launch_bounds__(256) void chol_inv_base_kernel(double *__restrict__ W, int nmax, int o,
-                                                            int *__restrict__ info)
+                                                            int *__restrict__ info, LeafOffs LO)
 {
+    W += LO.d[blockIdx.y];   // fused leaves: the same block of another leaf of the same size
     constexpr int NB = CHOL_NB;
     __shared__ double G[NB][LD64], X[NB][LD64], T32[32][33], T16[16][17];
     double *Ws = W + (size_t)blockIdx.x * nmax * nmax + (size_t)o * nmax + o;
@@ -1311,9 +1312,9 @@ __global__ __launch_bounds__(256) void chol_inv_base_kernel(double *__restrict__
     if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + bad);
 }
 
-void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipStream_t st)
+void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipStream_t st, const LeafOffs &LO)
 {
-    hipLaunchKernelGGL(chol_inv_base_kernel, dim3(count), dim3(256), 0, st, W, nmax, o, info);
+    hipLaunchKernelGGL(chol_inv_base_kernel, dim3(count, LO.n), dim3(256), 0, st, W, nmax, o, info, LO);
 }
 
 // 64 x 64 x 64 product on LDS operands with the FP64 matrix cores: store(i, j, sum_k A(i,k) B(k,j)).
@@ -1360,8 +1361,9 @@ __device__ long long g_node128_prof[32];
 #define N128_MARK(i)
 #endif
 __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restrict__ W, int nmax, int o,
-                                                               int *__restrict__ info)
+                                                               int *__restrict__ info, LeafOffs LO)
 {
+    W += LO.d[blockIdx.y];
     constexpr int NB = CHOL_NB, LD = NB + 1;
     __shared__ double X1[NB][LD];  // X11(i,k), later X22(i,k)
     __shared__ double Bf[NB][LD];  // H12 -> R12 -> U -> Q12          (row index = first block index)
@@ -1423,17 +1425,18 @@ __global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restric
     N128_MARK(8);
 }
 
-void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, hipStream_t st)
+void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, hipStream_t st, const LeafOffs &LO)
 {
-    hipLaunchKernelGGL(chol_inv_node128_kernel, dim3(count), dim3(256), 0, st, W, nmax, o, info);
+    hipLaunchKernelGGL(chol_inv_node128_kernel, dim3(count, LO.n), dim3(256), 0, st, W, nmax, o, info, LO);
 }
 
 // dst block <- src block (column-major blocks inside strided batches); zero when src == nullptr
 __global__ __launch_bounds__(256) void block_copy_kernel(double *__restrict__ dst, int ldd, size_t sd,
                                                          const double *__restrict__ src, int lds_, size_t ss,
-                                                         int rows, int cols)
+                                                         int rows, int cols, int batch, LeafOffs LO)
 {
-    const int b = blockIdx.z;
+    const int b = blockIdx.z % batch;
+    dst += LO.d[blockIdx.z / batch];   // fused leaves (only used for clearing: src == nullptr then)
     const int i = blockIdx.x * 64 + (threadIdx.x & 63);
     const int j0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
     if (i >= rows) return;
@@ -1445,11 +1448,11 @@ __global__ __launch_bounds__(256) void block_copy_kernel(double *__restrict__ ds
 }
 
 void launch_block_copy(double *dst, int ldd, size_t sd, const double *src, int lds_, size_t ss, int rows,
-                       int cols, int batch, hipStream_t st)
+                       int cols, int batch, hipStream_t st, const LeafOffs &LO)
 {
     if (rows <= 0 || cols <= 0 || batch <= 0) return;
-    hipLaunchKernelGGL(block_copy_kernel, dim3((rows + 63) / 64, (cols + 15) / 16, batch), dim3(256), 0, st,
-                       dst, ldd, sd, src, lds_, ss, rows, cols);
+    hipLaunchKernelGGL(block_copy_kernel, dim3((rows + 63) / 64, (cols + 15) / 16, batch * LO.n), dim3(256), 0, st,
+                       dst, ldd, sd, src, lds_, ss, rows, cols, batch, LO);
 }
 
 // z_v = (sum over parts containing v of p_s[local v]) / dup_v ; partial dots c_i = y_i . z
