@@ -675,8 +675,9 @@ int build_device_mesh(dotmi_handle *h)
             }
             h->tmp_stride = std::max(h->tmp_stride, off);
         }
-        // leaves of the same padded size are factorised together (one batched launch covers them in every subdomain):
-        // the first of a size class leads, the others become displacements of its operands
+        // leaves of the same padded size are factorised together (one batched launch / pointer-array GEMM covers them in
+        // every subdomain): the first of a size class leads, the others become displacements of its operands.  (Internal
+        // nodes would additionally need identical tails all the way down; no mesh so far produced two such nodes.)
         {
             const char *fv = getenv("DOTMI_FUSE_LEAVES");
             if (!(fv && atoi(fv) == 0)) {
@@ -698,6 +699,8 @@ int build_device_mesh(dotmi_handle *h)
                         }
                     if (!merged) fused.push_back(U);
                 }
+                if (getenv("DOTMI_FUSE_LOG"))
+                    fprintf(stderr, "dotmi: %zu leaves of the dissection in %zu units\n", h->phases[0].size(), fused.size());
                 h->phases[0] = fused;
             }
         }
@@ -791,6 +794,41 @@ int free_slot(const dotmi_handle *h)
 // registers by chol_inv_base_kernel.  This replaces rocSOLVER potrf+potri, measured at 1-3.6 TFLOP/s
 // on these sizes against 60-70 TFLOP/s for dgemm (profiles/r01_factor_primitives.txt).  Role in the
 // reference: CHOLMODSolver::factorize (CHOLMODSolver.cpp:143) called from DOTTimeStepper.cpp:363-377.
+// C(m x n) = alpha * op(A) op(B) + beta * C for every subdomain of the group -- and, when the unit stands for several tree
+// nodes of identical shape (G.lw.n > 1), for each of them: then the batch is a pointer array over (node, subdomain), an
+// operand being displaced by G.lw.d[l] when it lives in W and by G.lt.d[l] when it lives in the scratch.
+rocblas_status gemm_group(dotmi_handle *h, const dotmi_handle::FactorGroup &G, rocblas_operation ta, rocblas_operation tb, int m,
+                          int n, int k, const double *alpha, const double *A, int la, rocblas_stride sa, const double *B, int lb,
+                          rocblas_stride sb, const double *beta, double *C, int lc, rocblas_stride sc)
+{
+    const DevParts &P = h->P;
+    const int batch = G.count, nleaf = G.lw.n;
+    h->flopCount += 2.0 * m * n * k * batch * nleaf;
+    if (nleaf == 1)
+        return rocblas_dgemm_strided_batched(G.blas, ta, tb, m, n, k, alpha, A, la, sa, B, lb, sb, beta, C, lc, sc, batch);
+    const size_t wN = (size_t)P.nParts * P.nmax * P.nmax;
+    auto delta = [&](const double *p, int l) { return (p >= P.W && p < P.W + wN) ? G.lw.d[l] : G.lt.d[l]; };
+    const int nb = batch * nleaf;
+    double **dev = nullptr;
+    if (h->ptrNext < h->ptrPool.size()) dev = h->ptrPool[h->ptrNext];
+    else {
+        std::vector<double *> host((size_t)3 * nb);
+        for (int l = 0; l < nleaf; ++l)
+            for (int b2 = 0; b2 < batch; ++b2) {
+                host[(size_t)l * batch + b2] = const_cast<double *>(A) + delta(A, l) + (size_t)b2 * sa;
+                host[(size_t)nb + l * batch + b2] = const_cast<double *>(B) + delta(B, l) + (size_t)b2 * sb;
+                host[(size_t)2 * nb + l * batch + b2] = C + delta(C, l) + (size_t)b2 * sc;
+            }
+        if (hipMalloc((void **)&dev, sizeof(double *) * host.size()) != hipSuccess) return rocblas_status_memory_error;
+        h->allocs.push_back(dev);
+        if (hipMemcpy(dev, host.data(), sizeof(double *) * host.size(), hipMemcpyHostToDevice) != hipSuccess)
+            return rocblas_status_memory_error;
+        h->ptrPool.push_back(dev);
+    }
+    h->ptrNext++;
+    return rocblas_dgemm_batched(G.blas, ta, tb, m, n, k, alpha, dev, la, dev + nb, lb, beta, dev + 2 * nb, lc, nb);
+}
+
 int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, int sz)
 {
     DevParts &P = h->P;
@@ -823,32 +861,7 @@ int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, in
     auto gemm = [&](rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double *alpha,
                     const double *A, int la, rocblas_stride sa, const double *B, int lb, rocblas_stride sb,
                     const double *beta, double *C, int lc, rocblas_stride sc) {
-        h->flopCount += 2.0 * m * n * k * batch * nleaf;
-        if (nleaf == 1)
-            return rocblas_dgemm_strided_batched(G.blas, ta, tb, m, n, k, alpha, A, la, sa, B, lb, sb, beta, C, lc, sc,
-                                                 batch);
-        // fused leaves: pointer-array batch over (leaf, subdomain); an operand lives either in W or in the scratch
-        const size_t wN = (size_t)P.nParts * lda * lda;
-        auto delta = [&](const double *p, int l) { return (p >= P.W && p < P.W + wN) ? G.lw.d[l] : G.lt.d[l]; };
-        const int nb = batch * nleaf;
-        double **dev = nullptr;
-        if (h->ptrNext < h->ptrPool.size()) dev = h->ptrPool[h->ptrNext];
-        else {
-            std::vector<double *> host((size_t)3 * nb);
-            for (int l = 0; l < nleaf; ++l)
-                for (int b2 = 0; b2 < batch; ++b2) {
-                    host[(size_t)l * batch + b2] = const_cast<double *>(A) + delta(A, l) + (size_t)b2 * sa;
-                    host[(size_t)nb + l * batch + b2] = const_cast<double *>(B) + delta(B, l) + (size_t)b2 * sb;
-                    host[(size_t)2 * nb + l * batch + b2] = C + delta(C, l) + (size_t)b2 * sc;
-                }
-            if (hipMalloc((void **)&dev, sizeof(double *) * host.size()) != hipSuccess) return rocblas_status_memory_error;
-            h->allocs.push_back(dev);
-            if (hipMemcpy(dev, host.data(), sizeof(double *) * host.size(), hipMemcpyHostToDevice) != hipSuccess)
-                return rocblas_status_memory_error;
-            h->ptrPool.push_back(dev);
-        }
-        h->ptrNext++;
-        return rocblas_dgemm_batched(G.blas, ta, tb, m, n, k, alpha, dev, la, dev + nb, lb, beta, dev + 2 * nb, lc, nb);
+        return gemm_group(h, G, ta, tb, m, n, k, alpha, A, la, sa, B, lb, sb, beta, C, lc, sc);
     };
     // Q11 and Q22 are upper triangular and only the upper triangle of H22 is needed: on the big nodes
     // each product is split 2x2 and the structurally-zero / unused quarter is skipped (3 GEMMs
@@ -937,10 +950,9 @@ struct TriMult {
     // C[ro..ro+m) (+)= alpha * op(Q[qi.., qj..]) * B[rb..rb+k)
     int gemm(int m, int k, int qi, int qj, int rb, int ro, double beta) const
     {
-        h->flopCount += 2.0 * m * ncols * k * G.count;
-        const rocblas_status st = rocblas_dgemm_strided_batched(
-            G.blas, trans ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none, m, ncols, k,
-            &alpha, Q(qi, qj), lda, sA, B + rb, ldb, sB, &beta, C + ro, ldc, sC, G.count);
+        const rocblas_status st = gemm_group(
+            h, G, trans ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none, m, ncols, k,
+            &alpha, Q(qi, qj), lda, sA, B + rb, ldb, sB, &beta, C + ro, ldc, sC);
         if (st != rocblas_status_success) {
             h->err = "rocblas_dgemm_strided_batched: status " + std::to_string((int)st);
             return DOTMI_E_DEVICE;
@@ -1033,18 +1045,16 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id, i
     }
     double *T2 = Tb + (size_t)mr * ns;
     if (part == 0 || part == 3) {
-        h->flopCount += 2.0 * ns * ns * mr * batch + 2.0 * mr * ns * ns * batch;  // R^T R and R Q_S below
-        RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Tt, Nn, ns, ns, mr, &mone, Tb, mr, sT, Tb, mr, sT, &one, Hss, lda,
-                                                 sA, batch));
+        // R^T R here, R Q_S below
+        RBCHECK(h, gemm_group(h, G, Tt, Nn, ns, ns, mr, &mone, Tb, mr, sT, Tb, mr, sT, &one, Hss, lda, sA));
         // R stays in scratch across the factorisation of the separator block; [Q_AS ; Q_CS] = -blockdiag(Q_A, Q_C)
         // (R Q_S) is then written straight into place
         dotmi_handle::FactorGroup G2 = G;
         G2.tmpOff = G.tmpOff + (size_t)mr * ns;
         if (int rc = chol_inv_node(h, G2, N.offS, ns)) return rc;
-        RBCHECK(h, rocblas_dgemm_strided_batched(G.blas, Nn, Nn, mr, ns, ns, &one, Tb, mr, sT, Hss, lda, sA, &zero, T2, mr,
-                                                 sT, batch));
+        RBCHECK(h, gemm_group(h, G, Nn, Nn, mr, ns, ns, &one, Tb, mr, sT, Hss, lda, sA, &zero, T2, mr, sT));
         // rows S, columns [A C] of the lower part hold the symmetric fill of H: clear them
-        launch_block_copy(Wg + N.offS + (size_t)N.off * lda, lda, (size_t)sA, nullptr, 0, 0, ns, m, batch, G.st);
+        launch_block_copy(Wg + N.offS + (size_t)N.off * lda, lda, (size_t)sA, nullptr, 0, 0, ns, m, batch, G.st, G.lw);
         if (part != 0) return 0;
     }
     {
