@@ -637,6 +637,35 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = upload(h, &P.trange, trange)) return rc;
     if (int rc = upload(h, &P.vp_ptr, vp_ptr)) return rc;
     if (int rc = upload(h, &P.vp_off, vp_off)) return rc;
+    {
+        // merge straight from the tile partials (merge_tiles_kernel): per global scalar dof the ppart entries that make
+        // up its value -- subdomain after subdomain (vp order), inside a subdomain the tiles that hold the column in
+        // tile order; the first entry of a subdomain is stored complemented.  Same sums, same order as
+        // reduce_partial_p + merge.
+        P.mt_ptr = nullptr;
+        P.mt_ent = nullptr;
+        const char *ev = getenv("DOTMI_MERGE_TILES");
+        const long long ppartN = (long long)P.nParts * P.nbmax * P.nmax;
+        if (!(ev && atoi(ev) == 0) && ppartN < (1ll << 31) && !h->gsdd) {
+            std::vector<int> mp((size_t)3 * nV + 1, 0), ment;
+            for (int v = 0; v < nV; ++v)
+                for (int d = 0; d < 3; ++d) {
+                    for (int k = vp_ptr[v]; k < vp_ptr[v + 1]; ++k) {
+                        const int ls = vp_off[k] / P.nmax, col = vp_off[k] % P.nmax + d;
+                        bool first = true;
+                        for (size_t b = 0; b < ranges[ls].size(); ++b)
+                            if (col >= ranges[ls][b].x && col < ranges[ls][b].y) {
+                                const int off = (int)(((long long)ls * P.nbmax + (long long)b) * P.nmax + col);
+                                ment.push_back(first ? ~off : off);
+                                first = false;
+                            }
+                    }
+                    mp[(size_t)3 * v + d + 1] = (int)ment.size();
+                }
+            if (int rc = upload(h, &P.mt_ptr, mp)) return rc;
+            if (int rc = upload(h, &P.mt_ent, ment)) return rc;
+        }
+    }
     if (int rc = upload(h, &P.dup, h->dup)) return rc;
     if (int rc = upload(h, &P.fill_dst, fill_dst)) return rc;
     if (int rc = upload(h, &P.fill_src, fill_src)) return rc;

@@ -61,6 +61,9 @@ struct DevParts {
                             // tiles read, contiguous -- filled by build_qpad (loop) or gathered from q (launch_gemv)
     // merge: per vertex list of positions in psub (all parts on this rank), CSR over vertices
     int *vp_ptr, *vp_off;
+    // the same merge straight from the tile partials: per global scalar dof (CSR mt_ptr over 3 nV) the offsets into ppart
+    // that make up its value, subdomain after subdomain; the first entry of a subdomain is stored complemented (~off)
+    int *mt_ptr, *mt_ent;
     int *dup;               // nV (global multiplicity, DOTTimeStepper.cpp:47-56)
     // dense fill list
     int nfill;

@@ -1083,8 +1083,9 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
         hipLaunchKernelGGL((backsolve_long_kernel<1>), dim3(P.nlwork), dim3(BSL_THREADS), 0, st, P.ltile, P.lwork, P.dofmap,
                            P.W, P.nmax, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl);
     }
-    hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.trange,
-                       P.ppart, P.nmax, P.nbmax, P.psub, ctl, 0);
+    if (!P.mt_ptr)   // merge_tiles_kernel sums the tile partials itself
+        hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.trange,
+                           P.ppart, P.nmax, P.nbmax, P.psub, ctl, 0);
 }
 
 // p[dofmap_s[k]] = psub_s[k] on the live positions of part s (p was cleared by the caller)
@@ -1533,9 +1534,85 @@ __global__ __launch_bounds__(256) void merge_kernel(int nV, const int *__restric
     if (with_dots) write_partials(acc, DEV ? HIST_MAX : Lr.m, partials, sm);
 }
 
+// The partial-sum reduce and the merge in one launch: thread = global scalar dof; its value is the sum over the
+// subdomains holding the vertex of (the sum over that subdomain's tiles holding the column of ppart[tile][column]) --
+// the additions of reduce_partial_p_kernel followed by merge_kernel, in their order, without the psub round trip and
+// without a launch in between.
+constexpr int MT_CH = 24;   // list entries in flight per thread (a dof has ~15: two subdomains x ~8 tiles)
+template <bool DEV>
+__global__ __launch_bounds__(256) void merge_tiles_kernel(int n3, const int *__restrict__ mt_ptr,
+                                                          const int *__restrict__ mt_ent, const int *__restrict__ dup,
+                                                          const double *__restrict__ ppart, LbfgsArgs L, int with_dots,
+                                                          int divide, double *__restrict__ z,
+                                                          double *__restrict__ partials, const DevLoop *__restrict__ ctl)
+{
+    __shared__ double sm[4 * RED_K];
+    if constexpr (DEV) {
+        if (ctl->status != 0 || ctl->phase != 0) return;
+    }
+    const LbfgsArgs &Lr = [&]() -> const LbfgsArgs & {
+        if constexpr (DEV) return ctl->L;
+        else return L;
+    }();
+    double acc[RED_K];
+#pragma unroll
+    for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += stride) {
+        const int e0 = mt_ptr[k], e1 = mt_ptr[k + 1];
+        const int d = divide ? dup[k / 3] : 1;
+        double yk[HIST_MAX];
+        if (with_dots) {
+#pragma unroll
+            for (int i = 0; i < HIST_MAX; ++i)
+                if (i < Lr.m) yk[i] = Lr.y[i][k];
+        }
+        double zk = 0.0, ps = 0.0;
+        // MT_CH entries at a time: offsets first, then the values, then the adds in list order
+        for (int e = e0; e < e1; e += MT_CH) {
+            int off[MT_CH];
+#pragma unroll
+            for (int u = 0; u < MT_CH; ++u) off[u] = (e + u < e1) ? mt_ent[e + u] : 0;
+            double w[MT_CH];
+#pragma unroll
+            for (int u = 0; u < MT_CH; ++u) {
+                const int o = off[u] < 0 ? ~off[u] : off[u];
+                w[u] = (e + u < e1) ? ppart[o] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < MT_CH; ++u)
+                if (e + u < e1) {
+                    if (off[u] < 0 && e + u > e0) {   // a new subdomain starts: close the previous one
+                        zk += ps;
+                        ps = 0.0;
+                    }
+                    ps += w[u];
+                }
+        }
+        zk += ps;
+        if (d > 1) zk /= d;
+        z[k] = zk;
+        if (with_dots) {
+#pragma unroll
+            for (int i = 0; i < HIST_MAX; ++i)
+                if (i < Lr.m) acc[i] += yk[i] * zk;
+        }
+    }
+    if (with_dots) write_partials(acc, DEV ? HIST_MAX : Lr.m, partials, sm);
+}
+
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
                   int with_dots, hipStream_t st, const DevLoop *ctl)
 {
+    if (P.mt_ptr) {   // (launch_gemv left the tile partials in ppart and skipped the reduce)
+        if (ctl)
+            hipLaunchKernelGGL(merge_tiles_kernel<true>, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup,
+                               P.ppart, L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl);
+        else
+            hipLaunchKernelGGL(merge_tiles_kernel<false>, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup,
+                               P.ppart, L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl);
+        return;
+    }
     // with_dots: bit0 = accumulate y_i.z partials, bit1 = divide by dup
     if (ctl)
         hipLaunchKernelGGL(merge_kernel<true>, dim3(NB_RED), dim3(256), 0, st, M.nV, P.vp_ptr, P.vp_off, P.dup, P.psub,
