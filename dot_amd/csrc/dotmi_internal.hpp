@@ -212,7 +212,6 @@ void launch_be_update(int nV, const uint8_t *fixed, double *x, double *xn, doubl
                       double dt, const double *gdtsq, hipStream_t st);
 void launch_scatter_rows(int n, const int *idx, const double *pos, double *x, hipStream_t st);
 void launch_copy(int n, const double *src, double *dst, hipStream_t st);
-void launch_div_dup(int nV, const int *dup, double *z, hipStream_t st);
 // sharded subdomains, after the all-reduce of the merged sums: z_v /= dup_v and the y_i . z partials
 void launch_zfinish(int nV, const int *dup, const LbfgsArgs &L, double *z, double *partials, hipStream_t st,
                     const DevLoop *ctl = nullptr);

@@ -40,27 +40,6 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
-// sum over a 256-thread block; result valid in thread 0.  sm: >= 4 doubles.
-__device__ __forceinline__ double block_sum256(double v, double *sm)
-{
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) sm[w] = v;
-    __syncthreads();
-    return (threadIdx.x == 0) ? ((sm[0] + sm[1]) + (sm[2] + sm[3])) : 0.0;
-}
-
-// every thread of the calling WAVE gets sum_b partials[b*stride + j] (fixed order)
-__device__ __forceinline__ double wave_sum_partials(const double *partials, int nblocks, int stride, int j)
-{
-    const int lane = threadIdx.x & 63;
-    double acc = 0.0;
-    for (int b = lane; b < nblocks; b += 64) acc += partials[(size_t)b * stride + j];
-    acc = wave_sum(acc);
-    return __shfl(acc, 0, 64);
-}
-
 // ------------------------------------------------------------------------------------------------
 // element pass: energy (+ inertia) partials and element gradients
 // ------------------------------------------------------------------------------------------------
@@ -185,7 +164,7 @@ __global__ __launch_bounds__(256) void elem_energy_grad_kernel(
                      dz = x[3 * v + 2] - xt[3 * v + 2];
         ine += (dx * dx + dy * dy + dz * dz) * mass[v] / 2.0;
     }
-    // both block sums through one exchange (same per-wave and cross-wave order as two block_sum256 calls)
+    // both block sums through one exchange
     const double we = wave_sum(acc), wi = wave_sum(ine);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) {
@@ -1669,22 +1648,6 @@ void launch_zfinish(int nV, const int *dup, const LbfgsArgs &L, double *z, doubl
     else hipLaunchKernelGGL(zfinish_kernel<false>, dim3(NB_RED), dim3(256), 0, st, nV, dup, L, z, partials, ctl);
 }
 
-__global__ void div_dup_kernel(int nV, const int *__restrict__ dup, double *__restrict__ z)
-{
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nV) return;
-    const int d = dup[v];
-    if (d > 1) {
-        z[3 * v] /= d;
-        z[3 * v + 1] /= d;
-        z[3 * v + 2] /= d;
-    }
-}
-void launch_div_dup(int nV, const int *dup, double *z, hipStream_t st)
-{
-    hipLaunchKernelGGL(div_dup_kernel, dim3((nV + 255) / 256), dim3(256), 0, st, nV, dup, z);
-}
-
 // ------------------------------------------------------------------------------------------------
 // alpha_0 = clamp(-p.g / p.Hp, alphaMin, 1): block-CSR SpMV fused with the two dot products
 // ------------------------------------------------------------------------------------------------
@@ -1813,7 +1776,7 @@ __global__ __launch_bounds__(256) void step_forward_kernel(int n, const double *
     if (threadIdx.x < 64) {
         double alpha = alpha_host;
         if (use_partials) {
-            double pg = 0.0, pHp = 0.0;  // both columns in flight together; same order as wave_sum_partials
+            double pg = 0.0, pHp = 0.0;  // both columns in flight together
             for (int b = threadIdx.x; b < NB_RED; b += 64) {
                 pg += spmv_partials[(size_t)b * RED_K];
                 pHp += spmv_partials[(size_t)b * RED_K + 1];
