@@ -1546,6 +1546,8 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
             // when all ranks agree (small integers in FP64), and every rank sees a disagreement from the same collective,
             // so they fail together instead of one of them waiting in the next all-reduce
             double mine[4] = {(double)C.status, (double)C.slots, (double)C.iter, (double)C.halvings}, sum[4];
+            if (const char *tv = getenv("DOTMI_TEST_DISAGREE"))   // test hook: this rank reports a different iteration count
+                if (atoi(tv) == h->rank) mine[2] += 1.0;
             memcpy(sum, mine, sizeof(mine));
             if (h->world > 1) {
                 HIPCHECK(h, hipMemcpyAsync(h->ctrlDev, sum, sizeof(sum), hipMemcpyHostToDevice, h->st));

@@ -97,3 +97,50 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_gpu_run(workload, steps, shar
     # conditioning of the subdomain matrices
     assert np.abs(z - R[0]["z"]).max() <= 1e-6 * np.abs(z).max()
     ts.close()
+
+
+def _worker_disagree(rank, world, initfile, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["DOTMI_SHARD_ELEMS"] = "0"
+    os.environ["DOTMI_TEST_DISAGREE"] = "1"       # rank 1 reports one iteration more than it made
+    os.environ["OMP_NUM_THREADS"] = "2"
+    import torch
+    import torch.distributed as dist
+    from tests.workloads import load_workload
+    from dot_amd.timestepper import DOTTimeStepper
+    from dot_amd.lib import DotmiError
+
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    sc, ep, n = load_workload("bunny5K_LTSS")
+    ts = DOTTimeStepper(sc, ep, n, device=0, rank=rank, world=world,
+                        allreduce=lambda a: dist.all_reduce(torch.from_numpy(a)))
+    msg = ""
+    try:
+        ts.step()
+    except DotmiError as e:
+        msg = str(e)
+    with open(os.path.join(outdir, f"rank{rank}.txt"), "w") as f:
+        f.write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_that_disagree_fail_together_instead_of_hanging():
+    """The sharded loop ends every batch of slots with a sum of the ranks' loop states; a rank whose state differs (here:
+    forced through DOTMI_TEST_DISAGREE) makes EVERY rank return DOTMI_E_DEVICE from the same collective -- nobody is left
+    waiting in the next all-reduce."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=_worker_disagree, args=(r, 2, os.path.join(d, "init"), d)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=300)
+        alive = [p for p in procs if p.is_alive()]
+        for p in alive:
+            p.terminate()
+        assert not alive, "a rank hung"
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        msgs = [open(os.path.join(d, f"rank{r}.txt")).read() for r in range(2)]
+    assert all("different states" in m for m in msgs), msgs
