@@ -4,6 +4,7 @@
 //              activities, :882-888), then "<distortion> 0"
 //   <n>.obj    igl::writeOBJ(V_surf, F_surf) from Optimizer::saveStatus (Optimizer.cpp:1137-1150): surface vertices
 //              re-indexed, Eigen FullPrecision (15 significant digits), faces 1-based
+//   config.txt Config::saveToFile (Config.cpp:209-302), the echo of the effective script
 // The timer_step slots are filled from dotmi_step_stats.ms_phase (HIP events on the library's stream).
 #pragma once
 #include <array>
@@ -11,6 +12,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include "Scene.hpp"
 
 namespace dot_amd {
 
@@ -54,6 +57,53 @@ inline void write_info_txt(const std::string &path, int vertAmtInput, int nT, in
     print_timer(file, 14, t.step, TIMER_STEP_NAMES);
     print_timer(file, 7, t.temp3, TIMER_TEMP3_NAMES);
     file << 0.0 << " " << 0.0 << std::endl;
+}
+
+// output/<name>/config.txt: the effective script as Config::saveToFile echoes it (Config.cpp:209-302; written by
+// main.cpp:786).  Same tokens, order, conditions and default ostream number formatting; pinned byte for byte against
+// the reference's own saveToFile on every shipped script (tests/golden/ref_formats.json).
+inline void write_config_txt(const std::string &path, const Config &c)
+{
+    std::ofstream file(path);
+    if (!file) throw std::runtime_error("cannot write " + path);
+    file << "energy " << c.energy << std::endl;
+    file << "timeIntegration " << c.timeIntegration << std::endl;
+    file << "timeStepper " << c.timeStepper;
+    if (c.timeStepper == "ADMMDD" || c.timeStepper == "DOT" || c.timeStepper == "LBFGSJH" || c.timeStepper == "GSDD") {
+        if (c.blockSize > 0) file << " -1 " << c.blockSize;
+        else file << " " << c.partitionAmt;
+    } else if (c.timeStepper == "ADMM") {
+        file << " " << c.maxIterAPD;
+    }
+    file << std::endl;
+    file << "inexactSolve " << c.inexactSolve << std::endl;
+    file << "warmStart " << c.warmStart << std::endl;
+    file << "resolution " << c.resolution << std::endl;
+    file << "size " << c.size << std::endl;
+    file << "time " << c.duration << " " << c.dt << std::endl;
+    file << "density " << c.rho << std::endl;
+    file << "stiffness " << c.YM << " " << c.PR << std::endl;
+    if (!c.withGravity) file << "turnOffGravity" << std::endl;
+    file << "script " << c.script << std::endl;
+    if (c.handleRatio != 0.01) file << "handleRatio " << c.handleRatio << std::endl;
+    file << "shape " << c.shapeType;
+    if (c.shapeType == "input") file << " " << c.shapePath;
+    file << std::endl;
+    if (c.rotDeg != 0.0)
+        file << "rotateModel " << c.rotAxis[0] << " " << c.rotAxis[1] << " " << c.rotAxis[2] << " " << c.rotDeg << std::endl;
+    if (c.restart) file << "restart " << c.statusPath << std::endl;
+    if (!c.tuning.empty()) {
+        file << "tuning " << c.tuning.size() << std::endl;
+        for (double t : c.tuning) file << t << std::endl;
+    }
+    file << "view " << (c.orthographic ? "orthographic" : "perspective") << std::endl;
+    file << "zoom " << c.zoom << std::endl;
+    if (!c.appendStr.empty()) file << "appendStr " << c.appendStr << std::endl;
+    if (c.disableCout) file << "disableCout" << std::endl;
+    if (!c.tol.empty()) {
+        file << "tol " << c.tol.size() << std::endl;
+        for (double t : c.tol) file << t << std::endl;
+    }
 }
 
 // igl::writeOBJ(str, V, F) (libigl writeOBJ.cpp:100-120): IOFormat(FullPrecision, DontAlignCols, " ", "\n", "v ", "",

@@ -32,6 +32,13 @@ struct Config {  // subset of DOT::Config the DOT path reads; defaults Config.cp
     std::vector<double> tol;
     bool restart = false;       // `restart <status file>` (Config.cpp:164-167)
     std::string statusPath;
+    // fields the DOT path does not consume; kept so that output/<name>/config.txt echoes the script the way
+    // Config::saveToFile does (Config.cpp:209-302)
+    std::string timeIntegration = "BE", shapeType = "grid", appendStr;
+    int inexactSolve = 0, resolution = 100, maxIterAPD = 1000;
+    bool orthographic = false, disableCout = false;
+    double zoom = 1.0;
+    std::vector<double> tuning;
 };
 
 inline Config parse_script(const std::string &path)
@@ -63,7 +70,27 @@ inline Config parse_script(const std::string &path)
                     if (n < 0) ss >> c.blockSize;
                     else if (n < 2) c.partitionAmt = 4;
                 }
+            } else if (c.timeStepper == "ADMM") {   // Config.cpp:81-89
+                ss >> c.maxIterAPD;
+                if (c.maxIterAPD < 1) c.maxIterAPD = 10;
             }
+        } else if (tok == "timeIntegration") {
+            ss >> c.timeIntegration;
+            c.timeIntegration = "BE";   // the only entry of timeIntegrationTypeStrs, and the default of the lookup
+        } else if (tok == "inexactSolve") ss >> c.inexactSolve;
+        else if (tok == "resolution") ss >> c.resolution;
+        else if (tok == "view") {
+            std::string v;
+            ss >> v;
+            c.orthographic = v == "orthographic";
+        } else if (tok == "zoom") ss >> c.zoom;
+        else if (tok == "appendStr") ss >> c.appendStr;
+        else if (tok == "disableCout") c.disableCout = true;
+        else if (tok == "tuning") {
+            int n = 0;
+            ss >> n;
+            c.tuning.resize(n > 0 ? n : 0);
+            for (auto &t : c.tuning) in >> t;     // `file >> tuneI` (Config.cpp:183-191)
         } else if (tok == "size") ss >> c.size;
         else if (tok == "time") ss >> c.duration >> c.dt;
         else if (tok == "density") ss >> c.rho;
@@ -73,6 +100,10 @@ inline Config parse_script(const std::string &path)
         else if (tok == "shape") {
             std::string kind;
             ss >> kind;
+            static const char *shapes[] = {"grid", "square", "rectangle", "spikes", "Sharkey", "cylinder", "input"};
+            c.shapeType = "grid";   // default of getShapeTypeByStr (Config.cpp:402-411)
+            for (const char *k : shapes)
+                if (kind == k) c.shapeType = k;
             if (kind == "input") ss >> c.shapePath;
         } else if (tok == "rotateModel") ss >> c.rotAxis[0] >> c.rotAxis[1] >> c.rotAxis[2] >> c.rotDeg;  // axis first, Config.cpp:173-176
         else if (tok == "handleRatio") ss >> c.handleRatio;

@@ -7,13 +7,16 @@
 //                                 (Optimizer.cpp:227, DOTTimeStepper.cpp:338)
 //   output/<name>/status<n>       restartable state (Optimizer.cpp:1096-1132)
 //   output/<name>/<n>.obj         surface mesh per step (Optimizer.cpp:1137-1150)
+//   output/<name>/config.txt      echo of the effective script (Config::saveToFile, Config.cpp:209-302; main.cpp:786)
 //   output/<name>/info.txt        nV nT / steps innerIters / wall-clock summary (main.cpp:338-358)
 //   output/<name>/label.obj, wire.poly   partition labels of the surface triangles, surface wire frame
 //                                 (ADMMDDTimeStepper.cpp:375-442)
 // Script token `restart <status file>` resumes from a saved status (Optimizer.cpp:126-177).
 //
 // usage: dot_hip 100 <script.txt> [--mesh-root DIR] [--parts N] [--energy FCR|SNH] [--epart raw.i32]
-//                [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K] [--dump-config] [--dump-formats DIR] [--fast]
+//                [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K] [--dump-config] [--dump-formats DIR]
+//                [--echo-config FILE] [--fast]
+//        dot_hip --write-info FILE nV nT steps iters t0..t21
 #include <chrono>
 #include <cstring>
 #include <iostream>
@@ -32,6 +35,16 @@ static double now_s()
 
 int main(int argc, char **argv)
 {
+    // pure formatter (no script, no GPU): info.txt from given numbers -- compared byte for byte with what the reference's
+    // Timer::print writes for the same numbers (tests/golden/ref_formats.json)
+    if (argc == 3 + 4 + 22 && std::string(argv[1]) == "--write-info") {
+        RunTimers rt;
+        rt.descent = std::atof(argv[7]);
+        for (int k = 0; k < 14; ++k) rt.step[k] = std::atof(argv[8 + k]);
+        for (int k = 0; k < 7; ++k) rt.temp3[k] = std::atof(argv[22 + k]);
+        write_info_txt(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]), rt);
+        return 0;
+    }
     if (argc < 3) {
         std::fprintf(stderr, "usage: %s 100 <script.txt> [--mesh-root DIR] [--parts N] [--energy FCR|SNH] "
                              "[--epart raw.i32] [--frames K] [--out DIR] [--device D] [--no-files] [--dump-scene K] [--dump-config] [--dump-formats DIR] [--fast]\n", argv[0]);
@@ -45,7 +58,7 @@ int main(int argc, char **argv)
     std::string meshRoot = ".", outDir, epartFile, energyOverride;
     int partsOverride = -1, frames = -1, device = 0, dumpScene = -1;
     bool files = true, dumpConfig = false, fast = false;
-    std::string dumpFormats;
+    std::string dumpFormats, echoConfig;
     for (int i = 3; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) throw std::runtime_error("missing value for " + a); return argv[++i]; };
@@ -60,11 +73,16 @@ int main(int argc, char **argv)
         else if (a == "--dump-scene") dumpScene = std::stoi(next());
         else if (a == "--dump-config") dumpConfig = true;
         else if (a == "--dump-formats") dumpFormats = next();   // write 0.obj + info.txt of the initial scene into DIR (no GPU)
+        else if (a == "--echo-config") echoConfig = next();   // write config.txt (Config::saveToFile's echo) to this path and exit
         else if (a == "--fast") fast = true;   // device-resident loop: the loop slots of info.txt stay 0
         else { std::fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
     try {
         Config cfg = parse_script(scriptPath);
+        if (!echoConfig.empty()) {
+            write_config_txt(echoConfig, cfg);
+            return 0;
+        }
         if (dumpConfig) {
             // the parsed fields as "key value" lines, the format of oracle/ref_config.cpp (the reference's own
             // Config::loadFromFile): tests/test_oracle_pin.py compares the two on every input script of the reference
@@ -193,6 +211,7 @@ int main(int argc, char **argv)
             fLog = std::fopen((outDir + "/log.txt").c_str(), "w");
             if (!fIter || !fLog) throw std::runtime_error("cannot write into " + outDir);
             write_partition_files(outDir, mesh, x0, epart);
+            write_config_txt(outDir + "/config.txt", cfg);   // main.cpp:786
         }
         const SurfaceMesh surf = files ? build_surface_mesh(mesh) : SurfaceMesh();
         RunTimers timers;

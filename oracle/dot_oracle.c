@@ -171,6 +171,14 @@ void dor_svd3(const double F[9], double U[9], double S[3], double V[9])
     }
 }
 
+/* Optional replacement of the 3x3 SVD by a caller-supplied BATCH routine (n row-major matrices in, U, S, V out).
+ * tests/ bind this to oracle/_ref/librefpin.so:ref_svd, i.e. to the reference's own AVX kernel
+ * (Utils/SVD_EFTYCHIOS, staged as IglUtils.cpp:929-1085 does), so that the restated step can be run with exactly
+ * the singular values the reference feeds its energies and -- through the cached `svd` (redoSVD = false,
+ * DOTTimeStepper.cpp:580) -- its Hessian projection.  NULL (default) = dor_svd3. */
+static dor_svd_batch_fn g_svd_batch = NULL;
+void dor_set_svd_batch(dor_svd_batch_fn fn) { g_svd_batch = fn; }
+
 /* ------------------------------------------------------------------------------------------
  * materials in singular-value space
  * ---------------------------------------------------------------------------------------- */
@@ -376,23 +384,40 @@ static void elem_hessian_from_M(const double M[81], const double A[9], double H[
     }
 }
 
-void dor_elem_hessian_x(int mat, const double x4[12], const double A[9], double mu, double lam,
-                        double w, int project, double H[144])
+static void elem_hessian_usv(int mat, const double U[9], const double S[3], const double V[9], const double A[9],
+                             double mu, double lam, double w, int project, double H[144])
 {
-    double F[9], U[9], S[3], V[9], M[81];
-    deformation_gradient(x4, A, F);
-    dor_svd3(F, U, S, V);
+    double M[81];
     dor_dPdF(mat, U, S, V, mu, lam, w, project, M);
     elem_hessian_from_M(M, A, H);
 }
 
+void dor_elem_hessian_x(int mat, const double x4[12], const double A[9], double mu, double lam,
+                        double w, int project, double H[144])
+{
+    double F[9], U[9], S[3], V[9];
+    deformation_gradient(x4, A, F);
+    dor_svd3(F, U, S, V);
+    elem_hessian_usv(mat, U, S, V, A, mu, lam, w, project, H);
+}
+
 /* Energy.cpp:910-972 (SIMD path): P = U diag(dPsi/dsigma) V^T ; g_e = dF/dx^T : (w P) */
+static void elem_energy_grad_usv(int mat, const double U[9], const double S[3], const double V[9], const double A[9],
+                                 double mu, double lam, double w, double *psi_w, double g[12]);
+
 void dor_elem_energy_grad_x(int mat, const double x4[12], const double A[9], double mu, double lam,
                             double w, double *psi_w, double g[12])
 {
-    double F[9], U[9], S[3], V[9], d[3], P[9];
+    double F[9], U[9], S[3], V[9];
     deformation_gradient(x4, A, F);
     dor_svd3(F, U, S, V);
+    elem_energy_grad_usv(mat, U, S, V, A, mu, lam, w, psi_w, g);
+}
+
+static void elem_energy_grad_usv(int mat, const double U[9], const double S[3], const double V[9], const double A[9],
+                                 double mu, double lam, double w, double *psi_w, double g[12])
+{
+    double d[3], P[9];
     if (psi_w) *psi_w = w * dor_psi(mat, S, mu, lam);
     if (g) {
         dor_dpsi(mat, S, mu, lam, d);
@@ -442,6 +467,7 @@ struct dor_sim {
     int nh;
     /* scratch */
     double *ework, *gcont, *x0, *q, *gold, *Hp, *tmp_s, *tmp_y;
+    double *usv; /* per element U[9] S[3] V[9] of the last evaluation (svd_all) */
     /* logs */
     int log_n, log_cap;
     double *log_alpha, *log_E, *log_g2;
@@ -822,22 +848,59 @@ static void compute_xtilde(dor_sim *s)
         }
 }
 
+/* F, U, S, V of every element at x (Energy.cpp:294-423: F = Ds A, then the batch SVD).  21 doubles per element in
+ * s->usv: U[9] S[3] V[9].  With the batch hook the matrices go through it in slices of at most 65536 (the size the
+ * reference instantiates its helper for); without it every element runs dor_svd3. */
+static void svd_all(dor_sim *s, const double *x)
+{
+    int nT = s->nT;
+    if (!s->usv) s->usv = (double *)malloc(sizeof(double) * 21 * (size_t)nT);
+    if (!g_svd_batch) {
+#pragma omp parallel for schedule(static)
+        for (int e = 0; e < nT; ++e) {
+            const int *t = s->T + 4 * e;
+            double x4[12], F[9];
+            for (int k = 0; k < 4; ++k)
+                for (int d = 0; d < 3; ++d) x4[3 * k + d] = x[3 * t[k] + d];
+            deformation_gradient(x4, s->A + 9 * e, F);
+            double *o = s->usv + 21 * (size_t)e;
+            dor_svd3(F, o, o + 9, o + 12);
+        }
+        return;
+    }
+    const int CH = 65536;
+    double *F = (double *)malloc(sizeof(double) * 9 * CH), *U = (double *)malloc(sizeof(double) * 9 * CH),
+           *S = (double *)malloc(sizeof(double) * 3 * CH), *V = (double *)malloc(sizeof(double) * 9 * CH);
+    for (int e0 = 0; e0 < nT; e0 += CH) {
+        int n = nT - e0 < CH ? nT - e0 : CH;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < n; ++i) {
+            const int *t = s->T + 4 * (e0 + i);
+            double x4[12];
+            for (int k = 0; k < 4; ++k)
+                for (int d = 0; d < 3; ++d) x4[3 * k + d] = x[3 * t[k] + d];
+            deformation_gradient(x4, s->A + 9 * (size_t)(e0 + i), F + 9 * (size_t)i);
+        }
+        g_svd_batch(n, F, U, S, V);
+        for (int i = 0; i < n; ++i) {
+            double *o = s->usv + 21 * (size_t)(e0 + i);
+            memcpy(o, U + 9 * (size_t)i, 72);
+            memcpy(o + 9, S + 3 * (size_t)i, 24);
+            memcpy(o + 12, V + 9 * (size_t)i, 72);
+        }
+    }
+    free(F); free(U); free(S); free(V);
+}
+
 /* Optimizer.cpp:1183-1218 + Energy.cpp:426-437, :852-907 */
 double dor_eval_energy(dor_sim *s, const double *x)
 {
     double t0 = now_ms();
     int nT = s->nT, nV = s->nV;
+    svd_all(s, x);
 #pragma omp parallel for schedule(static)
-    for (int e = 0; e < nT; ++e) {
-        const int *t = s->T + 4 * e;
-        double x4[12];
-        for (int k = 0; k < 4; ++k)
-            for (int d = 0; d < 3; ++d) x4[3 * k + d] = x[3 * t[k] + d];
-        double F[9], U[9], S[3], V[9];
-        deformation_gradient(x4, s->A + 9 * e, F);
-        dor_svd3(F, U, S, V);
-        s->ework[e] = dor_psi(s->mat, S, s->mu[e], s->lam[e]) * s->vol[e];
-    }
+    for (int e = 0; e < nT; ++e)
+        s->ework[e] = dor_psi(s->mat, s->usv + 21 * (size_t)e + 9, s->mu[e], s->lam[e]) * s->vol[e];
     double sum = 0;
     for (int e = 0; e < nT; ++e) sum += s->ework[e];
     double E = s->dtSq * sum;
@@ -857,14 +920,12 @@ void dor_eval_gradient(dor_sim *s, const double *x, double *g)
 {
     double t0 = now_ms();
     int nT = s->nT, nV = s->nV;
+    svd_all(s, x);
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < nT; ++e) {
-        const int *t = s->T + 4 * e;
-        double x4[12];
-        for (int k = 0; k < 4; ++k)
-            for (int d = 0; d < 3; ++d) x4[3 * k + d] = x[3 * t[k] + d];
-        dor_elem_energy_grad_x(s->mat, x4, s->A + 9 * e, s->mu[e], s->lam[e],
-                               s->dtSq * s->vol[e], NULL, s->gcont + 12 * (size_t)e);
+        const double *o = s->usv + 21 * (size_t)e;
+        elem_energy_grad_usv(s->mat, o, o + 9, o + 12, s->A + 9 * e, s->mu[e], s->lam[e], s->dtSq * s->vol[e], NULL,
+                             s->gcont + 12 * (size_t)e);
     }
 #pragma omp parallel for schedule(static)
     for (int v = 0; v < nV; ++v) {
@@ -889,14 +950,12 @@ void dor_eval_gradient(dor_sim *s, const double *x, double *g)
 void dor_eval_elem_hessians(dor_sim *s, const double *x, double *H)
 {
     int nT = s->nT;
+    svd_all(s, x);
 #pragma omp parallel for schedule(static)
     for (int e = 0; e < nT; ++e) {
-        const int *t = s->T + 4 * e;
-        double x4[12];
-        for (int k = 0; k < 4; ++k)
-            for (int d = 0; d < 3; ++d) x4[3 * k + d] = x[3 * t[k] + d];
-        dor_elem_hessian_x(s->mat, x4, s->A + 9 * e, s->mu[e], s->lam[e], s->dtSq * s->vol[e], 1,
-                           H + 144 * (size_t)e);
+        const double *o = s->usv + 21 * (size_t)e;
+        elem_hessian_usv(s->mat, o, o + 9, o + 12, s->A + 9 * e, s->mu[e], s->lam[e], s->dtSq * s->vol[e], 1,
+                         H + 144 * (size_t)e);
     }
 }
 
@@ -1120,7 +1179,7 @@ void dor_destroy(dor_sim *s)
     free(s->adj_idx); free(s->eblk); free(s->Hval); free(s->He); free(s->epart); free(s->vpart); free(s->dup);
     free(s->x); free(s->xn); free(s->v); free(s->xt); free(s->g); free(s->p);
     free(s->ework); free(s->gcont); free(s->x0); free(s->q); free(s->gold); free(s->Hp); free(s->tmp_s); free(s->tmp_y);
-    free(s->log_alpha); free(s->log_E); free(s->log_g2);
+    free(s->log_alpha); free(s->log_E); free(s->log_g2); free(s->usv);
     free(s);
 }
 

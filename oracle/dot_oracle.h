@@ -49,6 +49,11 @@ void dor_elem_hessian_x(int mat, const double x4[12], const double A[9], double 
 void dor_elem_energy_grad_x(int mat, const double x4[12], const double A[9], double mu, double lam,
                             double w, double *psi_w, double g[12]);
 
+/* optional batch SVD (n row-major 3x3 in; U, S, V out) used by every simulation-level evaluation instead of dor_svd3;
+ * tests bind it to the reference's own AVX kernel (oracle/_ref/librefpin.so:ref_svd).  NULL restores dor_svd3. */
+typedef int (*dor_svd_batch_fn)(int n, const double *F, double *U, double *S, double *V);
+void dor_set_svd_batch(dor_svd_batch_fn fn);
+
 /* ---- simulation object ---- */
 typedef struct dor_sim dor_sim;
 

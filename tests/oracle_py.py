@@ -304,6 +304,14 @@ def ref():
     return _ref
 
 
+def use_reference_svd(on: bool):
+    """Route every simulation-level SVD of the oracle through the reference's own AVX kernel (librefpin.so:ref_svd,
+    Utils/SVD_EFTYCHIOS compiled in place) -- or back to dor_svd3."""
+    L = lib()
+    L.dor_set_svd_batch.argtypes = [C.c_void_p]
+    L.dor_set_svd_batch(C.cast(ref().ref_svd, C.c_void_p) if on else None)
+
+
 _refsolver = None
 
 

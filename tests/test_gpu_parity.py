@@ -608,8 +608,10 @@ def test_iteration_counts_equal_the_reference_published_runs():
     assert abs(ts.targetGRes - 2.75467e-05) < 1e-10
     ref = [11, 10, 9, 9, 9, 10, 11, 11, 12, 12, 13, 14]
     its = []
-    for _ in range(12):
+    for k in range(12):
         assert ts.solve(1) == 0
         its.append(ts.last_stats.iters)
+        if k == 0:   # header line of the reference's iterStats.txt for step 0: E, |g|^2 after initX
+            assert abs(ts.last_stats.E0 - 0.0560098) < 5e-8 and abs(ts.last_stats.g2_0 - 1.31642) < 5e-6
     ts.close()
     assert its[:9] == ref[:9] and all(abs(a - b) <= 1 for a, b in zip(its[9:], ref[9:]))

@@ -82,9 +82,15 @@ def test_horse7K_stretch_fcr_8_steps_match_oracle():
     iteration of those steps still agrees to rounding."""
     sc, ep, n, ts, orc = make_pair("horse7K_stretch")
     assert sc.cfg.energy == "FCR" and n == 8
+    # BASELINE.md section 2, the reference's own run of this script with 8 parts: 9 11 14 16 20 21 28 27 29 32.  The
+    # HIP path reproduces steps 0-1 exactly and 2-4 within one (13 17 19): this script back-tracks from step 2 on
+    # and the counts then depend on the SVD kernel's rounding (the oracle with the reference's own AVX SVD plugged
+    # in takes 9 12 13 17 19 -- also +-1, on other steps; see test_oracle_pin.py)
+    published = [9, 11, 14, 16, 20]
     for k in range(5):
         (st, so), = run_both(sc, ts, orc, 1)
         assert (st.status, st.iters, st.ls_halvings) == (so.status, so.iters, so.ls_halvings), k
+        assert st.iters == published[k] if k < 2 else abs(st.iters - published[k]) <= 1, (k, st.iters)
         assert st.g2 <= ts.targetGRes
         dx = np.abs(ts.getResult() - orc.state()[0]).max()
         if k < 4:
@@ -289,9 +295,13 @@ def test_device_assembly_spmv_and_solve_match_reference_cholmod_solver(k):
 # ---- the reference's shipped scripts use `timeStepper DOT 6`: subdomains of ~3000 vertices ---------------------------
 # iterations per step of the CPU oracle on this configuration (10 steps, ~2.5 s each on 8 threads, recorded from
 # oracle/dot_oracle.c; the first two are re-run live below).  BASELINE.md section 2 lists 9 10 12 14 14 15 15 16 15 16
-# for the reference's own run of the script as shipped: +-1 on four steps.  The 32-part / SNH and bunny5K 8-part lists
-# of the same table are reproduced exactly, so the difference is most likely the 6-way partition of that run (not
-# recorded), not the solver.
+# for the reference's own run of the script as shipped: +-1 on four steps.  MEASURED CAUSE (round 3,
+# tests/test_oracle_pin.py::test_published_bar17K_as_shipped_list_needs_the_references_svd_rounding): the SVD kernel's
+# rounding.  With the reference's own compiled AVX SVD plugged into the oracle and nothing else changed, the oracle
+# takes exactly the published 9 10 12 14 14 15 15 16 15 16.  The step-0 preconditioner is the projected Hessian of the
+# rest state, where makePD2d halves each B block on a rounding coin flip (88 % of the element Hessians differ by up
+# to 23 % between the two SVDs), and step 0 stops at |g|^2 / tol = 0.976 after 8 iterations with exact Jacobi
+# rotations (device and oracle) but needs a 9th with the reference kernel.  Partition and solver are not involved.
 BAR6_ITERS = [8, 10, 12, 14, 14, 14, 15, 15, 16, 15]
 BAR6_PUBLISHED = [9, 10, 12, 14, 14, 15, 15, 16, 15, 16]
 

@@ -454,3 +454,50 @@ def test_builtin_partitioner_quality_balance_and_determinism(workload, nparts, m
     assert not one.any()
     many = scene.partition_dual(sc.V_rest[:], sc.T[:50], 50)
     assert sorted(many.tolist()) == list(range(50))
+
+
+# ---- f2 pinned against files the REFERENCE's own writers produced --------------------------------
+FORMATS = os.path.join(ROOT, "tests", "golden", "ref_formats.json")
+
+
+def test_config_echo_is_byte_identical_to_the_references_saveToFile(tmp_path):
+    """output/<name>/config.txt (main.cpp:786): `dot_hip --echo-config` on each of the 62 shipped scripts (+5 texts with
+    the tokens none of them uses: tuning, appendStr, disableCout, restart, ADMM's iteration count, unknown view/shape
+    names) against the bytes Config::saveToFile of the reference itself wrote for the same text
+    (tests/golden/ref_formats.json, made by oracle/_ref/ref_formats = src/Config.cpp compiled in place).  The golden
+    texts carry no `script` line (oracle/ref_formats.cpp) and show the marker @SCRIPT@ there; ours prints the
+    parser's default name."""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "dot_amd", "dot_hip")
+    with open(FORMATS) as f:
+        G = json.load(f)["config"]
+    assert len(G) >= 65
+    for rel, rec in G.items():
+        src, dst = tmp_path / "s.txt", tmp_path / "config.txt"
+        src.write_text(rec["text"])
+        subprocess.check_call([exe, "100", str(src), "--echo-config", str(dst)])
+        ours = dst.read_bytes()
+        assert b"\nscript null\n" in ours, rel
+        assert ours.replace(b"\nscript null\n", b"\nscript @SCRIPT@\n") == rec["echo"].encode(), rel
+    # and the script token itself round-trips
+    src.write_text("energy FCR\ntimeStepper DOT 6\nscript twistnsns\nshape input a.msh\n")
+    subprocess.check_call([exe, "100", str(src), "--echo-config", str(dst)])
+    assert b"\nscript twistnsns\n" in dst.read_bytes()
+
+
+def test_info_txt_is_byte_identical_to_the_references_timer_print(tmp_path):
+    """info.txt (saveInfoForPresent, main.cpp:338-358): `dot_hip --write-info` against the file the reference's own
+    Timer::print (Utils/Timer.hpp:58-68, compiled in place) wrote for the same numbers -- widths, %g-style values,
+    totals, the three tables and the two header / one trailer lines."""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "dot_amd", "dot_hip")
+    with open(FORMATS) as f:
+        G = json.load(f)["info"]
+    assert len(G) >= 2
+    for rec in G:
+        dst = tmp_path / "info.txt"
+        args = [str(rec["nV"]), str(rec["nT"]), str(rec["iterNum"]), str(rec["inner"])] + [repr(t) for t in rec["t"]]
+        subprocess.check_call([exe, "--write-info", str(dst)] + args)
+        assert dst.read_bytes() == rec["text"].encode()

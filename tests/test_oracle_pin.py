@@ -256,3 +256,50 @@ def test_reference_config_live_tokens(tmp_path):
             assert _same(val, ref[key]), (t, key, val, ref[key])
         tol = [float(x) for x in ref["tol"].split()[1:]]
         assert (cfg.tol or []) == tol
+
+
+# ---- why the shipped bar17K script (FCR, `timeStepper DOT 6`) differs by +-1 from the published run --------------------
+@pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_published_bar17K_as_shipped_list_needs_the_references_svd_rounding():
+    """BASELINE.md section 2 lists 9 10 12 14 14 15 15 16 15 16 for the reference's own run of input/bar17K_twist_DOT.txt
+    as shipped; oracle and HIP path take 8 10 12 14 14 14 15 15 16 15.  Measured cause: the SVD kernel's rounding.
+    With the oracle's SVD calls routed through the reference's own compiled AVX kernel (dor_set_svd_batch ->
+    librefpin.so:ref_svd) and NOTHING else changed, the published list is reproduced on all ten steps (first three
+    asserted here, the other seven recorded in DESIGN.md section 7).  Mechanism: the first step's preconditioner is
+    the projected Hessian of the REST state, where every B block of compute_dP_div_dF (Energy.cpp:1151-1172) has a
+    zero eigenvalue and makePD2d (IglUtils.hpp:271-309) halves the block iff rounding made it negative -- three coin
+    flips per tet decided by the last bits of sigma.  The two SVDs disagree on 88 % (= 1 - 2^-3) of the rest-state
+    element Hessians by up to 23 %; step 0 then stops at |g|^2 / tol = 0.976 after 8 iterations (exact Jacobi) or
+    needs a 9th (reference kernel)."""
+    from tests.workloads import load_workload
+    sc, ep, n = load_workload("bar17K_twist", 6)
+    sc.cfg.energy = "FCR"
+    cfg = sc.cfg
+
+    def run(nsteps):
+        sim = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, n,
+                          cfg.with_gravity)
+        He = np.zeros((sc.T.shape[0], 144))
+        O.lib().dor_eval_elem_hessians(sim.h, dp(np.ascontiguousarray(sc.x0)), dp(He))
+        its, margin = [], []
+        for _ in range(nsteps):
+            idx, pos = sc.scripter.step(sim.state()[0], cfg.dt)
+            sim.move(idx, pos)
+            st = sim.step()
+            its.append(st.iters); margin.append(st.g2 / sim.target_gres)
+        sim.close()
+        return its, margin, He
+
+    own, m_own, He_own = run(1)
+    assert own == [8] and 0.95 < m_own[0] < 1.0          # stops with 2.4 % to spare
+    O.use_reference_svd(True)
+    try:
+        sc, ep, n = load_workload("bar17K_twist", 6)     # fresh scripter state
+        sc.cfg.energy = "FCR"
+        ref, m_ref, He_ref = run(3)
+    finally:
+        O.use_reference_svd(False)
+    assert ref == [9, 10, 12]                            # BASELINE.md section 2, "as shipped"
+    d = np.abs(He_own - He_ref).max(1) / np.abs(He_own).max(1)
+    frac = (d > 1e-6).mean()
+    assert 0.85 < frac < 0.90 and d.max() < 0.3
