@@ -27,9 +27,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DEFAULT_WORKLOAD = "bar17K_twist"  # BASELINE.json configs[1]
-# also reported (short runs) in the `workloads` array of the JSON line: BASELINE.json configs[0] (north_star names it next to
-# bar17K_twist) and configs[4], the 1 M-tet bar whose 3.4 GB of factors cannot sit in the 256 MB Infinity Cache
-EXTRA_WORKLOADS = "bunny5K_LTSS,synbar:140x35x35:256"
+# also reported (short runs, every N) in the `workloads` array of the JSON line: BASELINE.json configs[0] (north_star names
+# it next to bar17K_twist), configs[2] (the horse: horse7K red-refined once, 249 k tets, as the stand-in for the 136K mesh
+# the reference checkout lacks), configs[3] (stiff monkey, 64 subdomains) and configs[4], the 1 M-tet bar whose 4.5 GB of
+# factors cannot sit in the 256 MB Infinity Cache -- the three BASELINE.json assigns to 4 / 8 GPUs
+EXTRA_WORKLOADS = "bunny5K_LTSS,horse7K_stretch@r1:64,monkey18K_stiff,synbar:140x35x35:256"
+EXTRA_STEPS = {"bunny5K_LTSS": (12, 2), "horse7K_stretch@r1:64": (8, 2), "monkey18K_stiff": (5, 1),
+               "synbar:140x35x35:256": (6, 2)}   # (steps, warmup)
+# the reference's own code (TBB + CHOLMOD/MKL) on 8 vCPU of the build container, ms per time step
+REFERENCE_ANCHOR = {
+    "bar17K_twist": {"ms_per_step": [924, 1331], "iters": [16, 20, 25, 26, 26, 26, 26, 27, 27, 27]},
+    "bunny5K_LTSS": {"ms_per_step": [160, 360], "iters": [11, 10, 9, 9, 9, 10, 11, 11, 12, 12]},
+    "monkey18K_stiff": {"ms_per_step": [4024, 10152], "iters": [108, 85, 98, 88, 145, 135, 145, 162, 131, 126]},
+}
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
@@ -40,7 +50,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD)
     ap.add_argument("--extra-workloads", default=EXTRA_WORKLOADS,
-                    help="comma list of further workloads reported in the `workloads` array (N=1 only), or `none`")
+                    help="comma list of further workloads reported in the `workloads` array, or `none`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=12)
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -51,7 +61,7 @@ def main():
     import torch.distributed as dist
 
     from dot_amd import lib as dl
-    from tests.workloads import WORKLOADS, load_workload
+    from dot_amd.workloads import WORKLOADS, load_workload
     from dot_amd.timestepper import DOTTimeStepper, comm_unique_id
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,6 +98,51 @@ def main():
             if rec.get("workload") == workload:
                 return rec["hbm_bytes_per_backsolve"], os.path.relpath(f, ROOT)
         return None, None
+
+    def kernel_rooflines(ts, rec):
+        """SURVEY.md section 8(d) "per kernel class": every hot kernel of the path launched back to back on this
+        workload's resident data (dotmi_bench_kernel: HIP events around `reps` launches on the library's stream),
+        its algorithmic bytes (or flop) from the section 8(d) formulas, and the fraction of the 8 TB/s HBM peak."""
+        out = []
+        L = dl.load()
+        if not hasattr(L, "dotmi_bench_kernel"):
+            return out
+        import ctypes as C
+        for kind, name in enumerate(dl.BENCH_KERNELS):
+            ms, nbytes = C.c_double(), C.c_int64()
+            rc = L.dotmi_bench_kernel(ts._h, kind, 20, C.byref(ms), C.byref(nbytes))
+            if rc != 0 or ms.value <= 0:
+                continue
+            gbs = nbytes.value / (ms.value * 1e-3) / 1e9
+            out.append({"kernel": name, "us": round(1e3 * ms.value, 2), "algorithmic_bytes": int(nbytes.value),
+                        "GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+        return out
+
+    def reference_cholmod_leg(sc2, ep2, nparts, orc):
+        """Reference CHOLMODSolver (analyze once, then factorize + solve) on each subdomain's own-element matrix of the
+        bench workload at the oracle's current state, one thread, timed inside oracle/ref_linsys.cpp."""
+        from tests import oracle_py as O
+        if not O.ref_solver_available():
+            return {"error": "oracle/_ref/librefsolver.so or the image's MKL not present"}
+        nT = sc2.T.shape[0]
+        He = np.zeros((nT, 144))
+        x = np.ascontiguousarray(orc.state()[0])
+        O.lib().dor_eval_elem_hessians(orc.h, O._dp(x), O._dp(He))
+        _, _, mass, _, _ = orc.features()
+        tf = tsv = 0.0
+        nnzL = 0
+        for p in range(nparts):
+            el = np.nonzero(ep2 == p)[0]
+            verts = np.unique(sc2.T[el])
+            loc = -np.ones(sc2.V_rest.shape[0], dtype=np.int64)
+            loc[verts] = np.arange(verts.size)
+            f_ms, s_ms, nz = O.ref_linsys_time(loc[sc2.T[el]].astype(np.int32), sc2.fixed[verts], He[el], mass[verts], 3, 10)
+            tf += f_ms; tsv += s_ms; nnzL += nz
+        return {"factorize_ms_all_subdomains": round(tf, 2), "solve_ms_all_subdomains": round(tsv, 2), "cores": 1,
+                "subdomains": int(nparts), "nnz_L": int(nnzL),
+                "what": "src/LinSysSolver/CHOLMODSolver.cpp (reference, compiled in place) on vendored CHOLMOD 3.0.12 + MKL, "
+                        "one thread: numeric factorisation / one solve, summed over the subdomains (own-element matrices, "
+                        "the pattern of H_s); the reference runs them concurrently under TBB"}
 
     def run_workload(name, steps, warmup):
         """-> (record, per-step stats, scene, timestepper is closed)"""
@@ -136,6 +191,21 @@ def main():
         dense_bytes = int(sum(8 * n * n + 16 * n for n in ns))
         nmax = int(L.dotmi_padded_size(ts._h))
         traffic, traffic_src = pmc_traffic(name) if world == 1 else (None, None)
+        # ---- N > 1: what the step spends in collectives (rank 0's view) ---------------------------------------------
+        collectives = None
+        if world > 1:
+            calls = sum(s.collective_calls for s in stats)
+            tms, tn = sum(s.ms_collective for s in stats), sum(s.collective_timed for s in stats)
+            tb = sum(s.collective_timed_bytes for s in stats)
+            collectives = {
+                "allreduce_calls_per_step": round(calls / steps, 1),
+                "payload_MB_per_step": round(sum(s.collective_bytes for s in stats) / steps / 1e6, 3),
+                "timed": int(tn), "avg_ms_timed": round(tms / max(tn, 1), 5),
+                "avg_payload_bytes_timed": int(tb / max(tn, 1)),
+                # every 8th all-reduce is bracketed with HIP events on the library's stream; scaled to all of them
+                "est_ms_per_step": round(tms / max(tn, 1) * calls / steps, 3),
+                "note": "device time between events around ncclAllReduce on rank 0: includes waiting for the slowest rank",
+            }
         roofline = {
             "bound": "hbm", "kernel": "backsolve_kernel: subdomain back-solve p_s = X_s^T (X_s r_s), nested-dissection "
             "block-sparse inverse factors, one streaming pass",
@@ -167,11 +237,15 @@ def main():
                 "back_solve_kernels": round(avg_ms * float(np.mean(iters)), 3),
             },
             "roofline": roofline,
+            "collectives": collectives,
             "_ns": [int(v) for v in ns],
             "part_sizes": {"live_min": int(min(ns)), "live_mean": round(float(np.mean(ns)), 1), "live_max": int(max(ns)),
                            "padded": nmax},
         }
         target = ts.targetGRes
+        rec["roofline_by_kernel"] = kernel_rooflines(ts, rec) if rank == 0 or world == 1 else None
+        if rec["collectives"] is None:
+            del rec["collectives"]
         ts.close()
         return rec, stats, sc, nparts, target, elapsed
 
@@ -208,6 +282,17 @@ def main():
     })
     del rec["_ns"]
 
+    # ---- the other configurations BASELINE.json / north_star name, short runs (every rank takes part) --------------
+    extra = []
+    if args.extra_workloads and args.extra_workloads != "none":
+        for name in args.extra_workloads.split(","):
+            if name == args.workload:
+                continue
+            st_, wu_ = EXTRA_STEPS.get(name, (6, 2))
+            r2 = run_workload(name, st_, wu_)[0]
+            r2.pop("_ns", None)
+            extra.append(r2)
+
     out = None
     if rank == 0:
         out = {
@@ -228,16 +313,11 @@ def main():
             "roofline": roofline,
             "roofline_factor": roofline_factor,
         }
-        # ---- the other single-GPU configurations BASELINE.json / north_star name, short runs ------------------
-        if world == 1 and args.extra_workloads and args.extra_workloads != "none":
-            out["workloads"] = [rec]
-            for name in args.extra_workloads.split(","):
-                if name == args.workload:
-                    continue
-                big = name.startswith("synbar")
-                r2 = run_workload(name, 6 if big else 12, 2)[0]
-                r2.pop("_ns", None)
-                out["workloads"].append(r2)
+        if "collectives" in rec:
+            out["collectives"] = rec["collectives"]
+        out["roofline_by_kernel"] = rec.get("roofline_by_kernel")
+        if extra:
+            out["workloads"] = [rec] + extra
         # ---- CPU baseline on this box's host cores: bounded sample of the same workload ---------------
         if not args.no_cpu_baseline and world == 1:
             from tests import oracle_py as O
@@ -264,7 +344,16 @@ def main():
                 "value": round(1e3 * float(np.mean(times)), 2), "unit": "ms", "cores": threads, "kind": "port",
                 "sample": f"steps {nwarm}..{nwarm + len(times) - 1} of {args.workload} (same partition, same tolerance), "
                           f"oracle/dot_oracle.c with OpenMP, iters/step {cits}",
+                # the reference's own code cannot be built on this box (TBB); what BASELINE.md section 2 measured with it
+                "reference_anchor": dict(REFERENCE_ANCHOR.get(args.workload, {}), cores=8, source="BASELINE.md section 2: "
+                                         "the reference's unmodified sources, 8 vCPU Xeon 2.1 GHz, OMP_NUM_THREADS=8, MKL sequential"),
             }
+            # the one piece of the reference that IS compiled here, timed on the same subdomains: CHOLMODSolver
+            # factorize + solve (oracle/_ref/librefsolver.so = src/LinSysSolver/CHOLMODSolver.cpp on the vendored CHOLMOD)
+            try:
+                out["cpu_baseline"]["reference_cholmod"] = reference_cholmod_leg(sc2, ep2, nparts, orc)
+            except Exception as e:   # noqa: BLE001 - the leg is optional (needs oracle/_ref + the image's MKL)
+                out["cpu_baseline"]["reference_cholmod"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

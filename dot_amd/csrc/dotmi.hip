@@ -71,7 +71,65 @@ struct DBuf {
 
 }  // namespace
 
+// ---- tuning / ablation switches -----------------------------------------------------------------------------------
+// Read ONCE per dotmi_create from the environment; every one is optional and the defaults are the product path.  They
+// exist for the A/B measurements logged under profiles/ (tools/ab.sh) and for tests that force a code path; none changes
+// results beyond rounding.  Listed in include/dotmi.h ("Environment") and DESIGN.md section 10.
+struct Tuning {
+    int ndLevels = -1;        // DOTMI_ND_LEVELS      depth of the nested dissection (-1: nd_default_levels)
+    int ndMin = 768;          // DOTMI_ND_MIN         smallest region (scalars) that is still split
+    int tileRows = 0;         // DOTMI_TILE_ROWS      rows per back-solve tile (0: 64, or 32 for few subdomains)
+    bool splitBs = true;      // DOTMI_SPLIT_BS=0     one back-solve launch instead of wide / narrow tiles apart
+    bool mergeTiles = true;   // DOTMI_MERGE_TILES=0  reduce_partial_p + merge instead of merge_tiles_kernel
+    bool fuseLeaves = true;   // DOTMI_FUSE_LEAVES=0  one GEMM chain per leaf instead of equal-size leaves together
+    bool fuseLog = false;     // DOTMI_FUSE_LOG       print the fused-leaf units
+    bool splitRoot = true;    // DOTMI_ND_SPLIT_ROOT=0  the root's triangular products on one branch
+    bool factorGraph = true;  // DOTMI_FACTOR_GRAPH=0 direct rocBLAS calls instead of the captured hipGraph
+    bool ndParallel = true;   // DOTMI_ND_PARALLEL=0  tree nodes of one height one after the other
+    int factorStreams = 1;    // DOTMI_FACTOR_STREAMS subdomain groups factorised on streams of their own
+    int shardElems = -1;      // DOTMI_SHARD_ELEMS    0 / 1: force the replicated / sharded element pass (-1: by size)
+    int shardHess = -1;       // DOTMI_SHARD_HESS     0 / 1: force the replicated / sharded once-per-step phase
+    int timeStride = 8;       // DOTMI_TIME_STRIDE    DOTMI_FLAG_TIME_BACKSOLVE brackets every n-th back-solve
+    int splitMin = 512;       // DOTMI_SPLIT_MIN      smallest block whose recursion products are split 2x2
+    int splitMinTri = 512;    // DOTMI_SPLIT_MIN_TRI  the same for the triangular products of the tree
+    bool deviceLoop = true;   // DOTMI_DEVICE_LOOP=0  host-driven L-BFGS loop (same as DOTMI_FLAG_HOST_LOOP)
+    int patchElems = 0;       // DOTMI_PATCH_ELEMS    elements per patch of the element pass (0: default)
+    static int geti(const char *name, int dflt)
+    {
+        const char *ev = getenv(name);
+        return ev ? atoi(ev) : dflt;
+    }
+    static Tuning from_env()
+    {
+        Tuning t;
+        t.ndLevels = geti("DOTMI_ND_LEVELS", -1);
+        if (t.ndLevels < -1) t.ndLevels = 0;
+        t.ndMin = std::max(128, geti("DOTMI_ND_MIN", 768));
+        if (const char *ev = getenv("DOTMI_TILE_ROWS")) t.tileRows = std::min(64, std::max(8, atoi(ev) / 8 * 8));
+        t.splitBs = geti("DOTMI_SPLIT_BS", 1) != 0;
+        t.mergeTiles = geti("DOTMI_MERGE_TILES", 1) != 0;
+        t.fuseLeaves = geti("DOTMI_FUSE_LEAVES", 1) != 0;
+        t.fuseLog = getenv("DOTMI_FUSE_LOG") != nullptr;
+        t.splitRoot = geti("DOTMI_ND_SPLIT_ROOT", 1) != 0;
+        t.factorGraph = geti("DOTMI_FACTOR_GRAPH", 1) != 0;
+        t.ndParallel = geti("DOTMI_ND_PARALLEL", 1) != 0;
+        t.factorStreams = std::max(1, geti("DOTMI_FACTOR_STREAMS", 1));
+        t.shardElems = geti("DOTMI_SHARD_ELEMS", -1);
+        t.shardHess = geti("DOTMI_SHARD_HESS", -1);
+        t.timeStride = std::max(1, geti("DOTMI_TIME_STRIDE", 8));
+        t.splitMin = std::max(128, geti("DOTMI_SPLIT_MIN", 512));
+        t.splitMinTri = std::max(128, geti("DOTMI_SPLIT_MIN_TRI", 512));
+        t.deviceLoop = geti("DOTMI_DEVICE_LOOP", 1) != 0;
+        t.patchElems = std::max(0, geti("DOTMI_PATCH_ELEMS", 0));
+        return t;
+    }
+};
+
 struct dotmi_handle {
+    Tuning tune;
+#ifdef DOTMI_TEST_HOOKS
+    int testIterDelta = 0;   // fault injection for tests/test_gpu_two_ranks.py (libdotmi_testhooks.so only)
+#endif
     // configuration
     int nV = 0, nT = 0, n = 0, mat = 0, hist = 5, iterCap = 10000;
     double dt = 0, dtSq = 0, grav[3] = {0, 0, 0}, gdtsq[3] = {0, 0, 0}, relTol = 1e-5, alphaMin = 0.1;
@@ -208,6 +266,12 @@ struct dotmi_handle {
     int graphState = 0;  // 0 = not tried, 1 = ready, -1 = capture unavailable -> direct launches
     std::vector<hipEvent_t> evPre;  // DOTMI_FLAG_TIME_BACKSOLVE: (start, stop) pairs around each back-solve
     int evUsed = 0;
+    // the same flag samples the collectives of the sharded path (every timeStride-th one): (start, stop) pairs + payloads
+    std::vector<hipEvent_t> evAr;
+    std::vector<size_t> arTimedBytes;
+    int evArUsed = 0;
+    long long arCount = 0, arCallsStep = 0;
+    double arBytesStep = 0;
     int64_t precond_bytes = 0;
     int splitMin = 512, splitMinTri = 512;  // smallest block whose triangular products are split 2x2
     double flopCount = 0, factorFlops = 0;  // running counter of the recursion; FP64 flop of one factorisation
@@ -452,9 +516,8 @@ int build_device_mesh(dotmi_handle *h)
     DevParts &P = h->P;
     P.nParts = h->p1 - h->p0;
     // ---- nested-dissection layout of the owned subdomains ---------------------------------------
-    int ndLevels = -1, ndMin = 768;
-    if (const char *ev = getenv("DOTMI_ND_LEVELS")) ndLevels = std::max(0, atoi(ev));
-    if (const char *ev = getenv("DOTMI_ND_MIN")) ndMin = std::max(128, atoi(ev));
+    int ndLevels = h->tune.ndLevels;
+    const int ndMin = h->tune.ndMin;
     std::vector<std::vector<std::vector<int>>> region;  // [node][owned part] -> vertices of the leaf / separator
     {
         std::vector<std::vector<int>> sets(P.nParts);
@@ -481,7 +544,7 @@ int build_device_mesh(dotmi_handle *h)
     // rows per back-solve tile: 64, or 32 when 64-row tiles would not give every CU two workgroups (few subdomains:
     // the launch is then bound by the pass chain of a workgroup, which halves)
     int tileRows = ((long long)P.nParts * P.nmax / 64 < 2 * 256) ? 32 : 64;
-    if (const char *ev = getenv("DOTMI_TILE_ROWS")) tileRows = std::min(64, std::max(8, atoi(ev) / 8 * 8));
+    if (h->tune.tileRows > 0) tileRows = h->tune.tileRows;
     std::vector<int4> tiles;
     std::vector<std::vector<int2>> ranges(P.nParts);
     h->precond_bytes = 0;
@@ -582,8 +645,7 @@ int build_device_mesh(dotmi_handle *h)
     std::stable_partition(tiles.begin(), tiles.end(), [](const int4 &t) { return t.y + (t.z >> 16) - t.w > 2560; });
     P.ntilesWide = 0;
     for (const int4 &t : tiles) P.ntilesWide += (t.y + (t.z >> 16) - t.w > 2560);
-    if (const char *ev = getenv("DOTMI_SPLIT_BS"))
-        if (atoi(ev) == 0) P.ntilesWide = (P.maxTileLen > 2560) ? (int)tiles.size() : 0;   // one launch, as before
+    if (!h->tune.splitBs) P.ntilesWide = (P.maxTileLen > 2560) ? (int)tiles.size() : 0;   // one launch, as before
     P.ntiles = (int)tiles.size();
     P.nltiles = (int)ltiles.size();
     P.nlwork = (int)lwork.size();
@@ -644,9 +706,8 @@ int build_device_mesh(dotmi_handle *h)
         // reduce_partial_p + merge.
         P.mt_ptr = nullptr;
         P.mt_ent = nullptr;
-        const char *ev = getenv("DOTMI_MERGE_TILES");
         const long long ppartN = (long long)P.nParts * P.nbmax * P.nmax;
-        if (!(ev && atoi(ev) == 0) && ppartN < (1ll << 31) && !h->gsdd) {
+        if (h->tune.mergeTiles && ppartN < (1ll << 31) && !(h->flags & DOTMI_FLAG_GSDD)) {
             std::vector<int> mp((size_t)3 * nV + 1, 0), ment;
             for (int v = 0; v < nV; ++v)
                 for (int d = 0; d < 3; ++d) {
@@ -708,8 +769,7 @@ int build_device_mesh(dotmi_handle *h)
         // every subdomain): the first of a size class leads, the others become displacements of its operands.  (Internal
         // nodes would additionally need identical tails all the way down; no mesh so far produced two such nodes.)
         {
-            const char *fv = getenv("DOTMI_FUSE_LEAVES");
-            if (!(fv && atoi(fv) == 0)) {
+            if (h->tune.fuseLeaves) {
                 std::vector<dotmi_handle::FactorUnit> fused;
                 for (const auto &U : h->phases[0]) {
                     const NdNode &N = h->nd[U.node];
@@ -728,15 +788,14 @@ int build_device_mesh(dotmi_handle *h)
                         }
                     if (!merged) fused.push_back(U);
                 }
-                if (getenv("DOTMI_FUSE_LOG"))
+                if (h->tune.fuseLog)
                     fprintf(stderr, "dotmi: %zu leaves of the dissection in %zu units\n", h->phases[0].size(), fused.size());
                 h->phases[0] = fused;
             }
         }
         // the root is alone in the last phase: its two triangular products split into their child-A and child-C
         // halves (disjoint rows of the same scratch), which run on two branches
-        const char *sr = getenv("DOTMI_ND_SPLIT_ROOT");
-        if (hmax > 0 && !(sr && atoi(sr) == 0) && h->phases.back().size() == 1 && h->nd[0].sizeS > 0) {
+        if (hmax > 0 && h->tune.splitRoot && h->phases.back().size() == 1 && h->nd[0].sizeS > 0) {
             const dotmi_handle::FactorUnit R = h->phases.back()[0];
             h->phases.pop_back();
             for (int st = 0; st < 3; ++st) {
@@ -1136,8 +1195,7 @@ int run_factor(dotmi_handle *h)
 {
     if (h->graphState == 0) {
         h->graphState = -1;
-        const char *ev = getenv("DOTMI_FACTOR_GRAPH");
-        if (!(ev && atoi(ev) == 0)) {
+        if (h->tune.factorGraph) {
             // warm rocBLAS (kernel selection, lazy loads) outside of capture, then capture the same sequence
             h->flopCount = 0;
             if (int rc = issue_factor(h)) return rc;
@@ -1244,8 +1302,17 @@ int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
 // sum over the ranks of n doubles at `dev`, in place, ordered on the handle's stream: RCCL, or the host hook
 int allreduce_sum(dotmi_handle *h, double *dev, size_t n)
 {
+    h->arCallsStep++;
+    h->arBytesStep += 8.0 * (double)n;
     if (h->comm) {
+        const bool timed = !h->evAr.empty() && h->evArUsed + 2 <= (int)h->evAr.size() && (h->arCount++ % h->timeStride) == 0;
+        if (timed) HIPCHECK(h, hipEventRecord(h->evAr[h->evArUsed], h->st));
         NCCLCHECK(h, ncclAllReduce(dev, dev, n, ncclDouble, ncclSum, h->comm, h->st));
+        if (timed) {
+            HIPCHECK(h, hipEventRecord(h->evAr[h->evArUsed + 1], h->st));
+            h->arTimedBytes.push_back(8 * n);
+            h->evArUsed += 2;
+        }
         return 0;
     }
     if (!h->arCb) return 0;   // single rank without a communicator (cannot happen on the sharded path)
@@ -1542,26 +1609,34 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
             HIPCHECK(h, hipMemcpyAsync(h->h_ctl, h->ctl, sizeof(DevLoop), hipMemcpyDeviceToHost, h->st));
             HIPCHECK(h, hipStreamSynchronize(h->st));
             HIPCHECK(h, hipGetLastError());
-            // every rank contributes its (status, slots, iterations, halvings); the sums equal world x own values exactly
-            // when all ranks agree (small integers in FP64), and every rank sees a disagreement from the same collective,
-            // so they fail together instead of one of them waiting in the next all-reduce
-            double mine[4] = {(double)C.status, (double)C.slots, (double)C.iter, (double)C.halvings}, sum[4];
-            if (const char *tv = getenv("DOTMI_TEST_DISAGREE"))   // test hook: this rank reports a different iteration count
-                if (atoi(tv) == h->rank) mine[2] += 1.0;
-            memcpy(sum, mine, sizeof(mine));
+            // Every rank contributes v = (status, slots, iterations, halvings), its squares and a local error flag to ONE
+            // sum all-reduce.  All ranks see the same sums, so the verdict is a function of reduced data only and they
+            // fail together instead of one of them waiting in the next collective: the ranks agree exactly when the
+            // variance vanishes, world * sum(v^2) == (sum v)^2 (small integers, exact in FP64) -- the earlier test
+            // `sum == world * mine` could pass on one rank and fail on the others for world >= 3.
+            double mine[4] = {(double)C.status, (double)C.slots, (double)C.iter, (double)C.halvings}, red[9];
+#ifdef DOTMI_TEST_HOOKS
+            mine[2] += (double)h->testIterDelta;   // this process reports a different iteration count
+#endif
+            for (int i = 0; i < 4; ++i) {
+                red[i] = mine[i];
+                red[4 + i] = mine[i] * mine[i];
+            }
+            red[8] = 0.0;   // local error flag (set by a rank that cannot go on; summed like the rest)
             if (h->world > 1) {
-                HIPCHECK(h, hipMemcpyAsync(h->ctrlDev, sum, sizeof(sum), hipMemcpyHostToDevice, h->st));
-                if (int rc = allreduce_sum(h, h->ctrlDev, 4)) return rc;
-                HIPCHECK(h, hipMemcpyAsync(sum, h->ctrlDev, sizeof(sum), hipMemcpyDeviceToHost, h->st));
+                HIPCHECK(h, hipMemcpyAsync(h->ctrlDev, red, sizeof(red), hipMemcpyHostToDevice, h->st));
+                if (int rc = allreduce_sum(h, h->ctrlDev, 9)) return rc;
+                HIPCHECK(h, hipMemcpyAsync(red, h->ctrlDev, sizeof(red), hipMemcpyDeviceToHost, h->st));
                 HIPCHECK(h, hipStreamSynchronize(h->st));
             }
-            bool agree = true;
-            for (int i = 0; i < 4; ++i) agree = agree && sum[i] == (h->world > 1 ? h->world : 1) * mine[i];
+            const double w = h->world > 1 ? (double)h->world : 1.0;
+            bool agree = red[8] == 0.0;
+            for (int i = 0; i < 4; ++i) agree = agree && w * red[4 + i] == red[i] * red[i];
             if (!agree) {
                 h->err = "the ranks left the L-BFGS loop in different states (this rank: status " + std::to_string(C.status) +
                          " after " + std::to_string(C.slots) + " slots, " + std::to_string(C.iter) + " iterations; sum over " +
-                         std::to_string(h->world) + " ranks: " + std::to_string((long long)sum[0]) + " / " +
-                         std::to_string((long long)sum[1]) + " / " + std::to_string((long long)sum[2]) + ")";
+                         std::to_string(h->world) + " ranks: " + std::to_string((long long)red[0]) + " / " +
+                         std::to_string((long long)red[1]) + " / " + std::to_string((long long)red[2]) + ")";
                 h->poisoned = true;
                 return DOTMI_E_DEVICE;
             }
@@ -1871,6 +1946,7 @@ void dotmi_destroy(dotmi_handle *h)
     for (hipEvent_t e : h->evP)
         if (e) hipEventDestroy(e);
     for (hipEvent_t e : h->evPre) hipEventDestroy(e);
+    for (hipEvent_t e : h->evAr) hipEventDestroy(e);
     if (h->factorGraph) hipGraphExecDestroy(h->factorGraph);
     for (auto &G : h->groups) {
         if (G.blas && G.blas != h->blas) rocblas_destroy_handle(G.blas);
@@ -1935,6 +2011,10 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     h->rank = prm->rank;
     h->world = prm->world;
     h->flags = prm->flags;
+    h->tune = Tuning::from_env();
+#ifdef DOTMI_TEST_HOOKS
+    h->testIterDelta = Tuning::geti("DOTMI_TEST_ITER_DELTA", 0);
+#endif
     h->density = mesh->density;
     h->nPartsAll = mesh->nParts;
     h->T.assign(mesh->T, mesh->T + 4 * (size_t)h->nT);
@@ -1973,10 +2053,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     RBCHECK(h, rocblas_create_handle(&h->blas));
     RBCHECK(h, rocblas_set_stream(h->blas, h->st));
     h->dist = h->world > 1 || (h->flags & DOTMI_FLAG_FORCE_DIST);
-    {
-        const char *ev = getenv("DOTMI_SHARD_ELEMS");  // override for testing: 0 / 1
-        h->shardElems = h->dist && (ev ? atoi(ev) != 0 : h->nT >= 400000);
-    }
+    h->shardElems = h->dist && (h->tune.shardElems >= 0 ? h->tune.shardElems != 0 : h->nT >= 400000);
     h->arCb = prm->allreduce;
     h->arCtx = prm->allreduce_ctx;
     if (h->dist && !h->arCb) {
@@ -1992,20 +2069,22 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         h->ctrlDev = (double *)cd;
     }
 
-    if (const char *ev = getenv("DOTMI_TIME_STRIDE")) h->timeStride = std::max(1, atoi(ev));
+    h->timeStride = h->tune.timeStride;
     if (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) {
         h->evPre.resize(2 * 512);
         for (auto &e : h->evPre) HIPCHECK(h, hipEventCreate(&e));
+        if (h->dist) {
+            h->evAr.resize(2 * 512);
+            for (auto &e : h->evAr) HIPCHECK(h, hipEventCreate(&e));
+        }
     }
     host_features(h);
     h->targetGRes = host_target_gres(h);
-    if (const char *ev = getenv("DOTMI_SPLIT_MIN")) h->splitMin = std::max(128, atoi(ev));
-    if (const char *ev = getenv("DOTMI_SPLIT_MIN_TRI")) h->splitMinTri = std::max(128, atoi(ev));
+    h->splitMin = h->tune.splitMin;
+    h->splitMinTri = h->tune.splitMinTri;
     if (int rc = build_device_mesh(h)) return rc;
     {
-        const char *ev = getenv("DOTMI_FACTOR_STREAMS");
-        int ng = ev ? atoi(ev) : 1;
-        ng = std::max(1, std::min(ng, std::max(1, h->P.nParts)));
+        const int ng = std::max(1, std::min(h->tune.factorStreams, std::max(1, h->P.nParts)));
         HIPCHECK(h, hipEventCreateWithFlags(&h->evFill, hipEventDisableTiming));
         h->groups.resize(ng);
         for (int g = 0; g < ng; ++g) {
@@ -2025,10 +2104,9 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     }
 
     {
-        const char *ev = getenv("DOTMI_ND_PARALLEL");
         size_t width = 1;
         for (auto &ph : h->phases) width = std::max(width, ph.size());
-        if (!(ev && atoi(ev) == 0) && h->groups.size() == 1 && h->P.nParts > 0 && width > 1) {
+        if (h->tune.ndParallel && h->groups.size() == 1 && h->P.nParts > 0 && width > 1) {
             h->branches.resize(width - 1);
             for (auto &B : h->branches) {
                 HIPCHECK(h, hipStreamCreateWithFlags(&B.st, hipStreamNonBlocking));
@@ -2071,7 +2149,6 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     HIPCHECK(h, hipHostMalloc((void **)&h->h_partR, sizeof(double) * NB_RED * RED_K));
     HIPCHECK(h, hipHostMalloc((void **)&h->h_alpha, sizeof(double) * 8));
     {
-        const char *ev = getenv("DOTMI_DEVICE_LOOP");
         h->gsdd = (h->flags & DOTMI_FLAG_GSDD) != 0;
         h->newton = (h->flags & DOTMI_FLAG_NEWTON) != 0;
         if (h->newton && (h->dist || h->gsdd)) {
@@ -2083,7 +2160,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
             return DOTMI_E_INVALID;
         }
         h->devLoop = !h->gsdd && !h->newton && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) &&
-                     !(ev && atoi(ev) == 0);
+                     h->tune.deviceLoop;
         h->logCap = std::min(h->iterCap, 10001) + 1;
         h->kindCap = 4096;
         HIPCHECK(h, hipHostMalloc((void **)&h->h_ctl, sizeof(DevLoop)));
@@ -2236,6 +2313,10 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     h->m = 0;
     h->energy_evals = 0;
     h->evUsed = 0;
+    h->evArUsed = 0;
+    h->arTimedBytes.clear();
+    h->arCallsStep = 0;
+    h->arBytesStep = 0;
     h->log_alpha.clear();
     h->log_E.clear();
     h->log_g2.clear();
@@ -2407,6 +2488,15 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         }
         st->precond_bytes = h->precond_bytes;
         st->factor_flops = h->factorFlops;
+        for (int k = 0; k + 1 < h->evArUsed; k += 2) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, h->evAr[k], h->evAr[k + 1]);
+            st->ms_collective += ms;
+            st->collective_timed++;
+            st->collective_timed_bytes += (int64_t)h->arTimedBytes[k / 2];
+        }
+        st->collective_calls = h->arCallsStep;
+        st->collective_bytes = (int64_t)h->arBytesStep;
         for (int k = 0; k < DOTMI_T_COUNT; ++k) st->ms_phase[k] = h->phaseMs[k];
     }
     // a non-SPD subdomain: the step itself is complete (x, v advanced as the reference would have before it

@@ -60,6 +60,7 @@ struct Bisector {
     const std::vector<std::array<double, 3>> &cent;
     std::vector<int> side;   // per tet: -1 = not in the current subset, 0 / 1 = side of the running bisection
     std::vector<int32_t> &epart;
+    std::vector<char> locked = {};   // per tet: moved in the running refinement pass (all zero between passes)
 
     // gain of moving e to the other side: cut faces removed - cut faces added (neighbours inside the subset only)
     int gain(int e) const
@@ -88,7 +89,7 @@ struct Bisector {
         const int tol = std::max(2, n / 64);   // sizes within ~1.5 % of the target
         int left = 0;
         for (int e : ids) left += side[e] == 0;
-        std::vector<char> locked(G.nb.size(), 0);
+        if (locked.size() != G.nb.size()) locked.assign(G.nb.size(), 0);   // once per Bisector; every pass leaves it all zero
         for (int pass = 0; pass < 12; ++pass) {
             // buckets of boundary elements by gain (-4..4), FIFO inside a bucket, lazily validated
             std::vector<std::vector<int>> bucket(9);

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdotmi.so")
+# DOTMI_LIBRARY: another build of the same ABI (tests load libdotmi_testhooks.so, the build with the fault-injection hook)
+LIB_PATH = os.environ.get("DOTMI_LIBRARY") or os.path.join(_HERE, "libdotmi.so")
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)
@@ -49,7 +50,9 @@ class StepStats(C.Structure):
                 ("g2", C.c_double), ("ms_total", C.c_double), ("ms_loop", C.c_double),
                 ("ms_hessian", C.c_double), ("ms_factor", C.c_double), ("ms_precond", C.c_double),
                 ("precond_launches", C.c_int64), ("precond_bytes", C.c_int64),
-                ("factor_flops", C.c_double), ("ms_phase", C.c_double * 14)]
+                ("factor_flops", C.c_double), ("ms_phase", C.c_double * 14),
+                ("collective_calls", C.c_int64), ("collective_bytes", C.c_int64), ("ms_collective", C.c_double),
+                ("collective_timed", C.c_int64), ("collective_timed_bytes", C.c_int64)]
 
 
 EXPORTS = [

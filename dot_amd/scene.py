@@ -507,6 +507,31 @@ def synthetic_bar(nx: int, ny: int, nz: int, lx: float = 4.0, ly: float = 1.0, l
     return V, T
 
 
+def refine_red(V: np.ndarray, T: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Regular (red) refinement: every tet -> 8 (four corner tets + the inner octahedron cut along the m02-m13
+    diagonal, Bey's rule), one new vertex per edge.  Deterministic; used for the scale stand-in of the meshes the
+    reference checkout lacks (horse136K, .MISSING_LARGE_BLOBS:11)."""
+    nV = V.shape[0]
+    pairs = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    E = np.concatenate([np.sort(T[:, list(pq)], axis=1) for pq in pairs], axis=0).astype(np.int64)
+    key = E[:, 0] * nV + E[:, 1]
+    uniq, inv = np.unique(key, return_inverse=True)
+    mid = 0.5 * (V[uniq // nV] + V[uniq % nV])
+    V2 = np.concatenate([V, mid], axis=0)
+    nT = T.shape[0]
+    m = {pq: (nV + inv[k * nT:(k + 1) * nT]).astype(np.int32) for k, pq in enumerate(pairs)}
+    v = [T[:, k].astype(np.int32) for k in range(4)]
+    m01, m02, m03, m12, m13, m23 = (m[pq] for pq in pairs)
+    kids = [(v[0], m01, m02, m03), (m01, v[1], m12, m13), (m02, m12, v[2], m23), (m03, m13, m23, v[3]),
+            (m01, m02, m03, m13), (m01, m02, m12, m13), (m02, m03, m13, m23), (m02, m12, m13, m23)]
+    T2 = np.stack([np.stack(k, axis=1) for k in kids], axis=1).reshape(-1, 4).astype(np.int32)   # children of a tet adjacent
+    d = V2[T2[:, 1:]] - V2[T2[:, :1]]
+    det = np.einsum("ij,ij->i", d[:, 0], np.cross(d[:, 1], d[:, 2]))
+    neg = det < 0
+    T2[neg, 2], T2[neg, 3] = T2[neg, 3].copy(), T2[neg, 2].copy()
+    return V2, T2
+
+
 def partition_dual(V: np.ndarray, T: np.ndarray, nparts: int) -> np.ndarray:
     """The library's built-in partitioner (dotmi_partition, host only: recursive bisection of the tets' face-adjacency
     graph with Fiduccia-Mattheyses refinement) -- what stands in for METIS::partMesh on meshes without a fixture."""

@@ -59,9 +59,21 @@ class DOTTimeStepper:
         p.comm_id = C.cast(self._comm, C.c_void_p) if self._comm is not None else None
         p.flags = flags
         self._arcb = None
+        self._ar_error = None
         if allreduce is not None:
             def _cb(ctx, buf, n, _f=allreduce):
-                _f(np.ctypeslib.as_array(buf, shape=(n,)))
+                # an exception cannot cross the C frame: ctypes would print and swallow it and the library would carry
+                # on with this rank's un-reduced partial sums.  Record it, poison the payload (NaN spreads through
+                # every later sum, so the step fails its convergence test on this rank) and re-raise from _check.
+                a = np.ctypeslib.as_array(buf, shape=(n,))
+                try:
+                    if self._ar_error is None:
+                        _f(a)
+                    else:
+                        a[:] = np.nan
+                except BaseException as e:   # noqa: BLE001 - must not propagate into the C caller
+                    self._ar_error = e
+                    a[:] = np.nan
             self._arcb = _lib.ALLREDUCE_CB(_cb)          # kept alive with the handle
             p.allreduce = C.cast(self._arcb, C.c_void_p)
         x0 = np.ascontiguousarray(scene.x0, dtype=np.float64)
@@ -86,6 +98,9 @@ class DOTTimeStepper:
             pass
 
     def _check(self, rc, what):
+        if getattr(self, "_ar_error", None) is not None:
+            e, self._ar_error = self._ar_error, None
+            raise DotmiError(f"{what}: the all-reduce hook raised {type(e).__name__}: {e}") from e
         if rc < 0:
             raise DotmiError(f"{what} failed ({rc}): {self._L.dotmi_last_error(self._h).decode()}")
         return rc

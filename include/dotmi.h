@@ -87,8 +87,9 @@ typedef struct {
                                        stream time); totals land in dotmi_step_stats */
 #define DOTMI_FLAG_HOST_LOOP 8      /* drive the L-BFGS loop from the host (one stream synchronisation per
                                      * line-search trial) instead of the device-resident loop control; the
-                                     * two produce identical iterates -- kept for A/B tests and always used
-                                     * on the sharded multi-GPU path */
+                                     * two produce identical iterates -- kept for A/B tests.  (The sharded
+                                     * multi-GPU path runs the device-resident loop too, with deterministic
+                                     * slot batches; this flag selects the host loop there as well.) */
 
 #define DOTMI_FLAG_TIME_PHASES 16    /* drive the loop from the host and bracket every phase of an iteration with HIP
                                      * events on the handle's stream; the device times land in
@@ -150,6 +151,14 @@ typedef struct {
                              filled: MATRIX_COMPUTATION, MATRIX_ASSEMBLY, NUMERICAL_FACTORIZATION (HIP events of the
                              refresh at the end of the step).  The loop slots (BACKSOLVE ... FULLYIMPLICIT_ECOMP,
                              SOLVE_EXTRACOMP) only with DOTMI_FLAG_TIME_PHASES. */
+    /* sharded (N > 1) path: the all-reduces this rank issued during the step, end-of-step refresh included */
+    int64_t collective_calls;       /* number of all-reduces */
+    int64_t collective_bytes;       /* their summed payload (8 x doubles) */
+    double ms_collective;           /* DOTMI_FLAG_TIME_BACKSOLVE + RCCL: summed device time between HIP events put
+                                       around every 8th ncclAllReduce on the handle's stream (queueing behind the
+                                       slower rank included) */
+    int64_t collective_timed;       /* how many were bracketed */
+    int64_t collective_timed_bytes; /* and their payload */
 } dotmi_step_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

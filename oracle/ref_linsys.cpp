@@ -11,19 +11,16 @@
 #include "CHOLMODSolver.hpp"
 #include "IglUtils.hpp"
 
+#include <chrono>
 #include <cstring>
 #include <set>
 #include <vector>
 
 using Solver = DOT::CHOLMODSolver<Eigen::VectorXi, Eigen::VectorXd>;
 
-extern "C" {
-
-// T: nT*4, fixed: nV, He: nT*144 row-major element Hessians (already projected, dt^2 vol included), mass: nV
-// rhs, x: n = 3 nV.  Outputs: sol = A^-1 rhs, Ax = A x, and (if dense != NULL) the n*n matrix the solver holds.
-// returns 0, or 1 when the factorisation failed
-int ref_linsys_run(int nV, int nT, const int *T, const unsigned char *fixed, const double *He, const double *mass,
-                   const double *rhs, const double *x, double *sol, double *Ax, double *dense)
+namespace {
+// pattern + coefficients of a (sub-)mesh into the reference's solver object
+void assemble(Solver &solver, int nV, int nT, const int *T, const unsigned char *fixed, const double *He, const double *mass)
 {
     // Mesh::computeFeatures builds vNeighbor / vFLoc like this (Mesh.cpp:600-614)
     std::vector<std::set<int>> vNeighbor(nV);
@@ -37,12 +34,9 @@ int ref_linsys_run(int nV, int nT, const int *T, const unsigned char *fixed, con
     std::set<int> fixedVert;
     for (int v = 0; v < nV; ++v)
         if (fixed[v]) fixedVert.insert(v);
-
-    Solver solver;
     solver.set_type(1, 2);
     solver.set_pattern(vNeighbor, fixedVert);
     solver.analyze_pattern();
-
     // DOTTimeStepper::computeHElemAndFillIn, DOTTimeStepper.cpp:588-613 (vInds: Energy.cpp:771-775)
     solver.setZero();
     for (int vI = 0; vI < nV; ++vI) {
@@ -62,6 +56,44 @@ int ref_linsys_run(int nV, int nT, const int *T, const unsigned char *fixed, con
             solver.addCoeff(ind0 + 2, ind0 + 2, mass[vI]);
         }
     }
+}
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+extern "C" {
+
+// Timing leg of bench.py's cpu_baseline: the reference's CHOLMODSolver on one (sub-)mesh matrix -- analyze_pattern once
+// (as the reference does at set-up), then `nfact` numeric factorisations and `nsolve` solves; out = {ms per
+// factorisation, ms per solve, non-zeros of L}.  returns 1 when a factorisation failed
+int ref_linsys_time(int nV, int nT, const int *T, const unsigned char *fixed, const double *He, const double *mass,
+                    int nfact, int nsolve, double *out)
+{
+    Solver solver;
+    assemble(solver, nV, nT, T, fixed, He, mass);
+    const int n = 3 * nV;
+    double t0 = now_ms();
+    for (int k = 0; k < nfact; ++k)
+        if (solver.factorize()) return 1;
+    out[0] = (now_ms() - t0) / (nfact > 0 ? nfact : 1);
+    Eigen::VectorXd b = Eigen::VectorXd::Ones(n), r;
+    t0 = now_ms();
+    for (int k = 0; k < nsolve; ++k) solver.solve(b, r);
+    out[1] = (now_ms() - t0) / (nsolve > 0 ? nsolve : 1);
+    out[2] = 0.0;
+    return 0;
+}
+
+// T: nT*4, fixed: nV, He: nT*144 row-major element Hessians (already projected, dt^2 vol included), mass: nV
+// rhs, x: n = 3 nV.  Outputs: sol = A^-1 rhs, Ax = A x, and (if dense != NULL) the n*n matrix the solver holds.
+// returns 0, or 1 when the factorisation failed
+int ref_linsys_run(int nV, int nT, const int *T, const unsigned char *fixed, const double *He, const double *mass,
+                   const double *rhs, const double *x, double *sol, double *Ax, double *dense)
+{
+    Solver solver;
+    assemble(solver, nV, nT, T, fixed, He, mass);
     const int n = 3 * nV;
     if (dense) {
         Eigen::SparseMatrix<double> M;

@@ -320,9 +320,7 @@ def ref_solver_available():
         "/opt/conda/lib/libmkl_rt.so.1")
 
 
-def ref_linsys(T, fixed, He, mass, rhs, v, want_dense=False):
-    """The reference's LinSysSolver + CHOLMODSolver (oracle/ref_linsys.cpp): assemble the global matrix from the
-    element Hessians as DOTTimeStepper::computeHElemAndFillIn does, factorize, solve(rhs), multiply(v)."""
+def _load_refsolver():
     global _refsolver
     if _refsolver is None:
         os.environ.setdefault("MKL_THREADING_LAYER", "SEQUENTIAL")
@@ -331,6 +329,28 @@ def ref_linsys(T, fixed, He, mass, rhs, v, want_dense=False):
         _refsolver = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "librefsolver.so"))
         _refsolver.ref_linsys_run.argtypes = [C.c_int, C.c_int, c_ip, c_up, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
         _refsolver.ref_linsys_run.restype = C.c_int
+        _refsolver.ref_linsys_time.argtypes = [C.c_int, C.c_int, c_ip, c_up, c_dp, c_dp, C.c_int, C.c_int, c_dp]
+        _refsolver.ref_linsys_time.restype = C.c_int
+    return _refsolver
+
+
+def ref_linsys_time(T, fixed, He, mass, nfact=3, nsolve=10):
+    """(ms per numeric factorisation, ms per solve, 0) of the reference's CHOLMODSolver on the matrix of this (sub-)mesh"""
+    R = _load_refsolver()
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
+    He = np.ascontiguousarray(He, dtype=np.float64)
+    mass = np.ascontiguousarray(mass, dtype=np.float64)
+    out = np.zeros(3)
+    if R.ref_linsys_time(mass.size, T.shape[0], _ip(T), fixed.ctypes.data_as(c_up), _dp(He), _dp(mass), nfact, nsolve, _dp(out)):
+        raise RuntimeError("reference CHOLMODSolver::factorize failed")
+    return float(out[0]), float(out[1]), int(out[2])
+
+
+def ref_linsys(T, fixed, He, mass, rhs, v, want_dense=False):
+    """The reference's LinSysSolver + CHOLMODSolver (oracle/ref_linsys.cpp): assemble the global matrix from the
+    element Hessians as DOTTimeStepper::computeHElemAndFillIn does, factorize, solve(rhs), multiply(v)."""
+    _refsolver = _load_refsolver()
     T = np.ascontiguousarray(T, dtype=np.int32)
     fixed = np.ascontiguousarray(fixed, dtype=np.uint8)
     He = np.ascontiguousarray(He, dtype=np.float64)

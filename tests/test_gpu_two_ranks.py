@@ -102,7 +102,11 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_gpu_run(workload, steps, shar
 def _worker_disagree(rank, world, initfile, outdir):
     sys.path.insert(0, ROOT)
     os.environ["DOTMI_SHARD_ELEMS"] = "0"
-    os.environ["DOTMI_TEST_DISAGREE"] = "1"       # rank 1 reports one iteration more than it made
+    # the build with the fault-injection hook (the product library has none): this process reports its iteration count
+    # shifted by delta.  world 2: (0, +1).  world 3: (0, -1, +1) -- the sum over the ranks is then world x rank 0's
+    # value, the pattern the first version of the check let rank 0 pass
+    os.environ["DOTMI_LIBRARY"] = os.path.join(ROOT, "dot_amd", "libdotmi_testhooks.so")
+    os.environ["DOTMI_TEST_ITER_DELTA"] = str({2: (0, 1), 3: (0, -1, 1)}[world][rank])
     os.environ["OMP_NUM_THREADS"] = "2"
     import torch
     import torch.distributed as dist
@@ -125,14 +129,16 @@ def _worker_disagree(rank, world, initfile, outdir):
     dist.destroy_process_group()
 
 
-def test_ranks_that_disagree_fail_together_instead_of_hanging():
-    """The sharded loop ends every batch of slots with a sum of the ranks' loop states; a rank whose state differs (here:
-    forced through DOTMI_TEST_DISAGREE) makes EVERY rank return DOTMI_E_DEVICE from the same collective -- nobody is left
-    waiting in the next all-reduce."""
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_that_disagree_fail_together_instead_of_hanging(world):
+    """The sharded loop ends every batch of slots with an all-reduce of the ranks' loop states, their squares and an error
+    flag; ranks whose states differ (forced through the hook of libdotmi_testhooks.so) make EVERY rank return
+    DOTMI_E_DEVICE from the same collective -- nobody is left waiting in the next all-reduce.  world 3 reports
+    (k, k-1, k+1) iterations: the sums alone equal 3 x rank 0's values, the variance test still fails everywhere."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     with tempfile.TemporaryDirectory() as d:
-        procs = [ctx.Process(target=_worker_disagree, args=(r, 2, os.path.join(d, "init"), d)) for r in range(2)]
+        procs = [ctx.Process(target=_worker_disagree, args=(r, world, os.path.join(d, "init"), d)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
@@ -142,5 +148,5 @@ def test_ranks_that_disagree_fail_together_instead_of_hanging():
             p.terminate()
         assert not alive, "a rank hung"
         assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-        msgs = [open(os.path.join(d, f"rank{r}.txt")).read() for r in range(2)]
+        msgs = [open(os.path.join(d, f"rank{r}.txt")).read() for r in range(world)]
     assert all("different states" in m for m in msgs), msgs

@@ -2,7 +2,7 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.workloads import load_workload
+from dot_amd.workloads import load_workload
 from dot_amd.timestepper import DOTTimeStepper
 from tests import oracle_py as O
 name = sys.argv[1]; nsteps = int(sys.argv[2])

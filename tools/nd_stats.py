@@ -2,7 +2,7 @@
 import sys
 import numpy as np
 sys.path.insert(0, ".")
-from tests.workloads import load_workload
+from dot_amd.workloads import load_workload
 from dot_amd.sharding import plan_layout
 
 name = sys.argv[1] if len(sys.argv) > 1 else "bar17K_twist"

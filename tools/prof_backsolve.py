@@ -2,7 +2,7 @@
 import ctypes, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.workloads import load_workload
+from dot_amd.workloads import load_workload
 from dot_amd.timestepper import DOTTimeStepper
 from dot_amd import lib as dl
 sc, ep, n = load_workload(sys.argv[1] if len(sys.argv) > 1 else "bar17K_twist")

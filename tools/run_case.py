@@ -3,7 +3,7 @@
 import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
-from tests.workloads import load_workload
+from dot_amd.workloads import load_workload
 from dot_amd.timestepper import DOTTimeStepper
 name = sys.argv[1]; nparts = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "-" else None
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5

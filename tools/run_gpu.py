@@ -3,7 +3,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dot_amd import lib as dl
-from tests.workloads import load_workload
+from dot_amd.workloads import load_workload
 from dot_amd.timestepper import DOTTimeStepper
 name = sys.argv[1]; nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 t0 = time.time(); sc, ep, n = load_workload(name); t1 = time.time()
