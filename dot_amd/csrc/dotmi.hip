@@ -29,6 +29,7 @@
 #include "dotmi_internal.hpp"
 #include "elem_math.hpp"
 #include "partition.hpp"
+#include "patches.hpp"
 
 using namespace dotmi;
 
@@ -166,10 +167,11 @@ struct dotmi_handle {
     DevMesh M{};
     DevParts P{};
     int *elist = nullptr;
+    DevPatches PT, PTall;   // element patches: this rank's own elements / all elements (same unless shardElems)
     int nOwnElem = 0, v0 = 0, v1 = 0;
     double *x = nullptr, *x_trial = nullptr, *xn = nullptr, *v = nullptr, *xt = nullptr;
     double *g = nullptr, *g_trial = nullptr, *p = nullptr, *q = nullptr, *z = nullptr, *Hp = nullptr;
-    double *gcont = nullptr, *He = nullptr, *Hval = nullptr, *tmpn = nullptr;
+    double *He = nullptr, *Hval = nullptr, *tmpn = nullptr;
     double *S[HIST_MAX + 1] = {nullptr}, *Y[HIST_MAX + 1] = {nullptr};
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
     double *gstage = nullptr;   // sharded element pass, device loop: [g (n) ; 0 ; E] staging buffer of the gradient all-reduce
@@ -205,6 +207,7 @@ struct dotmi_handle {
     int timeStride = 8;                        // DOTMI_FLAG_TIME_BACKSOLVE brackets every timeStride-th back-solve
     int timeCount = 0;
     int nbE = 0;
+    long long mergeEntries = 0;   // tile partials the merge sums (for the byte count of dotmi_bench_kernel)
     int M_nbR() const { return NB_RED; }   // rows of the statistics partials
 
     // L-BFGS host state (chronological)
@@ -404,6 +407,51 @@ double host_target_gres(const dotmi_handle *h)
     return cn * h->dtSq * h->dtSq;
 }
 
+// patch lists + the element operands in patch order -> device
+int upload_patches(dotmi_handle *h, const HostPatches &H, DevPatches &D)
+{
+    D.nPatches = H.nPatches;
+    D.PE = H.PE;
+    D.PV = H.PV;
+    D.nSlots = H.nSlots;
+    const size_t ns = (size_t)H.nPatches * H.PE;
+    std::vector<ushort4> tl(ns);
+    std::vector<double> A(9 * ns, 0.0), mu(ns, 1.0), lam(ns, 1.0), vol(ns, 0.0);
+    D.nElem = 0;
+    for (size_t s = 0; s < ns; ++s) {
+        tl[s] = make_ushort4(H.tl[4 * s], H.tl[4 * s + 1], H.tl[4 * s + 2], H.tl[4 * s + 3]);
+        const int e = H.elem[s];
+        if (e < 0) continue;
+        D.nElem++;
+        for (int k = 0; k < 9; ++k) A[(size_t)k * ns + s] = h->A[(size_t)9 * e + k];
+        mu[s] = h->mu[e];
+        lam[s] = h->lam[e];
+        vol[s] = h->vol[e];
+    }
+    if (int rc = upload(h, &D.tl, tl)) return rc;
+    if (int rc = upload(h, &D.A, A)) return rc;
+    if (int rc = upload(h, &D.mu, mu)) return rc;
+    if (int rc = upload(h, &D.lam, lam)) return rc;
+    if (int rc = upload(h, &D.vol, vol)) return rc;
+    if (int rc = upload(h, &D.pv_gid, H.pv_gid)) return rc;
+    if (int rc = upload(h, &D.pv_slot, H.pv_slot)) return rc;
+    if (int rc = upload(h, &D.pv_cnt, H.pv_cnt)) return rc;
+    if (int rc = upload(h, &D.c_ptr, H.c_ptr)) return rc;
+    {
+        std::vector<ushort4> ep(ns);
+        for (size_t s2 = 0; s2 < ns; ++s2) ep[s2] = make_ushort4(H.epos[4 * s2], H.epos[4 * s2 + 1], H.epos[4 * s2 + 2], H.epos[4 * s2 + 3]);
+        if (int rc = upload(h, &D.epos, ep)) return rc;
+    }
+    {
+        std::vector<int2> rng(H.pp_rng.size() / 2);
+        for (size_t v = 0; v < rng.size(); ++v) rng[v] = make_int2(H.pp_rng[2 * v], H.pp_rng[2 * v + 1]);
+        if (int rc = upload(h, &D.pp_rng, rng)) return rc;
+    }
+    if (int rc = dalloc(h, &D.gpart, (size_t)3 * std::max(H.nSlots, 1))) return rc;
+    HIPCHECK(h, hipMemset(D.gpart, 0, sizeof(double) * 3 * (size_t)std::max(H.nSlots, 1)));
+    return 0;
+}
+
 int build_device_mesh(dotmi_handle *h)
 {
     const int nV = h->nV, nT = h->nT;
@@ -426,24 +474,6 @@ int build_device_mesh(dotmi_handle *h)
         if (int rc = upload(h, &M.mass, h->mass)) return rc;
         if (int rc = upload(h, &M.fixed, h->fixed)) return rc;
     }
-    // vFLoc
-    std::vector<int> vf_ptr(nV + 1, 0), vf_ent((size_t)4 * nT);
-    for (int e = 0; e < nT; ++e)
-        for (int k = 0; k < 4; ++k) vf_ptr[h->T[4 * e + k] + 1]++;
-    for (int v = 0; v < nV; ++v) vf_ptr[v + 1] += vf_ptr[v];
-    std::vector<int4> epos(nT);
-    {
-        std::vector<int> cur(vf_ptr.begin(), vf_ptr.end() - 1);
-        for (int e = 0; e < nT; ++e) {
-            int pk[4];
-            for (int k = 0; k < 4; ++k) {
-                pk[k] = cur[h->T[4 * e + k]]++;
-                vf_ent[pk[k]] = 4 * e + k;
-            }
-            epos[e] = make_int4(pk[0], pk[1], pk[2], pk[3]);
-        }
-    }
-    if (int rc = upload(h, &M.epos, epos)) return rc;
     // adjacency incl. self
     std::vector<int> adj_ptr, adj_idx;
     build_adjacency(nV, nT, h->T.data(), adj_ptr, adj_idx);
@@ -470,8 +500,6 @@ int build_device_mesh(dotmi_handle *h)
         for (int e = 0; e < nT; ++e)
             for (int ab = 0; ab < 16; ++ab) blk_ent[cur[eblk[(size_t)16 * e + ab]]++] = 16 * e + ab;
     }
-    if (int rc = upload(h, &M.vf_ptr, vf_ptr)) return rc;
-    if (int rc = upload(h, &M.vf_ent, vf_ent)) return rc;
     if (int rc = upload(h, &M.adj_ptr, adj_ptr)) return rc;
     if (int rc = upload(h, &M.adj_idx, adj_idx)) return rc;
     if (int rc = upload(h, &M.blk_ptr, blk_ptr)) return rc;
@@ -725,6 +753,7 @@ int build_device_mesh(dotmi_handle *h)
                 }
             if (int rc = upload(h, &P.mt_ptr, mp)) return rc;
             if (int rc = upload(h, &P.mt_ent, ment)) return rc;
+            h->mergeEntries = (long long)ment.size();
         }
     }
     if (int rc = upload(h, &P.dup, h->dup)) return rc;
@@ -845,6 +874,22 @@ int build_device_mesh(dotmi_handle *h)
         h->nOwnElem = nT;
         h->v0 = 0;
         h->v1 = nV;
+    }
+    // element patches (patches.hpp): PTall covers every element (the kernel-level entry points evaluate the whole mesh on
+    // every rank), PT this rank's own elements -- the same object unless the element pass is sharded
+    {
+        int PE = h->tune.patchElems > 0 ? (h->tune.patchElems <= 256 ? 256 : 512) : 256;
+        std::vector<int> all(nT);
+        for (int e = 0; e < nT; ++e) all[e] = e;
+        if (int rc = upload_patches(h, build_patches(nV, h->T.data(), h->Xrest.data(), all, PE), h->PTall)) return rc;
+        if (h->shardElems) {
+            std::vector<int> own;
+            for (int e = 0; e < nT; ++e)
+                if (h->epart[e] >= h->p0 && h->epart[e] < h->p1) own.push_back(e);
+            if (int rc = upload_patches(h, build_patches(nV, h->T.data(), h->Xrest.data(), own, PE), h->PT)) return rc;
+        } else {
+            h->PT = h->PTall;
+        }
     }
     return 0;
 }
@@ -1390,12 +1435,10 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
     // synchronisation is the only host<->device interaction of a line-search trial
     double *partE = h->shardElems ? h->partE : h->h_partE;
     double *partR = h->shardElems ? h->partR : h->h_partR;
-    launch_elem_energy_grad(h->M, h->mat, h->dtSq, xeval, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, h->gcont,
-                            partE, &nb, h->st);
+    launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, xeval, h->xt, h->v0, h->v1, 1, partE, &nb, h->st);
     h->nbE = nb;
     phase_mark(h, evalSlot);
     GatherArgs a;
-    a.gcont = h->gcont;
     a.x = xeval;
     a.xt = h->xt;
     a.g_old = h->g;
@@ -1409,10 +1452,10 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
     a.stage = 0;
     if (!h->shardElems) {
         a.make_pair = make_pair;
-        launch_vertex_gather(h->M, a, L, partR, h->st);
+        launch_vertex_gather(h->M, h->PT, a, L, partR, h->st);
     } else {
         a.make_pair = 0;
-        launch_vertex_gather(h->M, a, L, h->partR, h->st);
+        launch_vertex_gather(h->M, h->PT, a, L, h->partR, h->st);
         // pack E_local behind the gradient and reduce both in one collective
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
                            gout + h->n);
@@ -1497,11 +1540,9 @@ int enqueue_loop_slot(dotmi_handle *h)
     }
     launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st, h->ctl);
     int nb = 0;
-    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x_trial, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, h->gcont,
-                            h->partE, &nb, h->st, h->ctl);
+    launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st, h->ctl);
     GatherArgs a;
     memset(&a, 0, sizeof(a));
-    a.gcont = h->gcont;
     a.xt = h->xt;
     a.p = h->p;
     a.alpha_dev = h->alpha_dev;
@@ -1509,7 +1550,7 @@ int enqueue_loop_slot(dotmi_handle *h)
     a.iv1 = h->v1;
     if (!h->shardElems) {
         a.make_pair = 1;
-        launch_vertex_gather(h->M, a, L0, h->partR, h->st, h->ctl);
+        launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st, h->ctl);
         launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st);
         return 0;
     }
@@ -1520,7 +1561,7 @@ int enqueue_loop_slot(dotmi_handle *h)
     a.make_pair = 0;
     a.stage = 1;
     a.g_new = h->gstage;
-    launch_vertex_gather(h->M, a, L0, h->partR, h->st, h->ctl);
+    launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st, h->ctl);
     hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
                        h->gstage + n + 1);
     if (int rc = allreduce_sum(h, h->gstage, (size_t)n + 2)) return rc;
@@ -1567,12 +1608,10 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     {
         // energy and gradient at the start of the step, reduced by the controller (no host round trip)
         int nb = 0;
-        launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, h->gcont,
-                                h->partE, &nb, h->st);
+        launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st);
         GatherArgs a;
         memset(&a, 0, sizeof(a));
-        a.gcont = h->gcont;
-        a.x = h->x;
+            a.x = h->x;
         a.xt = h->xt;
         a.g_new = h->shardElems ? h->gstage : h->g;
         a.make_pair = 0;
@@ -1580,7 +1619,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
         a.iv1 = h->v1;
         LbfgsArgs L0;
         memset(&L0, 0, sizeof(L0));
-        launch_vertex_gather(h->M, a, L0, h->partR, h->st);
+        launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st);
         if (!h->shardElems) {
             launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
         } else {
@@ -2132,11 +2171,9 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         if (int rc = dalloc(h, &h->S[s], (size_t)n)) return rc;
         if (int rc = dalloc(h, &h->Y[s], (size_t)n)) return rc;
     }
-    if (int rc = dalloc(h, &h->gcont, (size_t)12 * h->nT)) return rc;
-    HIPCHECK(h, hipMemsetAsync(h->gcont, 0, sizeof(double) * 12 * (size_t)h->nT, h->st));
     if (int rc = dalloc(h, &h->He, (size_t)144 * h->nT)) return rc;
     if (int rc = dalloc(h, &h->Hval, (size_t)9 * h->M.nnzb)) return rc;
-    if (int rc = dalloc(h, &h->partE, (size_t)2 * 2048)) return rc;
+    if (int rc = dalloc(h, &h->partE, (size_t)2 * ELEM_NB_MAX)) return rc;
     double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG};
     for (double **pp : parts) {
         if (int rc = dalloc(h, pp, (size_t)NB_RED * RED_K)) return rc;
@@ -2145,7 +2182,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     if (int rc = dalloc(h, &h->alpha_dev, 8)) return rc;
     if (int rc = dalloc(h, &h->gstage, (size_t)n + 2)) return rc;
     HIPCHECK(h, hipMemsetAsync(h->gstage, 0, sizeof(double) * ((size_t)n + 2), h->st));
-    HIPCHECK(h, hipHostMalloc((void **)&h->h_partE, sizeof(double) * 2 * 2048));
+    HIPCHECK(h, hipHostMalloc((void **)&h->h_partE, sizeof(double) * 2 * ELEM_NB_MAX));
     HIPCHECK(h, hipHostMalloc((void **)&h->h_partR, sizeof(double) * NB_RED * RED_K));
     HIPCHECK(h, hipHostMalloc((void **)&h->h_alpha, sizeof(double) * 8));
     {
@@ -2518,7 +2555,7 @@ int dotmi_eval_energy(dotmi_handle *h, const double *x, double *E)
     HIPCHECK(h, hipSetDevice(h->device));
     if (int rc = upload_tmp(h, x, h->x_trial)) return rc;
     int nb = 0;
-    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x_trial, h->xt, nullptr, h->nT, 0, h->nV, nullptr, h->partE,
+    launch_elem_energy_grad(h->M, h->PTall, h->mat, h->dtSq, h->x_trial, h->xt, 0, h->nV, 0, h->partE,
                             &nb, h->st);
     HIPCHECK(h, hipMemcpyAsync(h->h_partE, h->partE, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, h->st));
     HIPCHECK(h, hipStreamSynchronize(h->st));
@@ -2537,12 +2574,10 @@ int dotmi_eval_gradient(dotmi_handle *h, const double *x, double *g)
     HIPCHECK(h, hipSetDevice(h->device));
     if (int rc = upload_tmp(h, x, h->x_trial)) return rc;
     int nb = 0;
-    HIPCHECK(h, hipMemsetAsync(h->gcont, 0, sizeof(double) * 12 * (size_t)h->nT, h->st));
-    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x_trial, h->xt, nullptr, h->nT, 0, h->nV, h->gcont, h->partE,
+    launch_elem_energy_grad(h->M, h->PTall, h->mat, h->dtSq, h->x_trial, h->xt, 0, h->nV, 1, h->partE,
                             &nb, h->st);
     GatherArgs a;
     memset(&a, 0, sizeof(a));
-    a.gcont = h->gcont;
     a.x = h->x_trial;
     a.xt = h->xt;
     a.g_new = h->g_trial;
@@ -2551,10 +2586,9 @@ int dotmi_eval_gradient(dotmi_handle *h, const double *x, double *g)
     a.iv1 = h->nV;
     LbfgsArgs L;
     memset(&L, 0, sizeof(L));
-    launch_vertex_gather(h->M, a, L, h->partR, h->st);
+    launch_vertex_gather(h->M, h->PTall, a, L, h->partR, h->st);
     HIPCHECK(h, hipMemcpyAsync(g, h->g_trial, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->st));
     HIPCHECK(h, hipStreamSynchronize(h->st));
-    if (h->shardElems) HIPCHECK(h, hipMemsetAsync(h->gcont, 0, sizeof(double) * 12 * (size_t)h->nT, h->st));
     return 0;
 }
 
@@ -2629,11 +2663,10 @@ int dotmi_probe_direction(dotmi_handle *h, const double *x, int32_t m, const dou
         HIPCHECK(h, hipMemcpyAsync(h->Y[i], Y + (size_t)i * n, bytes, hipMemcpyHostToDevice, h->st));
     }
     int nb = 0;
-    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->tmpn, h->xt, nullptr, h->nT, 0, h->nV, h->gcont, h->partE, &nb,
+    launch_elem_energy_grad(h->M, h->PTall, h->mat, h->dtSq, h->tmpn, h->xt, 0, h->nV, 1, h->partE, &nb,
                             h->st);
     GatherArgs a;
     memset(&a, 0, sizeof(a));
-    a.gcont = h->gcont;
     a.x = h->tmpn;
     a.xt = h->xt;
     a.g_new = h->g_trial;
@@ -2641,7 +2674,7 @@ int dotmi_probe_direction(dotmi_handle *h, const double *x, int32_t m, const dou
     a.iv1 = h->nV;
     LbfgsArgs L;
     memset(&L, 0, sizeof(L));
-    launch_vertex_gather(h->M, a, L, h->partR, h->st);
+    launch_vertex_gather(h->M, h->PTall, a, L, h->partR, h->st);
     std::vector<double> g(n);
     HIPCHECK(h, hipMemcpyAsync(g.data(), h->g_trial, bytes, hipMemcpyDeviceToHost, h->st));
     HIPCHECK(h, hipStreamSynchronize(h->st));
@@ -2671,7 +2704,7 @@ int dotmi_probe_direction(dotmi_handle *h, const double *x, int32_t m, const dou
     launch_build_p(n, h->z, L, h->partC, xi, h->p, h->st);
     launch_spmv_dots(h->M, h->Hval, h->p, h->g_trial, nullptr, 0, h->nV, h->partS, h->st);
     launch_step_forward(n, h->tmpn, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, h->h_alpha, h->st);
-    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x_trial, h->xt, nullptr, h->nT, 0, h->nV, nullptr, h->partE, &nb,
+    launch_elem_energy_grad(h->M, h->PTall, h->mat, h->dtSq, h->x_trial, h->xt, 0, h->nV, 0, h->partE, &nb,
                             h->st);
     HIPCHECK(h, hipMemcpyAsync(h->h_partE, h->partE, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, h->st));
     if (g_out) memcpy(g_out, g.data(), bytes);
@@ -2765,17 +2798,111 @@ int dotmi_bench_precond(dotmi_handle *h, int32_t reps, double *ms_per_launch, in
     return 0;
 }
 
+// One kernel class of the hot path launched `reps` times back to back on the handle's resident data (warm-up launch
+// first), HIP events on the library's stream around them.  bytes = the algorithmic bytes of ONE launch by the formulas
+// of SURVEY.md section 8(d) (spelled out per kind below and in DESIGN.md section 4).  The state of the handle is used as
+// it is (call between steps); kinds that would disturb it (Hessian refresh) write to their usual buffers, which the next
+// refresh overwrites anyway.  Kinds: enum dotmi_bench_kind.
+int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_per_launch, int64_t *bytes_per_launch)
+{
+    if (!h || reps < 1) return DOTMI_E_INVALID;
+    HIPCHECK(h, hipSetDevice(h->device));
+    const int n = h->n, nV = h->nV;
+    const int64_t nTo = h->PT.nElem, nVo = h->v1 - h->v0, m = h->m > 0 ? h->m : h->hist;
+    LbfgsArgs L = lbfgs_args(h);
+    L.m = (int)std::min<int64_t>(m, h->hist);   // as in a running step with a full history
+    for (int i = 0; i < L.m; ++i) {
+        L.s[i] = h->S[i];
+        L.y[i] = h->Y[i];
+        if (L.ys[i] == 0.0) L.ys[i] = 1.0;
+    }
+    int nb = 0;
+    int64_t bytes = 0;
+    std::function<void()> run;
+    GatherArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = h->x;
+    a.xt = h->xt;
+    a.g_old = h->g;
+    a.p = h->p;
+    a.alpha_dev = h->alpha_dev;
+    a.g_new = h->g_trial;
+    a.s_new = h->S[h->hist];
+    a.y_new = h->Y[h->hist];
+    a.iv0 = h->v0;
+    a.iv1 = h->v1;
+    a.make_pair = 1;
+    double xi[HIST_MAX] = {0, 0, 0, 0, 0, 0};
+    switch (kind) {
+    case DOTMI_BENCH_ELEM_ENERGY_GRAD:   // 112 nT + 56 nV: energy evaluation incl. inertia (the gradient entries stay on chip)
+        bytes = 112 * nTo + 56 * nVo;
+        run = [&] { launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st); };
+        break;
+    case DOTMI_BENCH_ELEM_ENERGY:        // 112 nT + 56 nV
+        bytes = 112 * nTo + 56 * nVo;
+        run = [&] { launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x, h->xt, h->v0, h->v1, 0, h->partE, &nb, h->st); };
+        break;
+    case DOTMI_BENCH_VERTEX_GATHER:      // g write + x, x~, m read (80 nV) + pair: g_old, p read, s, y write + 2m history vectors
+        bytes = 80 * (int64_t)nV + (int64_t)(4 + 2 * L.m) * 8 * n;
+        run = [&] { launch_vertex_gather(h->M, h->PT, a, L, h->partR, h->st); };
+        break;
+    case DOTMI_BENCH_SPMV_DOTS:          // 72 nnzb (full symmetric block rows) + p, g read
+        bytes = 72 * (int64_t)h->M.nnzb + 2 * 8 * (int64_t)n;
+        run = [&] { launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st); };
+        break;
+    case DOTMI_BENCH_BACKSOLVE:          // 8 x structural non-zeros of the block-sparse inverse factors
+        bytes = h->precond_bytes;
+        run = [&] { launch_gemv(h->P, h->q, h->st); };
+        break;
+    case DOTMI_BENCH_MERGE:              // z write + the tile partials that make it up + m history vectors (y_i . z)
+        bytes = 8 * (int64_t)n * (2 + L.m) + 8 * (int64_t)h->mergeEntries;
+        run = [&] { launch_merge(h->M, h->P, L, h->z, h->partC, 1 | 2, h->st); };
+        break;
+    case DOTMI_BENCH_BUILD_QPAD:         // g + m history vectors read, padded right-hand sides written
+        bytes = 8 * (int64_t)n * (1 + L.m) + 8 * (int64_t)h->P.nParts * h->P.nmax;
+        run = [&] { launch_build_qpad(h->P, h->g, L, xi, h->st); };
+        break;
+    case DOTMI_BENCH_BUILD_P:            // z + m history vectors read, p written
+        bytes = 8 * (int64_t)n * (2 + L.m);
+        run = [&] { launch_build_p(n, h->z, L, h->partC, xi, h->p, h->st); };
+        break;
+    case DOTMI_BENCH_STEP_FORWARD:       // x, p read, x_trial written
+        bytes = 8 * (int64_t)n * 3;
+        run = [&] { launch_step_forward(n, h->x, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st); };
+        break;
+    case DOTMI_BENCH_ELEM_HESSIAN:       // 112 nT in, 1152 nT out
+        bytes = (int64_t)(112 + 1152) * h->nT;
+        run = [&] { launch_elem_hessians(h->M, h->mat, h->dtSq, h->x, h->He, h->st); };
+        break;
+    case DOTMI_BENCH_ASSEMBLE:           // 1152 nT in, 72 nnzb out
+        bytes = (int64_t)1152 * h->nT + 72 * (int64_t)h->M.nnzb;
+        run = [&] { launch_assemble(h->M, h->He, h->Hval, h->st); };
+        break;
+    default:
+        return DOTMI_E_INVALID;
+    }
+    run();   // warm
+    HIPCHECK(h, hipEventRecord(h->ev0, h->st));
+    for (int i = 0; i < reps; ++i) run();
+    HIPCHECK(h, hipEventRecord(h->ev1, h->st));
+    HIPCHECK(h, hipEventSynchronize(h->ev1));
+    HIPCHECK(h, hipGetLastError());
+    float ms = 0;
+    HIPCHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (ms_per_launch) *ms_per_launch = ms / reps;
+    if (bytes_per_launch) *bytes_per_launch = bytes;
+    return 0;
+}
+
 int dotmi_bench_energy(dotmi_handle *h, int32_t reps, double *ms_per_launch, int64_t *bytes_per_launch)
 {
     if (!h || reps < 1) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
     int nb = 0;
-    launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, nullptr,
-                            h->partE, &nb, h->st);
+    launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x, h->xt, h->v0, h->v1, 0, h->partE, &nb, h->st);
     HIPCHECK(h, hipEventRecord(h->ev0, h->st));
     for (int i = 0; i < reps; ++i)
-        launch_elem_energy_grad(h->M, h->mat, h->dtSq, h->x, h->xt, h->elist, h->nOwnElem, h->v0, h->v1, nullptr,
-                                h->partE, &nb, h->st);
+        launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x, h->xt, h->v0, h->v1, 0, h->partE, &nb, h->st);
     HIPCHECK(h, hipEventRecord(h->ev1, h->st));
     HIPCHECK(h, hipEventSynchronize(h->ev1));
     float ms = 0;

@@ -11,6 +11,7 @@ constexpr int HIST_MAX = 6;     // L-BFGS pairs kept (reference uses 5, DOTTimeS
 constexpr int NB_RED = 256;     // blocks of every reducing kernel (fixed => run-to-run bit-identical sums)
 constexpr int RED_K = 3 * HIST_MAX + 3;  // partial values per block
 constexpr int BS_LONG = 4096;   // longest row (columns) the single-pass back-solve kernel holds in registers
+constexpr int ELEM_NB_MAX = 8192; // most workgroups (= partial energy rows) of the element pass; beyond, workgroups loop over patches
 constexpr int CHOL_NB = 64;     // base block of the recursive inverse-Cholesky (LDS resident)
 
 // ---- mesh + topology resident in HBM ------------------------------------------------------------
@@ -21,15 +22,25 @@ struct DevMesh {
     double *mu, *lam, *vol; // nT
     double *mass;           // nV
     uint8_t *fixed;         // nV
-    // vertex -> incident (elem*4+slot), ascending  (Mesh::vFLoc, Mesh.cpp:609-614)
-    int *vf_ptr, *vf_ent;
-    int4 *epos;             // nT: position of (elem, slot k) in its vertex's incidence list, k = x,y,z,w
     // block-CSR of the global Hessian: vertex adjacency incl. self, ascending
     int *adj_ptr, *adj_idx;
     int nnzb;
     // per block: contributing (elem*16 + a*4 + b), ascending elem  -> deterministic gather assembly
     int *blk_ptr, *blk_ent;
     int *blk_row;           // nnzb: row vertex of each block
+};
+
+// ---- element patches of the element pass (patches.hpp) ---------------------------------------------
+struct DevPatches {
+    int nPatches = 0, PE = 0, PV = 0, nSlots = 0, nElem = 0;
+    ushort4 *tl = nullptr;        // nPatches*PE: patch-local vertex indices of a slot's corners (x == 0xFFFF: padding slot)
+    double *A = nullptr;          // [9][nPatches*PE] rest-shape inverse in patch order, SoA
+    double *mu = nullptr, *lam = nullptr, *vol = nullptr;   // nPatches*PE in patch order (0 on padding)
+    int *pv_gid = nullptr, *pv_slot = nullptr, *pv_cnt = nullptr;   // nPatches*PV, nPatches*PV, nPatches
+    unsigned short *c_ptr = nullptr;   // per patch (PV+1): offsets of the vertices' corner runs
+    ushort4 *epos = nullptr;          // nPatches*PE: position of a slot's four corners in their vertices' runs
+    int2 *pp_rng = nullptr;       // nV: vertex v owns gpart[3*pp_rng[v].x .. 3*pp_rng[v].y)
+    double *gpart = nullptr;      // 3*nSlots per-(patch, vertex) partial gradients, vertex-major
 };
 
 // ---- subdomains owned by this rank ---------------------------------------------------------------
@@ -138,19 +149,20 @@ void launch_step_forward(int n, const double *x0, const double *p, double *x, co
                          double alpha_host, int use_partials, double alpha_min, double *alpha_out,
                          double *alpha_out_host, hipStream_t st, const DevLoop *ctl = nullptr);
 // element pass: partial energy sums (+ inertia) and, optionally, element gradients
-void launch_elem_energy_grad(const DevMesh &M, int mat, double dtSq, const double *x, const double *xt,
-                             const int *elist, int nElem, int v0, int v1, double *gcont /*or null*/,
-                             double *partials, int *nblocks_out, hipStream_t st, const DevLoop *ctl = nullptr);
+// grad != 0: the per-(patch, vertex) partial gradients go to PT.gpart (read by launch_vertex_gather)
+void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, double dtSq, const double *x,
+                             const double *xt, int v0, int v1, int grad, double *partials, int *nblocks_out,
+                             hipStream_t st, const DevLoop *ctl = nullptr);
 // vertex gather of element gradients + inertia; optional L-BFGS pair + stats partials
 struct GatherArgs {
-    const double *gcont, *x, *xt, *g_old, *p, *alpha_dev;
+    const double *x, *xt, *g_old, *p, *alpha_dev;
     double *g_new, *s_new, *y_new;
     int make_pair;
     int iv0, iv1;  // vertex range whose inertia term m_v (x_v - x~_v) this rank adds
     int stage;     // device loop, sharded element pass: g_new is a staging buffer (kept as passed), no pair
 };
-void launch_vertex_gather(const DevMesh &M, const GatherArgs &a, const LbfgsArgs &L, double *partials,
-                          hipStream_t st, const DevLoop *ctl = nullptr);
+void launch_vertex_gather(const DevMesh &M, const DevPatches &PT, const GatherArgs &a, const LbfgsArgs &L,
+                          double *partials, hipStream_t st, const DevLoop *ctl = nullptr);
 // pair + statistics from already summed gradients (multi-GPU: after the all-reduce of g)
 void launch_pair_stats(int n, const GatherArgs &a, const LbfgsArgs &L, double *partials, hipStream_t st,
                        const double *gsrc = nullptr, const DevLoop *ctl = nullptr);

@@ -41,25 +41,40 @@ __device__ __forceinline__ double wave_sum(double v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// element pass: energy (+ inertia) partials and element gradients
+// element pass: energy (+ inertia) partials and per-(patch, vertex) partial gradients
+//
+// One workgroup per PATCH of <= PE = 256 * EPT elements (patches.hpp): the positions of the patch's vertices are staged
+// in LDS (each read from HBM once per patch instead of once per incident corner), a lane computes F, Psi and the
+// 12 entries of the element gradient of its EPT elements -- all of its operands (corner indices, rest-shape inverse,
+// material, volume) are stored in patch order, so every load of a wave is one contiguous run --, drops the 12 entries
+// into LDS at the corner's position in its vertex's run, and the runs are then summed in ascending element order (the
+// reference's vFLoc order, Energy.cpp:543-563), one lane per (vertex, component).  HBM sees one 24-byte partial per (patch, vertex): ~2 per
+// vertex instead of the ~22 incident contributions of 24 bytes each that a global scatter / gather moves twice.
+// LDS: xs[3 * PV] | gs[3][4 PE] (component-major corner runs) | cptr | slot.
 // ------------------------------------------------------------------------------------------------
-template <int MAT, bool GRAD>
-__global__ __launch_bounds__(256) void elem_energy_grad_kernel(
-    const int4 *__restrict__ T, const double *__restrict__ A, int nTp, const double *__restrict__ mu,
-    const double *__restrict__ lam, const double *__restrict__ vol, const double *__restrict__ mass,
-    const double *__restrict__ x, const double *__restrict__ xt, const int *__restrict__ elist,
-    int nElem, int v0, int v1, double dtSq, const int4 *__restrict__ epos, double *__restrict__ gcont,
-    double *__restrict__ partials, const DevLoop *__restrict__ ctl)
+template <int MAT, bool GRAD, int EPT>
+__global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const double *__restrict__ mass,
+                                                         const double *__restrict__ x, const double *__restrict__ xt,
+                                                         int v0, int v1, double dtSq, double *__restrict__ partials,
+                                                         const DevLoop *__restrict__ ctl)
 {
+    extern __shared__ double lds[];
     __shared__ double sm[8];
     if (ctl) {
         if (ctl->status != 0) return;
         x = ctl->x_trial;
     }
-    double acc = 0.0;  // dtSq * vol * Psi
-    const int stride = gridDim.x * blockDim.x;
+    constexpr int PE = 256 * EPT;
+    // LDS: xs[3 PV] | gs[3][4 PE] | cptr[PV + 1 .. padded] (u16) | slot[PV] (i32)
+    double *xs = lds, *gs = lds + 3 * PT.PV;
+    unsigned short *cptr = reinterpret_cast<unsigned short *>(gs + (GRAD ? 12 * PE : 0));
+    int *vslot = reinterpret_cast<int *>(cptr + ((PT.PV + 1 + 3) & ~3));
+    const int tid = threadIdx.x;
+    const size_t strideA = (size_t)PT.nPatches * PE;
+    double acc = 0.0;  // sum vol * Psi
     // inertia operands of this thread's first vertex: independent of the element work, requested ahead of it
-    const int vfirst = v0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int gstride = gridDim.x * blockDim.x;
+    const int vfirst = v0 + blockIdx.x * blockDim.x + tid;
     double ix[3] = {0, 0, 0}, ixt[3] = {0, 0, 0}, im = 0.0;
     if (vfirst < v1) {
 #pragma unroll
@@ -69,89 +84,134 @@ __global__ __launch_bounds__(256) void elem_energy_grad_kernel(
         }
         im = mass[vfirst];
     }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nElem; i += stride) {
-        const int e = elist ? elist[i] : i;
-        const int4 t = T[e];
-        const int4 ps = GRAD ? epos[e] : make_int4(0, 0, 0, 0);  // needed last, requested first
-        const double x0[3] = {x[3 * t.x], x[3 * t.x + 1], x[3 * t.x + 2]};
-        const double x1[3] = {x[3 * t.y], x[3 * t.y + 1], x[3 * t.y + 2]};
-        const double x2[3] = {x[3 * t.z], x[3 * t.z + 1], x[3 * t.z + 2]};
-        const double x3[3] = {x[3 * t.w], x[3 * t.w + 1], x[3 * t.w + 2]};
-        double Ai[3][3];
+    for (int p = blockIdx.x; p < PT.nPatches; p += gridDim.x) {
+        // Everything a patch needs from HBM is requested here, before the first barrier: the element operands
+        // (EPT x (8 + 72 + 24) bytes per lane, contiguous per wave), the vertex lists and the corner lists of the
+        // vertex sums.  The only dependent round trip is vertex id -> position.
+        const int nv = PT.pv_cnt[p];
+        const size_t vb = (size_t)p * PT.PV;
+        const int gid0 = tid < nv ? PT.pv_gid[vb + tid] : -1;
+        ushort4 tl[EPT], ep[EPT];
+        double Ai[EPT][9], m[EPT], l[EPT], vo[EPT];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int u = 0; u < EPT; ++u) {
+            const size_t s = (size_t)p * PE + u * 256 + tid;
+            tl[u] = PT.tl[s];
+            if (GRAD) ep[u] = PT.epos[s];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) Ai[r][c] = A[(size_t)(3 * r + c) * nTp + e];
-        Mat3 F;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const double d0 = x1[r] - x0[r], d1 = x2[r] - x0[r], d2 = x3[r] - x0[r];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) F.m[r][c] = d0 * Ai[0][c] + d1 * Ai[1][c] + d2 * Ai[2][c];
+            for (int k = 0; k < 9; ++k) Ai[u][k] = PT.A[(size_t)k * strideA + s];
+            m[u] = PT.mu[s];
+            l[u] = PT.lam[s];
+            vo[u] = PT.vol[s];
         }
-        const double m = mu[e], l = lam[e], w = dtSq * vol[e];
-        double P[3][3];
-        if constexpr (MAT == 1) {
-            // Stable Neo-Hookean: Psi(sigma) = (mu (|sigma|^2 - 3) + lam (J - a)^2) / 2, a = 1 + mu / lam
-            // (StableNHEnergy.cpp:91-130), is a function of |F|_F^2 = |sigma|^2 and det F = J only (the reference's SVD has
-            // U, V in SO(3) and the sign of det F on sigma_3), and U diag(dPsi/dsigma) V^T = mu F + lam (J - a) cof F.
-            // Energy and first Piola stress therefore need no SVD here -- the Jacobi sweeps were 40 % of this kernel,
-            // which runs in every line-search trial; the Hessian (once per step) keeps the SVD.  Same values to rounding.
-            const double J = det3(F);
-            const double ic = F.m[0][0] * F.m[0][0] + F.m[0][1] * F.m[0][1] + F.m[0][2] * F.m[0][2] + F.m[1][0] * F.m[1][0] +
-                              F.m[1][1] * F.m[1][1] + F.m[1][2] * F.m[1][2] + F.m[2][0] * F.m[2][0] + F.m[2][1] * F.m[2][1] +
-                              F.m[2][2] * F.m[2][2];
-            const double JmA = J - (1.0 + m / l);
-            acc += (m * (ic - 3.0) + l * JmA * JmA) / 2.0 * vol[e];
-            if (GRAD) {
-                const double t = l * JmA;
+        if (GRAD) {
+            const unsigned short *cp = PT.c_ptr + (size_t)p * (PT.PV + 1);
+            for (int lv = tid; lv <= nv; lv += 256) cptr[lv] = cp[lv];
+            for (int lv = tid; lv < nv; lv += 256) vslot[lv] = PT.pv_slot[vb + lv];
+        }
+        if (gid0 >= 0) {
+            xs[3 * tid] = x[3 * gid0];
+            xs[3 * tid + 1] = x[3 * gid0 + 1];
+            xs[3 * tid + 2] = x[3 * gid0 + 2];
+        }
+        for (int lv = tid + 256; lv < nv; lv += 256) {
+            const int gid = PT.pv_gid[vb + lv];
+            xs[3 * lv] = x[3 * gid];
+            xs[3 * lv + 1] = x[3 * gid + 1];
+            xs[3 * lv + 2] = x[3 * gid + 2];
+        }
+        __syncthreads();
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const int r1 = (r + 1) % 3, r2 = (r + 2) % 3;
+        for (int u = 0; u < EPT; ++u) {
+            if (tl[u].x == 0xFFFF) continue;   // padding slot of the last patch
+            const double *p0 = xs + 3 * tl[u].x, *p1 = xs + 3 * tl[u].y, *p2 = xs + 3 * tl[u].z, *p3 = xs + 3 * tl[u].w;
+            Mat3 F;
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
-                        const double cof = F.m[r1][c1] * F.m[r2][c2] - F.m[r1][c2] * F.m[r2][c1];
-                        P[r][c] = w * (m * F.m[r][c] + t * cof);
+            for (int r = 0; r < 3; ++r) {
+                const double d0 = p1[r] - p0[r], d1 = p2[r] - p0[r], d2 = p3[r] - p0[r];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) F.m[r][c] = d0 * Ai[u][c] + d1 * Ai[u][3 + c] + d2 * Ai[u][6 + c];
+            }
+            const double w = dtSq * vo[u];
+            double P[3][3];
+            if constexpr (MAT == 1) {
+                // Stable Neo-Hookean: Psi(sigma) = (mu (|sigma|^2 - 3) + lam (J - a)^2) / 2, a = 1 + mu / lam
+                // (StableNHEnergy.cpp:91-130), is a function of |F|_F^2 = |sigma|^2 and det F = J only (the reference's SVD
+                // has U, V in SO(3) and the sign of det F on sigma_3), and U diag(dPsi/dsigma) V^T = mu F + lam (J - a) cof F.
+                // Energy and first Piola stress therefore need no SVD here; the Hessian (once per step) keeps the SVD.
+                const double J = det3(F);
+                const double ic = F.m[0][0] * F.m[0][0] + F.m[0][1] * F.m[0][1] + F.m[0][2] * F.m[0][2] +
+                                  F.m[1][0] * F.m[1][0] + F.m[1][1] * F.m[1][1] + F.m[1][2] * F.m[1][2] +
+                                  F.m[2][0] * F.m[2][0] + F.m[2][1] * F.m[2][1] + F.m[2][2] * F.m[2][2];
+                const double JmA = J - (1.0 + m[u] / l[u]);
+                acc += (m[u] * (ic - 3.0) + l[u] * JmA * JmA) / 2.0 * vo[u];
+                if (GRAD) {
+                    const double t = l[u] * JmA;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const int r1 = (r + 1) % 3, r2 = (r + 2) % 3;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int c1 = (c + 1) % 3, c2 = (c + 2) % 3;
+                            const double cof = F.m[r1][c1] * F.m[r2][c2] - F.m[r1][c2] * F.m[r2][c1];
+                            P[r][c] = w * (m[u] * F.m[r][c] + t * cof);
+                        }
                     }
                 }
-            }
-        } else {
-            Mat3 U, V;
-            double S[3];
-            svd3(F, U, S, V);
-            acc += psi<MAT>(S, m, l) * vol[e];
-            if (GRAD) {
-                double d[3];
-                dpsi<MAT>(S, m, l, d);
+            } else {
+                Mat3 U, V;
+                double S[3];
+                svd3(F, U, S, V);
+                acc += psi<MAT>(S, m[u], l[u]) * vo[u];
+                if (GRAD) {
+                    double d[3];
+                    dpsi<MAT>(S, m[u], l[u], d);
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            P[r][c] = w * (U.m[r][0] * d[0] * V.m[c][0] + U.m[r][1] * d[1] * V.m[c][1] +
+                                           U.m[r][2] * d[2] * V.m[c][2]);
+                }
+            }
+            if (GRAD) {
+                double g[12];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
 #pragma unroll
                     for (int c = 0; c < 3; ++c)
-                        P[r][c] = w * (U.m[r][0] * d[0] * V.m[c][0] + U.m[r][1] * d[1] * V.m[c][1] +
-                                       U.m[r][2] * d[2] * V.m[c][2]);
+                        g[3 + 3 * a + c] = Ai[u][3 * a] * P[c][0] + Ai[u][3 * a + 1] * P[c][1] + Ai[u][3 * a + 2] * P[c][2];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[c] = -g[3 + c] - g[6 + c] - g[9 + c];
+                const int pk[4] = {ep[u].x, ep[u].y, ep[u].z, ep[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    gs[pk[k]] = g[3 * k];
+                    gs[4 * PE + pk[k]] = g[3 * k + 1];
+                    gs[8 * PE + pk[k]] = g[3 * k + 2];
+                }
             }
         }
         if (GRAD) {
-            double g[12];
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    g[3 + 3 * a + c] = Ai[a][0] * P[c][0] + Ai[a][1] * P[c][1] + Ai[a][2] * P[c][2];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) g[c] = -g[3 + c] - g[6 + c] - g[9 + c];
-            // slot k of this tet lands at its position in the vertex's incidence list (vFLoc order), so the
-            // vertex gather reads one contiguous run per vertex and needs no index indirection
-            const int pk[4] = {ps.x, ps.y, ps.z, ps.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                double *o = gcont + (size_t)3 * pk[k];
-                o[0] = g[3 * k];
-                o[1] = g[3 * k + 1];
-                o[2] = g[3 * k + 2];
+            __syncthreads();
+            // one lane per (vertex, component): a contiguous run of LDS, four entries in flight, added in run order
+            for (int item = tid; item < 3 * nv; item += 256) {
+                const int d = item >= 2 * nv ? 2 : (item >= nv ? 1 : 0), lv = item - d * nv;
+                const int kb = cptr[lv], ke = cptr[lv + 1];
+                const double *run = gs + d * 4 * PE;
+                double sum = 0.0;
+                for (int k = kb; k < ke; k += 4) {
+                    const double w0 = run[k], w1 = k + 1 < ke ? run[k + 1] : 0.0, w2 = k + 2 < ke ? run[k + 2] : 0.0,
+                                 w3 = k + 3 < ke ? run[k + 3] : 0.0;
+                    sum += w0;
+                    if (k + 1 < ke) sum += w1;
+                    if (k + 2 < ke) sum += w2;
+                    if (k + 3 < ke) sum += w3;
+                }
+                PT.gpart[(size_t)3 * vslot[lv] + d] = sum;
             }
         }
+        __syncthreads();   // the next patch of this workgroup reuses xs / gs
     }
     // inertia: sum_v 1/2 m_v |x_v - x~_v|^2 over this rank's vertex slice
     double ine = 0.0;
@@ -159,45 +219,54 @@ __global__ __launch_bounds__(256) void elem_energy_grad_kernel(
         const double dx = ix[0] - ixt[0], dy = ix[1] - ixt[1], dz = ix[2] - ixt[2];
         ine += (dx * dx + dy * dy + dz * dz) * im / 2.0;
     }
-    for (int v = vfirst + stride; v < v1; v += stride) {
+    for (int v = vfirst + gstride; v < v1; v += gstride) {
         const double dx = x[3 * v] - xt[3 * v], dy = x[3 * v + 1] - xt[3 * v + 1],
                      dz = x[3 * v + 2] - xt[3 * v + 2];
         ine += (dx * dx + dy * dy + dz * dz) * mass[v] / 2.0;
     }
     // both block sums through one exchange
     const double we = wave_sum(acc), wi = wave_sum(ine);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = tid & 63, w = tid >> 6;
     if (lane == 0) {
         sm[w] = we;
         sm[4 + w] = wi;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        partials[2 * blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);      // to be scaled by dtSq on the host
+    if (tid == 0) {
+        partials[2 * blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);      // to be scaled by dtSq by the consumer
         partials[2 * blockIdx.x + 1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
     }
 }
 
-void launch_elem_energy_grad(const DevMesh &M, int mat, double dtSq, const double *x, const double *xt,
-                             const int *elist, int nElem, int v0, int v1, double *gcont,
-                             double *partials, int *nblocks_out, hipStream_t st, const DevLoop *ctl)
+void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, double dtSq, const double *x,
+                             const double *xt, int v0, int v1, int grad, double *partials, int *nblocks_out,
+                             hipStream_t st, const DevLoop *ctl)
 {
-    int work = nElem > (v1 - v0) ? nElem : (v1 - v0);
-    int nb = (work + 255) / 256;
-    if (nb > 2048) nb = 2048;
+    int nb = PT.nPatches;
+    const int nbv = (v1 - v0 + 255) / 256;
+    if (nb < nbv) nb = nbv;    // the inertia loop likes one vertex per thread on small meshes
+    if (nb > ELEM_NB_MAX) nb = ELEM_NB_MAX;
     if (nb < 1) nb = 1;
     *nblocks_out = nb;
-#define DM_LAUNCH(MATV, GRADV)                                                                       \
-    hipLaunchKernelGGL((elem_energy_grad_kernel<MATV, GRADV>), dim3(nb), dim3(256), 0, st, M.T, M.A,  \
-                       M.nTp, M.mu, M.lam, M.vol, M.mass, x, xt, elist, nElem, v0, v1, dtSq, M.epos, \
-                       gcont, partials, ctl)
+    const int ept = PT.PE / 256;
+    const size_t shm = sizeof(double) * ((size_t)3 * PT.PV + (grad ? (size_t)12 * PT.PE : 0)) +
+                       (grad ? 2 * (size_t)((PT.PV + 1 + 3) & ~3) + 4 * (size_t)PT.PV : 0);
+#define DM_LAUNCH(MATV, GRADV, EPTV)                                                                            \
+    hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV>), dim3(nb), dim3(256), shm, st, PT, M.mass, x, xt, \
+                       v0, v1, dtSq, partials, ctl)
+#define DM_LAUNCH_E(MATV, GRADV)      \
+    do {                              \
+        if (ept == 1) DM_LAUNCH(MATV, GRADV, 1); \
+        else DM_LAUNCH(MATV, GRADV, 2);          \
+    } while (0)
     if (mat == 0) {
-        if (gcont) DM_LAUNCH(0, true);
-        else DM_LAUNCH(0, false);
+        if (grad) DM_LAUNCH_E(0, true);
+        else DM_LAUNCH_E(0, false);
     } else {
-        if (gcont) DM_LAUNCH(1, true);
-        else DM_LAUNCH(1, false);
+        if (grad) DM_LAUNCH_E(1, true);
+        else DM_LAUNCH_E(1, false);
     }
+#undef DM_LAUNCH_E
 #undef DM_LAUNCH
 }
 
@@ -289,12 +358,15 @@ __device__ __forceinline__ double group8_sum(double v)
     return v;
 }
 
-// 8 lanes cooperate on one vertex: each sums every 8th incident (element, slot) contribution, the
-// butterfly combines them, then lanes 0..2 of the group own the x, y, z degree of freedom.
-constexpr int GATHER_R = 3;   // vertices a lane group works on at a time
+// One lane per scalar degree of freedom k = 3 v + d: the vertex's per-patch partial gradients (usually 1-4 of them,
+// contiguous in gpart, ascending patch) are added in that order, then the inertia term; the new L-BFGS pair and its
+// statistics follow from the same registers.  GATHER_R dofs per lane and trip, one grid stride apart, so that the two
+// dependent round trips of a trip (partial range -> partials) are paid once for all of them.
+constexpr int GATHER_R = 4;
+constexpr int GATHER_P = 4;   // partials requested together; a vertex with more takes further rounds
 template <bool DEV>
 __global__ __launch_bounds__(256) void vertex_gather_kernel(
-    int nV, const int *__restrict__ vf_ptr, const int *__restrict__ vf_ent,
+    int nV, const int2 *__restrict__ pp_rng, const double *__restrict__ gpart,
     const uint8_t *__restrict__ fixed, const double *__restrict__ mass, GatherArgs a, LbfgsArgs L,
     double *__restrict__ partials, const DevLoop *__restrict__ ctl)
 {
@@ -315,113 +387,92 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
 #pragma unroll
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
     const double alpha = a.make_pair ? *a.alpha_dev : 0.0;
-    const int sub = threadIdx.x & 7;
-    const int ngroups = gridDim.x * 32;
-    // GATHER_R vertices per lane group and trip, interleaved (see spmv_dots_kernel): the dependent chain of a trip
-    // (incidence range -> contributions) is paid once for all of them; the statistics are accumulated vertex by vertex
-    // in the order of the one-vertex loop
+    const int n = 3 * nV, G = gridDim.x * blockDim.x;
     constexpr int R = GATHER_R;
-    for (int vbase = blockIdx.x * 32 + (threadIdx.x >> 3); vbase < nV; vbase += R * ngroups) {
-        double g0[R], g1[R], g2[R], ine[R], gold[R], pk[R], si[R][HIST_MAX], yi[R][HIST_MAX];
-        int kb[R], ke[R];
-        bool live[R], fx[R];
+    for (int kbase = blockIdx.x * blockDim.x + threadIdx.x; kbase < n; kbase += R * G) {
+        double gn[R], ine[R], gold[R], pk[R], si[R][HIST_MAX], yi[R][HIST_MAX];
+        int kb[R], ke[R], dd[R];
+        bool live[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            const int v = vbase + u * ngroups;
-            live[u] = v < nV;
-            g0[u] = g1[u] = g2[u] = ine[u] = gold[u] = pk[u] = 0.0;
-            kb[u] = ke[u] = 0;
-            fx[u] = true;
+            const int k = kbase + u * G;
+            live[u] = k < n;
+            gn[u] = ine[u] = gold[u] = pk[u] = 0.0;
+            kb[u] = ke[u] = dd[u] = 0;
             if (live[u]) {
-                fx[u] = fixed[v];
-                kb[u] = vf_ptr[v];
-                ke[u] = vf_ptr[v + 1];
-                // everything the pair needs that does not depend on the gathered gradient is requested up front, so
-                // the dependent chain of a pass is two memory round trips (incidence range -> contributions)
-                const int k = 3 * v + (sub < 3 ? sub : 0);
-                if (sub < 3) {
-                    if (!fx[u] && v >= a.iv0 && v < a.iv1) ine[u] = mass[v] * (a.x[k] - a.xt[k]);
-                    if (a.make_pair) {
-                        gold[u] = a.g_old[k];
-                        pk[u] = a.p[k];
+                const int v = k / 3;
+                dd[u] = k - 3 * v;
+                const bool fx = fixed[v];
+                if (!fx) {   // fixed rows of the gradient are zero (Optimizer.cpp:1239-1252)
+                    const int2 r = pp_rng[v];
+                    kb[u] = r.x;
+                    ke[u] = r.y;
+                    if (v >= a.iv0 && v < a.iv1) ine[u] = mass[v] * (a.x[k] - a.xt[k]);
+                }
+                if (a.make_pair) {
+                    gold[u] = a.g_old[k];
+                    pk[u] = a.p[k];
 #pragma unroll
-                        for (int i = 0; i < HIST_MAX; ++i) {
-                            si[u][i] = (i < Lr.m) ? Lr.s[i][k] : 0.0;
-                            yi[u][i] = (i < Lr.m) ? Lr.y[i][k] : 0.0;
-                        }
+                    for (int i = 0; i < HIST_MAX; ++i) {
+                        si[u][i] = (i < Lr.m) ? Lr.s[i][k] : 0.0;
+                        yi[u][i] = (i < Lr.m) ? Lr.y[i][k] : 0.0;
                     }
                 }
             }
         }
-        // three incidence entries per lane, vertex and trip (24 of the ~20 incident slots per 8-lane group): their loads
-        // are in flight together; the adds keep the order of the one-entry loop
         int nkmax = 0;
 #pragma unroll
-        for (int u = 0; u < R; ++u) nkmax = max(nkmax, fx[u] ? 0 : ke[u] - kb[u]);
-        for (int t = sub; t < nkmax; t += 24) {
-            double w[R][3][3];
+        for (int u = 0; u < R; ++u) nkmax = max(nkmax, ke[u] - kb[u]);
+        for (int t = 0; t < nkmax; t += GATHER_P) {
+            double w[R][GATHER_P];
 #pragma unroll
             for (int u = 0; u < R; ++u)
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    if (!fx[u] && kb[u] + t + 8 * j < ke[u]) {
-                        const double *ge = a.gcont + (size_t)3 * (kb[u] + t + 8 * j);
-                        w[u][j][0] = ge[0];
-                        w[u][j][1] = ge[1];
-                        w[u][j][2] = ge[2];
-                    }
+                for (int j = 0; j < GATHER_P; ++j)
+                    if (kb[u] + t + j < ke[u]) w[u][j] = gpart[(size_t)3 * (kb[u] + t + j) + dd[u]];
 #pragma unroll
             for (int u = 0; u < R; ++u)
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    if (!fx[u] && kb[u] + t + 8 * j < ke[u]) {
-                        g0[u] += w[u][j][0];
-                        g1[u] += w[u][j][1];
-                        g2[u] += w[u][j][2];
-                    }
+                for (int j = 0; j < GATHER_P; ++j)
+                    if (kb[u] + t + j < ke[u]) gn[u] += w[u][j];
         }
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            if (!live[u]) continue;   // uniform over the lane group
-            const int v = vbase + u * ngroups;
-            const double t0 = group8_sum(g0[u]), t1 = group8_sum(g1[u]), t2 = group8_sum(g2[u]);
-            if (sub < 3) {
-                const int k = 3 * v + sub;
-                double gn = (sub == 0) ? t0 : ((sub == 1) ? t1 : t2);
-                gn += ine[u];
-                a.g_new[k] = gn;
-                if (a.make_pair) {
-                    const double sn = alpha * pk[u];
-                    const double yn = gn - gold[u];
-                    a.s_new[k] = sn;
-                    a.y_new[k] = yn;
-                    acc[0] += gn * gn;
-                    acc[1] += yn * sn;
-                    acc[2] += sn * gn;
+            if (!live[u]) continue;
+            const int k = kbase + u * G;
+            const double g = gn[u] + ine[u];
+            a.g_new[k] = g;
+            if (a.make_pair) {
+                const double sn = alpha * pk[u];
+                const double yn = g - gold[u];
+                a.s_new[k] = sn;
+                a.y_new[k] = yn;
+                acc[0] += g * g;
+                acc[1] += yn * sn;
+                acc[2] += sn * g;
 #pragma unroll
-                    for (int i = 0; i < HIST_MAX; ++i)
-                        if (i < Lr.m) {
-                            acc[3 + i] += si[u][i] * yn;
-                            acc[3 + HIST_MAX + i] += sn * yi[u][i];
-                            acc[3 + 2 * HIST_MAX + i] += si[u][i] * gn;
-                        }
-                } else {
-                    acc[0] += gn * gn;
-                }
+                for (int i = 0; i < HIST_MAX; ++i)
+                    if (i < Lr.m) {
+                        acc[3 + i] += si[u][i] * yn;
+                        acc[3 + HIST_MAX + i] += sn * yi[u][i];
+                        acc[3 + 2 * HIST_MAX + i] += si[u][i] * g;
+                    }
+            } else {
+                acc[0] += g * g;
             }
         }
     }
     write_partials(acc, a.make_pair ? RED_K : 1, partials, sm);
 }
 
-void launch_vertex_gather(const DevMesh &M, const GatherArgs &a, const LbfgsArgs &L, double *partials,
-                          hipStream_t st, const DevLoop *ctl)
+void launch_vertex_gather(const DevMesh &M, const DevPatches &PT, const GatherArgs &a, const LbfgsArgs &L,
+                          double *partials, hipStream_t st, const DevLoop *ctl)
 {
     if (ctl)
-        hipLaunchKernelGGL(vertex_gather_kernel<true>, dim3(NB_RED), dim3(256), 0, st, M.nV, M.vf_ptr, M.vf_ent,
+        hipLaunchKernelGGL(vertex_gather_kernel<true>, dim3(NB_RED), dim3(256), 0, st, M.nV, PT.pp_rng, PT.gpart,
                            M.fixed, M.mass, a, L, partials, ctl);
     else
-        hipLaunchKernelGGL(vertex_gather_kernel<false>, dim3(NB_RED), dim3(256), 0, st, M.nV, M.vf_ptr, M.vf_ent,
+        hipLaunchKernelGGL(vertex_gather_kernel<false>, dim3(NB_RED), dim3(256), 0, st, M.nV, PT.pp_rng, PT.gpart,
                            M.fixed, M.mass, a, L, partials, ctl);
 }
 

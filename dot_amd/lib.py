@@ -55,12 +55,16 @@ class StepStats(C.Structure):
                 ("collective_timed", C.c_int64), ("collective_timed_bytes", C.c_int64)]
 
 
+# enum dotmi_bench_kind (include/dotmi.h)
+BENCH_KERNELS = ["elem_energy_grad", "elem_energy", "vertex_gather", "spmv_dots", "backsolve", "merge", "build_qpad",
+                 "build_p", "step_forward", "elem_hessian", "assemble"]
+
 EXPORTS = [
     "dotmi_create", "dotmi_destroy", "dotmi_last_error", "dotmi_comm_unique_id", "dotmi_set_state",
     "dotmi_get_state", "dotmi_set_dirichlet", "dotmi_refix", "dotmi_step", "dotmi_last_iter_log",
     "dotmi_target_gres", "dotmi_eval_energy", "dotmi_eval_gradient", "dotmi_eval_elem_hessians",
     "dotmi_refactor", "dotmi_apply_precond", "dotmi_spmv", "dotmi_get_features", "dotmi_part_size", "dotmi_padded_size",
-    "dotmi_part_matrix", "dotmi_probe_direction", "dotmi_bench_precond", "dotmi_bench_energy", "dotmi_plan_shards", "dotmi_plan_layout", "dotmi_plan_rank", "dotmi_partition",
+    "dotmi_part_matrix", "dotmi_probe_direction", "dotmi_bench_precond", "dotmi_bench_energy", "dotmi_bench_kernel", "dotmi_plan_shards", "dotmi_plan_layout", "dotmi_plan_rank", "dotmi_partition",
 ]
 
 _lib = None
@@ -109,6 +113,7 @@ def load() -> C.CDLL:
     L.dotmi_probe_direction.argtypes = [H, c_dp, C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.dotmi_bench_precond.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]
     L.dotmi_bench_energy.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]
+    L.dotmi_bench_kernel.argtypes = [H, C.c_int32, C.c_int32, c_dp, C.POINTER(C.c_int64)]
     L.dotmi_plan_shards.argtypes = [C.c_int32, c_ip, C.c_int32, c_ip]
     L.dotmi_plan_rank.argtypes = [C.c_int32, C.c_int32, c_ip, c_ip, C.c_int32, C.c_int32, C.c_int32, c_ip, c_ip, c_ip, c_ip,
                                   c_ip, c_ip, c_ip]

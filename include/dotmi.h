@@ -258,6 +258,24 @@ int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *M, int
  * and return the average milliseconds per launch and the algorithmic bytes per launch. */
 int dotmi_bench_precond(dotmi_handle *h, int32_t reps, double *ms_per_launch, int64_t *bytes_per_launch);
 int dotmi_bench_energy(dotmi_handle *h, int32_t reps, double *ms_per_launch, int64_t *bytes_per_launch);
+/* The same for every kernel class of the path (SURVEY.md section 8d "per kernel class"): `reps` back-to-back launches on
+ * the handle's resident state between two HIP events on the library's stream; bytes = algorithmic bytes of one launch
+ * (formulas: DESIGN.md section 4).  Call between steps. */
+enum dotmi_bench_kind {
+    DOTMI_BENCH_ELEM_ENERGY_GRAD = 0, /* element pass: energy + per-(patch, vertex) partial gradients */
+    DOTMI_BENCH_ELEM_ENERGY = 1,      /* element pass, energy only (line-search retries) */
+    DOTMI_BENCH_VERTEX_GATHER = 2,    /* vertex pass: gradient + new L-BFGS pair + its 21 statistics */
+    DOTMI_BENCH_SPMV_DOTS = 3,        /* H p and the two dots of alpha_0 */
+    DOTMI_BENCH_BACKSOLVE = 4,        /* subdomain back-solve (all kernels of one application) */
+    DOTMI_BENCH_MERGE = 5,            /* sum over subdomains / dup (+ y_i . z) */
+    DOTMI_BENCH_BUILD_QPAD = 6,       /* two-loop first half into the padded right-hand sides */
+    DOTMI_BENCH_BUILD_P = 7,          /* two-loop second half */
+    DOTMI_BENCH_STEP_FORWARD = 8,     /* x_trial = x + alpha p */
+    DOTMI_BENCH_ELEM_HESSIAN = 9,     /* projected 12x12 element Hessians (once per step) */
+    DOTMI_BENCH_ASSEMBLE = 10,        /* global block-CSR assembly (once per step) */
+    DOTMI_BENCH_COUNT = 11
+};
+int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_per_launch, int64_t *bytes_per_launch);
 
 #ifdef __cplusplus
 }
