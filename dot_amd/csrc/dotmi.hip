@@ -95,6 +95,9 @@ struct Tuning {
     int splitMinTri = 512;    // DOTMI_SPLIT_MIN_TRI  the same for the triangular products of the tree
     bool deviceLoop = true;   // DOTMI_DEVICE_LOOP=0  host-driven L-BFGS loop (same as DOTMI_FLAG_HOST_LOOP)
     int patchElems = 0;       // DOTMI_PATCH_ELEMS    elements per patch of the element pass (0: default)
+    bool tileFactor = true;   // DOTMI_TILE_FACTOR=0  recursive rocBLAS formulation instead of the level-scheduled tile tasks
+    int tileEagerMin = 2;     // DOTMI_TILE_EAGER_MIN early products a critical-path tile task may keep
+    int tileEagerChunk = 1;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
     static int geti(const char *name, int dflt)
     {
         const char *ev = getenv(name);
@@ -122,6 +125,9 @@ struct Tuning {
         t.splitMinTri = std::max(128, geti("DOTMI_SPLIT_MIN_TRI", 512));
         t.deviceLoop = geti("DOTMI_DEVICE_LOOP", 1) != 0;
         t.patchElems = std::max(0, geti("DOTMI_PATCH_ELEMS", 0));
+        t.tileFactor = geti("DOTMI_TILE_FACTOR", 1) != 0;
+        t.tileEagerMin = std::max(0, geti("DOTMI_TILE_EAGER_MIN", 2));
+        t.tileEagerChunk = std::max(1, geti("DOTMI_TILE_EAGER_CHUNK", 1));
         return t;
     }
 };
@@ -167,6 +173,15 @@ struct dotmi_handle {
     DevMesh M{};
     DevParts P{};
     int *elist = nullptr;
+    // level-scheduled tile factorisation (tile_factor.hpp)
+    bool tileMode = false;
+    TileTask *ttasks = nullptr;
+    TileProd *tprods = nullptr;
+    double **tclear = nullptr;
+    double *tscratch = nullptr;
+    int nTclear = 0;
+    std::vector<int> tlevelStart;
+    double tileFlops = 0;
     DevPatches PT, PTall;   // element patches: this rank's own elements / all elements (same unless shardElems)
     int nOwnElem = 0, v0 = 0, v1 = 0;
     double *x = nullptr, *x_trial = nullptr, *xn = nullptr, *v = nullptr, *xt = nullptr;
@@ -761,6 +776,52 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = upload(h, &P.fill_src, fill_src)) return rc;
     if (int rc = upload(h, &P.pad_dst, pad_dst)) return rc;
     if (int rc = dalloc(h, &P.W, (size_t)P.nParts * P.nmax * P.nmax)) return rc;
+    // ---- tile schedule of the factorisation (tile_factor.hpp) ------------------------------------------------
+    h->tileMode = h->tune.tileFactor && P.nParts > 0;
+    if (h->tileMode) {
+        const int nt = P.nmax / TILE;
+        std::vector<std::vector<uint8_t>> live(P.nParts, std::vector<uint8_t>(nt, 0)), pat(P.nParts);
+        for (int ls = 0; ls < P.nParts; ++ls) {
+            for (int r = 0; r < P.nmax; ++r)
+                if (dofmap[(size_t)ls * P.nmax + r] >= 0) live[ls][r / TILE] = 1;
+            pat[ls].assign((size_t)nt * nt, 0);
+        }
+        const long long bs = (long long)P.nmax * P.nmax;
+        for (size_t f = 0; f < fill_dst.size(); ++f) {
+            const int ls = (int)(fill_dst[f] / bs);
+            const long long o = fill_dst[f] % bs;
+            const int r0 = (int)(o / P.nmax), c0 = (int)(o % P.nmax);   // memory row / column of the 3x3 block's corner
+            for (int a = 0; a < 3; a += 2)
+                for (int b = 0; b < 3; b += 2) {
+                    const int I = (c0 + b) / TILE, J = (r0 + a) / TILE;   // column-major element (c0+b, r0+a)
+                    if (I <= J) pat[ls][(size_t)I * nt + J] = 1;
+                }
+        }
+        TileSchedule S;
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<TileTaskL> all;
+            size_t sn = 0;
+            S = TileSchedule();
+            for (int ls = 0; ls < P.nParts; ++ls)
+                plan_subdomain_tiles(ls, nt, P.nmax, P.W + (size_t)ls * bs, live[ls], pat[ls], h->tscratch, sn, all,
+                                     S.clearTiles, S.flops, S.qTiles, h->tune.tileEagerMin, h->tune.tileEagerChunk);
+            S.scratchTiles = sn;
+            if (pass == 0) {
+                if (int rc = dalloc(h, &h->tscratch, std::max<size_t>(sn, 1) * TILE * TILE)) return rc;
+                continue;
+            }
+            finish_tile_schedule(all, S);
+        }
+        if (int rc = upload(h, &h->ttasks, S.tasks)) return rc;
+        if (int rc = upload(h, &h->tprods, S.prods)) return rc;
+        if (int rc = upload(h, &h->tclear, S.clearTiles)) return rc;
+        h->nTclear = (int)S.clearTiles.size();
+        h->tlevelStart = S.levelStart;
+        h->tileFlops = S.flops;
+        if (h->tune.fuseLog)
+            fprintf(stderr, "dotmi: tile schedule: %zu tasks, %zu products, %zu levels, %lld Q tiles, %.1f GF\n", S.tasks.size(),
+                    S.prods.size(), S.levelStart.size() - 1, S.qTiles, S.flops / 1e9);
+    }
     // factorisation schedule: nodes by height; scratch of a node = R12 / U blocks of the dense recursion,
     // [R_AS; R_CS] of a dissection node; the nodes of one height run concurrently on disjoint scratch
     {
@@ -851,7 +912,7 @@ int build_device_mesh(dotmi_handle *h)
         h->nClearSeg = (int)segs.size();
         if (int rc = upload(h, &h->clearSeg, segs)) return rc;
     }
-    if (int rc = dalloc(h, &P.Wtmp, (size_t)P.nParts * h->tmp_stride)) return rc;
+    if (int rc = dalloc(h, &P.Wtmp, h->tileMode ? 64 : (size_t)P.nParts * h->tmp_stride)) return rc;
     if (int rc = dalloc(h, &P.ppart, (size_t)P.nParts * P.nbmax * P.nmax)) return rc;
     if (int rc = dalloc(h, &P.psub, (size_t)P.nParts * P.nmax)) return rc;
     if (int rc = dalloc(h, &P.rpad, (size_t)P.nParts * P.nmax + 8)) return rc;
@@ -1203,6 +1264,14 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id, i
 // issue (or replay) the inverse-Cholesky recursion of every owned subdomain on h->st
 int issue_factor(dotmi_handle *h)
 {
+    if (h->tileMode) {
+        // one launch per level of the static tile schedule; a launch boundary is the only synchronisation
+        for (size_t l = 0; l + 1 < h->tlevelStart.size(); ++l)
+            launch_tile_level(h->ttasks + h->tlevelStart[l], h->tlevelStart[l + 1] - h->tlevelStart[l], h->tprods, h->info_dev,
+                              h->st);
+        h->flopCount = h->tileFlops;
+        return 0;
+    }
     h->ptrNext = 0;
     HIPCHECK(h, hipEventRecord(h->evFill, h->st));
     for (auto &G : h->groups) {
@@ -1280,7 +1349,8 @@ int refactor_issue(dotmi_handle *h, const double *x)
     // only the blocks the factorisation leaves non-zero are cleared before the refill: the leaf squares and
     // the separator panels; the (A,C) blocks and the cleared mirror panels stay zero for the handle's life
     if (h->wDirty) {
-        launch_clear_segments(h->P, h->clearSeg, h->nClearSeg, h->st);
+        if (h->tileMode) launch_clear_tiles(h->tclear, h->nTclear, h->P.nmax, h->st);
+        else launch_clear_segments(h->P, h->clearSeg, h->nClearSeg, h->st);
     } else if (h->P.nParts > 0) {
         HIPCHECK(h, hipMemsetAsync(h->P.W, 0, (size_t)h->P.nParts * h->P.nmax * h->P.nmax * sizeof(double), h->st));
         h->wDirty = true;
@@ -2776,7 +2846,13 @@ int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *Mout, 
     const auto &pos = h->partPos[ls];
     for (int i = 0; i < ns; ++i)
         for (int j = 0; j < ns; ++j)
-            Mout[(size_t)i * ns + j] = full[(size_t)(pos[i / 3] + i % 3) * lda + pos[j / 3] + j % 3];
+        {
+            // memory row r holds row r of X up to the diagonal; the other triangle is not part of X (the tile
+            // factorisation leaves the mirror copy of H there) -- and H_s itself is read symmetrically
+            const int r = pos[i / 3] + i % 3, c = pos[j / 3] + j % 3;
+            Mout[(size_t)i * ns + j] = inverse ? (c <= r ? full[(size_t)r * lda + c] : 0.0)
+                                               : full[(size_t)std::max(r, c) * lda + std::min(r, c)];
+        }
     if (l2g)
         for (size_t i = 0; i < h->partVerts[part].size(); ++i) l2g[i] = h->partVerts[part][i];
     return 0;

@@ -1461,6 +1461,142 @@ void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, h
     hipLaunchKernelGGL(chol_inv_node128_kernel, dim3(count, LO.n), dim3(256), 0, st, W, nmax, o, info, LO);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tile-level inverse-Cholesky (tile_factor.hpp): one workgroup = one tile task, one launch = one level of the
+// static schedule.  64 x 64 tiles, products on v_mfma_f64_16x16x4_f64 from LDS (layout of mfma_gemm64), the next
+// product's two tiles in flight (global -> registers) while the current one is multiplied; the accumulator tile
+// stays in registers over the whole product list.  Product forms: TF_FACT  C -= A^T B ;  TF_INV  C += A B.
+// ------------------------------------------------------------------------------------------------
+template <bool TRANS_A>
+__device__ __forceinline__ void mfma_acc64(mfma_v4d (&acc)[4], double (*La)[CHOL_NB + 1], double (*Lb)[CHOL_NB + 1],
+                                           double sign, int tid)
+{
+    const int lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+        const double a = sign * (TRANS_A ? La[4 * kk + lk][16 * w + lr] : La[16 * w + lr][4 * kk + lk]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double b = Lb[4 * kk + lk][16 * t + lr];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+    }
+}
+
+// LDS tile G[k][j] (element (row k, column j)) -> column-major global tile, 16-byte stores along the columns
+__device__ __forceinline__ void blk64_store(double (*G)[CHOL_NB + 1], double *__restrict__ dst, size_t ld, int tid)
+{
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int idx2 = tid + 256 * u, j = idx2 >> 5, k = 2 * (idx2 & 31);
+        *reinterpret_cast<double2 *>(dst + (size_t)j * ld + k) = make_double2(G[k][j], G[k + 1][j]);
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_task_kernel(const TileTask *__restrict__ tasks,
+                                                        const TileProd *__restrict__ prods, int *__restrict__ info)
+{
+    constexpr int NB = CHOL_NB, LD = NB + 1;
+    __shared__ double La[NB][LD], Lb[NB][LD], T32[32][33], T16[16][17];
+    const TileTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const bool fact = t.form == TF_FACT;   // C -= A^T B on H tiles;  else C += A B
+    const TileProd *pl = prods + t.first;
+    mfma_v4d acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
+    Blk64 ra, rb;
+    if (t.nprod > 0) {
+        ra = blk64_load(pl[0].a, t.lda, tid);
+        if (pl[0].b != pl[0].a) rb = blk64_load(pl[0].b, t.ldb, tid);
+    } else if (t.post == TP_ROW) {
+        ra = blk64_load(t.q, t.lda, tid);
+    }
+    if (t.init) {
+        blk64_to_lds(blk64_load(t.c, t.ldc, tid), La, tid);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[q][r] = La[16 * w + lk + 4 * r][16 * q + lr];
+        __syncthreads();
+    }
+    for (int p = 0; p < t.nprod; ++p) {
+        const bool same = pl[p].b == pl[p].a;
+        blk64_to_lds(ra, La, tid);
+        if (!same) blk64_to_lds(rb, Lb, tid);
+        __syncthreads();
+        if (p + 1 < t.nprod) {
+            ra = blk64_load(pl[p + 1].a, t.lda, tid);
+            if (pl[p + 1].b != pl[p + 1].a) rb = blk64_load(pl[p + 1].b, t.ldb, tid);
+        } else if (t.post == TP_ROW) {
+            ra = blk64_load(t.q, t.lda, tid);   // Q_kk for the final multiplication
+        }
+        if (fact) mfma_acc64<true>(acc, La, same ? La : Lb, -1.0, tid);
+        else mfma_acc64<false>(acc, La, Lb, 1.0, tid);
+        __syncthreads();
+    }
+    if (t.post == TP_STORE || t.post == TP_NEG) {
+        const double sg = t.post == TP_NEG ? -1.0 : 1.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) La[16 * w + lk + 4 * r][16 * q + lr] = sg * acc[q][r];
+        __syncthreads();
+        blk64_store(La, t.c, t.ldc, tid);
+        return;
+    }
+    // G = updated H tile -> LDS
+    double (*G)[LD] = t.post == TP_ROW ? Lb : La;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) G[16 * w + lk + 4 * r][16 * q + lr] = acc[q][r];
+    if (t.post == TP_ROW) {
+        // R_kj = Q_kk^T G:  R(i,j) = sum_k X(i,k) G(k,j),  X(i,k) = element (k,i) of the stored Q_kk tile
+        blk64_to_lds(ra, La, tid);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
+        mfma_acc64<true>(acc, La, Lb, 1.0, tid);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Lb[16 * w + lk + 4 * r][16 * q + lr] = acc[q][r];
+        __syncthreads();
+        blk64_store(Lb, t.c, t.ldc, tid);
+        return;
+    }
+    __syncthreads();
+    const int bad = block_chol_inv<64>(La, Lb, 0, T32, T16, tid);
+    // Q_jj = X^T: column i of the stored tile, row k <- X(i,k) (zero for k > i: the strictly lower part is cleared)
+    for (int idx = tid; idx < NB * NB; idx += 256) {
+        const int i = idx / NB, k = idx % NB;
+        t.c[(size_t)i * t.ldc + k] = Lb[i][k];
+    }
+    if (tid == 0 && bad) atomicMax(info + t.sub, t.pivotBase + bad);
+}
+
+void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st)
+{
+    if (ntasks > 0) hipLaunchKernelGGL(tile_task_kernel, dim3(ntasks), dim3(256), 0, st, tasks, prods, info);
+}
+
+// zero a list of 64 x 64 tiles (the tiles a factorisation leaves non-zero, before the refill)
+__global__ __launch_bounds__(256) void clear_tiles_kernel(double *const *__restrict__ tiles, int lda)
+{
+    double *tp = tiles[blockIdx.x];
+    for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
+        const int c = idx >> 5, r2 = idx & 31;
+        *reinterpret_cast<double2 *>(tp + (size_t)c * lda + 2 * r2) = make_double2(0.0, 0.0);
+    }
+}
+void launch_clear_tiles(double *const *tiles, int ntiles, int lda, hipStream_t st)
+{
+    if (ntiles > 0) hipLaunchKernelGGL(clear_tiles_kernel, dim3(ntiles), dim3(256), 0, st, tiles, lda);
+}
+
 // dst block <- src block (column-major blocks inside strided batches); zero when src == nullptr
 __global__ __launch_bounds__(256) void block_copy_kernel(double *__restrict__ dst, int ldd, size_t sd,
                                                          const double *__restrict__ src, int lds_, size_t ss,

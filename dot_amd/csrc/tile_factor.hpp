@@ -1,0 +1,240 @@
+// tile_factor.hpp -- static schedule of the tile-level inverse-Cholesky of the subdomain blocks (host only).
+//
+// Role in the reference: CHOLMODSolver::factorize (CHOLMODSolver.cpp:143, called from DOTTimeStepper.cpp:363-377), with
+// the symbolic analysis of CHOLMODSolver::analyze_pattern (:103-141) done here at tile granularity.
+//
+// Every subdomain block (nmax x nmax, column-major, nested-dissection order) is cut into 64 x 64 tiles.  With H = R^T R
+// (R upper) and Q = R^-1, the tiles of R and then of Q overwrite those of H in place:
+//   DIAG(j)    G = H_jj - sum_m R_mj^T R_mj ;  Q_jj = chol(G)^-1
+//   ROW(k,j)   G = H_kj - sum_m R_mk^T R_mj ;  R_kj = Q_kk^T G                       (k < j)
+//   TINV(i,j)  T_ij = sum_{i <= m < j} Q_im R_mj   -> scratch                            (i < j)
+//   QFIN(i,j)  Q_ij = -T_ij Q_jj                   -> overwrites R_ij
+// Only tiles that can be non-zero exist: the tile pattern of H (from the fill list) is closed under the symbolic
+// factorisation, the pattern of Q under the symbolic inversion; tiles that consist of identity padding only are
+// skipped altogether -- so the flop count follows each subdomain's own size, not the padded shared layout.
+// A task's LEVEL is one more than the highest level among the tasks it reads from (and, for QFIN, among the tasks that
+// still read the R tile it overwrites); all tasks of one level, over all subdomains and all tree nodes, run in ONE
+// kernel launch (one workgroup per task), the launches of a factorisation being the levels in order.  The four
+// leaves of a subdomain advance in the same launches, the separators follow, the inversion of a column overlaps the
+// factorisation of the later ones: ~2 launches per tile column on the critical path instead of the ~15 dependent
+// GEMM / diagonal-block launches per 128 columns of the recursive formulation.
+// Products whose operands exist early are applied eagerly (see `emit`), so a launch is as long as a few products, not as
+// the longest product list.  Every sum has a fixed order, so results are bit-identical run to run.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+namespace dotmi {
+
+constexpr int TILE = 64;
+
+// a task:  acc = (init ? tile c : 0);  acc (-)+= products;  post
+enum TileForm { TF_FACT = 0 /* acc -= A^T B */, TF_INV = 1 /* acc += A B */ };
+enum TilePost {
+    TP_STORE = 0,   // c = acc                       (eager partial update of an H tile / of a scratch T tile)
+    TP_DIAG = 1,    // c = (chol(acc)^-1)^T          (Q_jj; strictly lower part zero)
+    TP_ROW = 2,     // c = Q_kk^T acc                (R_kj; q = tile of Q_kk)
+    TP_NEG = 3      // c = -acc                      (Q_ij = -T_ij Q_jj)
+};
+
+struct TileProd {
+    double *a, *b;   // origins of the two tiles (column-major)
+};
+struct TileTask {
+    int form, init, post, nprod;   // TileForm, read c first?, TilePost, number of products
+    int first, sub;                // products [first, first + nprod) of the level-ordered product array; owned subdomain
+    int lda, ldb, ldc;             // leading dimensions of the A tiles, the B tiles and the c tile (scratch tiles: 64)
+    int pivotBase;                 // TP_DIAG: scalar offset of the tile's first row (for the non-SPD report)
+    double *c;                     // the tile read (init) and written
+    double *q;                     // TP_ROW: tile of Q_kk
+};
+
+struct TileSchedule {
+    std::vector<TileTask> tasks;      // level after level
+    std::vector<TileProd> prods;      // in task order
+    std::vector<int> levelStart;      // tasks of level l are [levelStart[l], levelStart[l+1])
+    std::vector<double *> clearTiles; // origins of the tiles a factorisation leaves non-zero (cleared before the refill)
+    size_t scratchTiles = 0;          // 64 x 64 scratch tiles needed (T_ij)
+    double flops = 0;                 // FP64 flop of one factorisation as executed
+    long long liveTiles = 0, qTiles = 0;
+};
+
+// One subdomain: nt tiles per side; live[t] = tile row/column t holds at least one live scalar; hpat = upper tile
+// pattern of H (hpat[i * nt + j], i <= j).  Appends the subdomain's tasks (with levels) to the lists.
+struct TileTaskL {
+    TileTask t;
+    int level;
+    std::vector<TileProd> prods;
+};
+
+inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std::vector<uint8_t> &live,
+                                 std::vector<uint8_t> pat /* by value: gets the fill */, double *scratch, size_t &scratchNext,
+                                 std::vector<TileTaskL> &out, std::vector<double *> &clearTiles, double &flops,
+                                 long long &qTiles, int eagerMin = 2, int eagerChunk = 1)
+{
+    auto tile = [&](int i, int j) { return W + (size_t)j * TILE * lda + (size_t)i * TILE; };
+    auto P = [&](int i, int j) -> uint8_t & { return pat[(size_t)i * nt + j]; };
+    for (int j = 0; j < nt; ++j)
+        if (live[j]) P(j, j) = 1;
+    // symbolic factorisation: struct(R)
+    for (int k = 0; k < nt; ++k) {
+        if (!live[k]) continue;
+        std::vector<int> row;
+        for (int j = k + 1; j < nt; ++j)
+            if (P(k, j)) row.push_back(j);
+        for (size_t a = 0; a < row.size(); ++a)
+            for (size_t b = a; b < row.size(); ++b) P(row[a], row[b]) = 1;
+    }
+    std::vector<uint8_t> rpat = pat;   // struct(R), diagonal included
+    auto Rp = [&](int i, int j) { return rpat[(size_t)i * nt + j] != 0; };
+    // symbolic inversion: struct(Q col j) = {j} + union of struct(Q col m) over m < j with R_mj != 0
+    std::vector<std::vector<int>> qcol(nt);
+    std::vector<uint8_t> qp((size_t)nt * nt, 0);
+    for (int j = 0; j < nt; ++j) {
+        if (!live[j]) continue;
+        std::vector<uint8_t> in(nt, 0);
+        in[j] = 1;
+        for (int m = 0; m < j; ++m)
+            if (Rp(m, j))
+                for (int i : qcol[m]) in[i] = 1;
+        for (int i = 0; i <= j; ++i)
+            if (in[i]) {
+                qcol[j].push_back(i);
+                qp[(size_t)i * nt + j] = 1;
+            }
+    }
+    auto Qp = [&](int i, int j) { return qp[(size_t)i * nt + j] != 0; };
+    // A target tile with its products and the level after which each product's operands exist.  Products that are ready
+    // early are applied EAGERLY, in tasks of their own at the first possible level (where the GPU has room anyway), so
+    // that the task on the critical path -- the one that must wait for the last operand -- only carries the last few
+    // products: the level's duration is that of its longest product loop.  A tile is touched by at most one task per
+    // level (its eager tasks have distinct levels, all below the final one), so there is no race and the order of the
+    // additions is fixed.
+    struct PA {
+        TileProd p;
+        int avail;
+    };
+    const int EAGER_MIN = eagerMin;   // early products a task on the critical path may keep (besides the last level's)
+    const size_t CHUNK = (size_t)std::max(1, eagerChunk);   // early products per eager task (ties in availability stay together)
+    auto emit = [&](int form, int post, double *c, int ldc, double *q, int lda_, int ldb_, int pivotBase, std::vector<PA> &pa,
+                    int minFinal, bool initFromC) -> int {
+        std::stable_sort(pa.begin(), pa.end(), [](const PA &x, const PA &y) { return x.avail < y.avail; });
+        int amax = 0;
+        for (auto &x : pa) amax = std::max(amax, x.avail);
+        const int lf = std::max(amax, minFinal) + 1;
+        // eager part: everything available before level lf - 1, grouped by availability, as long as more than EAGER_MIN
+        // products would otherwise wait for the final task
+        size_t nEarly = 0;
+        while (nEarly < pa.size() && pa[nEarly].avail + 1 < lf) ++nEarly;
+        if (nEarly <= (size_t)EAGER_MIN) nEarly = 0;
+        bool have = initFromC;
+        size_t k0 = 0;
+        while (k0 < nEarly) {
+            size_t k1 = std::min(nEarly, k0 + CHUNK);
+            while (k1 < nEarly && pa[k1].avail == pa[k1 - 1].avail) ++k1;
+            TileTaskL E;
+            E.t = TileTask{form, have ? 1 : 0, TP_STORE, 0, 0, sub, lda_, ldb_, ldc, 0, c, nullptr};
+            for (size_t k = k0; k < k1; ++k) E.prods.push_back(pa[k].p);
+            E.level = pa[k1 - 1].avail + 1;
+            flops += 2.0 * TILE * TILE * TILE * E.prods.size();
+            out.push_back(std::move(E));
+            have = true;
+            k0 = k1;
+        }
+        TileTaskL F;
+        F.t = TileTask{form, have ? 1 : 0, post, 0, 0, sub, lda_, ldb_, ldc, pivotBase, c, q};
+        for (size_t k = nEarly; k < pa.size(); ++k) F.prods.push_back(pa[k].p);
+        F.level = lf;
+        flops += 2.0 * TILE * TILE * TILE * (F.prods.size() + (post == TP_ROW ? 1 : 0)) +
+                 (post == TP_DIAG ? 2.0 / 3.0 * TILE * TILE * TILE : 0.0);
+        out.push_back(std::move(F));
+        return lf;
+    };
+    // levels of the factorisation
+    std::vector<int> lvR((size_t)nt * nt, 0), lvD(nt, 0);
+    auto LR = [&](int i, int j) -> int & { return lvR[(size_t)i * nt + j]; };
+    std::vector<PA> pa;
+    for (int j = 0; j < nt; ++j) {
+        if (!live[j]) continue;
+        for (int k = 0; k < j; ++k) {
+            if (!Rp(k, j)) continue;
+            pa.clear();
+            for (int m = 0; m < k; ++m)
+                if (Rp(m, k) && Rp(m, j)) pa.push_back({{tile(m, k), tile(m, j)}, std::max(LR(m, k), LR(m, j))});
+            LR(k, j) = emit(TF_FACT, TP_ROW, tile(k, j), lda, tile(k, k), lda, lda, 0, pa, lvD[k], true);
+        }
+        pa.clear();
+        for (int m = 0; m < j; ++m)
+            if (Rp(m, j)) pa.push_back({{tile(m, j), tile(m, j)}, LR(m, j)});
+        lvD[j] = emit(TF_FACT, TP_DIAG, tile(j, j), lda, nullptr, lda, lda, j * TILE, pa, 0, true);
+    }
+    // levels of the inversion; lvQ(i,j) = level after which tile (i,j) holds Q_ij
+    std::vector<int> lvQ((size_t)nt * nt, 0);
+    auto LQ = [&](int i, int j) -> int & { return lvQ[(size_t)i * nt + j]; };
+    for (int j = 0; j < nt; ++j)
+        if (live[j]) LQ(j, j) = lvD[j];
+    for (int j = 0; j < nt; ++j) {
+        if (!live[j]) continue;
+        clearTiles.push_back(tile(j, j));
+        ++qTiles;
+        std::vector<int> lvT(nt, 0);
+        std::vector<double *> tsc(nt, nullptr);
+        for (int i : qcol[j]) {
+            if (i == j) continue;
+            clearTiles.push_back(tile(i, j));
+            ++qTiles;
+            double *ts = scratch + (scratchNext++) * (size_t)TILE * TILE;
+            tsc[i] = ts;
+            pa.clear();
+            for (int m = i; m < j; ++m)
+                if (Qp(i, m) && Rp(m, j)) pa.push_back({{tile(i, m), tile(m, j)}, std::max(LQ(i, m), LR(m, j))});
+            lvT[i] = emit(TF_INV, TP_STORE, ts, TILE, nullptr, lda, lda, 0, pa, 0, false);
+        }
+        // QFIN(i,j) overwrites R_ij: after every reader of R_ij -- DIAG(j), ROW(k,j) for i < k < j, ROW(j,j') for j' > j,
+        // TINV(i',j) for i' <= i (their eager parts run earlier than their final tasks, whose levels are used here)
+        int runT = 0;   // max level of TINV(i', j) over i' <= i (qcol ascending)
+        for (int i : qcol[j]) {
+            if (i == j) continue;
+            runT = std::max(runT, lvT[i]);
+            int lv = std::max(runT, lvD[j]);
+            if (Rp(i, j)) {
+                for (int k = i + 1; k < j; ++k)
+                    if (Rp(i, k) && Rp(k, j)) lv = std::max(lv, LR(k, j));
+                for (int j2 = j + 1; j2 < nt; ++j2)
+                    if (Rp(i, j2) && Rp(j, j2)) lv = std::max(lv, LR(j, j2));
+            }
+            pa.clear();
+            pa.push_back({{tsc[i], tile(j, j)}, lv});
+            LQ(i, j) = emit(TF_INV, TP_NEG, tile(i, j), lda, nullptr, TILE, lda, 0, pa, 0, false);
+        }
+    }
+}
+
+// merge the per-subdomain task lists into level order
+inline void finish_tile_schedule(std::vector<TileTaskL> &all, TileSchedule &S)
+{
+    int maxLevel = 0;
+    for (auto &t : all) maxLevel = std::max(maxLevel, t.level);
+    std::vector<std::vector<size_t>> byLevel(maxLevel + 1);
+    for (size_t k = 0; k < all.size(); ++k) byLevel[all[k].level].push_back(k);
+    S.levelStart.assign(1, 0);
+    for (int l = 1; l <= maxLevel; ++l) {
+        // long tasks first inside a level: the launch ends with its short ones
+        auto &v = byLevel[l];
+        std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) {
+            auto cost = [&](const TileTaskL &t) { return (int)t.prods.size() + (t.t.post == TP_DIAG ? 4 : 0); };
+            return cost(all[a]) > cost(all[b]);
+        });
+        for (size_t k : v) {
+            TileTask t = all[k].t;
+            t.first = (int)S.prods.size();
+            t.nprod = (int)all[k].prods.size();
+            for (auto &p : all[k].prods) S.prods.push_back(p);
+            S.tasks.push_back(t);
+        }
+        S.levelStart.push_back((int)S.tasks.size());
+    }
+}
+
+}  // namespace dotmi

@@ -7,6 +7,8 @@ import csv,sys,collections
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 def cls(n):
+    if 'tile_task' in n: return 'tile'
+    if 'clear_tiles' in n: return 'clear'
     if 'node128' in n: return 'node128'
     if 'chol_inv_base' in n: return 'base64'
     if 'block_copy' in n: return 'copy'
@@ -22,10 +24,11 @@ for r in rows:
     c=cls(r['Kernel_Name'])
     if c: cur.append(r)
     else:
-        if len(cur)>50: runs.append(cur)
+        if len(cur)>20: runs.append(cur)
         cur=[]
-if len(cur)>50: runs.append(cur)
-run=runs[-1]
+if len(cur)>20: runs.append(cur)
+fr=[r for r in runs if any(cls(k['Kernel_Name']) in ('tile','gemm') for k in r)]
+run=fr[-1]
 t0=int(run[0]['Start_Timestamp'])
 qs={}
 for r in run:
