@@ -96,8 +96,9 @@ struct Tuning {
     bool deviceLoop = true;   // DOTMI_DEVICE_LOOP=0  host-driven L-BFGS loop (same as DOTMI_FLAG_HOST_LOOP)
     int patchElems = 0;       // DOTMI_PATCH_ELEMS    elements per patch of the element pass (0: default)
     bool tileFactor = true;   // DOTMI_TILE_FACTOR=0  recursive rocBLAS formulation instead of the level-scheduled tile tasks
-    int tileEagerMin = 2;     // DOTMI_TILE_EAGER_MIN early products a critical-path tile task may keep
-    int tileEagerChunk = 1;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
+    bool tileXcdOrder = true; // DOTMI_TILE_XCD_ORDER=0 tile tasks of a level longest first instead of grouped per XCD
+    int tileEagerMin = 0;     // DOTMI_TILE_EAGER_MIN early products a critical-path tile task may keep
+    int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
     static int geti(const char *name, int dflt)
     {
         const char *ev = getenv(name);
@@ -126,8 +127,9 @@ struct Tuning {
         t.deviceLoop = geti("DOTMI_DEVICE_LOOP", 1) != 0;
         t.patchElems = std::max(0, geti("DOTMI_PATCH_ELEMS", 0));
         t.tileFactor = geti("DOTMI_TILE_FACTOR", 1) != 0;
-        t.tileEagerMin = std::max(0, geti("DOTMI_TILE_EAGER_MIN", 2));
-        t.tileEagerChunk = std::max(1, geti("DOTMI_TILE_EAGER_CHUNK", 1));
+        t.tileXcdOrder = geti("DOTMI_TILE_XCD_ORDER", 1) != 0;
+        t.tileEagerMin = std::max(0, geti("DOTMI_TILE_EAGER_MIN", 0));
+        t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
         return t;
     }
 };
@@ -797,6 +799,10 @@ int build_device_mesh(dotmi_handle *h)
                     if (I <= J) pat[ls][(size_t)I * nt + J] = 1;
                 }
         }
+        // eager partial updates shorten the launches of a latency-bound factorisation (few subdomains) and cost tile
+        // traffic in a throughput-bound one (measured: profiles/r03_factor_tiles.txt)
+        const int eagerMin = h->tune.tileEagerMin > 0 ? h->tune.tileEagerMin : (P.nParts <= 64 ? 4 : 8);
+        const int eagerChunk = h->tune.tileEagerChunk > 0 ? h->tune.tileEagerChunk : (P.nParts <= 64 ? 4 : 8);
         TileSchedule S;
         for (int pass = 0; pass < 2; ++pass) {
             std::vector<TileTaskL> all;
@@ -804,13 +810,13 @@ int build_device_mesh(dotmi_handle *h)
             S = TileSchedule();
             for (int ls = 0; ls < P.nParts; ++ls)
                 plan_subdomain_tiles(ls, nt, P.nmax, P.W + (size_t)ls * bs, live[ls], pat[ls], h->tscratch, sn, all,
-                                     S.clearTiles, S.flops, S.qTiles, h->tune.tileEagerMin, h->tune.tileEagerChunk);
+                                     S.clearTiles, S.flops, S.qTiles, eagerMin, eagerChunk);
             S.scratchTiles = sn;
             if (pass == 0) {
                 if (int rc = dalloc(h, &h->tscratch, std::max<size_t>(sn, 1) * TILE * TILE)) return rc;
                 continue;
             }
-            finish_tile_schedule(all, S);
+            finish_tile_schedule(all, S, h->tune.tileXcdOrder);
         }
         if (int rc = upload(h, &h->ttasks, S.tasks)) return rc;
         if (int rc = upload(h, &h->tprods, S.prods)) return rc;

@@ -65,6 +65,7 @@ struct TileSchedule {
 struct TileTaskL {
     TileTask t;
     int level;
+    int row = 0;   // tile row of the target: tasks of one subdomain and row share their A operands
     std::vector<TileProd> prods;
 };
 
@@ -117,8 +118,8 @@ inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std:
     };
     const int EAGER_MIN = eagerMin;   // early products a task on the critical path may keep (besides the last level's)
     const size_t CHUNK = (size_t)std::max(1, eagerChunk);   // early products per eager task (ties in availability stay together)
-    auto emit = [&](int form, int post, double *c, int ldc, double *q, int lda_, int ldb_, int pivotBase, std::vector<PA> &pa,
-                    int minFinal, bool initFromC) -> int {
+    auto emit = [&](int row, int form, int post, double *c, int ldc, double *q, int lda_, int ldb_, int pivotBase,
+                    std::vector<PA> &pa, int minFinal, bool initFromC) -> int {
         std::stable_sort(pa.begin(), pa.end(), [](const PA &x, const PA &y) { return x.avail < y.avail; });
         int amax = 0;
         for (auto &x : pa) amax = std::max(amax, x.avail);
@@ -137,6 +138,7 @@ inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std:
             E.t = TileTask{form, have ? 1 : 0, TP_STORE, 0, 0, sub, lda_, ldb_, ldc, 0, c, nullptr};
             for (size_t k = k0; k < k1; ++k) E.prods.push_back(pa[k].p);
             E.level = pa[k1 - 1].avail + 1;
+            E.row = row;
             flops += 2.0 * TILE * TILE * TILE * E.prods.size();
             out.push_back(std::move(E));
             have = true;
@@ -146,6 +148,7 @@ inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std:
         F.t = TileTask{form, have ? 1 : 0, post, 0, 0, sub, lda_, ldb_, ldc, pivotBase, c, q};
         for (size_t k = nEarly; k < pa.size(); ++k) F.prods.push_back(pa[k].p);
         F.level = lf;
+        F.row = row;
         flops += 2.0 * TILE * TILE * TILE * (F.prods.size() + (post == TP_ROW ? 1 : 0)) +
                  (post == TP_DIAG ? 2.0 / 3.0 * TILE * TILE * TILE : 0.0);
         out.push_back(std::move(F));
@@ -162,12 +165,12 @@ inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std:
             pa.clear();
             for (int m = 0; m < k; ++m)
                 if (Rp(m, k) && Rp(m, j)) pa.push_back({{tile(m, k), tile(m, j)}, std::max(LR(m, k), LR(m, j))});
-            LR(k, j) = emit(TF_FACT, TP_ROW, tile(k, j), lda, tile(k, k), lda, lda, 0, pa, lvD[k], true);
+            LR(k, j) = emit(k, TF_FACT, TP_ROW, tile(k, j), lda, tile(k, k), lda, lda, 0, pa, lvD[k], true);
         }
         pa.clear();
         for (int m = 0; m < j; ++m)
             if (Rp(m, j)) pa.push_back({{tile(m, j), tile(m, j)}, LR(m, j)});
-        lvD[j] = emit(TF_FACT, TP_DIAG, tile(j, j), lda, nullptr, lda, lda, j * TILE, pa, 0, true);
+        lvD[j] = emit(j, TF_FACT, TP_DIAG, tile(j, j), lda, nullptr, lda, lda, j * TILE, pa, 0, true);
     }
     // levels of the inversion; lvQ(i,j) = level after which tile (i,j) holds Q_ij
     std::vector<int> lvQ((size_t)nt * nt, 0);
@@ -189,7 +192,7 @@ inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std:
             pa.clear();
             for (int m = i; m < j; ++m)
                 if (Qp(i, m) && Rp(m, j)) pa.push_back({{tile(i, m), tile(m, j)}, std::max(LQ(i, m), LR(m, j))});
-            lvT[i] = emit(TF_INV, TP_STORE, ts, TILE, nullptr, lda, lda, 0, pa, 0, false);
+            lvT[i] = emit(i, TF_INV, TP_STORE, ts, TILE, nullptr, lda, lda, 0, pa, 0, false);
         }
         // QFIN(i,j) overwrites R_ij: after every reader of R_ij -- DIAG(j), ROW(k,j) for i < k < j, ROW(j,j') for j' > j,
         // TINV(i',j) for i' <= i (their eager parts run earlier than their final tasks, whose levels are used here)
@@ -206,13 +209,13 @@ inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std:
             }
             pa.clear();
             pa.push_back({{tsc[i], tile(j, j)}, lv});
-            LQ(i, j) = emit(TF_INV, TP_NEG, tile(i, j), lda, nullptr, TILE, lda, 0, pa, 0, false);
+            LQ(i, j) = emit(i, TF_INV, TP_NEG, tile(i, j), lda, nullptr, TILE, lda, 0, pa, 0, false);
         }
     }
 }
 
 // merge the per-subdomain task lists into level order
-inline void finish_tile_schedule(std::vector<TileTaskL> &all, TileSchedule &S)
+inline void finish_tile_schedule(std::vector<TileTaskL> &all, TileSchedule &S, bool xcdGroups = true)
 {
     int maxLevel = 0;
     for (auto &t : all) maxLevel = std::max(maxLevel, t.level);
@@ -220,12 +223,57 @@ inline void finish_tile_schedule(std::vector<TileTaskL> &all, TileSchedule &S)
     for (size_t k = 0; k < all.size(); ++k) byLevel[all[k].level].push_back(k);
     S.levelStart.assign(1, 0);
     for (int l = 1; l <= maxLevel; ++l) {
-        // long tasks first inside a level: the launch ends with its short ones
+        // Order inside a level: tasks of the same subdomain and target row read the same A tiles (R_mk / Q_im), so
+        // they are made neighbours ON ONE XCD -- workgroup b runs on XCD b % 8, each XCD has its own 4 MB L2 -- and their
+        // shared operands come from that L2 instead of HBM.  Groups are dealt to the eight XCD lanes, heaviest first.
         auto &v = byLevel[l];
+        if (!xcdGroups) {   // plain: long tasks first
+            std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) {
+                auto cost = [&](const TileTaskL &t) { return (int)t.prods.size() + (t.t.post == TP_DIAG ? 4 : 0); };
+                return cost(all[a]) > cost(all[b]);
+            });
+        } else {
         std::stable_sort(v.begin(), v.end(), [&](size_t a, size_t b) {
-            auto cost = [&](const TileTaskL &t) { return (int)t.prods.size() + (t.t.post == TP_DIAG ? 4 : 0); };
-            return cost(all[a]) > cost(all[b]);
+            if (all[a].t.sub != all[b].t.sub) return all[a].t.sub < all[b].t.sub;
+            if (all[a].row != all[b].row) return all[a].row < all[b].row;
+            return all[a].prods.size() > all[b].prods.size();
         });
+        {
+            std::vector<std::pair<size_t, size_t>> groups;   // [first, end) in v
+            for (size_t i = 0; i < v.size();) {
+                size_t j = i;
+                while (j < v.size() && all[v[j]].t.sub == all[v[i]].t.sub && all[v[j]].row == all[v[i]].row) ++j;
+                groups.push_back({i, j});
+                i = j;
+            }
+            auto weight = [&](const std::pair<size_t, size_t> &g) {
+                size_t wsum = 0;
+                for (size_t i = g.first; i < g.second; ++i) wsum += all[v[i]].prods.size() + 2 + (all[v[i]].t.post == TP_DIAG ? 4 : 0);
+                return wsum;
+            };
+            std::stable_sort(groups.begin(), groups.end(),
+                             [&](const std::pair<size_t, size_t> &a, const std::pair<size_t, size_t> &b) { return weight(a) > weight(b); });
+            constexpr int NX = 8;
+            std::vector<size_t> lane[NX];
+            size_t load[NX] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (auto &g : groups) {
+                int x = 0;
+                for (int y = 1; y < NX; ++y)
+                    if (load[y] < load[x]) x = y;
+                for (size_t i = g.first; i < g.second; ++i) lane[x].push_back(v[i]);
+                load[x] += weight(g);
+            }
+            std::vector<size_t> order;
+            size_t longest = 0;
+            for (int x = 0; x < NX; ++x) longest = std::max(longest, lane[x].size());
+            // position 8 n + x belongs to lane x; a lane that has run out leaves its positions to the others
+            std::vector<size_t> pos(NX, 0);
+            while (order.size() < v.size())
+                for (int x = 0; x < NX; ++x)
+                    if (pos[x] < lane[x].size()) order.push_back(lane[x][pos[x]++]);
+            v.swap(order);
+        }
+        }
         for (size_t k : v) {
             TileTask t = all[k].t;
             t.first = (int)S.prods.size();
