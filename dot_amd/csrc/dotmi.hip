@@ -175,6 +175,11 @@ struct dotmi_handle {
     DevMesh M{};
     DevParts P{};
     int *elist = nullptr;
+    // sharded once-per-step refresh (N > 1 with a sharded element pass): this rank computes the element Hessians of the
+    // elements that touch its vertices only and assembles the block rows it reads only
+    bool shardHess = false;
+    int *hessElems = nullptr, *hessBlk = nullptr, *hessBlkPtr = nullptr, *hessBlkEnt = nullptr;
+    int nHessElems = 0, nHessBlk = 0;
     // level-scheduled tile factorisation (tile_factor.hpp)
     bool tileMode = false;
     TileTask *ttasks = nullptr;
@@ -942,6 +947,41 @@ int build_device_mesh(dotmi_handle *h)
         h->v0 = 0;
         h->v1 = nV;
     }
+    // ---- sharded refresh lists ------------------------------------------------------------------------------------
+    // The block rows this rank reads: the rows of its subdomains' vertices (dense fill of H_s = R_s H R_s^T) and its
+    // slice [v0, v1) of the SpMV.  Their blocks are sums over the elements incident to the row vertex, so the elements
+    // needed are the rank's own plus the halo that touches its interface vertices -- recomputed locally instead of
+    // exchanging 1152 bytes per element (DOTTimeStepper.cpp:349-380, :574-616 run on every rank's share).
+    h->shardHess = h->shardElems && (h->tune.shardHess >= 0 ? h->tune.shardHess != 0 : true);
+    h->nHessElems = nT;
+    if (h->shardHess) {
+        std::vector<uint8_t> needV(nV, 0);
+        for (int pI = h->p0; pI < h->p1; ++pI)
+            for (int v : h->partVerts[pI]) needV[v] = 1;
+        for (int v = h->v0; v < h->v1; ++v) needV[v] = 1;
+        std::vector<int> el, e2c(nT, -1);
+        for (int e = 0; e < nT; ++e)
+            if (needV[h->T[4 * e]] || needV[h->T[4 * e + 1]] || needV[h->T[4 * e + 2]] || needV[h->T[4 * e + 3]]) {
+                e2c[e] = (int)el.size();
+                el.push_back(e);
+            }
+        std::vector<int> bl, bptr(1, 0), bent;
+        for (int v = 0; v < nV; ++v) {
+            if (!needV[v]) continue;
+            for (int k = adj_ptr[v]; k < adj_ptr[v + 1]; ++k) {
+                bl.push_back(k);
+                for (int i = blk_ptr[k]; i < blk_ptr[k + 1]; ++i)
+                    bent.push_back((e2c[blk_ent[i] >> 4] << 4) | (blk_ent[i] & 15));   // every contributor touches v: listed
+                bptr.push_back((int)bent.size());
+            }
+        }
+        h->nHessElems = (int)el.size();
+        h->nHessBlk = (int)bl.size();
+        if (int rc = upload(h, &h->hessElems, el)) return rc;
+        if (int rc = upload(h, &h->hessBlk, bl)) return rc;
+        if (int rc = upload(h, &h->hessBlkPtr, bptr)) return rc;
+        if (int rc = upload(h, &h->hessBlkEnt, bent)) return rc;
+    }
     // element patches (patches.hpp): PTall covers every element (the kernel-level entry points evaluate the whole mesh on
     // every rank), PT this rank's own elements -- the same object unless the element pass is sharded
     {
@@ -1349,8 +1389,13 @@ int run_factor(dotmi_handle *h)
 int refactor_issue(dotmi_handle *h, const double *x)
 {
     HIPCHECK(h, hipEventRecord(h->ev0, h->st));
-    launch_elem_hessians(h->M, h->mat, h->dtSq, x, h->He, h->st);
-    launch_assemble(h->M, h->He, h->Hval, h->st);
+    if (h->shardHess) {
+        launch_elem_hessians(h->M, h->mat, h->dtSq, x, h->He, h->st, h->hessElems, h->nHessElems);
+        launch_assemble(h->M, h->He, h->Hval, h->st, h->hessBlk, h->nHessBlk, h->hessBlkPtr, h->hessBlkEnt);
+    } else {
+        launch_elem_hessians(h->M, h->mat, h->dtSq, x, h->He, h->st);
+        launch_assemble(h->M, h->He, h->Hval, h->st);
+    }
     HIPCHECK(h, hipEventRecord(h->evA, h->st));
     // only the blocks the factorisation leaves non-zero are cleared before the refill: the leaf squares and
     // the separator panels; the (A,C) blocks and the cleared mirror panels stay zero for the handle's life
@@ -2247,7 +2292,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         if (int rc = dalloc(h, &h->S[s], (size_t)n)) return rc;
         if (int rc = dalloc(h, &h->Y[s], (size_t)n)) return rc;
     }
-    if (int rc = dalloc(h, &h->He, (size_t)144 * h->nT)) return rc;
+    if (int rc = dalloc(h, &h->He, (size_t)144 * std::max(h->nHessElems, 1))) return rc;
     if (int rc = dalloc(h, &h->Hval, (size_t)9 * h->M.nnzb)) return rc;
     if (int rc = dalloc(h, &h->partE, (size_t)2 * ELEM_NB_MAX)) return rc;
     double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG};
@@ -2800,6 +2845,10 @@ int dotmi_probe_direction(dotmi_handle *h, const double *x, int32_t m, const dou
 int dotmi_spmv(dotmi_handle *h, const double *p, double *Hp)
 {
     if (!h || !p || !Hp) return DOTMI_E_INVALID;
+    if (h->shardHess) {
+        h->err = "dotmi_spmv: the rows of the global Hessian are sharded over the ranks on this handle (DOTMI_SHARD_HESS=0 keeps them replicated)";
+        return DOTMI_E_INVALID;
+    }
     HIPCHECK(h, hipSetDevice(h->device));
     if (int rc = upload_tmp(h, p, h->tmpn)) return rc;
     launch_spmv_dots(h->M, h->Hval, h->tmpn, nullptr, h->Hp, 0, h->nV, h->partS, h->st);
@@ -2953,12 +3002,18 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
         run = [&] { launch_step_forward(n, h->x, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st); };
         break;
     case DOTMI_BENCH_ELEM_HESSIAN:       // 112 nT in, 1152 nT out
-        bytes = (int64_t)(112 + 1152) * h->nT;
-        run = [&] { launch_elem_hessians(h->M, h->mat, h->dtSq, h->x, h->He, h->st); };
+        bytes = (int64_t)(112 + 1152) * h->nHessElems;
+        run = [&] {
+            if (h->shardHess) launch_elem_hessians(h->M, h->mat, h->dtSq, h->x, h->He, h->st, h->hessElems, h->nHessElems);
+            else launch_elem_hessians(h->M, h->mat, h->dtSq, h->x, h->He, h->st);
+        };
         break;
     case DOTMI_BENCH_ASSEMBLE:           // 1152 nT in, 72 nnzb out
-        bytes = (int64_t)1152 * h->nT + 72 * (int64_t)h->M.nnzb;
-        run = [&] { launch_assemble(h->M, h->He, h->Hval, h->st); };
+        bytes = (int64_t)1152 * h->nHessElems + 72 * (int64_t)(h->shardHess ? h->nHessBlk : h->M.nnzb);
+        run = [&] {
+            if (h->shardHess) launch_assemble(h->M, h->He, h->Hval, h->st, h->hessBlk, h->nHessBlk, h->hessBlkPtr, h->hessBlkEnt);
+            else launch_assemble(h->M, h->He, h->Hval, h->st);
+        };
         break;
     default:
         return DOTMI_E_INVALID;

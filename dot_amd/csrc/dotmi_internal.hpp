@@ -200,9 +200,12 @@ void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, con
 void launch_loop_control(DevLoop *ctl, const double *partE, int nbE, const double *partR,
                          const double *alpha_dev, int *flags_host, hipStream_t st, int init = 0);
 // element Hessians (12x12 projected), one wavefront per element in the expansion phase
+// elist != null: only the listed elements (row i of He = element elist[i]);  blist != null: only the listed blocks, whose
+// contribution lists blk_ptr / blk_ent then index by list position and name rows of that compact He
 void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *x, double *He,
-                          hipStream_t st);
-void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st);
+                          hipStream_t st, const int *elist = nullptr, int nList = 0);
+void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st, const int *blist = nullptr,
+                     int nList = 0, const int *blk_ptr = nullptr, const int *blk_ent = nullptr);
 void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st);
 void launch_clear_segments(const DevParts &P, const int4 *seg, int nseg, hipStream_t st);
 // Leaves of the dissection tree that have the same padded size are factorised together: one launch / one batched GEMM

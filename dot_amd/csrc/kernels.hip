@@ -2285,13 +2285,15 @@ __global__ __launch_bounds__(64) void elem_hessian_kernel(const int4 *__restrict
                                                           const double *__restrict__ lam,
                                                           const double *__restrict__ vol,
                                                           const double *__restrict__ x, double dtSq,
-                                                          double *__restrict__ He)
+                                                          const int *__restrict__ elist, double *__restrict__ He)
 {
     // tet-major, odd row length: the 16 lanes of a tet read different fields of one row (distinct banks)
     __shared__ double pack[64][EH_FIELDS + 1];
     const int lane = threadIdx.x;
-    const int e = blockIdx.x * 64 + lane;
-    if (e < nT) {
+    // elist: the elements this rank needs (sharded refresh); row i of He then belongs to element elist[i]
+    const int ei = blockIdx.x * 64 + lane;
+    const int e = (elist && ei < nT) ? elist[ei] : ei;
+    if (ei < nT) {
         const int4 t = T[e];
         double xs[4][3];
         const int vid[4] = {t.x, t.y, t.z, t.w};
@@ -2387,15 +2389,17 @@ __global__ __launch_bounds__(64) void elem_hessian_kernel(const int4 *__restrict
 }
 
 void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *x, double *He,
-                          hipStream_t st)
+                          hipStream_t st, const int *elist, int nList)
 {
-    const int nb = (M.nT + 63) / 64;
+    const int n = elist ? nList : M.nT;
+    const int nb = (n + 63) / 64;
+    if (nb <= 0) return;
     if (mat == 0)
-        hipLaunchKernelGGL((elem_hessian_kernel<0>), dim3(nb), dim3(64), 0, st, M.T, M.A, M.nTp, M.nT, M.mu, M.lam, M.vol,
-                           x, dtSq, He);
+        hipLaunchKernelGGL((elem_hessian_kernel<0>), dim3(nb), dim3(64), 0, st, M.T, M.A, M.nTp, n, M.mu, M.lam, M.vol,
+                           x, dtSq, elist, He);
     else
-        hipLaunchKernelGGL((elem_hessian_kernel<1>), dim3(nb), dim3(64), 0, st, M.T, M.A, M.nTp, M.nT, M.mu, M.lam, M.vol,
-                           x, dtSq, He);
+        hipLaunchKernelGGL((elem_hessian_kernel<1>), dim3(nb), dim3(64), 0, st, M.T, M.A, M.nTp, n, M.mu, M.lam, M.vol,
+                           x, dtSq, elist, He);
 }
 
 // global block-CSR assembly in gather form: thread = (block k, entry rc)
@@ -2406,11 +2410,14 @@ __global__ __launch_bounds__(256) void assemble_kernel(int nnzb, const int *__re
                                                        const uint8_t *__restrict__ fixed,
                                                        const double *__restrict__ mass,
                                                        const double *__restrict__ He,
-                                                       double *__restrict__ Hval)
+                                                       const int *__restrict__ blist, double *__restrict__ Hval)
 {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)nnzb * 9) return;
-    const int k = (int)(t / 9), rc = (int)(t % 9);
+    // blist: the blocks this rank needs (sharded refresh): blk_ptr / blk_ent are then indexed by the position in the
+    // list and name rows of the rank's compact He
+    const int ki = (int)(t / 9), rc = (int)(t % 9);
+    const int k = blist ? blist[ki] : ki;
     const int r = rc / 3, c = rc % 3;
     const int vr = blk_row[k], vc = adj_idx[k];
     double acc = 0.0;
@@ -2418,8 +2425,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(int nnzb, const int *__re
         acc = (vr == vc && r == c) ? 1.0 : 0.0;  // IglUtils.hpp:148-157
     } else if (!fixed[vc]) {
         // contributions four at a time: index loads first, then the four value loads, then the adds in list order
-        const int b1 = blk_ptr[k + 1];
-        for (int i = blk_ptr[k]; i < b1; i += 4) {
+        const int b1 = blk_ptr[ki + 1];
+        for (int i = blk_ptr[ki]; i < b1; i += 4) {
             int ent[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) ent[u] = (i + u < b1) ? blk_ent[i + u] : -1;
@@ -2436,14 +2443,17 @@ __global__ __launch_bounds__(256) void assemble_kernel(int nnzb, const int *__re
         }
         if (vr == vc && r == c) acc += mass[vr];  // DOTTimeStepper.cpp:598-607
     }
-    Hval[t] = acc;
+    Hval[(size_t)9 * k + rc] = acc;
 }
 
-void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st)
+void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st, const int *blist, int nList,
+                     const int *blk_ptr, const int *blk_ent)
 {
-    const long long tot = (long long)M.nnzb * 9;
-    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, M.nnzb,
-                       M.blk_ptr, M.blk_ent, M.blk_row, M.adj_idx, M.fixed, M.mass, He, Hval);
+    const long long tot = (long long)(blist ? nList : M.nnzb) * 9;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (int)(tot / 9),
+                       blist ? blk_ptr : M.blk_ptr, blist ? blk_ent : M.blk_ent, M.blk_row, M.adj_idx, M.fixed, M.mass, He,
+                       blist, Hval);
 }
 
 // dense principal sub-matrices: W_s[(3i+r)*lda + 3j+c] = H[l2g_i, l2g_j][r][c]

@@ -49,14 +49,20 @@ def _worker(rank, world, initfile, outdir, workload, shard_elems, steps):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shard_elems", ["0", "1"])
-@pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 4), ("horse7K_stretch", 4)])
-def test_two_ranks_on_one_gpu_reproduce_the_single_gpu_run(workload, steps, shard_elems):
+# (workload, steps, sharded element pass + refresh, world).  The last two are the configurations BASELINE.json assigns to
+# 4 / 8 GPUs, reduced to what one GPU holds several times over: the stiff monkey (64 subdomains, back-tracking) on two
+# ranks and the synthetic bar with the sharded element pass / sharded Hessian refresh on FOUR ranks (four processes on
+# one device).
+CASES = [("bunny5K_LTSS", 4, "0", 2), ("bunny5K_LTSS", 4, "1", 2), ("horse7K_stretch", 4, "0", 2),
+         ("horse7K_stretch", 4, "1", 2), ("monkey18K_stiff", 1, "0", 2), ("synbar:40x10x10:32", 2, "1", 4)]
+
+
+@pytest.mark.parametrize("workload,steps,shard_elems,world", CASES)
+def test_ranks_on_one_gpu_reproduce_the_single_gpu_run(workload, steps, shard_elems, world):
     import torch.multiprocessing as mp
     from tests.workloads import load_workload
     from dot_amd.timestepper import DOTTimeStepper
 
-    world = 2
     ctx = mp.get_context("spawn")
     with tempfile.TemporaryDirectory() as d:
         initfile = os.path.join(d, "init")
@@ -73,12 +79,14 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_gpu_run(workload, steps, shar
         assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
         R = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
     # the ranks hold the same replicated state, bit for bit
-    for k in ("x", "v", "its", "halv", "E", "z"):
-        assert np.array_equal(R[0][k], R[1][k]), k
+    for r in range(1, world):
+        for k in ("x", "v", "its", "halv", "E", "z"):
+            assert np.array_equal(R[0][k], R[r][k]), (r, k)
     # the loop runs on the device; replicated element pass: ONE collective per slot (+ the end-of-batch agreement);
     # sharded element pass: z + alpha_0 scalars + staged [g ; 0 ; E] per slot
     per_iter = 1 if shard_elems == "0" else 3
-    assert int(R[0]["calls"]) == int(R[1]["calls"]) >= per_iter * int(R[0]["its"].sum())
+    assert all(int(R[r]["calls"]) == int(R[0]["calls"]) for r in range(world))
+    assert int(R[0]["calls"]) >= per_iter * int(R[0]["its"].sum())
     # and it is the single-GPU run up to the summation order of the exchanged vectors
     sc, ep, n = load_workload(workload)
     ts = DOTTimeStepper(sc, ep, n)
@@ -89,6 +97,13 @@ def test_two_ranks_on_one_gpu_reproduce_the_single_gpu_run(workload, steps, shar
         ts.setDirichlet(idx, pos)
         st = ts.step()
         its.append(st.iters); halv.append(st.ls_halvings)
+    if workload == "monkey18K_stiff":
+        # ~100 iterations with as many back-tracking halvings in one step: the summation order of the exchanged vectors
+        # (all-reduce vs single-GPU merge) is amplified by the line search -- same
+        # tolerance reached, iteration count in the same range
+        assert all(abs(a - b) <= 0.25 * b for a, b in zip(R[0]["its"].tolist(), its))
+        ts.close()
+        return
     assert its == R[0]["its"].tolist() and halv == R[0]["halv"].tolist()
     assert np.abs(ts.getResult() - R[0]["x"]).max() < 1e-9
     r = np.random.default_rng(3).standard_normal(sc.x0.shape) * (1 - sc.fixed[:, None])
@@ -150,3 +165,65 @@ def test_ranks_that_disagree_fail_together_instead_of_hanging(world):
         assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
         msgs = [open(os.path.join(d, f"rank{r}.txt")).read() for r in range(world)]
     assert all("different states" in m for m in msgs), msgs
+
+
+def _worker_rccl(rank, world, port, outdir, workload, steps):
+    sys.path.insert(0, ROOT)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch
+    import torch.distributed as dist
+    from tests.workloads import load_workload
+    from dot_amd.timestepper import DOTTimeStepper, comm_unique_id
+
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    if rank == 0:
+        buf.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(buf, 0)
+    sc, ep, n = load_workload(workload)
+    ts = DOTTimeStepper(sc, ep, n, device=rank, rank=rank, world=world, comm_id=bytes(buf.cpu().numpy().tobytes()))
+    its = []
+    for _ in range(steps):
+        idx, pos = sc.scripter.step(ts.getResult(), sc.cfg.dt)
+        ts.setDirichlet(idx, pos)
+        its.append(ts.step().iters)
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), x=ts.getResult(), its=its)
+    ts.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_real_rccl_ranks_when_the_box_has_two_gpus():
+    """The same run over RCCL itself (ncclAllReduce on the handles' streams, one process per GPU) -- skipped on a one-GPU
+    box, active by itself on any box with two or more."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    import torch.multiprocessing as mp
+    from tests.workloads import load_workload
+    from dot_amd.timestepper import DOTTimeStepper
+    workload, steps, world = "bunny5K_LTSS", 3, 2
+    ctx = mp.get_context("spawn")
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=_worker_rccl, args=(r, world, 29611, d, workload, steps)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=600)
+        alive = [p for p in procs if p.is_alive()]
+        for p in alive:
+            p.terminate()
+        assert not alive and all(p.exitcode == 0 for p in procs)
+        R = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
+    assert np.array_equal(R[0]["x"], R[1]["x"]) and np.array_equal(R[0]["its"], R[1]["its"])
+    sc, ep, n = load_workload(workload)
+    ts = DOTTimeStepper(sc, ep, n)
+    its = []
+    for _ in range(steps):
+        idx, pos = sc.scripter.step(ts.getResult(), sc.cfg.dt)
+        ts.setDirichlet(idx, pos)
+        its.append(ts.step().iters)
+    assert its == R[0]["its"].tolist() and np.abs(ts.getResult() - R[0]["x"]).max() < 1e-9
+    ts.close()
