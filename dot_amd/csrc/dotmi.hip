@@ -185,6 +185,10 @@ struct dotmi_handle {
     TileTask *ttasks = nullptr;
     TileProd *tprods = nullptr;
     double **tclear = nullptr;
+    int *tclearLd = nullptr;
+    std::vector<long long> rtOff;   // host copy of the RowTile table (dotmi_part_matrix)
+    std::vector<int> rtLd, rtC0;
+    size_t wTotal = 0;
     double *tscratch = nullptr;
     int nTclear = 0;
     std::vector<int> tlevelStart;
@@ -576,18 +580,7 @@ int build_device_mesh(dotmi_handle *h)
         nd_plan(sets, nV, adj_ptr, adj_idx, h->Xrest.data(), ndLevels, ndMin, h->nd, region);
     }
     P.nmax = h->nd[0].size;
-    {
-        // the dense blocks are the one allocation that grows quadratically: refuse what cannot fit instead of failing
-        // somewhere inside hipMalloc (the reference's sparse CHOLMOD factors have no such limit, CHOLMODSolver.cpp:136-163)
-        size_t freeB = 0, totalB = 0;
-        HIPCHECK(h, hipMemGetInfo(&freeB, &totalB));
-        const double need = 8.0 * P.nParts * (double)P.nmax * P.nmax * 1.25;
-        if (need > 0.9 * (double)freeB) {
-            h->err = "the dense subdomain factors need " + std::to_string((long long)(need / 1e9)) + " GB (" +
-                     std::to_string(P.nParts) + " blocks of " + std::to_string(P.nmax) + "^2), more than the free HBM: use more subdomains";
-            return DOTMI_E_INVALID;
-        }
-    }
+    h->tileMode = h->tune.tileFactor && P.nParts > 0;
     // per part: padded position of every local vertex, tiles of the back-solve, structural non-zeros
     h->partPos.assign(P.nParts, {});
     std::vector<int> dofmap((size_t)P.nParts * P.nmax, -1);
@@ -628,8 +621,10 @@ int build_device_mesh(dotmi_handle *h)
             // the rows of a region start at their node's first column (a leaf's padding sits in front of its
             // live rows and is skipped; 16-column granularity keeps the 128-byte lines whole)
             const int cb = N.a < 0 ? (ro & ~15) : N.off;
-            for (int r0 = ro; r0 < ro + used; r0 += tileRows) {
-                const int rows = std::min(tileRows, ro + used - r0);
+            // a tile stays inside one 64-row block of the factor storage (RowTile): the first tile of a region ends
+            // at the next multiple of 64
+            for (int r0 = ro, rows = 0; r0 < ro + used; r0 += rows) {
+                rows = std::min(std::min(tileRows, ro + used - r0), 64 - (r0 & 63));
                 tiles.push_back(make_int4(ls, r0, b | (rows << 16), cb));
                 ranges[ls].push_back(make_int2(cb, r0 + rows));
                 ++b;
@@ -712,26 +707,85 @@ int build_device_mesh(dotmi_handle *h)
             for (int i = 0; i < (int)pv.size(); ++i) vp_off[cur[pv[i]]++] = ls * P.nmax + h->partPos[ls][i];
         }
     }
-    // dense fill list
+    // ---- factor storage: 64-row blocks (RowTile) ---------------------------------------------------------------
+    const int ntl = P.nmax / 64;
+    std::vector<RowTile> rtab((size_t)std::max(P.nParts, 1) * ntl, RowTile{-1, 0, 0});
+    std::vector<long long> rtOff(rtab.size(), -1);
+    std::vector<int> rtLd(rtab.size(), 0), rtC0(rtab.size(), 0);
+    size_t wTotal = 0;
+    {
+        // first column a row of the layout can have non-zero: that of its tree node
+        std::vector<int> nodeC0(P.nmax, 0);
+        for (const NdNode &N : h->nd) {
+            if (N.a < 0)
+                for (int r = N.off; r < N.off + N.size; ++r) nodeC0[r] = N.off;
+            else
+                for (int r = N.offS; r < N.offS + N.sizeS; ++r) nodeC0[r] = N.off;
+        }
+        for (int ls = 0; ls < P.nParts; ++ls)
+            for (int J = 0; J < ntl; ++J) {
+                RowTile &R = rtab[(size_t)ls * ntl + J];
+                if (!h->tileMode) {   // dense: 64 rows of the subdomain's nmax x nmax array
+                    R = RowTile{(long long)ls * P.nmax * P.nmax + (long long)J * 64 * P.nmax, P.nmax, 0};
+                } else {
+                    bool live = false;
+                    for (int r = 64 * J; r < 64 * J + 64 && !live; ++r) live = dofmap[(size_t)ls * P.nmax + r] >= 0;
+                    if (!live) continue;   // identity padding only: nothing stored, nothing read
+                    const int c0 = nodeC0[64 * J];
+                    R = RowTile{(long long)wTotal, 64 * (J + 1) - c0, c0};
+                    wTotal += (size_t)64 * R.ld;
+                }
+                rtOff[(size_t)ls * ntl + J] = R.off;
+                rtLd[(size_t)ls * ntl + J] = R.ld;
+                rtC0[(size_t)ls * ntl + J] = R.c0;
+            }
+        if (!h->tileMode) wTotal = (size_t)P.nParts * P.nmax * P.nmax;
+        // the factors are the one allocation that grows with the square of the subdomain size: refuse what cannot fit
+        // instead of failing somewhere inside hipMalloc
+        size_t freeB = 0, totalB = 0;
+        HIPCHECK(h, hipMemGetInfo(&freeB, &totalB));
+        const double need = 8.0 * (double)wTotal * (h->tileMode ? 2.1 : 1.25);   // + scratch of the factorisation
+        if (need > 0.9 * (double)freeB) {
+            h->err = "the subdomain factors need " + std::to_string((long long)(need / 1e9)) + " GB (" + std::to_string(P.nParts) +
+                     " subdomains, padded size " + std::to_string(P.nmax) + "), more than the free HBM: use more subdomains";
+            return DOTMI_E_INVALID;
+        }
+    }
+    h->rtOff = rtOff;
+    h->rtLd = rtLd;
+    h->rtC0 = rtC0;
+    h->wTotal = wTotal;
+    // offset in W of (memory row r, column c) of owned subdomain ls, or -1 when that place is not stored
+    auto waddr = [&](int ls, int r, int c) -> long long {
+        const RowTile &R = rtab[(size_t)ls * ntl + (r >> 6)];
+        if (R.off < 0 || c < R.c0 || c >= R.c0 + R.ld) return -1;
+        return R.off + (long long)(r & 63) * R.ld + (c - R.c0);
+    };
+    // dense fill list: per scalar of every 3x3 block of the principal sub-matrix
     std::vector<long long> fill_dst, pad_dst;
     std::vector<int> fill_src;
+    std::vector<int4> fillBlk;   // (owned subdomain, memory row, memory column) of the blocks' corners, for the tile pattern
     {
         std::vector<int> g2p(nV, -1);
         for (int ls = 0; ls < P.nParts; ++ls) {
             const auto &pv = h->partVerts[h->p0 + ls];
             for (int i = 0; i < (int)pv.size(); ++i) g2p[pv[i]] = h->partPos[ls][i];
-            const long long base = (long long)ls * P.nmax * P.nmax;
             for (int i = 0; i < (int)pv.size(); ++i) {
                 const int v = pv[i];
                 for (int k = adj_ptr[v]; k < adj_ptr[v + 1]; ++k) {
                     const int j = g2p[adj_idx[k]];
                     if (j < 0) continue;
-                    fill_dst.push_back(base + (long long)h->partPos[ls][i] * P.nmax + j);
+                    const int r0 = h->partPos[ls][i];
+                    for (int rc = 0; rc < 9; ++rc) fill_dst.push_back(waddr(ls, r0 + rc / 3, j + rc % 3));
                     fill_src.push_back(k);
+                    fillBlk.push_back(make_int4(ls, r0, j, 0));
                 }
             }
             for (int r = 0; r < P.nmax; ++r)
-                if (dofmap[(size_t)ls * P.nmax + r] < 0) pad_dst.push_back(base + (long long)r * P.nmax + r);
+                if (dofmap[(size_t)ls * P.nmax + r] < 0) {
+                    const long long a = waddr(ls, r, r);
+                    if (a >= 0) pad_dst.push_back(a);
+                }
             for (int v : pv) g2p[v] = -1;
         }
     }
@@ -782,9 +836,9 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = upload(h, &P.fill_dst, fill_dst)) return rc;
     if (int rc = upload(h, &P.fill_src, fill_src)) return rc;
     if (int rc = upload(h, &P.pad_dst, pad_dst)) return rc;
-    if (int rc = dalloc(h, &P.W, (size_t)P.nParts * P.nmax * P.nmax)) return rc;
+    if (int rc = dalloc(h, &P.W, std::max<size_t>(wTotal, 64))) return rc;
+    if (int rc = upload(h, &P.rt, rtab)) return rc;
     // ---- tile schedule of the factorisation (tile_factor.hpp) ------------------------------------------------
-    h->tileMode = h->tune.tileFactor && P.nParts > 0;
     if (h->tileMode) {
         const int nt = P.nmax / TILE;
         std::vector<std::vector<uint8_t>> live(P.nParts, std::vector<uint8_t>(nt, 0)), pat(P.nParts);
@@ -793,11 +847,8 @@ int build_device_mesh(dotmi_handle *h)
                 if (dofmap[(size_t)ls * P.nmax + r] >= 0) live[ls][r / TILE] = 1;
             pat[ls].assign((size_t)nt * nt, 0);
         }
-        const long long bs = (long long)P.nmax * P.nmax;
-        for (size_t f = 0; f < fill_dst.size(); ++f) {
-            const int ls = (int)(fill_dst[f] / bs);
-            const long long o = fill_dst[f] % bs;
-            const int r0 = (int)(o / P.nmax), c0 = (int)(o % P.nmax);   // memory row / column of the 3x3 block's corner
+        for (const int4 &fb : fillBlk) {
+            const int ls = fb.x, r0 = fb.y, c0 = fb.z;   // memory row / column of the 3x3 block's corner
             for (int a = 0; a < 3; a += 2)
                 for (int b = 0; b < 3; b += 2) {
                     const int I = (c0 + b) / TILE, J = (r0 + a) / TILE;   // column-major element (c0+b, r0+a)
@@ -814,8 +865,9 @@ int build_device_mesh(dotmi_handle *h)
             size_t sn = 0;
             S = TileSchedule();
             for (int ls = 0; ls < P.nParts; ++ls)
-                plan_subdomain_tiles(ls, nt, P.nmax, P.W + (size_t)ls * bs, live[ls], pat[ls], h->tscratch, sn, all,
-                                     S.clearTiles, S.flops, S.qTiles, eagerMin, eagerChunk);
+                plan_subdomain_tiles(ls, nt, P.W, &rtOff[(size_t)ls * nt], &rtLd[(size_t)ls * nt], &rtC0[(size_t)ls * nt],
+                                     live[ls], pat[ls], h->tscratch, sn, all, S.clearTiles, S.clearLd, S.flops, S.qTiles,
+                                     eagerMin, eagerChunk);
             S.scratchTiles = sn;
             if (pass == 0) {
                 if (int rc = dalloc(h, &h->tscratch, std::max<size_t>(sn, 1) * TILE * TILE)) return rc;
@@ -826,6 +878,7 @@ int build_device_mesh(dotmi_handle *h)
         if (int rc = upload(h, &h->ttasks, S.tasks)) return rc;
         if (int rc = upload(h, &h->tprods, S.prods)) return rc;
         if (int rc = upload(h, &h->tclear, S.clearTiles)) return rc;
+        if (int rc = upload(h, &h->tclearLd, S.clearLd)) return rc;
         h->nTclear = (int)S.clearTiles.size();
         h->tlevelStart = S.levelStart;
         h->tileFlops = S.flops;
@@ -1400,10 +1453,10 @@ int refactor_issue(dotmi_handle *h, const double *x)
     // only the blocks the factorisation leaves non-zero are cleared before the refill: the leaf squares and
     // the separator panels; the (A,C) blocks and the cleared mirror panels stay zero for the handle's life
     if (h->wDirty) {
-        if (h->tileMode) launch_clear_tiles(h->tclear, h->nTclear, h->P.nmax, h->st);
+        if (h->tileMode) launch_clear_tiles(h->tclear, h->tclearLd, h->nTclear, h->st);
         else launch_clear_segments(h->P, h->clearSeg, h->nClearSeg, h->st);
     } else if (h->P.nParts > 0) {
-        HIPCHECK(h, hipMemsetAsync(h->P.W, 0, (size_t)h->P.nParts * h->P.nmax * h->P.nmax * sizeof(double), h->st));
+        HIPCHECK(h, hipMemsetAsync(h->P.W, 0, h->wTotal * sizeof(double), h->st));
         h->wDirty = true;
     }
     launch_dense_fill(h->P, h->Hval, h->st);
@@ -2873,6 +2926,7 @@ int32_t dotmi_part_size(const dotmi_handle *h, int32_t part)
 }
 
 int32_t dotmi_padded_size(const dotmi_handle *h) { return h ? h->P.nmax : DOTMI_E_INVALID; }
+int64_t dotmi_factor_storage_bytes(const dotmi_handle *h) { return h ? (int64_t)(8 * h->wTotal) : DOTMI_E_INVALID; }
 
 int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *Mout, int32_t *l2g)
 {
@@ -2880,33 +2934,48 @@ int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *Mout, 
     HIPCHECK(h, hipSetDevice(h->device));
     const int ls = part - h->p0;
     const int ns = 3 * (int)h->partVerts[part].size();
-    const int lda = h->P.nmax;
-    double *W = h->P.W + (size_t)ls * lda * lda;
+    const int nmax = h->P.nmax, ntl = nmax / 64;
+    double *W = h->P.W;
     double *tmp = nullptr;
     if (!inverse) {
-        // rebuild H_s from the resident block-CSR into a scratch block
-        HIPCHECK(h, hipMalloc((void **)&tmp, sizeof(double) * (size_t)h->P.nParts * lda * lda));
+        // rebuild H_s from the resident block-CSR into a scratch copy of the factor storage
+        HIPCHECK(h, hipMalloc((void **)&tmp, sizeof(double) * std::max<size_t>(h->wTotal, 64)));
         DevParts Pt = h->P;
         Pt.W = tmp;
-        HIPCHECK(h, hipMemsetAsync(tmp, 0, sizeof(double) * (size_t)h->P.nParts * lda * lda, h->st));
+        HIPCHECK(h, hipMemsetAsync(tmp, 0, sizeof(double) * h->wTotal, h->st));
         launch_dense_fill(Pt, h->Hval, h->st);
-        W = tmp + (size_t)ls * lda * lda;
+        W = tmp;
     }
-    // the dense block lives in the padded nested-dissection order: gather it back to ascending vertices
-    std::vector<double> full((size_t)lda * lda);
-    hipError_t e = hipMemcpyAsync(full.data(), W, sizeof(double) * full.size(), hipMemcpyDeviceToHost, h->st);
+    // the subdomain's row blocks (RowTile) lie one after the other in W: copy their span, then read (row, column) through
+    // the table -- back into ascending vertex order
+    long long lo = -1, hi = -1;
+    for (int J = 0; J < ntl; ++J) {
+        const long long o = h->rtOff[(size_t)ls * ntl + J];
+        if (o < 0) continue;
+        if (lo < 0) lo = o;
+        hi = o + 64ll * h->rtLd[(size_t)ls * ntl + J];
+    }
+    std::vector<double> span((size_t)std::max<long long>(hi - lo, 1));
+    hipError_t e = lo >= 0 ? hipMemcpyAsync(span.data(), W + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToHost, h->st)
+                           : hipSuccess;
     hipStreamSynchronize(h->st);
     if (tmp) hipFree(tmp);
     HIPCHECK(h, e);
+    auto at = [&](int r, int c) -> double {   // memory row r, column c; what is not stored is zero
+        const size_t k = (size_t)ls * ntl + (r >> 6);
+        const long long o = h->rtOff[k];
+        const int c0 = h->rtC0[k], ld = h->rtLd[k];
+        if (o < 0 || c < c0 || c >= c0 + ld) return 0.0;
+        return span[(size_t)(o - lo + (long long)(r & 63) * ld + (c - c0))];
+    };
     const auto &pos = h->partPos[ls];
     for (int i = 0; i < ns; ++i)
-        for (int j = 0; j < ns; ++j)
-        {
+        for (int j = 0; j < ns; ++j) {
             // memory row r holds row r of X up to the diagonal; the other triangle is not part of X (the tile
-            // factorisation leaves the mirror copy of H there) -- and H_s itself is read symmetrically
+            // factorisation leaves the mirror copy of H there, the compact layout does not even store it) -- and H_s
+            // itself is read symmetrically from the stored triangle
             const int r = pos[i / 3] + i % 3, c = pos[j / 3] + j % 3;
-            Mout[(size_t)i * ns + j] = inverse ? (c <= r ? full[(size_t)r * lda + c] : 0.0)
-                                               : full[(size_t)std::max(r, c) * lda + std::min(r, c)];
+            Mout[(size_t)i * ns + j] = inverse ? (c <= r ? at(r, c) : 0.0) : at(std::max(r, c), std::min(r, c));
         }
     if (l2g)
         for (size_t i = 0; i < h->partVerts[part].size(); ++i) l2g[i] = h->partVerts[part][i];

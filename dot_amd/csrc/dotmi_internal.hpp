@@ -44,13 +44,26 @@ struct DevPatches {
     double *gpart = nullptr;      // 3*nSlots per-(patch, vertex) partial gradients, vertex-major
 };
 
+// ---- factor storage -------------------------------------------------------------------------------
+// A subdomain's X_s (first H_s) is kept by 64-row blocks.  Memory row i of block J = i / 64, column c (c0 <= c <
+// 64 (J + 1)) is at W[off + (i - 64 J) * ld + (c - c0)].  Dense layout (recursive rocBLAS factorisation): every block
+// is 64 rows of the subdomain's nmax x nmax array (ld = nmax, c0 = 0).  Compact layout (tile factorisation): a block
+// only holds what its rows can have non-zero -- from the first column of the rows' tree node to the end of the
+// block's diagonal tile (ld = 64 (J + 1) - c0) --, blocks of pure padding rows hold nothing (off = -1): the
+// storage is ~1.2x the structural non-zeros the back-solve streams instead of nmax^2 per subdomain.
+struct RowTile {
+    long long off;
+    int ld, c0;
+};
+
 // ---- subdomains owned by this rank ---------------------------------------------------------------
 struct DevParts {
     int nParts;             // owned
     int nmax;               // padded scalar size of every owned dense block (multiple of 64) = its lda
     int *dofmap;            // owned * nmax: padded local position -> global scalar dof, -1 = padding
-    double *W;              // owned * nmax*nmax dense blocks: H_s, then X_s = chol(H_s)^-1 with memory row i =
-                            // row i of X_s (column-major upper factor Q = R^-1 of H_s = R^T R)
+    double *W;              // factor storage of the owned subdomains (RowTile): H_s, then X_s = chol(H_s)^-1 with memory
+                            // row i = row i of X_s (column-major upper factor Q = R^-1 of H_s = R^T R)
+    RowTile *rt;            // owned * (nmax / 64) row blocks
     double *Wtmp;           // owned * tmp_stride scratch of the recursion
     int ntiles;             // back-solve jobs, heavy first:
     int4 *tile;             //   (part, first row, tile index within the part | rows << 16, first column)
@@ -79,7 +92,7 @@ struct DevParts {
     int *dup;               // nV (global multiplicity, DOTTimeStepper.cpp:47-56)
     // dense fill list
     int nfill;
-    long long *fill_dst;    // offset of the 3x3 block's (0,0) in W
+    long long *fill_dst;    // per scalar of every 3x3 block (9 nfill): its offset in W, or -1 (not stored)
     int *fill_src;          // block index in Hval
     int npad;               // identity padding entries
     long long *pad_dst;
@@ -221,7 +234,7 @@ void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, h
                              const LeafOffs &LO = LeafOffs());
 // one level of the tile schedule (tile_factor.hpp): one workgroup per task
 void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st);
-void launch_clear_tiles(double *const *tiles, int ntiles, int lda, hipStream_t st);
+void launch_clear_tiles(double *const *tiles, const int *lds_, int ntiles, hipStream_t st);
 void launch_block_copy(double *dst, int ldd, size_t sd, const double *src, int lds_, size_t ss, int rows,
                        int cols, int batch, hipStream_t st, const LeafOffs &LO = LeafOffs());
 // small helpers

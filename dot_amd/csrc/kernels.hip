@@ -757,7 +757,7 @@ typedef double nt_double2 __attribute__((ext_vector_type(2)));
 // and LDS exchange -- is what bounds a tile, not its byte count.
 template <int THREADS, int MAXCH, int SUB>
 __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restrict__ dofmap,
-                                               const double *__restrict__ W, int nmax,
+                                               const double *__restrict__ W, int nmax, const RowTile *__restrict__ rt,
                                                const double *__restrict__ q, double *__restrict__ ppart,
                                                int nbmax, double (*sm)[THREADS / 64][32])
 {
@@ -768,7 +768,11 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
     // tile's node is structurally zero); whole 128-byte lines are loaded
     const int ncol = min((ns + 15) & ~15, nmax);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double *Ws = W + (size_t)s * nmax * nmax;
+    // the tile's rows lie in ONE 64-row block of the factor storage (dotmi_internal.hpp RowTile): row i, column c is at
+    // W[rt.off + (i - first row of the block) * rt.ld + (c - rt.c0)]
+    const RowTile rb = rt[(size_t)s * (nmax >> 6) + (i0 >> 6)];
+    const int ldw = rb.ld;
+    const double *Ws = W + (rb.off - (long long)(i0 & ~63) * ldw - rb.c0);
     const int *dm = dofmap + (size_t)s * nmax;
     const double *rp = q + (size_t)s * nmax;   // right-hand side in padded order (zeros on the padding)
     double2 r[MAXCH], pacc[MAXCH];
@@ -790,7 +794,7 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
         double2 y[SUB][MAXCH];
 #pragma unroll
         for (int rr = 0; rr < SUB; ++rr) {
-            const double *row = Ws + (size_t)min(ib + rr, ns - 1) * nmax;
+            const double *row = Ws + (long long)min(ib + rr, ns - 1) * ldw;
             // a row is zero right of its diagonal: stop at the end of its own 128-byte line, not of the tile
             const int rend = ((ib + rr) < ns) ? min(ncol, (ib + rr + 16) & ~15) : 0;
 #pragma unroll
@@ -874,6 +878,7 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restrict__ job,
                                                             const int *__restrict__ dofmap,
                                                             const double *__restrict__ W, int nmax,
+                                                            const RowTile *__restrict__ rt,
                                                             const double *__restrict__ q,
                                                             double *__restrict__ ppart, int nbmax,
                                                             const DevLoop *__restrict__ ctl)
@@ -895,14 +900,14 @@ __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restri
     }
 #endif
     if constexpr (THREADS == 256) {
-        if (len <= 512) backsolve_tile<256, 1, 32>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
-        else if (len <= 1024) backsolve_tile<256, 2, 16>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
-        else if (len <= 1536) backsolve_tile<256, 3, 8>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
-        else backsolve_tile<256, 5, 8>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
+        if (len <= 512) backsolve_tile<256, 1, 32>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
+        else if (len <= 1024) backsolve_tile<256, 2, 16>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
+        else if (len <= 1536) backsolve_tile<256, 3, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
+        else backsolve_tile<256, 5, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
     } else {
-        if (len <= 1024) backsolve_tile<512, 1, 32>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
-        else if (len <= 2048) backsolve_tile<512, 2, 16>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
-        else backsolve_tile<512, 4, 8>(jb, dofmap, W, nmax, q, ppart, nbmax, sm);
+        if (len <= 1024) backsolve_tile<512, 1, 32>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
+        else if (len <= 2048) backsolve_tile<512, 2, 16>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
+        else backsolve_tile<512, 4, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
     }
 #ifdef BS_PROFILE
     __syncthreads();
@@ -979,6 +984,7 @@ __global__ __launch_bounds__(BSL_THREADS) void backsolve_long_kernel(const int4 
                                                                      const int2 *__restrict__ lwork,
                                                                      const int *__restrict__ dofmap,
                                                                      const double *__restrict__ W, int nmax,
+                                                                     const RowTile *__restrict__ rt,
                                                                      const double *__restrict__ q,
                                                                      double *__restrict__ tdots, int maxChunks,
                                                                      double *__restrict__ ppart, int nbmax,
@@ -995,7 +1001,9 @@ __global__ __launch_bounds__(BSL_THREADS) void backsolve_long_kernel(const int4 
     const int ncol = min((ns + 15) & ~15, nmax);
     const int c0 = cb + wk.y * BSL_CW;           // this workgroup's columns [c0, c0 + BSL_CW) ∩ [cb, ncol)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const double *Ws = W + (size_t)s * nmax * nmax;
+    const RowTile rb = rt[(size_t)s * (nmax >> 6) + (i0 >> 6)];
+    const int ldw = rb.ld;
+    const double *Ws = W + (rb.off - (long long)(i0 & ~63) * ldw - rb.c0);
     const int *dm = dofmap + (size_t)s * nmax;
     int cend[BSL_CH];
     double2 r[BSL_CH], pacc[BSL_CH];
@@ -1024,7 +1032,7 @@ __global__ __launch_bounds__(BSL_THREADS) void backsolve_long_kernel(const int4 
         double2 y[8][BSL_CH];
 #pragma unroll
         for (int rr = 0; rr < 8; ++rr) {
-            const double *row = Ws + (size_t)min(ib + rr, ns - 1) * nmax;
+            const double *row = Ws + (long long)min(ib + rr, ns - 1) * ldw;
             const int rend = ((ib + rr) < ns) ? min(ncol, (ib + rr + 16) & ~15) : 0;
 #pragma unroll
             for (int m = 0; m < BSL_CH; ++m) {
@@ -1094,24 +1102,24 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
     if (nW > 0) {
         if (timed)
             hipExtLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, ev0, nN > 0 ? (hipEvent_t) nullptr : ev1, 0,
-                                  P.tile, P.dofmap, P.W, P.nmax, (const double *)P.rpad, P.ppart, P.nbmax, ctl);
+                                  P.tile, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, ctl);
         else
-            hipLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax, P.rpad,
+            hipLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax, P.rt, P.rpad,
                                P.ppart, P.nbmax, ctl);
     }
     if (nN > 0) {
         if (timed)
             hipExtLaunchKernelGGL((backsolve_kernel<256>), dim3(nN), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
-                                  P.tile + nW, P.dofmap, P.W, P.nmax, (const double *)P.rpad, P.ppart, P.nbmax, ctl);
+                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, ctl);
         else
-            hipLaunchKernelGGL((backsolve_kernel<256>), dim3(nN), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax,
+            hipLaunchKernelGGL((backsolve_kernel<256>), dim3(nN), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax, P.rt,
                                P.rpad, P.ppart, P.nbmax, ctl);
     }
     if (P.nltiles > 0) {
         hipLaunchKernelGGL((backsolve_long_kernel<0>), dim3(P.nlwork), dim3(BSL_THREADS), 0, st, P.ltile, P.lwork, P.dofmap,
-                           P.W, P.nmax, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl);
+                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl);
         hipLaunchKernelGGL((backsolve_long_kernel<1>), dim3(P.nlwork), dim3(BSL_THREADS), 0, st, P.ltile, P.lwork, P.dofmap,
-                           P.W, P.nmax, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl);
+                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl);
     }
     if (!P.mt_ptr)   // merge_tiles_kernel sums the tile partials itself
         hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.trange,
@@ -1137,17 +1145,17 @@ void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, con
                        q, P.rpad + (size_t)ls * P.nmax);
     if (njobs > 0) {
         if (P.maxTileLen <= 2560)
-            hipLaunchKernelGGL((backsolve_kernel<256>), dim3(njobs), dim3(256), 0, st, job, P.dofmap, P.W, P.nmax, P.rpad,
+            hipLaunchKernelGGL((backsolve_kernel<256>), dim3(njobs), dim3(256), 0, st, job, P.dofmap, P.W, P.nmax, P.rt, P.rpad,
                                P.ppart, P.nbmax, (const DevLoop *)nullptr);
         else
-            hipLaunchKernelGGL((backsolve_kernel<512>), dim3(njobs), dim3(512), 0, st, job, P.dofmap, P.W, P.nmax, P.rpad,
+            hipLaunchKernelGGL((backsolve_kernel<512>), dim3(njobs), dim3(512), 0, st, job, P.dofmap, P.W, P.nmax, P.rt, P.rpad,
                                P.ppart, P.nbmax, (const DevLoop *)nullptr);
     }
     if (nlwork > 0) {   // rows beyond the register tile: the two-phase kernel on this part's work items
         hipLaunchKernelGGL((backsolve_long_kernel<0>), dim3(nlwork), dim3(BSL_THREADS), 0, st, P.ltileByPart, lwork, P.dofmap,
-                           P.W, P.nmax, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, (const DevLoop *)nullptr);
+                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, (const DevLoop *)nullptr);
         hipLaunchKernelGGL((backsolve_long_kernel<1>), dim3(nlwork), dim3(BSL_THREADS), 0, st, P.ltileByPart, lwork, P.dofmap,
-                           P.W, P.nmax, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, (const DevLoop *)nullptr);
+                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, (const DevLoop *)nullptr);
     }
     hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, 1), dim3(256), 0, st, P.trange, P.ppart, P.nmax,
                        P.nbmax, P.psub, (const DevLoop *)nullptr, ls);
@@ -1507,10 +1515,10 @@ __global__ __launch_bounds__(256) void tile_task_kernel(const TileTask *__restri
     for (int q = 0; q < 4; ++q) acc[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
     Blk64 ra, rb;
     if (t.nprod > 0) {
-        ra = blk64_load(pl[0].a, t.lda, tid);
-        if (pl[0].b != pl[0].a) rb = blk64_load(pl[0].b, t.ldb, tid);
+        ra = blk64_load(pl[0].a, pl[0].lda, tid);
+        if (pl[0].b != pl[0].a) rb = blk64_load(pl[0].b, pl[0].ldb, tid);
     } else if (t.post == TP_ROW) {
-        ra = blk64_load(t.q, t.lda, tid);
+        ra = blk64_load(t.q, t.ldq, tid);
     }
     if (t.init) {
         blk64_to_lds(blk64_load(t.c, t.ldc, tid), La, tid);
@@ -1527,10 +1535,10 @@ __global__ __launch_bounds__(256) void tile_task_kernel(const TileTask *__restri
         if (!same) blk64_to_lds(rb, Lb, tid);
         __syncthreads();
         if (p + 1 < t.nprod) {
-            ra = blk64_load(pl[p + 1].a, t.lda, tid);
-            if (pl[p + 1].b != pl[p + 1].a) rb = blk64_load(pl[p + 1].b, t.ldb, tid);
+            ra = blk64_load(pl[p + 1].a, pl[p + 1].lda, tid);
+            if (pl[p + 1].b != pl[p + 1].a) rb = blk64_load(pl[p + 1].b, pl[p + 1].ldb, tid);
         } else if (t.post == TP_ROW) {
-            ra = blk64_load(t.q, t.lda, tid);   // Q_kk for the final multiplication
+            ra = blk64_load(t.q, t.ldq, tid);   // Q_kk for the final multiplication
         }
         if (fact) mfma_acc64<true>(acc, La, same ? La : Lb, -1.0, tid);
         else mfma_acc64<false>(acc, La, Lb, 1.0, tid);
@@ -1584,17 +1592,18 @@ void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods,
 }
 
 // zero a list of 64 x 64 tiles (the tiles a factorisation leaves non-zero, before the refill)
-__global__ __launch_bounds__(256) void clear_tiles_kernel(double *const *__restrict__ tiles, int lda)
+__global__ __launch_bounds__(256) void clear_tiles_kernel(double *const *__restrict__ tiles, const int *__restrict__ lds_)
 {
     double *tp = tiles[blockIdx.x];
+    const int lda = lds_[blockIdx.x];
     for (int idx = threadIdx.x; idx < 64 * 32; idx += 256) {
         const int c = idx >> 5, r2 = idx & 31;
         *reinterpret_cast<double2 *>(tp + (size_t)c * lda + 2 * r2) = make_double2(0.0, 0.0);
     }
 }
-void launch_clear_tiles(double *const *tiles, int ntiles, int lda, hipStream_t st)
+void launch_clear_tiles(double *const *tiles, const int *lds_, int ntiles, hipStream_t st)
 {
-    if (ntiles > 0) hipLaunchKernelGGL(clear_tiles_kernel, dim3(ntiles), dim3(256), 0, st, tiles, lda);
+    if (ntiles > 0) hipLaunchKernelGGL(clear_tiles_kernel, dim3(ntiles), dim3(256), 0, st, tiles, lds_);
 }
 
 // dst block <- src block (column-major blocks inside strided batches); zero when src == nullptr
@@ -2457,15 +2466,17 @@ void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream
 }
 
 // dense principal sub-matrices: W_s[(3i+r)*lda + 3j+c] = H[l2g_i, l2g_j][r][c]
-__global__ __launch_bounds__(256) void dense_fill_kernel(int nfill, const long long *__restrict__ dst,
-                                                         const int *__restrict__ src, int lda,
+__global__ __launch_bounds__(256) void dense_fill_kernel(long long nfill9, const long long *__restrict__ dst,
+                                                         const int *__restrict__ src,
                                                          const double *__restrict__ Hval,
                                                          double *__restrict__ W)
 {
+    // one thread per scalar of a 3x3 block: dst[t] = its place in the factor storage, or -1 when that place is not
+    // stored (the mirror copy right of a row block's diagonal tile in the compact layout)
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)nfill * 9) return;
-    const int f = (int)(t / 9), rc = (int)(t % 9);
-    W[dst[f] + (long long)(rc / 3) * lda + rc % 3] = Hval[(size_t)9 * src[f] + rc];
+    if (t >= nfill9) return;
+    const long long d = dst[t];
+    if (d >= 0) W[d] = Hval[(size_t)9 * src[t / 9] + t % 9];
 }
 __global__ void pad_identity_kernel(int npad, const long long *__restrict__ dst, double *__restrict__ W)
 {
@@ -2494,8 +2505,8 @@ void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st)
     // the caller has cleared W (or the blocks of it a factorisation dirtied)
     if (P.nfill) {
         const long long tot = (long long)P.nfill * 9;
-        hipLaunchKernelGGL(dense_fill_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, P.nfill,
-                           P.fill_dst, P.fill_src, P.nmax, Hval, P.W);
+        hipLaunchKernelGGL(dense_fill_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot,
+                           P.fill_dst, P.fill_src, Hval, P.W);
     }
     if (P.npad)
         hipLaunchKernelGGL(pad_identity_kernel, dim3((P.npad + 255) / 256), dim3(256), 0, st, P.npad,

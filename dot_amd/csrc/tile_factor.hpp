@@ -40,12 +40,13 @@ enum TilePost {
 
 struct TileProd {
     double *a, *b;   // origins of the two tiles (column-major)
+    int lda, ldb;    // their leading dimensions (a tile's rows live in one row block of the factor storage; scratch: 64)
 };
 struct TileTask {
     int form, init, post, nprod;   // TileForm, read c first?, TilePost, number of products
     int first, sub;                // products [first, first + nprod) of the level-ordered product array; owned subdomain
-    int lda, ldb, ldc;             // leading dimensions of the A tiles, the B tiles and the c tile (scratch tiles: 64)
-    int pivotBase;                 // TP_DIAG: scalar offset of the tile's first row (for the non-SPD report)
+    int ldc, ldq;                  // leading dimensions of the c tile and of the q tile
+    int pivotBase, pad;            // TP_DIAG: scalar offset of the tile's first row (for the non-SPD report)
     double *c;                     // the tile read (init) and written
     double *q;                     // TP_ROW: tile of Q_kk
 };
@@ -55,6 +56,7 @@ struct TileSchedule {
     std::vector<TileProd> prods;      // in task order
     std::vector<int> levelStart;      // tasks of level l are [levelStart[l], levelStart[l+1])
     std::vector<double *> clearTiles; // origins of the tiles a factorisation leaves non-zero (cleared before the refill)
+    std::vector<int> clearLd;         // and their leading dimensions
     size_t scratchTiles = 0;          // 64 x 64 scratch tiles needed (T_ij)
     double flops = 0;                 // FP64 flop of one factorisation as executed
     long long liveTiles = 0, qTiles = 0;
@@ -69,12 +71,17 @@ struct TileTaskL {
     std::vector<TileProd> prods;
 };
 
-inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std::vector<uint8_t> &live,
-                                 std::vector<uint8_t> pat /* by value: gets the fill */, double *scratch, size_t &scratchNext,
-                                 std::vector<TileTaskL> &out, std::vector<double *> &clearTiles, double &flops,
-                                 long long &qTiles, int eagerMin = 2, int eagerChunk = 1)
+// rtOff / rtLd / rtC0: the subdomain's row blocks of the factor storage (dotmi_internal.hpp RowTile), W its base.  Tile
+// (i, j) of the column-major matrix = memory rows of block j, memory columns 64 i ...: origin W + off_j + 64 i - c0_j,
+// leading dimension ld_j.
+inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rtOff, const int *rtLd, const int *rtC0,
+                                 const std::vector<uint8_t> &live, std::vector<uint8_t> pat /* by value: gets the fill */,
+                                 double *scratch, size_t &scratchNext, std::vector<TileTaskL> &out,
+                                 std::vector<double *> &clearTiles, std::vector<int> &clearLd, double &flops, long long &qTiles,
+                                 int eagerMin = 2, int eagerChunk = 1)
 {
-    auto tile = [&](int i, int j) { return W + (size_t)j * TILE * lda + (size_t)i * TILE; };
+    auto tile = [&](int i, int j) { return W + rtOff[j] + (long long)i * TILE - rtC0[j]; };
+    auto tld = [&](int j) { return rtLd[j]; };
     auto P = [&](int i, int j) -> uint8_t & { return pat[(size_t)i * nt + j]; };
     for (int j = 0; j < nt; ++j)
         if (live[j]) P(j, j) = 1;
@@ -118,8 +125,8 @@ inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std:
     };
     const int EAGER_MIN = eagerMin;   // early products a task on the critical path may keep (besides the last level's)
     const size_t CHUNK = (size_t)std::max(1, eagerChunk);   // early products per eager task (ties in availability stay together)
-    auto emit = [&](int row, int form, int post, double *c, int ldc, double *q, int lda_, int ldb_, int pivotBase,
-                    std::vector<PA> &pa, int minFinal, bool initFromC) -> int {
+    auto emit = [&](int row, int form, int post, double *c, int ldc, double *q, int ldq, int pivotBase, std::vector<PA> &pa,
+                    int minFinal, bool initFromC) -> int {
         std::stable_sort(pa.begin(), pa.end(), [](const PA &x, const PA &y) { return x.avail < y.avail; });
         int amax = 0;
         for (auto &x : pa) amax = std::max(amax, x.avail);
@@ -135,7 +142,7 @@ inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std:
             size_t k1 = std::min(nEarly, k0 + CHUNK);
             while (k1 < nEarly && pa[k1].avail == pa[k1 - 1].avail) ++k1;
             TileTaskL E;
-            E.t = TileTask{form, have ? 1 : 0, TP_STORE, 0, 0, sub, lda_, ldb_, ldc, 0, c, nullptr};
+            E.t = TileTask{form, have ? 1 : 0, TP_STORE, 0, 0, sub, ldc, 0, 0, 0, c, nullptr};
             for (size_t k = k0; k < k1; ++k) E.prods.push_back(pa[k].p);
             E.level = pa[k1 - 1].avail + 1;
             E.row = row;
@@ -145,7 +152,7 @@ inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std:
             k0 = k1;
         }
         TileTaskL F;
-        F.t = TileTask{form, have ? 1 : 0, post, 0, 0, sub, lda_, ldb_, ldc, pivotBase, c, q};
+        F.t = TileTask{form, have ? 1 : 0, post, 0, 0, sub, ldc, ldq, pivotBase, 0, c, q};
         for (size_t k = nEarly; k < pa.size(); ++k) F.prods.push_back(pa[k].p);
         F.level = lf;
         F.row = row;
@@ -164,13 +171,14 @@ inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std:
             if (!Rp(k, j)) continue;
             pa.clear();
             for (int m = 0; m < k; ++m)
-                if (Rp(m, k) && Rp(m, j)) pa.push_back({{tile(m, k), tile(m, j)}, std::max(LR(m, k), LR(m, j))});
-            LR(k, j) = emit(k, TF_FACT, TP_ROW, tile(k, j), lda, tile(k, k), lda, lda, 0, pa, lvD[k], true);
+                if (Rp(m, k) && Rp(m, j))
+                    pa.push_back({{tile(m, k), tile(m, j), tld(k), tld(j)}, std::max(LR(m, k), LR(m, j))});
+            LR(k, j) = emit(k, TF_FACT, TP_ROW, tile(k, j), tld(j), tile(k, k), tld(k), 0, pa, lvD[k], true);
         }
         pa.clear();
         for (int m = 0; m < j; ++m)
-            if (Rp(m, j)) pa.push_back({{tile(m, j), tile(m, j)}, LR(m, j)});
-        lvD[j] = emit(j, TF_FACT, TP_DIAG, tile(j, j), lda, nullptr, lda, lda, j * TILE, pa, 0, true);
+            if (Rp(m, j)) pa.push_back({{tile(m, j), tile(m, j), tld(j), tld(j)}, LR(m, j)});
+        lvD[j] = emit(j, TF_FACT, TP_DIAG, tile(j, j), tld(j), nullptr, 0, j * TILE, pa, 0, true);
     }
     // levels of the inversion; lvQ(i,j) = level after which tile (i,j) holds Q_ij
     std::vector<int> lvQ((size_t)nt * nt, 0);
@@ -180,19 +188,22 @@ inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std:
     for (int j = 0; j < nt; ++j) {
         if (!live[j]) continue;
         clearTiles.push_back(tile(j, j));
+        clearLd.push_back(tld(j));
         ++qTiles;
         std::vector<int> lvT(nt, 0);
         std::vector<double *> tsc(nt, nullptr);
         for (int i : qcol[j]) {
             if (i == j) continue;
             clearTiles.push_back(tile(i, j));
+            clearLd.push_back(tld(j));
             ++qTiles;
             double *ts = scratch + (scratchNext++) * (size_t)TILE * TILE;
             tsc[i] = ts;
             pa.clear();
             for (int m = i; m < j; ++m)
-                if (Qp(i, m) && Rp(m, j)) pa.push_back({{tile(i, m), tile(m, j)}, std::max(LQ(i, m), LR(m, j))});
-            lvT[i] = emit(i, TF_INV, TP_STORE, ts, TILE, nullptr, lda, lda, 0, pa, 0, false);
+                if (Qp(i, m) && Rp(m, j))
+                    pa.push_back({{tile(i, m), tile(m, j), tld(m), tld(j)}, std::max(LQ(i, m), LR(m, j))});
+            lvT[i] = emit(i, TF_INV, TP_STORE, ts, TILE, nullptr, 0, 0, pa, 0, false);
         }
         // QFIN(i,j) overwrites R_ij: after every reader of R_ij -- DIAG(j), ROW(k,j) for i < k < j, ROW(j,j') for j' > j,
         // TINV(i',j) for i' <= i (their eager parts run earlier than their final tasks, whose levels are used here)
@@ -208,8 +219,8 @@ inline void plan_subdomain_tiles(int sub, int nt, int lda, double *W, const std:
                     if (Rp(i, j2) && Rp(j, j2)) lv = std::max(lv, LR(j, j2));
             }
             pa.clear();
-            pa.push_back({{tsc[i], tile(j, j)}, lv});
-            LQ(i, j) = emit(i, TF_INV, TP_NEG, tile(i, j), lda, nullptr, TILE, lda, 0, pa, 0, false);
+            pa.push_back({{tsc[i], tile(j, j), TILE, tld(j)}, lv});
+            LQ(i, j) = emit(i, TF_INV, TP_NEG, tile(i, j), tld(j), nullptr, 0, 0, pa, 0, false);
         }
     }
 }

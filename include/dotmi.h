@@ -251,6 +251,9 @@ int32_t dotmi_part_size(const dotmi_handle *h, int32_t part);
 /* padded scalar size of the dense block every subdomain of this rank is stored in (the shared dissection layout: node
  * sizes are the maximum over the subdomains, rounded up to 64) -- what the factorisation's flop count is executed on */
 int32_t dotmi_padded_size(const dotmi_handle *h);
+/* bytes of HBM that hold the factors X_s of this rank's subdomains (compact 64-row blocks: ~1.2x the structural
+ * non-zeros dotmi_step_stats.precond_bytes counts; DOTMI_TILE_FACTOR=0: nParts x padded_size^2 x 8) */
+int64_t dotmi_factor_storage_bytes(const dotmi_handle *h);
 int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *M, int32_t *l2g);
 
 /* ---- measurement ------------------------------------------------------------------------------ */

@@ -8,6 +8,7 @@ from dot_amd.timestepper import DOTTimeStepper
 name = sys.argv[1]; nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 t0 = time.time(); sc, ep, n = load_workload(name); t1 = time.time()
 ts = DOTTimeStepper(sc, ep, n, flags=dl.FLAG_TIME_BACKSOLVE); t2 = time.time()
+print(f"factor storage {dl.load().dotmi_factor_storage_bytes(ts._h)/1e9:.3f} GB", flush=True)
 print(f"{name}: nV {sc.V_rest.shape[0]} nT {sc.T.shape[0]} parts {n} | load {t1-t0:.1f}s create {t2-t1:.1f}s tol {ts.targetGRes:.4e}", flush=True)
 for k in range(nsteps):
     t = time.time(); rc = ts.solve(1); st = ts.last_stats
