@@ -87,10 +87,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def pmc_by_kernel(workload):
+        """HBM bytes per launch of every kernel class from the PMC counters (FETCH_SIZE / WRITE_SIZE need their own
+        rocprofv3 passes, so they are collected separately on the same kernels + workload by tools/pmc_kernels.sh and
+        committed under profiles/): -> ({bench kernel name: bytes}, file) or ({}, None)"""
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")), reverse=True):
+            with open(f) as fh:
+                rec = json.load(fh)
+            if rec.get("workload") != workload or "kernels" not in rec:
+                continue
+            K = rec["kernels"]
+
+            def pick(cls, must=None, total=False):
+                inst = {k: v for k, v in K.get(cls, {}).items() if "hbm_bytes_per_launch" in v and (must is None or must in k)}
+                if not inst:
+                    return None
+                vals = [v["hbm_bytes_per_launch"] for v in inst.values()]
+                return int(sum(vals)) if total else int(vals[0])
+            out = {"elem_energy_grad": pick("elem_pass", "true,"), "elem_energy": pick("elem_pass", "false,"),
+                   "vertex_gather": pick("vertex_gather", "<false>"), "spmv_dots": pick("spmv_dots"),
+                   "backsolve": pick("backsolve", total=True), "merge": pick("merge", "<false>"),
+                   "build_qpad": pick("build_qpad", "<false>"), "build_p": pick("build_p", "<false>"),
+                   "step_forward": pick("step_forward"), "elem_hessian": pick("elem_hessian"), "assemble": pick("assemble")}
+            return {k: v for k, v in out.items() if v}, os.path.relpath(f, ROOT)
+        return {}, None
+
     def pmc_traffic(workload):
-        """HBM bytes of one back-solve launch from the PMC counters (FETCH_SIZE / WRITE_SIZE need their own rocprofv3
-        passes, so they are collected separately on the same kernel + workload by tools/pmc_backsolve.sh and committed
-        under profiles/): -> (bytes, file) or (None, None)"""
+        """HBM bytes of one back-solve (all its launches) from the newest committed PMC file of this workload"""
+        t, f = pmc_by_kernel(workload)
+        if "backsolve" in t:
+            return t["backsolve"], f
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_backsolve_pmc*.json")), reverse=True):
             with open(f) as fh:
@@ -108,6 +135,7 @@ def main():
         if not hasattr(L, "dotmi_bench_kernel"):
             return out
         import ctypes as C
+        traffic, tsrc = pmc_by_kernel(rec["workload"]) if world == 1 else ({}, None)
         for kind, name in enumerate(dl.BENCH_KERNELS):
             ms, nbytes = C.c_double(), C.c_int64()
             rc = L.dotmi_bench_kernel(ts._h, kind, 20, C.byref(ms), C.byref(nbytes))
@@ -115,7 +143,8 @@ def main():
                 continue
             gbs = nbytes.value / (ms.value * 1e-3) / 1e9
             out.append({"kernel": name, "us": round(1e3 * ms.value, 2), "algorithmic_bytes": int(nbytes.value),
-                        "GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)})
+                        "GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                        "traffic": traffic.get(name), "traffic_source": tsrc if name in traffic else None})
         return out
 
     def reference_cholmod_leg(sc2, ep2, nparts, orc):
@@ -239,6 +268,7 @@ def main():
             "roofline": roofline,
             "collectives": collectives,
             "_ns": [int(v) for v in ns],
+            "factor_storage_bytes": int(L.dotmi_factor_storage_bytes(ts._h)),
             "part_sizes": {"live_min": int(min(ns)), "live_mean": round(float(np.mean(ns)), 1), "live_max": int(max(ns)),
                            "padded": nmax},
         }
@@ -261,25 +291,16 @@ def main():
     fact_ms = float(np.mean([s.ms_factor for s in stats]))
     fact_tf = stats[0].factor_flops / (fact_ms * 1e-3) / 1e12 if fact_ms > 0 else 0.0
     roofline_factor = {
-        "bound": "mfma", "kernel": "block-sparse inverse-Cholesky of the subdomain blocks (rocBLAS dgemm_strided_batched "
-        "+ chol_inv_node128 / chol_inv_base), once per step",
+        "bound": "mfma", "kernel": "tile_task_kernel: block-sparse inverse-Cholesky of the subdomain blocks as level-scheduled 64x64 "
+        "tile tasks (v_mfma_f64_16x16x4_f64 from LDS), once per step",
         "achieved": round(fact_tf, 2), "peak": FP64_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(fact_tf / FP64_MFMA_PEAK, 4),
         "flop_per_factorisation": float(stats[0].factor_flops), "avg_ms": round(fact_ms, 4),
-        "note": "flop as executed (identity padding included); the phase is bound by chains of small dependent kernels, "
-                "see profiles/r01_factor_experiments.txt",
+        "note": "flop as executed on the tiles that can be non-zero in each subdomain (padding only inside 64-tiles); see "
+                "profiles/r03_factor_tiles.txt",
     }
-    # how much of that is padding: every subdomain is factorised in the shared layout of `padded` rows while it has
-    # n_s live ones; cubic work => live share ~ mean((n_s / padded)^3).  For scale: a dense potrf + trtri on the live
-    # sizes would be (2/3) sum n_s^3 flop -- the dissection executes a fraction of that even with its padding.
-    ps = rec["part_sizes"]
-    live_share = float(np.mean([(n / ps["padded"]) ** 3 for n in rec["_ns"]]))
-    dense_flop = float(sum(2.0 / 3.0 * n ** 3 for n in rec["_ns"]))
-    roofline_factor.update({
-        "live_flop_share_estimate": round(live_share, 3),
-        "achieved_on_live_flop_estimate": round(fact_tf * live_share, 2),
-        "frac_on_live_flop_estimate": round(fact_tf * live_share / FP64_MFMA_PEAK, 4),
-        "dense_potrf_trtri_flop_on_live_sizes": dense_flop,
-    })
+    # for scale: a dense potrf + trtri on the live sizes would be (2/3) sum n_s^3 flop
+    roofline_factor["dense_potrf_trtri_flop_on_live_sizes"] = float(sum(2.0 / 3.0 * n ** 3 for n in rec["_ns"]))
+    roofline_factor["factor_storage_bytes"] = rec.get("factor_storage_bytes")
     del rec["_ns"]
 
     # ---- the other configurations BASELINE.json / north_star name, short runs (every rank takes part) --------------

@@ -4,13 +4,13 @@ tag=${1:-r02x}
 cd /tmp && export TMPDIR=/tmp
 out=/root/repo/gpurun_out
 mkdir -p $out
-python /root/repo/bench.py > $out/${tag}_bench.log 2>&1
+timeout 900 python /root/repo/bench.py > $out/${tag}_bench.log 2>&1
 grep '^{' $out/${tag}_bench.log | tail -1 > $out/${tag}_bench.json
 for wl in bar17K_twist bunny5K_LTSS synbar:140x35x35:256; do
-  slug=$(echo $wl | tr ':x' '__')
+  slug=$(echo $wl | tr ':x@' '___')
   steps=20; [ "$slug" != "${slug#synbar}" ] && steps=6
   rm -rf /tmp/prof_$tag
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python /root/repo/bench.py --workload $wl --steps $steps --no-cpu-baseline --extra-workloads none > /tmp/prof_$tag.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python /root/repo/bench.py --workload $wl --steps $steps --no-cpu-baseline --extra-workloads none > /tmp/prof_$tag.log 2>&1
   f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1)
   cp $f $out/${tag}_bench_${slug}_kernel_stats.csv
   grep '^{' /tmp/prof_$tag.log | tail -1 > $out/${tag}_bench_${slug}_under_rocprof.json
