@@ -96,6 +96,7 @@ struct Tuning {
     bool deviceLoop = true;   // DOTMI_DEVICE_LOOP=0  host-driven L-BFGS loop (same as DOTMI_FLAG_HOST_LOOP)
     int patchElems = 0;       // DOTMI_PATCH_ELEMS    elements per patch of the element pass (0: default)
     bool tileFactor = true;   // DOTMI_TILE_FACTOR=0  recursive rocBLAS formulation instead of the level-scheduled tile tasks
+    int tileThreads = 512;    // DOTMI_TILE_THREADS   256 or 512 threads per tile task (512: two waves per SIMD share a task)
     bool tileXcdOrder = true; // DOTMI_TILE_XCD_ORDER=0 tile tasks of a level longest first instead of grouped per XCD
     int tileEagerMin = 0;     // DOTMI_TILE_EAGER_MIN early products a critical-path tile task may keep
     int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
@@ -127,6 +128,7 @@ struct Tuning {
         t.deviceLoop = geti("DOTMI_DEVICE_LOOP", 1) != 0;
         t.patchElems = std::max(0, geti("DOTMI_PATCH_ELEMS", 0));
         t.tileFactor = geti("DOTMI_TILE_FACTOR", 1) != 0;
+        t.tileThreads = geti("DOTMI_TILE_THREADS", 512) == 256 ? 256 : 512;
         t.tileXcdOrder = geti("DOTMI_TILE_XCD_ORDER", 1) != 0;
         t.tileEagerMin = std::max(0, geti("DOTMI_TILE_EAGER_MIN", 0));
         t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
@@ -1367,7 +1369,7 @@ int issue_factor(dotmi_handle *h)
         // one launch per level of the static tile schedule; a launch boundary is the only synchronisation
         for (size_t l = 0; l + 1 < h->tlevelStart.size(); ++l)
             launch_tile_level(h->ttasks + h->tlevelStart[l], h->tlevelStart[l + 1] - h->tlevelStart[l], h->tprods, h->info_dev,
-                              h->st);
+                              h->st, h->tune.tileThreads);
         h->flopCount = h->tileFlops;
         return 0;
     }

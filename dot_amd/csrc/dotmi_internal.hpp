@@ -233,7 +233,7 @@ void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipS
 void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, hipStream_t st,
                              const LeafOffs &LO = LeafOffs());
 // one level of the tile schedule (tile_factor.hpp): one workgroup per task
-void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st);
+void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, int threads = 256);
 void launch_clear_tiles(double *const *tiles, const int *lds_, int ntiles, hipStream_t st);
 void launch_block_copy(double *dst, int ldd, size_t sd, const double *src, int lds_, size_t ss, int rows,
                        int cols, int batch, hipStream_t st, const LeafOffs &LO = LeafOffs());

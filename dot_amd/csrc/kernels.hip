@@ -1233,7 +1233,7 @@ __device__ __forceinline__ void mfma_gemm_small(FA A, FB B, FS store, int tid)
     static_assert(M == 16 || M == 32, "one tile per wave");
     const int lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
     const int ti = (M == 32) ? (w >> 1) : 0, tj = (M == 32) ? (w & 1) : 0;
-    const bool active = (M == 32) || w == 0;
+    const bool active = (M == 32 && w < 4) || w == 0;   // workgroups of more than four waves: the others only keep the barriers
     mfma_v4d acc = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
     if (active) {
 #pragma unroll
@@ -1475,120 +1475,159 @@ void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, h
 // product's two tiles in flight (global -> registers) while the current one is multiplied; the accumulator tile
 // stays in registers over the whole product list.  Product forms: TF_FACT  C -= A^T B ;  TF_INV  C += A B.
 // ------------------------------------------------------------------------------------------------
-template <bool TRANS_A>
-__device__ __forceinline__ void mfma_acc64(mfma_v4d (&acc)[4], double (*La)[CHOL_NB + 1], double (*Lb)[CHOL_NB + 1],
-                                           double sign, int tid)
+// THREADS = 256: wave w owns rows [16 w, 16 w + 16) and all four 16-column tiles;  THREADS = 512: wave w owns rows
+// [16 (w & 3), ...) and the two column tiles 2 (w >> 2), 2 (w >> 2) + 1 -- twice the waves per workgroup on the same
+// LDS, so one wave's LDS reads and tile loads overlap the other's matrix-core time.
+template <int THREADS>
+struct TileGeom {
+    static constexpr int NT = THREADS == 256 ? 4 : 2;   // 16-column tiles per wave
+    static constexpr int NL = 2048 / THREADS;           // 16-byte pieces of a 64 x 64 tile per thread
+};
+template <int THREADS>
+struct BlkT {
+    double2 v[TileGeom<THREADS>::NL];
+};
+template <int THREADS>
+__device__ __forceinline__ BlkT<THREADS> tile_load(const double *__restrict__ src, size_t ld, int tid)
 {
+    BlkT<THREADS> b;
+#pragma unroll
+    for (int u = 0; u < TileGeom<THREADS>::NL; ++u) {
+        const int idx2 = tid + THREADS * u;
+        b.v[u] = *reinterpret_cast<const double2 *>(src + (size_t)(idx2 >> 5) * ld + 2 * (idx2 & 31));
+    }
+    return b;
+}
+template <int THREADS>
+__device__ __forceinline__ void tile_to_lds(const BlkT<THREADS> &b, double (*G)[CHOL_NB + 1], int tid)
+{
+#pragma unroll
+    for (int u = 0; u < TileGeom<THREADS>::NL; ++u) {
+        const int idx2 = tid + THREADS * u, j = idx2 >> 5, k = 2 * (idx2 & 31);
+        G[k][j] = b.v[u].x;
+        G[k + 1][j] = b.v[u].y;
+    }
+}
+// LDS tile G[k][j] (element (row k, column j)) -> column-major global tile, 16-byte stores along the columns
+template <int THREADS>
+__device__ __forceinline__ void tile_store(double (*G)[CHOL_NB + 1], double *__restrict__ dst, size_t ld, int tid)
+{
+#pragma unroll
+    for (int u = 0; u < TileGeom<THREADS>::NL; ++u) {
+        const int idx2 = tid + THREADS * u, j = idx2 >> 5, k = 2 * (idx2 & 31);
+        *reinterpret_cast<double2 *>(dst + (size_t)j * ld + k) = make_double2(G[k][j], G[k + 1][j]);
+    }
+}
+template <int THREADS, bool TRANS_A>
+__device__ __forceinline__ void mfma_acc_tile(mfma_v4d (&acc)[TileGeom<THREADS>::NT], double (*La)[CHOL_NB + 1],
+                                              double (*Lb)[CHOL_NB + 1], double sign, int tid)
+{
+    constexpr int NT = TileGeom<THREADS>::NT;
     const int lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int rb = 16 * (w & 3), cb = 16 * NT * (w >> 2);
 #pragma unroll 4
     for (int kk = 0; kk < 16; ++kk) {
-        const double a = sign * (TRANS_A ? La[4 * kk + lk][16 * w + lr] : La[16 * w + lr][4 * kk + lk]);
+        const double a = sign * (TRANS_A ? La[4 * kk + lk][rb + lr] : La[rb + lr][4 * kk + lk]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const double b = Lb[4 * kk + lk][16 * t + lr];
+        for (int t = 0; t < NT; ++t) {
+            const double b = Lb[4 * kk + lk][cb + 16 * t + lr];
             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
         }
     }
 }
 
-// LDS tile G[k][j] (element (row k, column j)) -> column-major global tile, 16-byte stores along the columns
-__device__ __forceinline__ void blk64_store(double (*G)[CHOL_NB + 1], double *__restrict__ dst, size_t ld, int tid)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 2) void tile_task_kernel(const TileTask *__restrict__ tasks,
+                                                               const TileProd *__restrict__ prods, int *__restrict__ info)
 {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int idx2 = tid + 256 * u, j = idx2 >> 5, k = 2 * (idx2 & 31);
-        *reinterpret_cast<double2 *>(dst + (size_t)j * ld + k) = make_double2(G[k][j], G[k + 1][j]);
-    }
-}
-
-__global__ __launch_bounds__(256) void tile_task_kernel(const TileTask *__restrict__ tasks,
-                                                        const TileProd *__restrict__ prods, int *__restrict__ info)
-{
-    constexpr int NB = CHOL_NB, LD = NB + 1;
+    constexpr int NB = CHOL_NB, LD = NB + 1, NT = TileGeom<THREADS>::NT;
     __shared__ double La[NB][LD], Lb[NB][LD], T32[32][33], T16[16][17];
     const TileTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    const int rb = 16 * (w & 3), cb = 16 * NT * (w >> 2);   // this wave's rows / first column of the accumulator tiles
     const bool fact = t.form == TF_FACT;   // C -= A^T B on H tiles;  else C += A B
     const TileProd *pl = prods + t.first;
-    mfma_v4d acc[4];
+    mfma_v4d acc[NT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
-    Blk64 ra, rb;
+    for (int q = 0; q < NT; ++q) acc[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
+    BlkT<THREADS> ra, rbk;
     if (t.nprod > 0) {
-        ra = blk64_load(pl[0].a, pl[0].lda, tid);
-        if (pl[0].b != pl[0].a) rb = blk64_load(pl[0].b, pl[0].ldb, tid);
+        ra = tile_load<THREADS>(pl[0].a, pl[0].lda, tid);
+        if (pl[0].b != pl[0].a) rbk = tile_load<THREADS>(pl[0].b, pl[0].ldb, tid);
     } else if (t.post == TP_ROW) {
-        ra = blk64_load(t.q, t.ldq, tid);
+        ra = tile_load<THREADS>(t.q, t.ldq, tid);
     }
     if (t.init) {
-        blk64_to_lds(blk64_load(t.c, t.ldc, tid), La, tid);
+        tile_to_lds<THREADS>(tile_load<THREADS>(t.c, t.ldc, tid), La, tid);
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NT; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[q][r] = La[16 * w + lk + 4 * r][16 * q + lr];
+            for (int r = 0; r < 4; ++r) acc[q][r] = La[rb + lk + 4 * r][cb + 16 * q + lr];
         __syncthreads();
     }
     for (int p = 0; p < t.nprod; ++p) {
         const bool same = pl[p].b == pl[p].a;
-        blk64_to_lds(ra, La, tid);
-        if (!same) blk64_to_lds(rb, Lb, tid);
+        tile_to_lds<THREADS>(ra, La, tid);
+        if (!same) tile_to_lds<THREADS>(rbk, Lb, tid);
         __syncthreads();
         if (p + 1 < t.nprod) {
-            ra = blk64_load(pl[p + 1].a, pl[p + 1].lda, tid);
-            if (pl[p + 1].b != pl[p + 1].a) rb = blk64_load(pl[p + 1].b, pl[p + 1].ldb, tid);
+            ra = tile_load<THREADS>(pl[p + 1].a, pl[p + 1].lda, tid);
+            if (pl[p + 1].b != pl[p + 1].a) rbk = tile_load<THREADS>(pl[p + 1].b, pl[p + 1].ldb, tid);
         } else if (t.post == TP_ROW) {
-            ra = blk64_load(t.q, t.ldq, tid);   // Q_kk for the final multiplication
+            ra = tile_load<THREADS>(t.q, t.ldq, tid);   // Q_kk for the final multiplication
         }
-        if (fact) mfma_acc64<true>(acc, La, same ? La : Lb, -1.0, tid);
-        else mfma_acc64<false>(acc, La, Lb, 1.0, tid);
+        if (fact) mfma_acc_tile<THREADS, true>(acc, La, same ? La : Lb, -1.0, tid);
+        else mfma_acc_tile<THREADS, false>(acc, La, Lb, 1.0, tid);
         __syncthreads();
     }
     if (t.post == TP_STORE || t.post == TP_NEG) {
         const double sg = t.post == TP_NEG ? -1.0 : 1.0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NT; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) La[16 * w + lk + 4 * r][16 * q + lr] = sg * acc[q][r];
+            for (int r = 0; r < 4; ++r) La[rb + lk + 4 * r][cb + 16 * q + lr] = sg * acc[q][r];
         __syncthreads();
-        blk64_store(La, t.c, t.ldc, tid);
+        tile_store<THREADS>(La, t.c, t.ldc, tid);
         return;
     }
     // G = updated H tile -> LDS
     double (*G)[LD] = t.post == TP_ROW ? Lb : La;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NT; ++q)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) G[16 * w + lk + 4 * r][16 * q + lr] = acc[q][r];
+        for (int r = 0; r < 4; ++r) G[rb + lk + 4 * r][cb + 16 * q + lr] = acc[q][r];
     if (t.post == TP_ROW) {
         // R_kj = Q_kk^T G:  R(i,j) = sum_k X(i,k) G(k,j),  X(i,k) = element (k,i) of the stored Q_kk tile
-        blk64_to_lds(ra, La, tid);
+        tile_to_lds<THREADS>(ra, La, tid);
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
-        mfma_acc64<true>(acc, La, Lb, 1.0, tid);
+        for (int q = 0; q < NT; ++q) acc[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
+        mfma_acc_tile<THREADS, true>(acc, La, Lb, 1.0, tid);
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < NT; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Lb[16 * w + lk + 4 * r][16 * q + lr] = acc[q][r];
+            for (int r = 0; r < 4; ++r) Lb[rb + lk + 4 * r][cb + 16 * q + lr] = acc[q][r];
         __syncthreads();
-        blk64_store(Lb, t.c, t.ldc, tid);
+        tile_store<THREADS>(Lb, t.c, t.ldc, tid);
         return;
     }
     __syncthreads();
     const int bad = block_chol_inv<64>(La, Lb, 0, T32, T16, tid);
     // Q_jj = X^T: column i of the stored tile, row k <- X(i,k) (zero for k > i: the strictly lower part is cleared)
-    for (int idx = tid; idx < NB * NB; idx += 256) {
+    for (int idx = tid; idx < NB * NB; idx += THREADS) {
         const int i = idx / NB, k = idx % NB;
         t.c[(size_t)i * t.ldc + k] = Lb[i][k];
     }
     if (tid == 0 && bad) atomicMax(info + t.sub, t.pivotBase + bad);
 }
 
-void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st)
+void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, int threads)
 {
-    if (ntasks > 0) hipLaunchKernelGGL(tile_task_kernel, dim3(ntasks), dim3(256), 0, st, tasks, prods, info);
+    if (ntasks <= 0) return;
+    if (threads == 512) hipLaunchKernelGGL(tile_task_kernel<512>, dim3(ntasks), dim3(512), 0, st, tasks, prods, info);
+    else hipLaunchKernelGGL(tile_task_kernel<256>, dim3(ntasks), dim3(256), 0, st, tasks, prods, info);
 }
 
 // zero a list of 64 x 64 tiles (the tiles a factorisation leaves non-zero, before the refill)
