@@ -80,6 +80,7 @@ struct Tuning {
     int ndLevels = -1;        // DOTMI_ND_LEVELS      depth of the nested dissection (-1: nd_default_levels)
     int ndMin = 768;          // DOTMI_ND_MIN         smallest region (scalars) that is still split
     int tileRows = 0;         // DOTMI_TILE_ROWS      rows per back-solve tile (0: 64, or 32 for few subdomains)
+    int tileRowsLong = 64;    // DOTMI_TILE_ROWS_LONG rows per back-solve tile when the rows have more than 1536 columns
     bool splitBs = true;      // DOTMI_SPLIT_BS=0     one back-solve launch instead of wide / narrow tiles apart
     bool mergeTiles = true;   // DOTMI_MERGE_TILES=0  reduce_partial_p + merge instead of merge_tiles_kernel
     bool fuseLeaves = true;   // DOTMI_FUSE_LEAVES=0  one GEMM chain per leaf instead of equal-size leaves together
@@ -112,6 +113,7 @@ struct Tuning {
         if (t.ndLevels < -1) t.ndLevels = 0;
         t.ndMin = std::max(128, geti("DOTMI_ND_MIN", 768));
         if (const char *ev = getenv("DOTMI_TILE_ROWS")) t.tileRows = std::min(64, std::max(8, atoi(ev) / 8 * 8));
+        t.tileRowsLong = std::min(64, std::max(8, geti("DOTMI_TILE_ROWS_LONG", 64) / 8 * 8));
         t.splitBs = geti("DOTMI_SPLIT_BS", 1) != 0;
         t.mergeTiles = geti("DOTMI_MERGE_TILES", 1) != 0;
         t.fuseLeaves = geti("DOTMI_FUSE_LEAVES", 1) != 0;
@@ -625,8 +627,11 @@ int build_device_mesh(dotmi_handle *h)
             const int cb = N.a < 0 ? (ro & ~15) : N.off;
             // a tile stays inside one 64-row block of the factor storage (RowTile): the first tile of a region ends
             // at the next multiple of 64
+            // rows of more than 1536 columns (the separators of the upper tree levels) can take fewer rows per tile
+            // (DOTMI_TILE_ROWS_LONG): measured, no gain -- profiles/r03_factor_tiles.txt section E
+            const int trows = (ro + used - cb > 1536) ? std::min(tileRows, h->tune.tileRowsLong) : tileRows;
             for (int r0 = ro, rows = 0; r0 < ro + used; r0 += rows) {
-                rows = std::min(std::min(tileRows, ro + used - r0), 64 - (r0 & 63));
+                rows = std::min(std::min(trows, ro + used - r0), 64 - (r0 & 63));
                 tiles.push_back(make_int4(ls, r0, b | (rows << 16), cb));
                 ranges[ls].push_back(make_int2(cb, r0 + rows));
                 ++b;
