@@ -2029,6 +2029,106 @@ int dotmi_plan_shards(int32_t nParts, const int32_t *part_scalar_size, int32_t w
 
 const char *dotmi_last_error(const dotmi_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
+// host-only: the element patches of patches.hpp for all elements of a mesh.  First call with elem == NULL for the sizes
+// (n_patches, pv, n_slots), then with arrays of nPatches*PE (elem), 4*nPatches*PE (tl, epos: uint16), nPatches*PV (pv_gid,
+// pv_slot), nPatches (pv_cnt), nPatches*(PV+1) (c_ptr: uint16) and 2*nV (pp_rng).  tests/test_patches.py checks the
+// invariants the element pass relies on and replays the two-stage gradient sum in numpy.
+int dotmi_plan_patches(int32_t nV, int32_t nT, const int32_t *T, const double *X, int32_t PE, int32_t *n_patches, int32_t *pv,
+                       int32_t *n_slots, int32_t *elem, uint16_t *tl, uint16_t *epos, int32_t *pv_gid, int32_t *pv_slot,
+                       int32_t *pv_cnt, uint16_t *c_ptr, int32_t *pp_rng)
+{
+    if (nV < 1 || nT < 1 || !T || !X || (PE != 256 && PE != 512) || !n_patches || !pv || !n_slots) return DOTMI_E_INVALID;
+    std::vector<int> all(nT);
+    for (int e = 0; e < nT; ++e) all[e] = e;
+    const HostPatches H = build_patches(nV, T, X, all, PE);
+    *n_patches = H.nPatches;
+    *pv = H.PV;
+    *n_slots = H.nSlots;
+    if (!elem) return 0;
+    std::copy(H.elem.begin(), H.elem.end(), elem);
+    std::copy(H.tl.begin(), H.tl.end(), tl);
+    std::copy(H.epos.begin(), H.epos.end(), epos);
+    std::copy(H.pv_gid.begin(), H.pv_gid.end(), pv_gid);
+    std::copy(H.pv_slot.begin(), H.pv_slot.end(), pv_slot);
+    std::copy(H.pv_cnt.begin(), H.pv_cnt.end(), pv_cnt);
+    std::copy(H.c_ptr.begin(), H.c_ptr.end(), c_ptr);
+    std::copy(H.pp_rng.begin(), H.pp_rng.end(), pp_rng);
+    return 0;
+}
+
+// host-only: the level schedule of tile_factor.hpp for ONE block of nt x nt tiles with the given upper tile pattern, in the
+// compact row-block layout (c0[j] = first tile column stored for tile row j, c0[j] <= every pattern entry of column j).
+// Offsets are in doubles into one array: the factor storage first, the scratch tiles after it (*scratch_base).
+//   tasks: 10 int64 per task  {level, form, init, post, nprod, first product, c offset, q offset (-1), ldc, ldq}
+//   prods:  4 int64 per product {a offset, b offset, lda, ldb}
+// With tasks == NULL only the counts are returned.  The tests execute the schedule in numpy, level after level, and
+// compare with a dense inverse Cholesky factor (tests/test_tile_schedule.py).
+int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0, int32_t eager_min,
+                             int32_t eager_chunk, int64_t *tasks, int64_t *prods, int64_t *n_tasks, int64_t *n_prods,
+                             int64_t *n_levels, int64_t *storage, int64_t *scratch_base, int64_t *row_off, int32_t *row_ld)
+{
+    if (nt < 1 || !live || !pattern || !c0 || !n_tasks || !n_prods) return DOTMI_E_INVALID;
+    std::vector<long long> rtOff(nt, -1);
+    std::vector<int> rtLd(nt, 0), rtC0(nt, 0);
+    long long tot = 0;
+    for (int j = 0; j < nt; ++j) {
+        if (!live[j]) continue;
+        rtC0[j] = 64 * c0[j];
+        rtLd[j] = 64 * (j + 1) - rtC0[j];
+        rtOff[j] = tot;
+        tot += 64ll * rtLd[j];
+    }
+    double *const W = reinterpret_cast<double *>(1ull << 40);   // never dereferenced: only offsets leave this function
+    double *const scratch = W + tot;
+    std::vector<uint8_t> lv(live, live + nt), pat(pattern, pattern + (size_t)nt * nt);
+    std::vector<TileTaskL> all;
+    TileSchedule S;
+    size_t sn = 0;
+    plan_subdomain_tiles(0, nt, W, rtOff.data(), rtLd.data(), rtC0.data(), lv, pat, scratch, sn, all, S.clearTiles, S.clearLd,
+                         S.flops, S.qTiles, std::max(1, eager_min), std::max(1, eager_chunk));
+    std::vector<int> levelOf;
+    {
+        // finish_tile_schedule reorders inside levels; keep the level of every task
+        std::stable_sort(all.begin(), all.end(), [](const TileTaskL &a, const TileTaskL &b) { return a.level < b.level; });
+        for (auto &t : all) levelOf.push_back(t.level);
+    }
+    size_t np = 0;
+    for (auto &t : all) np += t.prods.size();
+    *n_tasks = (int64_t)all.size();
+    *n_prods = (int64_t)np;
+    if (n_levels) *n_levels = all.empty() ? 0 : all.back().level;
+    if (storage) *storage = tot;
+    if (scratch_base) *scratch_base = tot;
+    if (row_off)
+        for (int j = 0; j < nt; ++j) row_off[j] = rtOff[j];
+    if (row_ld)
+        for (int j = 0; j < nt; ++j) row_ld[j] = rtLd[j];
+    if (!tasks || !prods) return 0;
+    size_t pi = 0;
+    for (size_t k = 0; k < all.size(); ++k) {
+        const TileTask &t = all[k].t;
+        int64_t *o = tasks + 10 * k;
+        o[0] = all[k].level;
+        o[1] = t.form;
+        o[2] = t.init;
+        o[3] = t.post;
+        o[4] = (int64_t)all[k].prods.size();
+        o[5] = (int64_t)pi;
+        o[6] = t.c - W;
+        o[7] = t.q ? t.q - W : -1;
+        o[8] = t.ldc;
+        o[9] = t.ldq;
+        for (auto &pr : all[k].prods) {
+            int64_t *q = prods + 4 * pi++;
+            q[0] = pr.a - W;
+            q[1] = pr.b - W;
+            q[2] = pr.lda;
+            q[3] = pr.ldb;
+        }
+    }
+    return 0;
+}
+
 // host-only: the nested-dissection layout build_device_mesh() would use for parts [p0,p1)
 int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xrest, const int32_t *epart,
                       int32_t nParts, int32_t p0, int32_t p1, int32_t levels, int32_t min_split, int32_t node_cap,

@@ -193,6 +193,16 @@ int dotmi_plan_rank(int32_t nV, int32_t nT, const int32_t *T, const int32_t *epa
  * sizeS} (children -1 for a dense leaf, root = row 0); nmax: padded scalar size (multiple of 64);
  * pos: for every part in [p0,p1), for every local vertex in ascending global id, the padded scalar
  * position of its first dof.  levels < 0 / min_split < 128 select the defaults.  nodes, pos may be NULL. */
+/* (host only) the element patches of the element pass for all elements of a mesh (dot_amd/csrc/patches.hpp); call with
+ * elem == NULL for the sizes first.  tests/test_patches.py */
+int dotmi_plan_patches(int32_t nV, int32_t nT, const int32_t *T, const double *X, int32_t PE, int32_t *n_patches, int32_t *pv,
+                       int32_t *n_slots, int32_t *elem, uint16_t *tl, uint16_t *epos, int32_t *pv_gid, int32_t *pv_slot,
+                       int32_t *pv_cnt, uint16_t *c_ptr, int32_t *pp_rng);
+/* (host only) the level schedule of the tile factorisation for one nt x nt tile block with the given upper tile pattern in
+ * the compact row-block layout; see dot_amd/csrc/tile_factor.hpp and tests/test_tile_schedule.py */
+int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0, int32_t eager_min,
+                             int32_t eager_chunk, int64_t *tasks, int64_t *prods, int64_t *n_tasks, int64_t *n_prods,
+                             int64_t *n_levels, int64_t *storage, int64_t *scratch_base, int64_t *row_off, int32_t *row_ld);
 int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xrest, const int32_t *epart,
                       int32_t nParts, int32_t p0, int32_t p1, int32_t levels, int32_t min_split,
                       int32_t node_cap, int32_t *nodes, int32_t *n_nodes, int32_t *nmax, int32_t *pos);

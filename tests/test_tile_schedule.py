@@ -1,0 +1,177 @@
+"""The level schedule of the tile factorisation (dot_amd/csrc/tile_factor.hpp) executed in numpy on the CPU: the host-only
+entry dotmi_plan_tile_schedule returns the tasks of one block with their levels; running them level after level --
+every task of a level reading the state left by the levels before it -- must give the inverse Cholesky factor, no two
+tasks of a level may write the same tile, and no task may read a tile that another task of its level writes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from dot_amd import lib as dl
+
+TF_FACT, TF_INV = 0, 1
+TP_STORE, TP_DIAG, TP_ROW, TP_NEG = 0, 1, 2, 3
+
+
+def plan(nt, live, pat, c0, eager_min, eager_chunk):
+    L = C.CDLL(dl.LIB_PATH)
+    f = L.dotmi_plan_tile_schedule
+    u8, i32, i64 = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    f.argtypes = [C.c_int32, u8, u8, i32, C.c_int32, C.c_int32, i64, i64, i64, i64, i64, i64, i64, i64, i32]
+    live = np.ascontiguousarray(live, dtype=np.uint8)
+    pat = np.ascontiguousarray(pat, dtype=np.uint8)
+    c0 = np.ascontiguousarray(c0, dtype=np.int32)
+    n = [C.c_int64() for _ in range(5)]
+    roff, rld = np.zeros(nt, dtype=np.int64), np.zeros(nt, dtype=np.int32)
+    args = lambda t, p: (nt, live.ctypes.data_as(u8), pat.ctypes.data_as(u8), c0.ctypes.data_as(i32), eager_min, eager_chunk, t,
+                         p, C.byref(n[0]), C.byref(n[1]), C.byref(n[2]), C.byref(n[3]), C.byref(n[4]),
+                         roff.ctypes.data_as(i64), rld.ctypes.data_as(i32))
+    assert f(*args(None, None)) == 0
+    tasks = np.zeros((n[0].value, 10), dtype=np.int64)
+    prods = np.zeros((max(n[1].value, 1), 4), dtype=np.int64)
+    assert f(*args(tasks.ctypes.data_as(i64), prods.ctypes.data_as(i64))) == 0
+    return tasks, prods, n[2].value, n[3].value, roff, rld
+
+
+def nd_pattern(nt, leaves, seps, rng, drop=0.0):
+    """upper tile pattern of a nested-dissection ordered matrix: `leaves` diagonal bands, separators coupled to their leaves"""
+    pat = np.zeros((nt, nt), dtype=np.uint8)
+    c0 = np.arange(nt, dtype=np.int32)
+    for (a, b) in leaves:
+        for i in range(a, b):
+            for j in range(i, b):
+                if j - i <= 2 and rng.random() >= drop:
+                    pat[i, j] = 1
+            pat[i, i] = 1
+        c0[a:b] = a
+    for (a, b, first) in seps:          # separator rows a..b couple to every tile column from `first`
+        for j in range(a, b):
+            for i in range(first, j + 1):
+                if i >= a or rng.random() < 0.5:
+                    pat[i, j] = 1
+            pat[j, j] = 1
+        c0[a:b] = first
+    return pat, c0
+
+
+def run_schedule(nt, live, pat, c0, eager_min, eager_chunk, seed):
+    rng = np.random.default_rng(seed)
+    tasks, prods, nlev, storage, roff, rld = plan(nt, live, pat, c0, eager_min, eager_chunk)
+    n = 64 * nt
+    # an SPD matrix with exactly this tile pattern (symmetric), identity on the rows of non-live tiles
+    H = np.zeros((n, n))
+    for i in range(nt):
+        for j in range(i, nt):
+            if pat[i, j] and live[i] and live[j]:
+                B = rng.standard_normal((64, 64)) * 0.05
+                H[64 * i:64 * i + 64, 64 * j:64 * j + 64] = B
+    H = np.triu(H) + np.triu(H, 1).T
+    H += np.diag(np.abs(H).sum(1) + 1.0)
+    for j in range(nt):
+        if not live[j]:
+            H[64 * j:64 * j + 64, :] = 0
+            H[:, 64 * j:64 * j + 64] = 0
+            H[64 * j:64 * j + 64, 64 * j:64 * j + 64] = np.eye(64)
+    nscr = int(tasks[:, 6].max() // 4096 + 2)
+    M = np.zeros(storage + 4096 * nscr)
+
+    def tile(off, ld):      # column-major 64 x 64 view
+        return np.lib.stride_tricks.as_strided(M[off:], shape=(64, 64), strides=(8, 8 * ld))
+
+    # fill: column-major element (r, c), r <= c in tile terms, lives in row block c // 64
+    for j in range(nt):
+        if not live[j]:
+            continue
+        for i in range(int(c0[j]), j + 1):
+            tile(roff[j] + 64 * i - 64 * c0[j], rld[j])[:, :] = H[64 * i:64 * i + 64, 64 * j:64 * j + 64]
+    order = np.argsort(tasks[:, 0], kind="stable")
+    lv = 0
+    k = 0
+    while k < len(order):
+        lv = tasks[order[k], 0]
+        group = []
+        while k < len(order) and tasks[order[k], 0] == lv:
+            group.append(order[k]); k += 1
+        snap = M.copy()
+        written, read = set(), set()
+
+        def stile(off, ld):
+            return np.lib.stride_tricks.as_strided(snap[off:], shape=(64, 64), strides=(8, 8 * ld)).copy()
+        for t in group:
+            _, form, init, post, nprod, first, coff, qoff, ldc, ldq = tasks[t]
+            acc = stile(coff, ldc) if init else np.zeros((64, 64))
+            if init:
+                read.add(coff)
+            for p in range(first, first + nprod):
+                a, b, lda, ldb = prods[p]
+                A, Bm = stile(a, lda), stile(b, ldb)
+                read.update((a, b))
+                acc = acc - A.T @ Bm if form == TF_FACT else acc + A @ Bm
+            if post == TP_DIAG:
+                R = np.linalg.cholesky(acc).T          # acc = R^T R
+                out = np.linalg.inv(R)                  # Q_jj (upper)
+            elif post == TP_ROW:
+                read.add(qoff)
+                out = stile(qoff, ldq).T @ acc
+            elif post == TP_NEG:
+                out = -acc
+            else:
+                out = acc
+            assert coff not in written, "two tasks of one level write the same tile"
+            written.add(coff)
+            tile(coff, ldc)[:, :] = out
+        # a tile written in this level may only be read by the task that writes it (its own init)
+        for t in group:
+            _, form, init, post, nprod, first, coff, qoff, ldc, ldq = tasks[t]
+            others = written - {coff}
+            ops = {prods[p][0] for p in range(first, first + nprod)} | {prods[p][1] for p in range(first, first + nprod)}
+            if post == TP_ROW:
+                ops.add(qoff)
+            assert not (ops & others) and coff not in ops, "a task reads a tile that is written in its own level"
+    # compare with the dense inverse factor: H = R^T R, Q = R^-1 (upper), stored tile (i, j) = Q[64 i.., 64 j..]
+    Q = np.linalg.inv(np.linalg.cholesky(H).T)
+    worst = 0.0
+    for j in range(nt):
+        if not live[j]:
+            continue
+        for i in range(int(c0[j]), j + 1):
+            got = tile(roff[j] + 64 * i - 64 * c0[j], rld[j])
+            ref = Q[64 * i:64 * i + 64, 64 * j:64 * j + 64]
+            if i == j:
+                worst = max(worst, np.abs(np.triu(got) - ref).max())
+            elif np.abs(ref).max() > 0 or np.abs(got).max() > 0:
+                worst = max(worst, np.abs(got - ref).max())
+    # what lies outside the stored columns must be structurally zero in Q
+    for j in range(nt):
+        assert np.abs(Q[:64 * int(c0[j]), 64 * j:64 * j + 64]).max() < 1e-13 if c0[j] > 0 else True
+    return worst, nlev, len(tasks)
+
+
+@pytest.mark.parametrize("eager", [(1000, 1), (2, 1), (4, 4)])
+def test_schedule_of_a_two_level_dissection(eager):
+    """four leaves, two level-1 separators, a root separator; some padding-only tile rows"""
+    rng = np.random.default_rng(1)
+    nt = 14
+    leaves = [(0, 3), (3, 5), (6, 8), (8, 11)]
+    seps = [(5, 6, 0), (11, 12, 6), (12, 14, 0)]
+    pat, c0 = nd_pattern(nt, leaves, seps, rng)
+    live = np.ones(nt, dtype=np.uint8)
+    live[3] = 0            # a tile row of pure identity padding inside a leaf region
+    pat[3, :] = 0; pat[:, 3] = 0
+    worst, nlev, ntask = run_schedule(nt, live, pat, c0, eager[0], eager[1], seed=2)
+    assert worst < 1e-10, worst
+    assert nlev <= 2 * nt + 2          # ~two launches per tile column on the critical path
+
+
+def test_schedule_of_a_dense_block_and_of_random_patterns():
+    rng = np.random.default_rng(5)
+    nt = 6
+    pat = np.triu(np.ones((nt, nt), dtype=np.uint8))
+    worst, nlev, _ = run_schedule(nt, np.ones(nt, dtype=np.uint8), pat, np.zeros(nt, dtype=np.int32), 2, 1, seed=3)
+    assert worst < 1e-10 and nlev == 2 * nt + 1   # 2 per tile column + the last column of the inverse
+    for seed in range(4):
+        nt = int(rng.integers(4, 10))
+        pat = np.triu((rng.random((nt, nt)) < 0.35).astype(np.uint8))
+        np.fill_diagonal(pat, 1)
+        worst, _, _ = run_schedule(nt, np.ones(nt, dtype=np.uint8), pat, np.zeros(nt, dtype=np.int32), 3, 2, seed=10 + seed)
+        assert worst < 1e-9, (seed, worst)
