@@ -55,7 +55,8 @@ struct TileSchedule {
     std::vector<TileTask> tasks;      // level after level
     std::vector<TileProd> prods;      // in task order
     std::vector<int> levelStart;      // tasks of level l are [levelStart[l], levelStart[l+1])
-    std::vector<double *> clearTiles; // origins of the tiles a factorisation leaves non-zero (cleared before the refill)
+    std::vector<double *> clearTiles; // origins of the tiles the fill writes into (cleared before the refill; fill-in tiles are
+                                      // written before they are read)
     std::vector<int> clearLd;         // and their leading dimensions
     size_t scratchTiles = 0;          // 64 x 64 scratch tiles needed (T_ij)
     double flops = 0;                 // FP64 flop of one factorisation as executed
@@ -85,6 +86,8 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
     auto P = [&](int i, int j) -> uint8_t & { return pat[(size_t)i * nt + j]; };
     for (int j = 0; j < nt; ++j)
         if (live[j]) P(j, j) = 1;
+    const std::vector<uint8_t> hpat = pat;   // tiles the fill writes into (before the symbolic fill-in)
+    auto Hp = [&](int i, int j) { return hpat[(size_t)i * nt + j] != 0; };
     // symbolic factorisation: struct(R)
     for (int k = 0; k < nt; ++k) {
         if (!live[k]) continue;
@@ -173,7 +176,8 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
             for (int m = 0; m < k; ++m)
                 if (Rp(m, k) && Rp(m, j))
                     pa.push_back({{tile(m, k), tile(m, j), tld(k), tld(j)}, std::max(LR(m, k), LR(m, j))});
-            LR(k, j) = emit(k, TF_FACT, TP_ROW, tile(k, j), tld(j), tile(k, k), tld(k), 0, pa, lvD[k], true);
+            // a pure fill-in tile holds nothing to start from: its first task starts from zero, and nobody has to clear it
+            LR(k, j) = emit(k, TF_FACT, TP_ROW, tile(k, j), tld(j), tile(k, k), tld(k), 0, pa, lvD[k], Hp(k, j));
         }
         pa.clear();
         for (int m = 0; m < j; ++m)
@@ -194,8 +198,10 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
         std::vector<double *> tsc(nt, nullptr);
         for (int i : qcol[j]) {
             if (i == j) continue;
-            clearTiles.push_back(tile(i, j));
-            clearLd.push_back(tld(j));
+            if (Hp(i, j)) {   // only the tiles the fill writes into are read before they are written
+                clearTiles.push_back(tile(i, j));
+                clearLd.push_back(tld(j));
+            }
             ++qTiles;
             double *ts = scratch + (scratchNext++) * (size_t)TILE * TILE;
             tsc[i] = ts;

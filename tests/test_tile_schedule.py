@@ -73,7 +73,9 @@ def run_schedule(nt, live, pat, c0, eager_min, eager_chunk, seed):
             H[:, 64 * j:64 * j + 64] = 0
             H[64 * j:64 * j + 64, 64 * j:64 * j + 64] = np.eye(64)
     nscr = int(tasks[:, 6].max() // 4096 + 2)
-    M = np.zeros(storage + 4096 * nscr)
+    # everything starts as NaN: only the tiles the fill writes into (the pattern of H) are cleared and filled on the device;
+    # pure fill-in tiles and the scratch must be written before they are read
+    M = np.full(storage + 4096 * nscr, np.nan)
 
     def tile(off, ld):      # column-major 64 x 64 view
         return np.lib.stride_tricks.as_strided(M[off:], shape=(64, 64), strides=(8, 8 * ld))
@@ -83,7 +85,8 @@ def run_schedule(nt, live, pat, c0, eager_min, eager_chunk, seed):
         if not live[j]:
             continue
         for i in range(int(c0[j]), j + 1):
-            tile(roff[j] + 64 * i - 64 * c0[j], rld[j])[:, :] = H[64 * i:64 * i + 64, 64 * j:64 * j + 64]
+            if pat[i, j] or i == j:
+                tile(roff[j] + 64 * i - 64 * c0[j], rld[j])[:, :] = H[64 * i:64 * i + 64, 64 * j:64 * j + 64]
     order = np.argsort(tasks[:, 0], kind="stable")
     lv = 0
     k = 0
@@ -138,9 +141,13 @@ def run_schedule(nt, live, pat, c0, eager_min, eager_chunk, seed):
             got = tile(roff[j] + 64 * i - 64 * c0[j], rld[j])
             ref = Q[64 * i:64 * i + 64, 64 * j:64 * j + 64]
             if i == j:
+                assert np.isfinite(got).all()
                 worst = max(worst, np.abs(np.triu(got) - ref).max())
-            elif np.abs(ref).max() > 0 or np.abs(got).max() > 0:
+            elif np.abs(ref).max() > 0:
+                assert np.isfinite(got).all(), "a tile of Q was never written"
                 worst = max(worst, np.abs(got - ref).max())
+            else:
+                assert np.all(np.isnan(got)) or np.abs(got).max() < 1e-13   # outside the pattern of Q: untouched or zero
     # what lies outside the stored columns must be structurally zero in Q
     for j in range(nt):
         assert np.abs(Q[:64 * int(c0[j]), 64 * j:64 * j + 64]).max() < 1e-13 if c0[j] > 0 else True
