@@ -72,15 +72,19 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    comm_id = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl")
+
+    def fresh_comm_id():
+        """a new RCCL unique id per handle (an id serves ONE communicator), made on rank 0 and broadcast"""
+        if world <= 1:
+            return None
         buf = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             buf.copy_(torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8))
         dist.broadcast(buf, 0)
-        comm_id = bytes(buf.cpu().numpy().tobytes())
+        return bytes(buf.cpu().numpy().tobytes())
 
     def sync():
         if world > 1:
@@ -177,7 +181,7 @@ def main():
         """-> (record, per-step stats, scene, timestepper is closed)"""
         sc, ep, nparts = load_workload(name)
         cfg = sc.cfg
-        ts = DOTTimeStepper(sc, ep, nparts, device=local_rank, rank=rank, world=world, comm_id=comm_id,
+        ts = DOTTimeStepper(sc, ep, nparts, device=local_rank, rank=rank, world=world, comm_id=fresh_comm_id(),
                             flags=dl.FLAG_TIME_BACKSOLVE)
         # scripted (Dirichlet) vertices are never moved by the solver: the scripter keeps their positions itself, as
         # the reference's host mesh does, instead of reading all positions back every step
