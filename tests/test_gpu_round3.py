@@ -98,3 +98,25 @@ def test_bench_kernel_entry_covers_every_kernel_class():
     # the state of the handle is still good for stepping
     assert ts.solve(1) == 0
     ts.close()
+
+
+@pytest.mark.parametrize("env", [{"DOTMI_PATCH_ELEMS": "512"}, {"DOTMI_TILE_THREADS": "256"},
+                                 {"DOTMI_TILE_EAGER_MIN": "1000"}, {"DOTMI_TILE_EAGER_MIN": "1", "DOTMI_TILE_EAGER_CHUNK": "1"},
+                                 {"DOTMI_TILE_XCD_ORDER": "0", "DOTMI_TILE_ROWS_LONG": "16"}])
+def test_tuning_switches_do_not_change_results(env):
+    """Every tuning variable of DESIGN.md section 10 that selects another variant of a round-3 kernel / schedule: same
+    iterations as the oracle, positions to 1e-9 (horse7K: FCR with SVD in the element pass, 8 subdomains, back-tracking)."""
+    os.environ.update(env)
+    try:
+        sc, ep, n, ts, orc = _pair("horse7K_stretch")
+    finally:
+        for k in env:
+            del os.environ[k]
+    for _ in range(3):
+        idx, pos = sc.scripter.step(ts.getResult(), sc.cfg.dt)
+        ts.setDirichlet(idx, pos)
+        orc.move(idx, pos)
+        st, so = ts.step(), orc.step()
+        assert (st.status, st.iters, st.ls_halvings) == (so.status, so.iters, so.ls_halvings)
+    assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
+    ts.close(); orc.close()
