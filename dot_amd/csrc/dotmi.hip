@@ -97,9 +97,12 @@ struct Tuning {
     bool deviceLoop = true;   // DOTMI_DEVICE_LOOP=0  host-driven L-BFGS loop (same as DOTMI_FLAG_HOST_LOOP)
     int patchElems = 0;       // DOTMI_PATCH_ELEMS    elements per patch of the element pass (0: default)
     bool tileFactor = true;   // DOTMI_TILE_FACTOR=0  recursive rocBLAS formulation instead of the level-scheduled tile tasks
+    int tileSplit = -1;       // DOTMI_TILE_SPLIT     0 / 1: one task kernel per level / diagonal and half-tile kernels side by side
+                              //                      (-1: the latter above 64 subdomains, where the factorisation is throughput-bound)
     int tileThreads = 512;    // DOTMI_TILE_THREADS   256 or 512 threads per tile task (512: two waves per SIMD share a task)
     bool tileXcdOrder = true; // DOTMI_TILE_XCD_ORDER=0 tile tasks of a level longest first instead of grouped per XCD
     int tileEagerMin = 0;     // DOTMI_TILE_EAGER_MIN early products a critical-path tile task may keep
+    int tileEagerMinDiag = 0; // DOTMI_TILE_EAGER_MIN_DIAG early products a diagonal tile task may keep
     int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
     static int geti(const char *name, int dflt)
     {
@@ -130,9 +133,11 @@ struct Tuning {
         t.deviceLoop = geti("DOTMI_DEVICE_LOOP", 1) != 0;
         t.patchElems = std::max(0, geti("DOTMI_PATCH_ELEMS", 0));
         t.tileFactor = geti("DOTMI_TILE_FACTOR", 1) != 0;
+        t.tileSplit = geti("DOTMI_TILE_SPLIT", -1);
         t.tileThreads = geti("DOTMI_TILE_THREADS", 512) == 256 ? 256 : 512;
         t.tileXcdOrder = geti("DOTMI_TILE_XCD_ORDER", 1) != 0;
         t.tileEagerMin = std::max(0, geti("DOTMI_TILE_EAGER_MIN", 0));
+        t.tileEagerMinDiag = std::max(0, geti("DOTMI_TILE_EAGER_MIN_DIAG", 0));
         t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
         return t;
     }
@@ -195,7 +200,10 @@ struct dotmi_handle {
     size_t wTotal = 0;
     double *tscratch = nullptr;
     int nTclear = 0;
-    std::vector<int> tlevelStart;
+    std::vector<int> tlevelStart, tlevelDiag;
+    bool tileSplit = false;
+    hipStream_t stDiag = nullptr;              // side stream of the diagonal-block tasks
+    std::vector<hipEvent_t> tFork, tJoin;      // per level
     double tileFlops = 0;
     DevPatches PT, PTall;   // element patches: this rank's own elements / all elements (same unless shardElems)
     int nOwnElem = 0, v0 = 0, v1 = 0;
@@ -874,7 +882,7 @@ int build_device_mesh(dotmi_handle *h)
             for (int ls = 0; ls < P.nParts; ++ls)
                 plan_subdomain_tiles(ls, nt, P.W, &rtOff[(size_t)ls * nt], &rtLd[(size_t)ls * nt], &rtC0[(size_t)ls * nt],
                                      live[ls], pat[ls], h->tscratch, sn, all, S.clearTiles, S.clearLd, S.flops, S.qTiles,
-                                     eagerMin, eagerChunk);
+                                     eagerMin, eagerChunk, h->tune.tileEagerMinDiag);
             S.scratchTiles = sn;
             if (pass == 0) {
                 if (int rc = dalloc(h, &h->tscratch, std::max<size_t>(sn, 1) * TILE * TILE)) return rc;
@@ -888,6 +896,15 @@ int build_device_mesh(dotmi_handle *h)
         if (int rc = upload(h, &h->tclearLd, S.clearLd)) return rc;
         h->nTclear = (int)S.clearTiles.size();
         h->tlevelStart = S.levelStart;
+        h->tlevelDiag = S.levelDiag;
+        h->tileSplit = h->tune.tileSplit >= 0 ? h->tune.tileSplit != 0 : P.nParts > 64;
+        if (h->tileSplit) {
+            HIPCHECK(h, hipStreamCreateWithFlags(&h->stDiag, hipStreamNonBlocking));
+            h->tFork.resize(S.levelDiag.size());
+            h->tJoin.resize(S.levelDiag.size());
+            for (auto &e : h->tFork) HIPCHECK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto &e : h->tJoin) HIPCHECK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
         h->tileFlops = S.flops;
         if (h->tune.fuseLog)
             fprintf(stderr, "dotmi: tile schedule: %zu tasks, %zu products, %zu levels, %lld Q tiles, %.1f GF\n", S.tasks.size(),
@@ -1372,9 +1389,29 @@ int issue_factor(dotmi_handle *h)
 {
     if (h->tileMode) {
         // one launch per level of the static tile schedule; a launch boundary is the only synchronisation
-        for (size_t l = 0; l + 1 < h->tlevelStart.size(); ++l)
-            launch_tile_level(h->ttasks + h->tlevelStart[l], h->tlevelStart[l + 1] - h->tlevelStart[l], h->tprods, h->info_dev,
-                              h->st, h->tune.tileThreads);
+        for (size_t l = 0; l + 1 < h->tlevelStart.size(); ++l) {
+            const int n = h->tlevelStart[l + 1] - h->tlevelStart[l];
+            if (!h->tileSplit) {
+                launch_tile_level(h->ttasks + h->tlevelStart[l], n, h->tprods, h->info_dev, h->st, h->tune.tileThreads);
+                continue;
+            }
+            // the level's diagonal-block tasks (77 KB of LDS, ~20 us each) on the side stream, its product / row / inverse
+            // tasks (half tiles, four workgroups per CU) on the main one, side by side; the next level waits for both
+            const int nd = h->tlevelDiag[l], ng = n - nd;
+            const TileTask *t0 = h->ttasks + h->tlevelStart[l];
+            if (nd > 0 && ng > 0) {
+                HIPCHECK(h, hipEventRecord(h->tFork[l], h->st));
+                HIPCHECK(h, hipStreamWaitEvent(h->stDiag, h->tFork[l], 0));
+                launch_tile_level(t0, nd, h->tprods, h->info_dev, h->stDiag, h->tune.tileThreads);
+                launch_tile_gemm(t0 + nd, ng, h->tprods, h->st);
+                HIPCHECK(h, hipEventRecord(h->tJoin[l], h->stDiag));
+                HIPCHECK(h, hipStreamWaitEvent(h->st, h->tJoin[l], 0));
+            } else if (nd > 0) {
+                launch_tile_level(t0, nd, h->tprods, h->info_dev, h->st, h->tune.tileThreads);
+            } else {
+                launch_tile_gemm(t0, ng, h->tprods, h->st);
+            }
+        }
         h->flopCount = h->tileFlops;
         return 0;
     }
@@ -2265,6 +2302,9 @@ void dotmi_destroy(dotmi_handle *h)
     if (h->evA) hipEventDestroy(h->evA);
     for (hipEvent_t e : h->evP)
         if (e) hipEventDestroy(e);
+    for (hipEvent_t e : h->tFork) hipEventDestroy(e);
+    for (hipEvent_t e : h->tJoin) hipEventDestroy(e);
+    if (h->stDiag) hipStreamDestroy(h->stDiag);
     for (hipEvent_t e : h->evPre) hipEventDestroy(e);
     for (hipEvent_t e : h->evAr) hipEventDestroy(e);
     if (h->factorGraph) hipGraphExecDestroy(h->factorGraph);

@@ -1623,11 +1623,155 @@ __global__ __launch_bounds__(THREADS, 2) void tile_task_kernel(const TileTask *_
     if (tid == 0 && bad) atomicMax(info + t.sub, t.pivotBase + bad);
 }
 
+// The product / row / inverse tasks (everything but TP_DIAG) on HALF tiles: LDS holds 32 x 64 of A and of B at a time
+// (33 KB instead of the 77 KB of the task kernel above), registers the accumulator and one prefetched half pair, so
+// four workgroups are resident per CU instead of two -- a launch of ~600-1700 short tasks runs in half the rounds, and
+// the diagonal-block tasks of the same level run next to it from their own launch (launch_tile_level).
+//   TF_FACT  acc -= sum_k A(k, i) B(k, j):  K = the tiles' rows;  TF_INV  acc += sum_k A(i, k) B(k, j):  K = A's columns.
+// In both cases the A half is stored K-major, La[k][i], so one inner loop serves both.
+__global__ __launch_bounds__(256, 4) void tile_gemm_kernel(const TileTask *__restrict__ tasks,
+                                                           const TileProd *__restrict__ prods)
+{
+    constexpr int KH = 32, LD = CHOL_NB + 1;
+    __shared__ double Ls[2 * KH * LD];                     // La | Lb, or one whole 64 x 65 tile (4160 doubles either way)
+    double (*La)[LD] = reinterpret_cast<double (*)[LD]>(Ls);
+    double (*Lb)[LD] = reinterpret_cast<double (*)[LD]>(Ls + KH * LD);
+    double (*Lf)[LD] = reinterpret_cast<double (*)[LD]>(Ls);
+    const TileTask t = tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4, rb = 16 * w;
+    const bool fact = t.form == TF_FACT;
+    const TileProd *pl = prods + t.first;
+    const int nsteps = 2 * t.nprod;
+    // half tiles: `rows` = rows [32 h, 32 h + 32) of all 64 columns (K = rows), `cols` = columns [32 h, ...) (K = columns)
+    auto load_rows = [&](const double *p, int ld, int h, double2 (&v)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx2 = tid + 256 * u;
+            v[u] = *reinterpret_cast<const double2 *>(p + (size_t)(idx2 >> 4) * ld + 32 * h + 2 * (idx2 & 15));
+        }
+    };
+    auto store_rows = [&](const double2 (&v)[4], double (*Lx)[LD]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx2 = tid + 256 * u, j = idx2 >> 4, k = 2 * (idx2 & 15);
+            Lx[k][j] = v[u].x;
+            Lx[k + 1][j] = v[u].y;
+        }
+    };
+    auto load_cols = [&](const double *p, int ld, int h, double2 (&v)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx2 = tid + 256 * u;
+            v[u] = *reinterpret_cast<const double2 *>(p + (size_t)(32 * h + (idx2 >> 5)) * ld + 2 * (idx2 & 31));
+        }
+    };
+    auto store_cols = [&](const double2 (&v)[4], double (*Lx)[LD]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx2 = tid + 256 * u, c = idx2 >> 5, r = 2 * (idx2 & 31);
+            Lx[c][r] = v[u].x;
+            Lx[c][r + 1] = v[u].y;
+        }
+    };
+    double2 ra[4], rbk[4];
+    auto fetch = [&](int s) {   // half step s of the product list
+        const TileProd pr = pl[s >> 1];
+        if (fact) load_rows(pr.a, pr.lda, s & 1, ra);
+        else load_cols(pr.a, pr.lda, s & 1, ra);
+        load_rows(pr.b, pr.ldb, s & 1, rbk);
+    };
+    auto mfma_half = [&](mfma_v4d (&acc)[4], double sign) {
+#pragma unroll
+        for (int kk = 0; kk < KH / 4; ++kk) {
+            const double a = sign * La[4 * kk + lk][rb + lr];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double b = Lb[4 * kk + lk][16 * q + lr];
+                acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+            }
+        }
+    };
+    mfma_v4d acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
+    if (nsteps > 0) fetch(0);
+    else if (t.post == TP_ROW) load_rows(t.q, t.ldq, 0, ra);
+    if (t.init) {
+        // the c tile through LDS into the accumulator layout (element (i, j) of acc[q][r]: i = rb + lk + 4 r, j = 16 q + lr)
+        double2 c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx2 = tid + 256 * u;
+            c[u] = *reinterpret_cast<const double2 *>(t.c + (size_t)(idx2 >> 5) * t.ldc + 2 * (idx2 & 31));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx2 = tid + 256 * u, j = idx2 >> 5, r = 2 * (idx2 & 31);
+            Lf[r][j] = c[u].x;
+            Lf[r + 1][j] = c[u].y;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[q][r] = Lf[rb + lk + 4 * r][16 * q + lr];
+        __syncthreads();
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        if (fact) store_rows(ra, La);
+        else store_cols(ra, La);
+        store_rows(rbk, Lb);
+        __syncthreads();
+        if (s + 1 < nsteps) fetch(s + 1);
+        else if (t.post == TP_ROW) load_rows(t.q, t.ldq, 0, ra);   // first half of Q_kk for the final multiplication
+        mfma_half(acc, fact ? -1.0 : 1.0);
+        __syncthreads();
+    }
+    if (t.post == TP_ROW) {
+        // R_kj = Q_kk^T G:  R(i, j) = sum_k Q(k, i) G(k, j), K in two halves: the Q half from HBM, the G half from the
+        // accumulators of the two waves that own those rows
+        mfma_v4d acc2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc2[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            store_rows(ra, La);
+            if ((w >> 1) == h) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Lb[rb - 32 * h + lk + 4 * r][16 * q + lr] = acc[q][r];
+            }
+            __syncthreads();
+            if (h == 0) load_rows(t.q, t.ldq, 1, ra);
+            mfma_half(acc2, 1.0);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = acc2[q];
+    }
+    const double sg = t.post == TP_NEG ? -1.0 : 1.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Lf[rb + lk + 4 * r][16 * q + lr] = sg * acc[q][r];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int idx2 = tid + 256 * u, j = idx2 >> 5, r = 2 * (idx2 & 31);
+        *reinterpret_cast<double2 *>(t.c + (size_t)j * t.ldc + r) = make_double2(Lf[r][j], Lf[r + 1][j]);
+    }
+}
+
 void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, int threads)
 {
     if (ntasks <= 0) return;
     if (threads == 512) hipLaunchKernelGGL(tile_task_kernel<512>, dim3(ntasks), dim3(512), 0, st, tasks, prods, info);
     else hipLaunchKernelGGL(tile_task_kernel<256>, dim3(ntasks), dim3(256), 0, st, tasks, prods, info);
+}
+void launch_tile_gemm(const TileTask *tasks, int ntasks, const TileProd *prods, hipStream_t st)
+{
+    if (ntasks > 0) hipLaunchKernelGGL(tile_gemm_kernel, dim3(ntasks), dim3(256), 0, st, tasks, prods);
 }
 
 // zero a list of 64 x 64 tiles (the tiles a factorisation leaves non-zero, before the refill)

@@ -55,6 +55,7 @@ struct TileSchedule {
     std::vector<TileTask> tasks;      // level after level
     std::vector<TileProd> prods;      // in task order
     std::vector<int> levelStart;      // tasks of level l are [levelStart[l], levelStart[l+1])
+    std::vector<int> levelDiag;       // the first levelDiag[l] of them are the TP_DIAG tasks (run by the diagonal-block kernel)
     std::vector<double *> clearTiles; // origins of the tiles the fill writes into (cleared before the refill; fill-in tiles are
                                       // written before they are read)
     std::vector<int> clearLd;         // and their leading dimensions
@@ -79,7 +80,7 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
                                  const std::vector<uint8_t> &live, std::vector<uint8_t> pat /* by value: gets the fill */,
                                  double *scratch, size_t &scratchNext, std::vector<TileTaskL> &out,
                                  std::vector<double *> &clearTiles, std::vector<int> &clearLd, double &flops, long long &qTiles,
-                                 int eagerMin = 2, int eagerChunk = 1)
+                                 int eagerMin = 2, int eagerChunk = 1, int eagerMinDiag = 0)
 {
     auto tile = [&](int i, int j) { return W + rtOff[j] + (long long)i * TILE - rtC0[j]; };
     auto tld = [&](int j) { return rtLd[j]; };
@@ -138,7 +139,9 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
         // products would otherwise wait for the final task
         size_t nEarly = 0;
         while (nEarly < pa.size() && pa[nEarly].avail + 1 < lf) ++nEarly;
-        if (nEarly <= (size_t)EAGER_MIN) nEarly = 0;
+        // a diagonal task is the longest of its level (~20 us of factor + invert on one workgroup) and every later task of
+        // the column waits for it: it keeps no early product at all
+        if (nEarly <= (size_t)(post == TP_DIAG ? eagerMinDiag : EAGER_MIN)) nEarly = 0;
         bool have = initFromC;
         size_t k0 = 0;
         while (k0 < nEarly) {
@@ -239,6 +242,7 @@ inline void finish_tile_schedule(std::vector<TileTaskL> &all, TileSchedule &S, b
     std::vector<std::vector<size_t>> byLevel(maxLevel + 1);
     for (size_t k = 0; k < all.size(); ++k) byLevel[all[k].level].push_back(k);
     S.levelStart.assign(1, 0);
+    S.levelDiag.clear();
     for (int l = 1; l <= maxLevel; ++l) {
         // Order inside a level: tasks of the same subdomain and target row read the same A tiles (R_mk / Q_im), so
         // they are made neighbours ON ONE XCD -- workgroup b runs on XCD b % 8, each XCD has its own 4 MB L2 -- and their
@@ -291,6 +295,11 @@ inline void finish_tile_schedule(std::vector<TileTaskL> &all, TileSchedule &S, b
             v.swap(order);
         }
         }
+        // the diagonal-block tasks first: they go to a kernel of their own (tile_diag / tile_gemm, kernels.hip)
+        std::stable_partition(v.begin(), v.end(), [&](size_t k) { return all[k].t.post == TP_DIAG; });
+        int nd = 0;
+        for (size_t k : v) nd += all[k].t.post == TP_DIAG;
+        S.levelDiag.push_back(nd);
         for (size_t k : v) {
             TileTask t = all[k].t;
             t.first = (int)S.prods.size();

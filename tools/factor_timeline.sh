@@ -7,6 +7,7 @@ import csv,sys,collections
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 def cls(n):
+    if 'tile_gemm' in n: return 'tgemm'
     if 'tile_task' in n: return 'tile'
     if 'clear_tiles' in n: return 'clear'
     if 'node128' in n: return 'node128'
@@ -27,7 +28,7 @@ for r in rows:
         if len(cur)>20: runs.append(cur)
         cur=[]
 if len(cur)>20: runs.append(cur)
-fr=[r for r in runs if any(cls(k['Kernel_Name']) in ('tile','gemm') for k in r)]
+fr=[r for r in runs if any(cls(k['Kernel_Name']) in ('tile','tgemm','gemm') for k in r)]
 run=fr[-1]
 t0=int(run[0]['Start_Timestamp'])
 qs={}
