@@ -102,6 +102,7 @@ struct Tuning {
     int tileThreads = 512;    // DOTMI_TILE_THREADS   256 or 512 threads per tile task (512: two waves per SIMD share a task)
     bool tileXcdOrder = true; // DOTMI_TILE_XCD_ORDER=0 tile tasks of a level longest first instead of grouped per XCD
     int tileEagerMin = 0;     // DOTMI_TILE_EAGER_MIN early products a critical-path tile task may keep
+    bool tileBalance = true;  // DOTMI_TILE_BALANCE=0 every tile task at its earliest level (no second scheduling pass)
     int tileEagerMinDiag = 0; // DOTMI_TILE_EAGER_MIN_DIAG early products a diagonal tile task may keep
     int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
     static int geti(const char *name, int dflt)
@@ -137,6 +138,7 @@ struct Tuning {
         t.tileThreads = geti("DOTMI_TILE_THREADS", 512) == 256 ? 256 : 512;
         t.tileXcdOrder = geti("DOTMI_TILE_XCD_ORDER", 1) != 0;
         t.tileEagerMin = std::max(0, geti("DOTMI_TILE_EAGER_MIN", 0));
+        t.tileBalance = geti("DOTMI_TILE_BALANCE", 1) != 0;
         t.tileEagerMinDiag = std::max(0, geti("DOTMI_TILE_EAGER_MIN_DIAG", 0));
         t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
         return t;
@@ -882,7 +884,7 @@ int build_device_mesh(dotmi_handle *h)
             for (int ls = 0; ls < P.nParts; ++ls)
                 plan_subdomain_tiles(ls, nt, P.W, &rtOff[(size_t)ls * nt], &rtLd[(size_t)ls * nt], &rtC0[(size_t)ls * nt],
                                      live[ls], pat[ls], h->tscratch, sn, all, S.clearTiles, S.clearLd, S.flops, S.qTiles,
-                                     eagerMin, eagerChunk, h->tune.tileEagerMinDiag);
+                                     eagerMin, eagerChunk, h->tune.tileEagerMinDiag, h->tune.tileBalance);
             S.scratchTiles = sn;
             if (pass == 0) {
                 if (int rc = dalloc(h, &h->tscratch, std::max<size_t>(sn, 1) * TILE * TILE)) return rc;

@@ -23,6 +23,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <unordered_map>
 #include <vector>
 
 namespace dotmi {
@@ -80,8 +81,9 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
                                  const std::vector<uint8_t> &live, std::vector<uint8_t> pat /* by value: gets the fill */,
                                  double *scratch, size_t &scratchNext, std::vector<TileTaskL> &out,
                                  std::vector<double *> &clearTiles, std::vector<int> &clearLd, double &flops, long long &qTiles,
-                                 int eagerMin = 2, int eagerChunk = 1, int eagerMinDiag = 0)
+                                 int eagerMin = 2, int eagerChunk = 1, int eagerMinDiag = 0, bool balance = true)
 {
+    const size_t o0 = out.size();   // this subdomain's tasks are out[o0 ...)
     auto tile = [&](int i, int j) { return W + rtOff[j] + (long long)i * TILE - rtC0[j]; };
     auto tld = [&](int j) { return rtLd[j]; };
     auto P = [&](int i, int j) -> uint8_t & { return pat[(size_t)i * nt + j]; };
@@ -232,6 +234,70 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
             LQ(i, j) = emit(i, TF_INV, TP_NEG, tile(i, j), tld(j), nullptr, 0, 0, pa, 0, false);
         }
     }
+    if (!balance) return;
+    // ---- second pass: move the tasks that have slack out of the launches the critical path runs through ---------------
+    // The levels above are as-soon-as-possible.  The chain DIAG(j-1) -> ROW(j-1, j) -> DIAG(j) paces the factorisation:
+    // the launch that holds a diagonal task lasts >= ~25 us whatever else is in it, while the launch between two of them
+    // is as long as everything that was scheduled into it -- mostly eager updates and tasks of the inversion, which
+    // nobody needs for several levels.  Those go one level later, next to the diagonal tasks, whenever their
+    // latest possible level (as-late-as-possible, same total length) allows.
+    // Dependencies are re-derived from the tiles the tasks touch, in the order of the valid ASAP schedule: per tile, a
+    // writer comes after the previous writer and after every reader since then, a reader after the last writer.
+    const size_t n = out.size() - o0;
+    std::vector<size_t> ord(n);
+    for (size_t k = 0; k < n; ++k) ord[k] = o0 + k;
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return out[a].level < out[b].level; });
+    struct Acc {
+        int writer = -1;
+        std::vector<int> readers;
+    };
+    std::unordered_map<const double *, Acc> acc;
+    std::vector<std::vector<int>> pred(n), succ(n);
+    auto edge = [&](int u, int v) {
+        if (u < 0 || u == v) return;
+        pred[v].push_back(u);
+        succ[u].push_back(v);
+    };
+    for (size_t oi = 0; oi < n; ++oi) {
+        const int v = (int)(ord[oi] - o0);
+        const TileTaskL &T = out[ord[oi]];
+        auto rd = [&](const double *x) {
+            Acc &a = acc[x];
+            edge(a.writer, v);
+            a.readers.push_back(v);
+        };
+        for (auto &pr : T.prods) {
+            rd(pr.a);
+            if (pr.b != pr.a) rd(pr.b);
+        }
+        if (T.t.q) rd(T.t.q);
+        Acc &c = acc[T.t.c];
+        edge(c.writer, v);
+        for (int r : c.readers) edge(r, v);
+        c.writer = v;
+        c.readers.clear();
+    }
+    int lmax = 0;
+    std::vector<char> diagLevel;
+    for (size_t k = 0; k < n; ++k) lmax = std::max(lmax, out[o0 + k].level);
+    diagLevel.assign(lmax + 2, 0);
+    for (size_t k = 0; k < n; ++k)
+        if (out[o0 + k].t.post == TP_DIAG) diagLevel[out[o0 + k].level] = 1;
+    std::vector<int> latest(n, lmax), fin(n, 0);
+    for (size_t oi = n; oi-- > 0;) {
+        const int v = (int)(ord[oi] - o0);
+        for (int w : succ[v]) latest[v] = std::min(latest[v], latest[w] - 1);
+    }
+    for (size_t oi = 0; oi < n; ++oi) {
+        const int v = (int)(ord[oi] - o0);
+        TileTaskL &T = out[ord[oi]];
+        int lo = T.level;
+        for (int u : pred[v]) lo = std::max(lo, fin[u] + 1);
+        const bool bulk = T.t.post == TP_STORE || T.t.form == TF_INV;
+        if (bulk && !diagLevel[lo] && lo + 1 <= latest[v] && diagLevel[lo + 1]) ++lo;
+        fin[v] = lo;
+    }
+    for (size_t k = 0; k < n; ++k) out[o0 + k].level = fin[k];
 }
 
 // merge the per-subdomain task lists into level order
