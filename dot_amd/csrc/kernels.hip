@@ -1552,8 +1552,8 @@ __global__ __launch_bounds__(THREADS, 2) void tile_task_kernel(const TileTask *_
     for (int q = 0; q < NT; ++q) acc[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
     BlkT<THREADS> ra, rbk;
     if (t.nprod > 0) {
-        ra = tile_load<THREADS>(pl[0].a, pl[0].lda, tid);
-        if (pl[0].b != pl[0].a) rbk = tile_load<THREADS>(pl[0].b, pl[0].ldb, tid);
+        ra = tile_load<THREADS>(t.p0.a, t.p0.lda, tid);
+        if (t.p0.b != t.p0.a) rbk = tile_load<THREADS>(t.p0.b, t.p0.ldb, tid);
     } else if (t.post == TP_ROW) {
         ra = tile_load<THREADS>(t.q, t.ldq, tid);
     }
@@ -1675,7 +1675,7 @@ __global__ __launch_bounds__(256, 4) void tile_gemm_kernel(const TileTask *__res
     };
     double2 ra[4], rbk[4];
     auto fetch = [&](int s) {   // half step s of the product list
-        const TileProd pr = pl[s >> 1];
+        const TileProd pr = s < 2 ? t.p0 : pl[s >> 1];
         if (fact) load_rows(pr.a, pr.lda, s & 1, ra);
         else load_cols(pr.a, pr.lda, s & 1, ra);
         load_rows(pr.b, pr.ldb, s & 1, rbk);

@@ -50,6 +50,8 @@ struct TileTask {
     int pivotBase, pad;            // TP_DIAG: scalar offset of the tile's first row (for the non-SPD report)
     double *c;                     // the tile read (init) and written
     double *q;                     // TP_ROW: tile of Q_kk
+    TileProd p0;                   // copy of the first product: its tiles are requested straight from the descriptor, one
+                                   // dependent round trip earlier than through the product array
 };
 
 struct TileSchedule {
@@ -370,6 +372,7 @@ inline void finish_tile_schedule(std::vector<TileTaskL> &all, TileSchedule &S, b
             TileTask t = all[k].t;
             t.first = (int)S.prods.size();
             t.nprod = (int)all[k].prods.size();
+            t.p0 = all[k].prods.empty() ? TileProd{nullptr, nullptr, 0, 0} : all[k].prods[0];
             for (auto &p : all[k].prods) S.prods.push_back(p);
             S.tasks.push_back(t);
         }
