@@ -105,6 +105,8 @@ struct Tuning {
     bool tileBalance = true;  // DOTMI_TILE_BALANCE=0 every tile task at its earliest level (no second scheduling pass)
     int tileEagerMinDiag = 0; // DOTMI_TILE_EAGER_MIN_DIAG early products a diagonal tile task may keep
     int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
+    bool earlyBs = true;      // DOTMI_EARLY_BACKSOLVE=0 the back-solve after the controller, on q (instead of speculatively on the
+                              //                      trial gradient with the controller inside its launch)
     static int geti(const char *name, int dflt)
     {
         const char *ev = getenv(name);
@@ -141,6 +143,7 @@ struct Tuning {
         t.tileBalance = geti("DOTMI_TILE_BALANCE", 1) != 0;
         t.tileEagerMinDiag = std::max(0, geti("DOTMI_TILE_EAGER_MIN_DIAG", 0));
         t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
+        t.earlyBs = geti("DOTMI_EARLY_BACKSOLVE", 1) != 0;
         return t;
     }
 };
@@ -213,6 +216,9 @@ struct dotmi_handle {
     double *g = nullptr, *g_trial = nullptr, *p = nullptr, *q = nullptr, *z = nullptr, *Hp = nullptr;
     double *He = nullptr, *Hval = nullptr, *tmpn = nullptr;
     double *S[HIST_MAX + 1] = {nullptr}, *Y[HIST_MAX + 1] = {nullptr};
+    // early back-solve (enqueue_loop_slot): u = -M g of the current iterate, M y_i of the stored pairs (slots as Y)
+    bool earlyBs = false;
+    double *u_old = nullptr, *MY[HIST_MAX + 1] = {nullptr};
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
     double *gstage = nullptr;   // sharded element pass, device loop: [g (n) ; 0 ; E] staging buffer of the gradient all-reduce
     double *alpha_dev = nullptr;
@@ -1659,6 +1665,7 @@ int trial(dotmi_handle *h, const double *xeval, double *gout, int make_pair, con
     h->nbE = nb;
     phase_mark(h, evalSlot);
     GatherArgs a;
+    memset(&a, 0, sizeof(a));
     a.x = xeval;
     a.xt = h->xt;
     a.g_old = h->g;
@@ -1725,8 +1732,50 @@ void sum_stats(const dotmi_handle *h, int nvals, double *R)
 
 // One slot of the device-resident loop: the nine kernels of an L-BFGS iteration (or, when the controller
 // asked for a retry, only the three of a line-search trial -- the others return at once) and the controller.
+// Early back-solve (one rank, h->earlyBs): the preconditioner M is fixed during a step and linear, so the solve for the
+// next direction does not have to wait for the controller's verdict and for q.  The slot starts at build_p; after the
+// trial's gradient is gathered the back-solve runs on -g_trial with the CONTROLLER AS ONE WORKGROUP OF ITS LAUNCH, and
+// merge_early forms z = u - sum_j xi_j (M y_j) from the cached M y_j (the newest: u_old - u).  The controller's ~7 us
+// and its launch boundary leave the critical path of every iteration; a rejected trial (line-search halving) and the
+// last iteration of a step stream the factors once for nothing.  z differs from the q-based value by rounding only
+// (tests/test_gpu_round3.py: same iteration counts, positions to 1e-9).
+int enqueue_loop_slot_early(dotmi_handle *h)
+{
+    const int n = h->n;
+    LbfgsArgs L0;
+    memset(&L0, 0, sizeof(L0));
+    launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
+    launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st, h->ctl);
+    launch_step_forward(n, h->x, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st, h->ctl);
+    int nb = 0;
+    launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st, h->ctl);
+    GatherArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xt = h->xt;
+    a.p = h->p;
+    a.alpha_dev = h->alpha_dev;
+    a.iv0 = h->v0;
+    a.iv1 = h->v1;
+    a.make_pair = 1;
+    // -g_trial goes straight into the padded right-hand sides, whatever the controller will say about the trial
+    a.vp_ptr = h->P.vp_ptr;
+    a.vp_off = h->P.vp_off;
+    a.rpad = h->P.rpad;
+    launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st, h->ctl);
+    const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size() &&
+                       (h->timeCount++ % h->timeStride) == 0;
+    h->slotTimed.push_back(timed ? h->evUsed : -1);
+    CtlArgs ca{h->ctl, h->partE, h->partR, h->alpha_dev, h->h_flags, nb};
+    launch_gemv(h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr,
+                &ca);
+    if (timed) h->evUsed += 2;
+    launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl);
+    return 0;
+}
+
 int enqueue_loop_slot(dotmi_handle *h)
 {
+    if (h->earlyBs) return enqueue_loop_slot_early(h);
     const int n = h->n;
     LbfgsArgs L0;
     memset(&L0, 0, sizeof(L0));
@@ -1808,7 +1857,9 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     for (int s = 0; s <= h->hist; ++s) {
         C.S[s] = h->S[s];
         C.Y[s] = h->Y[s];
+        C.MY[s] = h->MY[s];
     }
+    C.u_old = h->u_old;
     C.log_alpha = h->dlog;
     C.log_E = h->dlog + h->logCap;
     C.log_g2 = h->dlog + 2 * (size_t)h->logCap;
@@ -1842,6 +1893,11 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
         launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st);
         if (!h->shardElems) {
             launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
+            if (h->earlyBs) {   // the first direction's solve: u = -M g_0, z = u
+                launch_build_qpad(h->P, h->g, L0, nullptr, h->st, h->ctl, 1);
+                launch_gemv(h->P, nullptr, h->st, h->ctl);
+                launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl);
+            }
         } else {
             hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
                                h->gstage + n_ + 1);
@@ -1949,6 +2005,8 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     const int nk = std::min(std::min(C.slots, enq), h->kindCap);
     if (nk > 0 && (h->flags & DOTMI_FLAG_TIME_BACKSOLVE))
         HIPCHECK(h, hipMemcpy(h->slotKind.data(), h->dkind, sizeof(int) * nk, hipMemcpyDeviceToHost));
+    if (h->earlyBs)   // every slot the controller judged streamed the factors (speculatively), retries included
+        for (int sl = 0; sl < nk; ++sl) h->slotKind[sl] = 1;
     return 0;
 }
 
@@ -2521,6 +2579,14 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         }
         h->devLoop = !h->gsdd && !h->newton && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) &&
                      h->tune.deviceLoop;
+        // one rank, merged tile partials: the back-solve of the next direction is issued on the trial gradient, beside
+        // the controller (enqueue_loop_slot)
+        h->earlyBs = h->devLoop && h->tune.earlyBs && !h->dist && !h->shardElems && h->P.mt_ptr != nullptr;
+        if (h->earlyBs) {
+            if (int rc = dalloc(h, &h->u_old, (size_t)h->n)) return rc;
+            for (int sl = 0; sl <= h->hist; ++sl)
+                if (int rc = dalloc(h, &h->MY[sl], (size_t)h->n)) return rc;
+        }
         h->logCap = std::min(h->iterCap, 10001) + 1;
         h->kindCap = 4096;
         HIPCHECK(h, hipHostMalloc((void **)&h->h_ctl, sizeof(DevLoop)));

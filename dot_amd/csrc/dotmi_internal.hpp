@@ -152,6 +152,16 @@ struct DevLoop {
     double *log_alpha, *log_E, *log_g2;
     int *slot_kind;        // per slot: 1 new direction, 2 retry (slots after the end are not logged)
     int logCap, kindCap;
+    // early back-solve (enqueue_loop_slot): u = -M g of the accepted iterate and M y_i of the stored pairs (same slots as Y)
+    int pairNew, pad1;     // the controller's last accept stored a pair (its M y goes to MY[order[m - 1]])
+    double *u_old, *MY[HIST_MAX + 1];
+};
+// the controller's operands when it runs as one workgroup of another launch (launch_gemv)
+struct CtlArgs {
+    DevLoop *ctl;
+    const double *partE, *partR, *alpha_dev;
+    int *flags_host;
+    int nbE;
 };
 
 // ---- kernel launchers (kernels.hip) --------------------------------------------------------------
@@ -174,6 +184,10 @@ struct GatherArgs {
     int make_pair;
     int iv0, iv1;  // vertex range whose inertia term m_v (x_v - x~_v) this rank adds
     int stage;     // device loop, sharded element pass: g_new is a staging buffer (kept as passed), no pair
+    // early back-solve: -g is also written straight into the padded right-hand sides of every subdomain that holds the
+    // vertex (DevParts::vp_ptr / vp_off), so no build_qpad launch stands between the gather and the back-solve
+    const int *vp_ptr, *vp_off;
+    double *rpad;
 };
 void launch_vertex_gather(const DevMesh &M, const DevPatches &PT, const GatherArgs &a, const LbfgsArgs &L,
                           double *partials, hipStream_t st, const DevLoop *ctl = nullptr);
@@ -188,11 +202,18 @@ void launch_build_q(int n, const double *g, const LbfgsArgs &L, const double *xi
                     hipStream_t st, const DevLoop *ctl = nullptr);
 // subdomain back-solve: psub_s = X_s^T (X_s q[dofmap_s])
 // q == nullptr: P.rpad already holds the right-hand sides (launch_build_qpad); else they are gathered from q first
+// ca: the loop controller runs as workgroup 0 of the (first) launch, beside the tiles, which then ignore the retry phase
+// (the back-solve is speculative: issued on the trial gradient before the controller has accepted the trial)
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
-                 hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                 hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr);
 // rpad_s[k] = q[dofmap_s[k]] with q = -g - sum_j xi_j y_j formed on the fly (same operations as build_q), 0 on padding
+// spec (device loop, early back-solve): 1: rpad = -g_cur, 2: rpad = -g_trial whatever the phase; no history terms
 void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, const double *xi_host, hipStream_t st,
-                       const DevLoop *ctl = nullptr);
+                       const DevLoop *ctl = nullptr, int spec = 0);
+// early back-solve: u = merge(tile partials) / dup = -M g;  M y of the newest pair = u_old - u;  z = u - sum_j xi_j M y_j
+// (+ partial dots y_i . z);  first: start of the step (no history, u_old is only set)
+void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
+                        const DevLoop *ctl);
 // one subdomain only (GSDD, DOTTimeStepper.cpp:507-565): psub_s = X_s^T (X_s q[dofmap_s]) for owned part `ls`, whose
 // tiles are job[0..njobs); then p = 0 except p[dofs of part ls] = psub_s  (ADMMDDTimeStepper::fill, :1646-1665)
 void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, const int2 *lwork, int nlwork, const double *q,

@@ -391,17 +391,21 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
     constexpr int R = GATHER_R;
     for (int kbase = blockIdx.x * blockDim.x + threadIdx.x; kbase < n; kbase += R * G) {
         double gn[R], ine[R], gold[R], pk[R], si[R][HIST_MAX], yi[R][HIST_MAX];
-        int kb[R], ke[R], dd[R];
+        int kb[R], ke[R], dd[R], cb[R], ce[R];
         bool live[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             const int k = kbase + u * G;
             live[u] = k < n;
             gn[u] = ine[u] = gold[u] = pk[u] = 0.0;
-            kb[u] = ke[u] = dd[u] = 0;
+            kb[u] = ke[u] = dd[u] = cb[u] = ce[u] = 0;
             if (live[u]) {
                 const int v = k / 3;
                 dd[u] = k - 3 * v;
+                if (a.rpad) {
+                    cb[u] = a.vp_ptr[v];
+                    ce[u] = a.vp_ptr[v + 1];
+                }
                 const bool fx = fixed[v];
                 if (!fx) {   // fixed rows of the gradient are zero (Optimizer.cpp:1239-1252)
                     const int2 r = pp_rng[v];
@@ -420,6 +424,13 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
                 }
             }
         }
+        // the first copies' padded positions are requested before the partial sums (off the stores' dependent chain)
+        constexpr int VC = 4;
+        int vo[R][VC];
+#pragma unroll
+        for (int u = 0; u < R; ++u)
+#pragma unroll
+            for (int c = 0; c < VC; ++c) vo[u][c] = (cb[u] + c < ce[u]) ? a.vp_off[cb[u] + c] : 0;
         int nkmax = 0;
 #pragma unroll
         for (int u = 0; u < R; ++u) nkmax = max(nkmax, ke[u] - kb[u]);
@@ -442,6 +453,10 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
             const int k = kbase + u * G;
             const double g = gn[u] + ine[u];
             a.g_new[k] = g;
+#pragma unroll
+            for (int c = 0; c < VC; ++c)
+                if (cb[u] + c < ce[u]) a.rpad[vo[u][c] + dd[u]] = -g;
+            for (int c = cb[u] + VC; c < ce[u]; ++c) a.rpad[a.vp_off[c] + dd[u]] = -g;
             if (a.make_pair) {
                 const double sn = alpha * pk[u];
                 const double yn = g - gold[u];
@@ -571,11 +586,12 @@ void launch_build_q(int n, const double *g, const LbfgsArgs &L, const double *xi
 template <bool DEV>
 __global__ __launch_bounds__(256) void build_qpad_kernel(int total, const int *__restrict__ dofmap,
                                                          const double *__restrict__ g, LbfgsArgs L, XiArgs X,
-                                                         double *__restrict__ rpad, const DevLoop *__restrict__ ctl)
+                                                         double *__restrict__ rpad, const DevLoop *__restrict__ ctl,
+                                                         int spec)
 {
     if constexpr (DEV) {
-        if (ctl->status != 0 || ctl->phase != 0) return;
-        g = ctl->g_cur;
+        if (ctl->status != 0 || (ctl->phase != 0 && spec != 2)) return;
+        g = spec == 2 ? ctl->g_trial : ctl->g_cur;
     }
     const LbfgsArgs &Lr = [&]() -> const LbfgsArgs & {
         if constexpr (DEV) return ctl->L;
@@ -585,6 +601,7 @@ __global__ __launch_bounds__(256) void build_qpad_kernel(int total, const int *_
         if constexpr (DEV) return ctl->X;
         else return X;
     }();
+    const int m = spec ? 0 : Lr.m;   // early back-solve: the history terms are applied after the solve (merge_early)
     const int stride = gridDim.x * blockDim.x;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < total; k += stride) {
         const int d = dofmap[k];
@@ -593,14 +610,14 @@ __global__ __launch_bounds__(256) void build_qpad_kernel(int total, const int *_
             v = -g[d];
 #pragma unroll
             for (int j = HIST_MAX - 1; j >= 0; --j)
-                if (j < Lr.m) v -= Xr.xi[j] * Lr.y[j][d];
+                if (j < m) v -= Xr.xi[j] * Lr.y[j][d];
         }
         rpad[k] = v;
     }
 }
 
 void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, const double *xi_host, hipStream_t st,
-                       const DevLoop *ctl)
+                       const DevLoop *ctl, int spec)
 {
     XiArgs X;
     for (int i = 0; i < HIST_MAX; ++i) X.xi[i] = (xi_host && i < L.m) ? xi_host[i] : 0.0;
@@ -608,8 +625,8 @@ void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, c
     if (total <= 0) return;
     int nb = (total + 255) / 256;
     if (nb > 2048) nb = 2048;
-    if (ctl) hipLaunchKernelGGL(build_qpad_kernel<true>, dim3(nb), dim3(256), 0, st, total, P.dofmap, g, L, X, P.rpad, ctl);
-    else hipLaunchKernelGGL(build_qpad_kernel<false>, dim3(nb), dim3(256), 0, st, total, P.dofmap, g, L, X, P.rpad, ctl);
+    if (ctl) hipLaunchKernelGGL(build_qpad_kernel<true>, dim3(nb), dim3(256), 0, st, total, P.dofmap, g, L, X, P.rpad, ctl, spec);
+    else hipLaunchKernelGGL(build_qpad_kernel<false>, dim3(nb), dim3(256), 0, st, total, P.dofmap, g, L, X, P.rpad, ctl, 0);
 }
 
 __global__ __launch_bounds__(256) void gather_pad_kernel(int total, const int *__restrict__ dofmap,
@@ -874,29 +891,29 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
 #ifdef BS_PROFILE
 __device__ long long g_bs_prof[8192][5];
 #endif
+__device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, const double *__restrict__ partE, int nbE,
+                                  const double *__restrict__ partR, const double *__restrict__ alpha_dev,
+                                  int *__restrict__ flags_host, int init);
+
+// the tile of job[jobIdx] by the calling workgroup
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restrict__ job,
-                                                            const int *__restrict__ dofmap,
-                                                            const double *__restrict__ W, int nmax,
-                                                            const RowTile *__restrict__ rt,
-                                                            const double *__restrict__ q,
-                                                            double *__restrict__ ppart, int nbmax,
-                                                            const DevLoop *__restrict__ ctl)
+__device__ __forceinline__ void backsolve_block(int jobIdx, const int4 *__restrict__ job, const int *__restrict__ dofmap,
+                                                const double *__restrict__ W, int nmax, const RowTile *__restrict__ rt,
+                                                const double *__restrict__ q, double *__restrict__ ppart, int nbmax,
+                                                double (*sm)[THREADS / 64][32])
 {
-    __shared__ double sm[2][THREADS / 64][32];
-    if (ctl && (ctl->status != 0 || ctl->phase != 0)) return;
-    const int4 jb = job[blockIdx.x];
+    const int4 jb = job[jobIdx];
     const int len = jb.y + (jb.z >> 16) - jb.w;   // longest row of the tile
 #ifdef BS_PROFILE
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    if (threadIdx.x == 0 && jobIdx < 8192) {
         unsigned hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_bs_prof[blockIdx.x][0] = wall_clock64();
-        g_bs_prof[blockIdx.x][2] = len;
-        g_bs_prof[blockIdx.x][3] = jb.z >> 16;
-        g_bs_prof[blockIdx.x][4] = (long long)hw | ((long long)(xcc & 15) << 32);
+        g_bs_prof[jobIdx][0] = wall_clock64();
+        g_bs_prof[jobIdx][2] = len;
+        g_bs_prof[jobIdx][3] = jb.z >> 16;
+        g_bs_prof[jobIdx][4] = (long long)hw | ((long long)(xcc & 15) << 32);
     }
 #endif
     if constexpr (THREADS == 256) {
@@ -911,8 +928,42 @@ __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restri
     }
 #ifdef BS_PROFILE
     __syncthreads();
-    if (threadIdx.x == 0 && blockIdx.x < 8192) g_bs_prof[blockIdx.x][1] = wall_clock64();
+    if (threadIdx.x == 0 && jobIdx < 8192) g_bs_prof[jobIdx][1] = wall_clock64();
 #endif
+}
+
+// spec: the launch is speculative (early back-solve, enqueue_loop_slot): it runs on the trial gradient before the
+// controller has decided about the trial, so the retry phase does not gate it
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restrict__ job,
+                                                            const int *__restrict__ dofmap,
+                                                            const double *__restrict__ W, int nmax,
+                                                            const RowTile *__restrict__ rt,
+                                                            const double *__restrict__ q,
+                                                            double *__restrict__ ppart, int nbmax,
+                                                            const DevLoop *__restrict__ ctl, int spec)
+{
+    __shared__ double sm[2][THREADS / 64][32];
+    if (ctl && (ctl->status != 0 || (ctl->phase != 0 && !spec))) return;
+    backsolve_block<THREADS>(blockIdx.x, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
+}
+
+// The same tiles with the loop controller as workgroup 0 of the launch: the controller's ~7 us (partial sums, the
+// decision about the trial, the history update) run beside the ~45 us of streaming instead of in front of them.  The
+// tiles read the loop state while workgroup 0 may be rewriting it: whichever value of `status` they see, the result is
+// only used (merge_early, after the launch) if the final state says so.
+__global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__restrict__ job, const int *__restrict__ dofmap,
+                                                            const double *__restrict__ W, int nmax,
+                                                            const RowTile *__restrict__ rt, const double *__restrict__ q,
+                                                            double *__restrict__ ppart, int nbmax, CtlArgs ca)
+{
+    __shared__ double sm[2][4][32];
+    if (blockIdx.x == 0) {
+        loop_control_body(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, 0);
+        return;
+    }
+    if (ca.ctl->status != 0) return;
+    backsolve_block<256>(blockIdx.x - 1, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
 }
 #ifdef BS_PROFILE
 extern "C" int dotmi_debug_bs_prof(long long *out, int n)
@@ -988,12 +1039,12 @@ __global__ __launch_bounds__(BSL_THREADS) void backsolve_long_kernel(const int4 
                                                                      const double *__restrict__ q,
                                                                      double *__restrict__ tdots, int maxChunks,
                                                                      double *__restrict__ ppart, int nbmax,
-                                                                     const DevLoop *__restrict__ ctl)
+                                                                     const DevLoop *__restrict__ ctl, int spec)
 {
     constexpr int NW = BSL_THREADS / 64;
     __shared__ double sm[2][NW][8];
     __shared__ double tsh[BS_ROWS];
-    if (ctl && (ctl->status != 0 || ctl->phase != 0)) return;
+    if (ctl && (ctl->status != 0 || (ctl->phase != 0 && !spec))) return;
     const int2 wk = lwork[blockIdx.x];          // (long-tile index, chunk)
     const int4 jb = ljob[wk.x];
     const int s = jb.x, i0 = jb.y, tileIdx = jb.z & 0xffff, cb = jb.w;
@@ -1083,7 +1134,8 @@ __global__ __launch_bounds__(BSL_THREADS) void backsolve_long_kernel(const int4 
     }
 }
 
-void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1)
+void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,
+                 const CtlArgs *ca)
 {
     if (P.ntiles == 0 && P.nltiles == 0) return;
     if (q) {   // right-hand sides not in padded order yet
@@ -1099,27 +1151,38 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
     // CU instead of one); the events (if any) span both launches: start of the first, stop of the last
     const int nW = P.ntilesWide, nN = P.ntiles - P.ntilesWide;
     const bool timed = ev0 && ev1;
+    const int spec = ca ? 1 : 0;
+    if (ca && nN == 0)   // no launch of the 256-thread kernel to host it: the controller on its own, in front
+        launch_loop_control(ca->ctl, ca->partE, ca->nbE, ca->partR, ca->alpha_dev, ca->flags_host, st, 0);
     if (nW > 0) {
         if (timed)
             hipExtLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, ev0, nN > 0 ? (hipEvent_t) nullptr : ev1, 0,
-                                  P.tile, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, ctl);
+                                  P.tile, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, ctl, spec);
         else
             hipLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax, P.rt, P.rpad,
-                               P.ppart, P.nbmax, ctl);
+                               P.ppart, P.nbmax, ctl, spec);
     }
-    if (nN > 0) {
+    if (nN > 0 && ca) {
+        // one workgroup more: the controller (backsolve_ctl_kernel)
+        if (timed)
+            hipExtLaunchKernelGGL(backsolve_ctl_kernel, dim3(nN + 1), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
+                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, *ca);
+        else
+            hipLaunchKernelGGL(backsolve_ctl_kernel, dim3(nN + 1), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax, P.rt,
+                               (const double *)P.rpad, P.ppart, P.nbmax, *ca);
+    } else if (nN > 0) {
         if (timed)
             hipExtLaunchKernelGGL((backsolve_kernel<256>), dim3(nN), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
-                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, ctl);
+                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, ctl, spec);
         else
             hipLaunchKernelGGL((backsolve_kernel<256>), dim3(nN), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax, P.rt,
-                               P.rpad, P.ppart, P.nbmax, ctl);
+                               P.rpad, P.ppart, P.nbmax, ctl, spec);
     }
     if (P.nltiles > 0) {
         hipLaunchKernelGGL((backsolve_long_kernel<0>), dim3(P.nlwork), dim3(BSL_THREADS), 0, st, P.ltile, P.lwork, P.dofmap,
-                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl);
+                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl, spec);
         hipLaunchKernelGGL((backsolve_long_kernel<1>), dim3(P.nlwork), dim3(BSL_THREADS), 0, st, P.ltile, P.lwork, P.dofmap,
-                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl);
+                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl, spec);
     }
     if (!P.mt_ptr)   // merge_tiles_kernel sums the tile partials itself
         hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.trange,
@@ -1146,16 +1209,16 @@ void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, con
     if (njobs > 0) {
         if (P.maxTileLen <= 2560)
             hipLaunchKernelGGL((backsolve_kernel<256>), dim3(njobs), dim3(256), 0, st, job, P.dofmap, P.W, P.nmax, P.rt, P.rpad,
-                               P.ppart, P.nbmax, (const DevLoop *)nullptr);
+                               P.ppart, P.nbmax, (const DevLoop *)nullptr, 0);
         else
             hipLaunchKernelGGL((backsolve_kernel<512>), dim3(njobs), dim3(512), 0, st, job, P.dofmap, P.W, P.nmax, P.rt, P.rpad,
-                               P.ppart, P.nbmax, (const DevLoop *)nullptr);
+                               P.ppart, P.nbmax, (const DevLoop *)nullptr, 0);
     }
     if (nlwork > 0) {   // rows beyond the register tile: the two-phase kernel on this part's work items
         hipLaunchKernelGGL((backsolve_long_kernel<0>), dim3(nlwork), dim3(BSL_THREADS), 0, st, P.ltileByPart, lwork, P.dofmap,
-                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, (const DevLoop *)nullptr);
+                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, (const DevLoop *)nullptr, 0);
         hipLaunchKernelGGL((backsolve_long_kernel<1>), dim3(nlwork), dim3(BSL_THREADS), 0, st, P.ltileByPart, lwork, P.dofmap,
-                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, (const DevLoop *)nullptr);
+                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, (const DevLoop *)nullptr, 0);
     }
     hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, 1), dim3(256), 0, st, P.trange, P.ppart, P.nmax,
                        P.nbmax, P.psub, (const DevLoop *)nullptr, ls);
@@ -1959,6 +2022,92 @@ __global__ __launch_bounds__(256) void merge_tiles_kernel(int n3, const int *__r
     if (with_dots) write_partials(acc, DEV ? HIST_MAX : Lr.m, partials, sm);
 }
 
+// Early back-solve (enqueue_loop_slot): the tiles hold the partials of u = -M g for the gradient of the iterate the
+// controller has just accepted.  M is fixed during a step and linear, so with the M y_i of the stored pairs kept beside
+// the y_i the preconditioned vector of the two-loop is  z = M (-g - sum_j xi_j y_j) = u - sum_j xi_j (M y_j), and the
+// newest pair's M y = M (g - g_old) = u_old - u costs no solve of its own.  Same sums per dof as merge_tiles_kernel
+// (tiles of a subdomain, then subdomains, then the division by the multiplicity), then the history terms newest first
+// like build_qpad's.  first: start of the step (no pair yet; u_old is only set).
+__global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const int *__restrict__ mt_ptr,
+                                                                const int *__restrict__ mt_ent, const int *__restrict__ dup,
+                                                                const double *__restrict__ ppart, int first,
+                                                                double *__restrict__ z, double *__restrict__ partials,
+                                                                const DevLoop *__restrict__ ctl)
+{
+    __shared__ double sm[4 * RED_K];
+    if (ctl->status != 0 || ctl->phase != 0) return;
+    const LbfgsArgs &Lr = ctl->L;
+    const int m = first ? 0 : Lr.m;
+    const bool pairNew = !first && ctl->pairNew != 0 && m > 0;
+    double *__restrict__ u_old = ctl->u_old;
+    const double *my[HIST_MAX];
+    double xi[HIST_MAX];
+    double *my_new = nullptr;
+#pragma unroll
+    for (int i = 0; i < HIST_MAX; ++i) {
+        my[i] = (i < m) ? ctl->MY[ctl->order[i]] : nullptr;
+        xi[i] = (i < m) ? ctl->X.xi[i] : 0.0;
+        if (pairNew && i == m - 1) my_new = ctl->MY[ctl->order[i]];
+    }
+    double acc[RED_K];
+#pragma unroll
+    for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += stride) {
+        const int e0 = mt_ptr[k], e1 = mt_ptr[k + 1];
+        const int d = dup[k / 3];
+        double yk[HIST_MAX], mk[HIST_MAX];
+#pragma unroll
+        for (int i = 0; i < HIST_MAX; ++i) {
+            yk[i] = (i < m) ? Lr.y[i][k] : 0.0;
+            mk[i] = (i < m && !(pairNew && i == m - 1)) ? my[i][k] : 0.0;
+        }
+        const double uo = first ? 0.0 : u_old[k];
+        double u = 0.0, ps = 0.0;
+        for (int e = e0; e < e1; e += MT_CH) {
+            int off[MT_CH];
+#pragma unroll
+            for (int q = 0; q < MT_CH; ++q) off[q] = (e + q < e1) ? mt_ent[e + q] : 0;
+            double w[MT_CH];
+#pragma unroll
+            for (int q = 0; q < MT_CH; ++q) {
+                const int o = off[q] < 0 ? ~off[q] : off[q];
+                w[q] = (e + q < e1) ? ppart[o] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < MT_CH; ++q)
+                if (e + q < e1) {
+                    if (off[q] < 0 && e + q > e0) {   // a new subdomain starts: close the previous one
+                        u += ps;
+                        ps = 0.0;
+                    }
+                    ps += w[q];
+                }
+        }
+        u += ps;
+        if (d > 1) u /= d;
+        u_old[k] = u;
+        const double myn = uo - u;   // M y of the pair the controller has just stored
+        if (pairNew) my_new[k] = myn;
+        double zk = u;
+#pragma unroll
+        for (int j = HIST_MAX - 1; j >= 0; --j)
+            if (j < m) zk -= xi[j] * ((pairNew && j == m - 1) ? myn : mk[j]);
+        z[k] = zk;
+#pragma unroll
+        for (int i = 0; i < HIST_MAX; ++i)
+            if (i < m) acc[i] += yk[i] * zk;
+    }
+    write_partials(acc, HIST_MAX, partials, sm);
+}
+
+void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
+                        const DevLoop *ctl)
+{
+    hipLaunchKernelGGL(merge_tiles_early_kernel, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup, P.ppart,
+                       first, z, partials, ctl);
+}
+
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
                   int with_dots, hipStream_t st, const DevLoop *ctl)
 {
@@ -2194,11 +2343,10 @@ void launch_step_forward(int n, const double *x0, const double *p, double *x, co
 // Optimizer.cpp:317-330), on the device.  One wavefront; the partial sums are added in block order,
 // the same order the host path uses, so both paths produce the same bits.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__ ctl,
-                                                           const double *__restrict__ partE, int nbE,
-                                                           const double *__restrict__ partR,
-                                                           const double *__restrict__ alpha_dev,
-                                                           int *__restrict__ flags_host, int init)
+// (a device function: the controller is a launch of its own, or workgroup 0 of the back-solve launch -- 256 threads)
+__device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, const double *__restrict__ partE, int nbE,
+                                  const double *__restrict__ partR, const double *__restrict__ alpha_dev,
+                                  int *__restrict__ flags_host, int init)
 {
     static_assert(sizeof(DevLoop) % 8 == 0, "DevLoop is copied as 8-byte words");
     static_assert(RED_K <= 32, "two passes of 16 columns");
@@ -2330,6 +2478,7 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
             }
             int m = C.L.m;
             const int hist = C.hist, newslot = C.slot;
+            C.pairNew = ys_new > 0.0 ? 1 : 0;
             if (ys_new > 0.0) {
                 int off = 0;
                 if (m == hist) {  // drop the oldest pair
@@ -2442,6 +2591,15 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
         flags_host[1] = C.slots;
         flags_host[0] = C.status;
     }
+}
+
+__global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__ ctl,
+                                                           const double *__restrict__ partE, int nbE,
+                                                           const double *__restrict__ partR,
+                                                           const double *__restrict__ alpha_dev,
+                                                           int *__restrict__ flags_host, int init)
+{
+    loop_control_body(ctl, partE, nbE, partR, alpha_dev, flags_host, init);
 }
 
 void launch_loop_control(DevLoop *ctl, const double *partE, int nbE, const double *partR,

@@ -272,10 +272,13 @@ def test_sharded_device_loop_is_bit_identical_to_sharded_host_loop(workload, ste
 
 
 @pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 6), ("monkey18K_stiff", 2)])
-def test_device_loop_control_is_bit_identical_to_host_loop(workload, steps):
+def test_device_loop_control_is_bit_identical_to_host_loop(workload, steps, monkeypatch):
     """The device-resident loop control (DevLoop + loop_control_kernel) replaces one host round trip per
     line-search trial; it must take exactly the decisions the host loop takes: same iterates bit for bit,
-    same per-iteration log, same counters (DOTMI_FLAG_HOST_LOOP selects the host-driven loop)."""
+    same per-iteration log, same counters (DOTMI_FLAG_HOST_LOOP selects the host-driven loop).
+    DOTMI_EARLY_BACKSOLVE=0: the device loop in the host loop's order of operations (the default order forms z from the
+    cached M y_j -- same z up to rounding, tests/test_gpu_round3.py::test_early_backsolve_matches_the_q_based_loop)."""
+    monkeypatch.setenv("DOTMI_EARLY_BACKSOLVE", "0")
     sc, ep, n = load_workload(workload)
     a = DOTTimeStepper(sc, ep, n)
     sc2, _, _ = load_workload(workload)
@@ -569,10 +572,11 @@ def test_every_dissection_depth_gives_the_same_preconditioner(levels, nd_min, mo
 
 
 @pytest.mark.parametrize("history", [2, 5, 6])
-def test_iteration_cap_and_history_lengths_in_both_loops(history):
+def test_iteration_cap_and_history_lengths_in_both_loops(history, monkeypatch):
     """Iteration cap (return code 2, Optimizer.cpp:317-330) and the L-BFGS history rotation at other lengths than
     the reference's 5 -- the device-resident loop control and the host loop must agree bit for bit, and a capped
     step must stop exactly at the cap."""
+    monkeypatch.setenv("DOTMI_EARLY_BACKSOLVE", "0")   # the host loop's order of operations (see above)
     sc, ep, n = load_workload("bunny5K_LTSS")
     a = DOTTimeStepper(sc, ep, n, history=history, iter_cap=7)
     sc2, _, _ = load_workload("bunny5K_LTSS")

@@ -102,7 +102,7 @@ def test_bench_kernel_entry_covers_every_kernel_class():
 
 @pytest.mark.parametrize("env", [{"DOTMI_PATCH_ELEMS": "512"}, {"DOTMI_TILE_THREADS": "256"},
                                  {"DOTMI_TILE_EAGER_MIN": "1000"}, {"DOTMI_TILE_EAGER_MIN": "1", "DOTMI_TILE_EAGER_CHUNK": "1"},
-                                 {"DOTMI_TILE_XCD_ORDER": "0", "DOTMI_TILE_ROWS_LONG": "16"}])
+                                 {"DOTMI_TILE_XCD_ORDER": "0", "DOTMI_TILE_ROWS_LONG": "16"}, {"DOTMI_EARLY_BACKSOLVE": "0"}])
 def test_tuning_switches_do_not_change_results(env):
     """Every tuning variable of DESIGN.md section 10 that selects another variant of a round-3 kernel / schedule: same
     iterations as the oracle, positions to 1e-9 (horse7K: FCR with SVD in the element pass, 8 subdomains, back-tracking)."""
@@ -120,3 +120,36 @@ def test_tuning_switches_do_not_change_results(env):
         assert (st.status, st.iters, st.ls_halvings) == (so.status, so.iters, so.ls_halvings)
     assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
     ts.close(); orc.close()
+
+
+@pytest.mark.parametrize("workload,nparts,steps,history", [("bar17K_twist", None, 6, 5), ("bunny5K_LTSS", None, 10, 5),
+                                                           ("horse7K_stretch", None, 4, 5), ("bar17K_twist", 6, 2, 5),
+                                                           ("kingkong18K_SS_1K", None, 2, 5), ("bunny5K_LTSS", None, 5, 2)])
+def test_early_backsolve_matches_the_q_based_loop(workload, nparts, steps, history):
+    """The default device loop issues the back-solve of the next direction on the trial gradient, with the controller as
+    one workgroup of that launch, and forms z = u - sum_j xi_j (M y_j) from cached M y_j (M is linear and fixed during a
+    step; M y_new = u_old - u).  DOTMI_EARLY_BACKSOLVE=0 is the order of the reference (DOTTimeStepper.cpp:406-494):
+    controller, q = -g - sum_j xi_j y_j, z = M q.  Same decisions in every step (iterations, back-tracking, energy
+    evaluations), the per-iteration log (step and energy to 1e-9 relative, |g|^2 to 1e-6), positions to 1e-9 -- rounding only.
+    Covers retries (bunny step 0 halves once), the long-row back-solve (bar17K in 6 subdomains, `DOT 6`: the launch that
+    hosts the controller is not the only one) and a history shorter than the step (pairs dropped)."""
+    sc, ep, n = load_workload(workload, nparts)
+    a = DOTTimeStepper(sc, ep, n, history=history)
+    os.environ["DOTMI_EARLY_BACKSOLVE"] = "0"
+    try:
+        sc2, _, _ = load_workload(workload, nparts)
+        b = DOTTimeStepper(sc2, ep, n, history=history)
+    finally:
+        del os.environ["DOTMI_EARLY_BACKSOLVE"]
+    for k in range(steps):
+        for ts, s_ in ((a, sc), (b, sc2)):
+            idx, pos = s_.scripter.step(ts.getResult(), s_.cfg.dt)
+            ts.setDirichlet(idx, pos)
+        sa, sb = a.step(), b.step()
+        assert (sa.status, sa.iters, sa.ls_halvings, sa.energy_evals) == (sb.status, sb.iters, sb.ls_halvings, sb.energy_evals), k
+        # |g|^2 near convergence is a small difference of large element forces: it follows the positions' rounding
+        # amplified by the stiffness, so its bar is wider
+        for (u, w), rtol in zip(zip(a.iterLog(), b.iterLog()), (1e-9, 1e-9, 1e-6)):
+            np.testing.assert_allclose(u, w, rtol=rtol, atol=0)
+        assert np.abs(a.getResult() - b.getResult()).max() < 1e-9
+    a.close(); b.close()
