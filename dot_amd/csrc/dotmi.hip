@@ -105,8 +105,10 @@ struct Tuning {
     bool tileBalance = true;  // DOTMI_TILE_BALANCE=0 every tile task at its earliest level (no second scheduling pass)
     int tileEagerMinDiag = 0; // DOTMI_TILE_EAGER_MIN_DIAG early products a diagonal tile task may keep
     int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
-    bool earlyBs = true;      // DOTMI_EARLY_BACKSOLVE=0 the back-solve after the controller, on q (instead of speculatively on the
-                              //                      trial gradient with the controller inside its launch)
+    bool earlyHostCtl = true; // DOTMI_EARLY_HOST_CTL=0 (ablation) early back-solve with the controller as a launch of its own
+    int earlyBs = 1;          // DOTMI_EARLY_BACKSOLVE 0: the back-solve after the controller, on q; 1: speculatively on the trial
+                              //                      gradient with the controller inside its launch, in the steps where
+                              //                      that pays (run_device_loop); 2: in every step
     static int geti(const char *name, int dflt)
     {
         const char *ev = getenv(name);
@@ -143,7 +145,8 @@ struct Tuning {
         t.tileBalance = geti("DOTMI_TILE_BALANCE", 1) != 0;
         t.tileEagerMinDiag = std::max(0, geti("DOTMI_TILE_EAGER_MIN_DIAG", 0));
         t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
-        t.earlyBs = geti("DOTMI_EARLY_BACKSOLVE", 1) != 0;
+        t.earlyBs = std::min(2, std::max(0, geti("DOTMI_EARLY_BACKSOLVE", 1)));
+        t.earlyHostCtl = geti("DOTMI_EARLY_HOST_CTL", 1) != 0;
         return t;
     }
 };
@@ -217,7 +220,9 @@ struct dotmi_handle {
     double *He = nullptr, *Hval = nullptr, *tmpn = nullptr;
     double *S[HIST_MAX + 1] = {nullptr}, *Y[HIST_MAX + 1] = {nullptr};
     // early back-solve (enqueue_loop_slot): u = -M g of the current iterate, M y_i of the stored pairs (slots as Y)
-    bool earlyBs = false;
+    bool earlyBs = false;     // possible on this handle (buffers exist)
+    bool earlyNow = false;    // chosen for the running step
+    int prevIters = -1, prevHalv = 0;   // last step's iterations / line-search halvings (-1: no step yet)
     double *u_old = nullptr, *MY[HIST_MAX + 1] = {nullptr};
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
     double *gstage = nullptr;   // sharded element pass, device loop: [g (n) ; 0 ; E] staging buffer of the gradient all-reduce
@@ -1766,8 +1771,10 @@ int enqueue_loop_slot_early(dotmi_handle *h)
                        (h->timeCount++ % h->timeStride) == 0;
     h->slotTimed.push_back(timed ? h->evUsed : -1);
     CtlArgs ca{h->ctl, h->partE, h->partR, h->alpha_dev, h->h_flags, nb};
+    if (!h->tune.earlyHostCtl)   // (ablation) the controller as a launch of its own, in front of the speculative solve
+        launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st);
     launch_gemv(h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr,
-                &ca);
+                h->tune.earlyHostCtl ? &ca : nullptr, 1);
     if (timed) h->evUsed += 2;
     launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl);
     return 0;
@@ -1775,7 +1782,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
 
 int enqueue_loop_slot(dotmi_handle *h)
 {
-    if (h->earlyBs) return enqueue_loop_slot_early(h);
+    if (h->earlyNow) return enqueue_loop_slot_early(h);
     const int n = h->n;
     LbfgsArgs L0;
     memset(&L0, 0, sizeof(L0));
@@ -1846,6 +1853,17 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
 {
     DevLoop &C = *h->h_ctl;
     memset(&C, 0, sizeof(C));
+    // Early back-solve or not, per step: it takes the controller (~9 us with its launch boundary) off every iteration and
+    // streams the factors once for nothing per rejected trial and once at the end of the step.  Decided from the last
+    // step's counts (a function of the handle's own history: the same from run to run).
+    // (bar17K: 27 iterations, no halving, 46 us per back-solve -> early, 4.09 -> 3.93 ms per step; horse7K / monkey18K halve
+    // in every second trial -> q-based; the 1 M-tet bar: the cached vectors' extra traffic eats the gain -> q-based)
+    h->earlyNow = h->earlyBs;
+    if (h->earlyBs && h->tune.earlyBs == 1) {
+        const double save_ms = 0.009 - 64.0 * h->n / 4e9;                  // per iteration; merge_early moves ~8 vectors more
+        const double wasted_ms = (double)h->precond_bytes / 5e9 + 0.012;   // one back-solve at ~5 TB/s + its merge
+        h->earlyNow = h->prevIters >= 0 && save_ms * h->prevIters > wasted_ms * (h->prevHalv + 1.0);
+    }
     C.iterCap = h->iterCap;
     C.hist = h->hist;
     C.tol = h->targetGRes;
@@ -1893,7 +1911,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
         launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st);
         if (!h->shardElems) {
             launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
-            if (h->earlyBs) {   // the first direction's solve: u = -M g_0, z = u
+            if (h->earlyNow) {   // the first direction's solve: u = -M g_0, z = u
                 launch_build_qpad(h->P, h->g, L0, nullptr, h->st, h->ctl, 1);
                 launch_gemv(h->P, nullptr, h->st, h->ctl);
                 launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl);
@@ -1987,6 +2005,8 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     HIPCHECK(h, hipStreamSynchronize(h->st));
     *it = C.iter;
     h->prevSlots = C.slots;
+    h->prevIters = C.iter;
+    h->prevHalv = C.halvings;
     *failed = C.status == 3;
     *lastE = C.E_cur;
     *g2 = C.g2_cur;
@@ -2005,7 +2025,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     const int nk = std::min(std::min(C.slots, enq), h->kindCap);
     if (nk > 0 && (h->flags & DOTMI_FLAG_TIME_BACKSOLVE))
         HIPCHECK(h, hipMemcpy(h->slotKind.data(), h->dkind, sizeof(int) * nk, hipMemcpyDeviceToHost));
-    if (h->earlyBs)   // every slot the controller judged streamed the factors (speculatively), retries included
+    if (h->earlyNow)   // every slot the controller judged streamed the factors (speculatively), retries included
         for (int sl = 0; sl < nk; ++sl) h->slotKind[sl] = 1;
     return 0;
 }
@@ -2581,7 +2601,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
                      h->tune.deviceLoop;
         // one rank, merged tile partials: the back-solve of the next direction is issued on the trial gradient, beside
         // the controller (enqueue_loop_slot)
-        h->earlyBs = h->devLoop && h->tune.earlyBs && !h->dist && !h->shardElems && h->P.mt_ptr != nullptr;
+        h->earlyBs = h->devLoop && h->tune.earlyBs != 0 && !h->dist && !h->shardElems && h->P.mt_ptr != nullptr;
         if (h->earlyBs) {
             if (int rc = dalloc(h, &h->u_old, (size_t)h->n)) return rc;
             for (int sl = 0; sl <= h->hist; ++sl)
@@ -2914,6 +2934,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         }
         st->precond_bytes = h->precond_bytes;
         st->factor_flops = h->factorFlops;
+        st->backsolve_launches = (h->devLoop && h->earlyNow) ? (int64_t)it + (h->numLineSearch - ls0) + 1 : (int64_t)it;
         for (int k = 0; k + 1 < h->evArUsed; k += 2) {
             float ms = 0;
             hipEventElapsedTime(&ms, h->evAr[k], h->evAr[k + 1]);

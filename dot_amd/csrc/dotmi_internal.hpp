@@ -205,7 +205,7 @@ void launch_build_q(int n, const double *g, const LbfgsArgs &L, const double *xi
 // ca: the loop controller runs as workgroup 0 of the (first) launch, beside the tiles, which then ignore the retry phase
 // (the back-solve is speculative: issued on the trial gradient before the controller has accepted the trial)
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
-                 hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr);
+                 hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr, int spec = 0);
 // rpad_s[k] = q[dofmap_s[k]] with q = -g - sum_j xi_j y_j formed on the fly (same operations as build_q), 0 on padding
 // spec (device loop, early back-solve): 1: rpad = -g_cur, 2: rpad = -g_trial whatever the phase; no history terms
 void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, const double *xi_host, hipStream_t st,

@@ -12,6 +12,7 @@
 #include "IglUtils.hpp"
 
 #include <chrono>
+#include <algorithm>
 #include <cstring>
 #include <set>
 #include <vector>
@@ -74,14 +75,22 @@ int ref_linsys_time(int nV, int nT, const int *T, const unsigned char *fixed, co
     Solver solver;
     assemble(solver, nV, nT, T, fixed, He, mass);
     const int n = 3 * nV;
-    double t0 = now_ms();
-    for (int k = 0; k < nfact; ++k)
+    // best of the repetitions: the first call pays the BLAS' own start-up, and the GPU boxes' host cores are shared
+    double best = 1e300;
+    for (int k = 0; k < nfact; ++k) {
+        const double t0 = now_ms();
         if (solver.factorize()) return 1;
-    out[0] = (now_ms() - t0) / (nfact > 0 ? nfact : 1);
+        best = std::min(best, now_ms() - t0);
+    }
+    out[0] = nfact > 0 ? best : 0.0;
     Eigen::VectorXd b = Eigen::VectorXd::Ones(n), r;
-    t0 = now_ms();
-    for (int k = 0; k < nsolve; ++k) solver.solve(b, r);
-    out[1] = (now_ms() - t0) / (nsolve > 0 ? nsolve : 1);
+    best = 1e300;
+    for (int k = 0; k < nsolve; ++k) {
+        const double t0 = now_ms();
+        solver.solve(b, r);
+        best = std::min(best, now_ms() - t0);
+    }
+    out[1] = nsolve > 0 ? best : 0.0;
     out[2] = 0.0;
     return 0;
 }

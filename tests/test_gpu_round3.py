@@ -102,7 +102,8 @@ def test_bench_kernel_entry_covers_every_kernel_class():
 
 @pytest.mark.parametrize("env", [{"DOTMI_PATCH_ELEMS": "512"}, {"DOTMI_TILE_THREADS": "256"},
                                  {"DOTMI_TILE_EAGER_MIN": "1000"}, {"DOTMI_TILE_EAGER_MIN": "1", "DOTMI_TILE_EAGER_CHUNK": "1"},
-                                 {"DOTMI_TILE_XCD_ORDER": "0", "DOTMI_TILE_ROWS_LONG": "16"}, {"DOTMI_EARLY_BACKSOLVE": "0"}])
+                                 {"DOTMI_TILE_XCD_ORDER": "0", "DOTMI_TILE_ROWS_LONG": "16"}, {"DOTMI_EARLY_BACKSOLVE": "0"},
+                                 {"DOTMI_EARLY_BACKSOLVE": "2"}])
 def test_tuning_switches_do_not_change_results(env):
     """Every tuning variable of DESIGN.md section 10 that selects another variant of a round-3 kernel / schedule: same
     iterations as the oracle, positions to 1e-9 (horse7K: FCR with SVD in the element pass, 8 subdomains, back-tracking)."""
@@ -134,9 +135,10 @@ def test_early_backsolve_matches_the_q_based_loop(workload, nparts, steps, histo
     Covers retries (bunny step 0 halves once), the long-row back-solve (bar17K in 6 subdomains, `DOT 6`: the launch that
     hosts the controller is not the only one) and a history shorter than the step (pairs dropped)."""
     sc, ep, n = load_workload(workload, nparts)
-    a = DOTTimeStepper(sc, ep, n, history=history)
-    os.environ["DOTMI_EARLY_BACKSOLVE"] = "0"
     try:
+        os.environ["DOTMI_EARLY_BACKSOLVE"] = "2"     # in every step (the default picks per step, by the last step's counts)
+        a = DOTTimeStepper(sc, ep, n, history=history)
+        os.environ["DOTMI_EARLY_BACKSOLVE"] = "0"
         sc2, _, _ = load_workload(workload, nparts)
         b = DOTTimeStepper(sc2, ep, n, history=history)
     finally:
