@@ -253,9 +253,11 @@ def main():
             "frac_if_priced_as_dense_8d": round(dense_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if pre_n else 0.0,
             # every 8th back-solve of the timed region is bracketed with HIP events (an event record costs ~6 us
             # of stream time, so bracketing all of them would inflate the metric by ~3%)
-            # launches_total: one per L-BFGS iteration, or -- in the steps whose device loop issues the back-solve
-            # speculatively on the trial gradient -- one per trial plus one at the end of the step
+            # launches_total: the back-solves that ran to their end (one per L-BFGS iteration); launches_stopped: the
+            # speculative ones of the early order that the controller stopped (one per rejected trial + one per step,
+            # DESIGN.md section 5) -- they are not among the timed launches
             "launches_timed": int(pre_n), "launches_total": int(sum(s.backsolve_launches for s in stats)),
+            "launches_stopped": int(sum(s.backsolve_stopped for s in stats)),
             "share_of_step_time": round(avg_ms * sum(s.backsolve_launches for s in stats) / (1e3 * elapsed), 3),
         }
         w = np.array(walls) * 1e3

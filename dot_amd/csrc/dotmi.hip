@@ -105,6 +105,7 @@ struct Tuning {
     bool tileBalance = true;  // DOTMI_TILE_BALANCE=0 every tile task at its earliest level (no second scheduling pass)
     int tileEagerMinDiag = 0; // DOTMI_TILE_EAGER_MIN_DIAG early products a diagonal tile task may keep
     int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
+    bool earlyAbort = true;   // DOTMI_EARLY_ABORT=0  (ablation) speculative back-solves run to their end even when the trial is rejected
     bool earlyHostCtl = true; // DOTMI_EARLY_HOST_CTL=0 (ablation) early back-solve with the controller as a launch of its own
     int earlyBs = 1;          // DOTMI_EARLY_BACKSOLVE 0: the back-solve after the controller, on q; 1: speculatively on the trial
                               //                      gradient with the controller inside its launch, in the steps where
@@ -147,6 +148,7 @@ struct Tuning {
         t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
         t.earlyBs = std::min(2, std::max(0, geti("DOTMI_EARLY_BACKSOLVE", 1)));
         t.earlyHostCtl = geti("DOTMI_EARLY_HOST_CTL", 1) != 0;
+        t.earlyAbort = geti("DOTMI_EARLY_ABORT", 1) != 0;
         return t;
     }
 };
@@ -1774,7 +1776,8 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     if (!h->tune.earlyHostCtl)   // (ablation) the controller as a launch of its own, in front of the speculative solve
         launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st);
     launch_gemv(h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr,
-                h->tune.earlyHostCtl ? &ca : nullptr, 1);
+                h->tune.earlyHostCtl ? &ca : nullptr,
+                h->tune.earlyAbort ? (int)h->slotTimed.size() /* the slot's epoch, 1-based */ : (1 << 30) /* never stopped */);
     if (timed) h->evUsed += 2;
     launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl);
     return 0;
@@ -1854,14 +1857,16 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     DevLoop &C = *h->h_ctl;
     memset(&C, 0, sizeof(C));
     // Early back-solve or not, per step: it takes the controller (~9 us with its launch boundary) off every iteration and
-    // streams the factors once for nothing per rejected trial and once at the end of the step.  Decided from the last
-    // step's counts (a function of the handle's own history: the same from run to run).
-    // (bar17K: 27 iterations, no halving, 46 us per back-solve -> early, 4.09 -> 3.93 ms per step; horse7K / monkey18K halve
-    // in every second trial -> q-based; the 1 M-tet bar: the cached vectors' extra traffic eats the gain -> q-based)
+    // starts a back-solve for nothing per rejected trial and once at the end of the step -- the controller tells it to
+    // stop (DevLoop::abortEpoch), which costs ~20 us.  Decided from the last step's counts (a function of the handle's own
+    // history: the same from run to run).
+    // (bar17K: 27 iterations, no halving -> early, 4.09 -> 3.90 ms per step; horse7K / monkey18K halve in every second
+    // trial -> q-based, measured equal within 2 % either way; the 1 M-tet bar: the cached vectors' extra traffic eats
+    // the gain -> q-based)
     h->earlyNow = h->earlyBs;
     if (h->earlyBs && h->tune.earlyBs == 1) {
-        const double save_ms = 0.009 - 64.0 * h->n / 4e9;                  // per iteration; merge_early moves ~8 vectors more
-        const double wasted_ms = (double)h->precond_bytes / 5e9 + 0.012;   // one back-solve at ~5 TB/s + its merge
+        const double save_ms = 0.009 - 64.0 * h->n / 4e9;   // per iteration; merge_early moves ~8 vectors more
+        const double wasted_ms = 0.02;                      // a speculative back-solve until it has noticed the verdict
         h->earlyNow = h->prevIters >= 0 && save_ms * h->prevIters > wasted_ms * (h->prevHalv + 1.0);
     }
     C.iterCap = h->iterCap;
@@ -2025,8 +2030,11 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     const int nk = std::min(std::min(C.slots, enq), h->kindCap);
     if (nk > 0 && (h->flags & DOTMI_FLAG_TIME_BACKSOLVE))
         HIPCHECK(h, hipMemcpy(h->slotKind.data(), h->dkind, sizeof(int) * nk, hipMemcpyDeviceToHost));
-    if (h->earlyNow)   // every slot the controller judged streamed the factors (speculatively), retries included
-        for (int sl = 0; sl < nk; ++sl) h->slotKind[sl] = 1;
+    if (h->earlyNow && (h->flags & DOTMI_FLAG_TIME_BACKSOLVE)) {
+        // early order: slot sl's back-solve ran to its end iff its trial was accepted and the loop went on, i.e. iff slot
+        // sl + 1 computed a new direction (kind 1); the others were told to stop and do not count as timed launches
+        for (int sl = 0; sl < nk; ++sl) h->slotKind[sl] = (sl + 1 < nk && h->slotKind[sl + 1] == 1) ? 1 : 0;
+    }
     return 0;
 }
 
@@ -2934,7 +2942,8 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         }
         st->precond_bytes = h->precond_bytes;
         st->factor_flops = h->factorFlops;
-        st->backsolve_launches = (h->devLoop && h->earlyNow) ? (int64_t)it + (h->numLineSearch - ls0) + 1 : (int64_t)it;
+        st->backsolve_launches = it;
+        st->backsolve_stopped = (h->devLoop && h->earlyNow) ? (h->numLineSearch - ls0) + 1 : 0;
         for (int k = 0; k + 1 < h->evArUsed; k += 2) {
             float ms = 0;
             hipEventElapsedTime(&ms, h->evAr[k], h->evAr[k + 1]);

@@ -153,7 +153,9 @@ struct DevLoop {
     int *slot_kind;        // per slot: 1 new direction, 2 retry (slots after the end are not logged)
     int logCap, kindCap;
     // early back-solve (enqueue_loop_slot): u = -M g of the accepted iterate and M y_i of the stored pairs (same slots as Y)
-    int pairNew, pad1;     // the controller's last accept stored a pair (its M y goes to MY[order[m - 1]])
+    int pairNew;           // the controller's last accept stored a pair (its M y goes to MY[order[m - 1]])
+    int abortEpoch;        // `slots` value of the last slot whose trial was rejected or that ended the loop: the speculative
+                           // back-solve of that slot (which knows its epoch) stops when it sees it
     double *u_old, *MY[HIST_MAX + 1];
 };
 // the controller's operands when it runs as one workgroup of another launch (launch_gemv)

@@ -776,7 +776,9 @@ template <int THREADS, int MAXCH, int SUB>
 __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restrict__ dofmap,
                                                const double *__restrict__ W, int nmax, const RowTile *__restrict__ rt,
                                                const double *__restrict__ q, double *__restrict__ ppart,
-                                               int nbmax, double (*sm)[THREADS / 64][32])
+                                               int nbmax, double (*sm)[THREADS / 64][32],
+                                               const int *__restrict__ abortp = nullptr, int epoch = 0,
+                                               int *s_abort = nullptr)
 {
     constexpr int NW = THREADS / 64;
     const int s = jb.x, i0 = jb.y, tileIdx = jb.z & 0xffff, cb = jb.w;
@@ -808,6 +810,13 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
     for (int sb = 0; sb < BS_ROWS / SUB; ++sb) {
         const int ib = i0 + sb * SUB;
         if (ib >= ns) break;
+        // speculative launch: has the controller (workgroup 0 of the launch) rejected the trial meanwhile?  One thread asks,
+        // the answer is shared through LDS behind this pass' barrier (double-buffered like sm), so the whole workgroup
+        // leaves together
+        // (requested here, in front of the pass' row loads; stored to LDS only next to the dot products, so that the
+        // asking wave does not wait for the answer before it issues its rows)
+        int abortSeen = 0;
+        if (abortp && tid == 0) abortSeen = __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double2 y[SUB][MAXCH];
 #pragma unroll
         for (int rr = 0; rr < SUB; ++rr) {
@@ -867,7 +876,9 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
             // lane bits (5,4,3) = (b2,b1,b0): row index = 4*b2 + 2*b1 + b0
             if ((lane & 7) == 0) sm[buf][wv][8 * g + (lane >> 3)] = e1;
         }
+        if (abortp && tid == 0) s_abort[sb & 1] = abortSeen;
         __syncthreads();
+        if (abortp && s_abort[sb & 1] == epoch) return;   // the result would not be used
 #pragma unroll
         for (int rr = 0; rr < SUB; ++rr) {
             double t = 0.0;
@@ -900,8 +911,14 @@ template <int THREADS>
 __device__ __forceinline__ void backsolve_block(int jobIdx, const int4 *__restrict__ job, const int *__restrict__ dofmap,
                                                 const double *__restrict__ W, int nmax, const RowTile *__restrict__ rt,
                                                 const double *__restrict__ q, double *__restrict__ ppart, int nbmax,
-                                                double (*sm)[THREADS / 64][32])
+                                                double (*sm)[THREADS / 64][32], const int *__restrict__ abortp = nullptr,
+                                                int epoch = 0, int *s_abort = nullptr)
 {
+    if (abortp) {   // workgroups that start after the verdict leave at once (one thread asks: a uniform answer)
+        if (threadIdx.x == 0) s_abort[2] = __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_abort[2] == epoch) return;
+    }
     const int4 jb = job[jobIdx];
     const int len = jb.y + (jb.z >> 16) - jb.w;   // longest row of the tile
 #ifdef BS_PROFILE
@@ -917,14 +934,14 @@ __device__ __forceinline__ void backsolve_block(int jobIdx, const int4 *__restri
     }
 #endif
     if constexpr (THREADS == 256) {
-        if (len <= 512) backsolve_tile<256, 1, 32>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
-        else if (len <= 1024) backsolve_tile<256, 2, 16>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
-        else if (len <= 1536) backsolve_tile<256, 3, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
-        else backsolve_tile<256, 5, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
+        if (len <= 512) backsolve_tile<256, 1, 32>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
+        else if (len <= 1024) backsolve_tile<256, 2, 16>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
+        else if (len <= 1536) backsolve_tile<256, 3, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
+        else backsolve_tile<256, 5, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
     } else {
-        if (len <= 1024) backsolve_tile<512, 1, 32>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
-        else if (len <= 2048) backsolve_tile<512, 2, 16>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
-        else backsolve_tile<512, 4, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
+        if (len <= 1024) backsolve_tile<512, 1, 32>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
+        else if (len <= 2048) backsolve_tile<512, 2, 16>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
+        else backsolve_tile<512, 4, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
     }
 #ifdef BS_PROFILE
     __syncthreads();
@@ -944,8 +961,12 @@ __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restri
                                                             const DevLoop *__restrict__ ctl, int spec)
 {
     __shared__ double sm[2][THREADS / 64][32];
+    __shared__ int s_abort[3];
     if (ctl && (ctl->status != 0 || (ctl->phase != 0 && !spec))) return;
-    backsolve_block<THREADS>(blockIdx.x, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
+    // spec > 0: the slot's epoch (its 1-based index in the step); the controller, which runs meanwhile, publishes the epoch
+    // of a slot whose trial it rejects or that ends the loop (DevLoop::abortEpoch)
+    backsolve_block<THREADS>(blockIdx.x, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm,
+                             (ctl && spec > 0 && spec < (1 << 30)) ? &ctl->abortEpoch : nullptr, spec, s_abort);
 }
 
 // The same tiles with the loop controller as workgroup 0 of the launch: the controller's ~7 us (partial sums, the
@@ -955,16 +976,19 @@ __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restri
 __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__restrict__ job, const int *__restrict__ dofmap,
                                                             const double *__restrict__ W, int nmax,
                                                             const RowTile *__restrict__ rt, const double *__restrict__ q,
-                                                            double *__restrict__ ppart, int nbmax, CtlArgs ca)
+                                                            double *__restrict__ ppart, int nbmax, CtlArgs ca,
+                                                            int epoch)
 {
     __shared__ double sm[2][4][32];
+    __shared__ int s_abort[3];
     // (which workgroup hosts the controller makes no difference: index 0 / 256 / 520 / last measured 47.0-47.5 us)
     if (blockIdx.x == 0) {
         loop_control_body(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, 0);
         return;
     }
     if (ca.ctl->status != 0) return;
-    backsolve_block<256>(blockIdx.x - 1, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm);
+    backsolve_block<256>(blockIdx.x - 1, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm,
+                         epoch < (1 << 30) ? &ca.ctl->abortEpoch : nullptr, epoch, s_abort);
 }
 #ifdef BS_PROFILE
 extern "C" int dotmi_debug_bs_prof(long long *out, int n)
@@ -1152,7 +1176,7 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
     // CU instead of one); the events (if any) span both launches: start of the first, stop of the last
     const int nW = P.ntilesWide, nN = P.ntiles - P.ntilesWide;
     const bool timed = ev0 && ev1;
-    if (ca) spec = 1;
+    if (ca && spec <= 0) spec = 1;   // (callers pass the slot's epoch: > 0)
     if (ca && nN == 0)   // no launch of the 256-thread kernel to host it: the controller on its own, in front
         launch_loop_control(ca->ctl, ca->partE, ca->nbE, ca->partR, ca->alpha_dev, ca->flags_host, st, 0);
     if (nW > 0) {
@@ -1167,10 +1191,10 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
         // one workgroup more: the controller (backsolve_ctl_kernel)
         if (timed)
             hipExtLaunchKernelGGL(backsolve_ctl_kernel, dim3(nN + 1), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
-                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, *ca);
+                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, *ca, spec);
         else
             hipLaunchKernelGGL(backsolve_ctl_kernel, dim3(nN + 1), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax, P.rt,
-                               (const double *)P.rpad, P.ppart, P.nbmax, *ca);
+                               (const double *)P.rpad, P.ppart, P.nbmax, *ca, spec);
     } else if (nN > 0) {
         if (timed)
             hipExtLaunchKernelGGL((backsolve_kernel<256>), dim3(nN), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
@@ -2435,6 +2459,9 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
         C.slots++;
         if (E > C.E_cur && alpha > 0.0) {
             // back-tracking (c1 = 0, lower bound 0)
+            // a speculative back-solve on this trial's gradient may be running beside this workgroup: tell it to stop
+            C.abortEpoch = C.slots;
+            __hip_atomic_store(&ctl->abortEpoch, C.slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             alpha /= 2.0;
             C.halvings++;
             if (alpha == 0.0) {
@@ -2458,6 +2485,12 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
             C.E_cur = E;
             const double g2 = R[0];
             C.g2_cur = g2;
+            if (C.iter + 1 >= C.iterCap || !(g2 > C.tol)) {
+                // the loop ends with this iterate: a speculative back-solve for the next direction (running beside this
+                // workgroup) may stop -- said before the history update below
+                C.abortEpoch = C.slots;
+                __hip_atomic_store(&ctl->abortEpoch, C.slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             // The history update and the first half of the two-loop below are the host loop's statements
             // (dotmi_step) with every array held in registers: all loops are unrolled to HIST_MAX with guards, so
             // nothing is indexed dynamically and no LDS round trip sits in the dependent chain.  The operations
@@ -2536,7 +2569,7 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
             int fs = C.slot;
             if (C.iter >= C.iterCap) C.status = 2;
             else if (!(g2 > C.tol)) C.status = 1;
-            else {
+            if (C.status == 0) {
                 // next direction: first half of the two-loop, free slot
 #pragma unroll
                 for (int i = H - 1; i >= 0; --i)

@@ -159,9 +159,10 @@ typedef struct {
                                        slower rank included) */
     int64_t collective_timed;       /* how many were bracketed */
     int64_t collective_timed_bytes; /* and their payload */
-    int64_t backsolve_launches;     /* back-solve launches of the step's loop: `iters`, or iters + ls_halvings + 1 in a step
-                                       whose device loop issued them speculatively on the trial gradient (DESIGN.md
-                                       section 5, DOTMI_EARLY_BACKSOLVE) */
+    int64_t backsolve_launches;     /* back-solves of the step's loop that ran to their end (= iters) */
+    int64_t backsolve_stopped;      /* speculative back-solves the controller stopped: ls_halvings + 1 in a step whose device
+                                       loop issued them on the trial gradient (DESIGN.md section 5,
+                                       DOTMI_EARLY_BACKSOLVE), else 0 */
 } dotmi_step_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
