@@ -222,6 +222,9 @@ struct dotmi_handle {
     double *He = nullptr, *Hval = nullptr, *tmpn = nullptr;
     double *S[HIST_MAX + 1] = {nullptr}, *Y[HIST_MAX + 1] = {nullptr};
     // early back-solve (enqueue_loop_slot): u = -M g of the current iterate, M y_i of the stored pairs (slots as Y)
+    hipEvent_t evLoop0 = nullptr, evLoop1 = nullptr;   // device-side bracket of a step's loop (asynchronous refresh)
+    bool refreshPending = false;   // DOTMI_FLAG_ASYNC_REFRESH: the last step's refresh is enqueued, not yet judged / timed
+    double carryHess = 0, carryFact = 0;   // device times of a refresh resolved outside dotmi_step (reported by the next step)
     bool earlyBs = false;     // possible on this handle (buffers exist)
     bool earlyNow = false;    // chosen for the running step
     int prevIters = -1, prevHalv = 0;   // last step's iterations / line-search halvings (-1: no step yet)
@@ -1577,6 +1580,22 @@ int refactor(dotmi_handle *h, const double *x, double *ms_hess, double *ms_fact)
     return refactor_finish(h, ms_hess, ms_fact);
 }
 
+// DOTMI_FLAG_ASYNC_REFRESH: wait for the refresh the last step left running, take its verdict and its device times
+// (into *ms_hess / *ms_fact, or carried to the next step's statistics)
+int resolve_refresh(dotmi_handle *h, double *ms_hess = nullptr, double *ms_fact = nullptr)
+{
+    if (!h->refreshPending) return 0;
+    h->refreshPending = false;
+    HIPCHECK(h, hipStreamSynchronize(h->st));
+    double a = 0, b = 0;
+    const int rc = refactor_finish(h, &a, &b);
+    if (ms_hess) *ms_hess += a;
+    else h->carryHess += a;
+    if (ms_fact) *ms_fact += b;
+    else h->carryFact += b;
+    return rc;
+}
+
 // sum over the ranks of n doubles at `dev`, in place, ordered on the handle's stream: RCCL, or the host hook
 int allreduce_sum(dotmi_handle *h, double *dev, size_t n)
 {
@@ -2390,6 +2409,8 @@ void dotmi_destroy(dotmi_handle *h)
     if (h->evA) hipEventDestroy(h->evA);
     for (hipEvent_t e : h->evP)
         if (e) hipEventDestroy(e);
+    if (h->evLoop0) hipEventDestroy(h->evLoop0);
+    if (h->evLoop1) hipEventDestroy(h->evLoop1);
     for (hipEvent_t e : h->tFork) hipEventDestroy(e);
     for (hipEvent_t e : h->tJoin) hipEventDestroy(e);
     if (h->stDiag) hipStreamDestroy(h->stDiag);
@@ -2654,6 +2675,7 @@ int dotmi_set_state(dotmi_handle *h, const double *x, const double *v, const dou
 {
     if (!h || !x || !v) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     const size_t bytes = sizeof(double) * h->n;
     HIPCHECK(h, hipMemcpyAsync(h->x, x, bytes, hipMemcpyHostToDevice, h->st));
     HIPCHECK(h, hipMemcpyAsync(h->v, v, bytes, hipMemcpyHostToDevice, h->st));
@@ -2675,6 +2697,7 @@ int dotmi_get_state(dotmi_handle *h, double *x, double *v, double *x_tilde)
 {
     if (!h) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     const size_t bytes = sizeof(double) * h->n;
     HIPCHECK(h, hipStreamSynchronize(h->st));
     if (x) HIPCHECK(h, hipMemcpy(x, h->x, bytes, hipMemcpyDeviceToHost));
@@ -2721,6 +2744,7 @@ int dotmi_refix(dotmi_handle *h, const uint8_t *fixed)
 {
     if (!h || !fixed) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     h->fixed.assign(fixed, fixed + h->nV);
     HIPCHECK(h, hipMemcpy(h->M.fixed, fixed, h->nV, hipMemcpyHostToDevice));
     return refactor(h, h->x, nullptr, nullptr);
@@ -2781,6 +2805,14 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     for (double &v : h->phaseMs) v = 0.0;
     h->evPn = 0;
     phase_mark(h, -1);
+    const bool asyncTimed = h->refreshPending;
+    if (asyncTimed) {
+        if (!h->evLoop0) {
+            HIPCHECK(h, hipEventCreate(&h->evLoop0));
+            HIPCHECK(h, hipEventCreate(&h->evLoop1));
+        }
+        HIPCHECK(h, hipEventRecord(h->evLoop0, h->st));
+    }
     // initX(2): x += dt v + dt^2 g on free vertices (Optimizer.cpp:442-582)
     launch_init_x(h->nV, h->M.fixed, h->v, h->dt, h->gdtsq, h->x, h->st);
     LbfgsArgs L = lbfgs_args(h);
@@ -2896,7 +2928,21 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         h->log_g2.push_back(g2);
         if (++it >= h->iterCap) break;
     } while (g2 > h->targetGRes);
-    const double Tloop1 = now_ms();
+    double Tloop1 = now_ms();
+    double TloopDev = -1.0;
+    if (asyncTimed) {
+        // the step started behind the previous step's refresh: its loop is timed on the device (from the moment the
+        // stream reached this step's first kernel), and that refresh is judged and timed now that the stream is idle
+        HIPCHECK(h, hipEventRecord(h->evLoop1, h->st));
+        HIPCHECK(h, hipEventSynchronize(h->evLoop1));
+        float ms = 0;
+        hipEventElapsedTime(&ms, h->evLoop0, h->evLoop1);
+        TloopDev = ms;
+    }
+    if (int rc = resolve_refresh(h, &ms_hess, &ms_fact)) return rc;
+    ms_hess += h->carryHess;
+    ms_fact += h->carryFact;
+    h->carryHess = h->carryFact = 0.0;
 
     const bool refreshAtEnd = !failed && !h->newton;   // Newton refreshes at the START of every iteration instead
     if (failed) status = 2;
@@ -2909,12 +2955,18 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     phase_mark(h, -1);
     launch_be_update(h->nV, h->M.fixed, h->x, h->xn, h->v, h->xt, h->dt, h->gdtsq, h->st);
     phase_mark(h, DOTMI_T_SOLVE_EXTRACOMP);
-    HIPCHECK(h, hipStreamSynchronize(h->st));
-    phase_collect(h);
-    HIPCHECK(h, hipGetLastError());
     int rcFactor = 0;
-    if (refreshAtEnd) rcFactor = refactor_finish(h, &ms_hess, &ms_fact);
-    if (rcFactor == DOTMI_E_DEVICE) return rcFactor;
+    const bool asyncRefresh = refreshAtEnd && (h->flags & DOTMI_FLAG_ASYNC_REFRESH) && h->devLoop && !h->dist;
+    if (asyncRefresh) {
+        // the refresh and the BE update stay queued; whoever needs their result next waits for them (resolve_refresh)
+        h->refreshPending = true;
+    } else {
+        HIPCHECK(h, hipStreamSynchronize(h->st));
+        phase_collect(h);
+        HIPCHECK(h, hipGetLastError());
+        if (refreshAtEnd) rcFactor = refactor_finish(h, &ms_hess, &ms_fact);
+        if (rcFactor == DOTMI_E_DEVICE) return rcFactor;
+    }
     if (st) {
         memset(st, 0, sizeof(*st));
         st->iters = it;
@@ -2926,7 +2978,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         st->E = lastE;
         st->g2 = g2;
         st->ms_total = now_ms() - T0;
-        st->ms_loop = Tloop1 - Tloop;
+        st->ms_loop = TloopDev >= 0.0 ? TloopDev : Tloop1 - Tloop;
         st->ms_hessian = ms_hess;
         st->ms_factor = ms_fact;
         std::vector<char> ran(h->evUsed / 2 + 1, h->devLoop ? 0 : 1);
@@ -2972,6 +3024,7 @@ int dotmi_eval_energy(dotmi_handle *h, const double *x, double *E)
 {
     if (!h || !x || !E) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     if (int rc = upload_tmp(h, x, h->x_trial)) return rc;
     int nb = 0;
     launch_elem_energy_grad(h->M, h->PTall, h->mat, h->dtSq, h->x_trial, h->xt, 0, h->nV, 0, h->partE,
@@ -2991,6 +3044,7 @@ int dotmi_eval_gradient(dotmi_handle *h, const double *x, double *g)
 {
     if (!h || !x || !g) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     if (int rc = upload_tmp(h, x, h->x_trial)) return rc;
     int nb = 0;
     launch_elem_energy_grad(h->M, h->PTall, h->mat, h->dtSq, h->x_trial, h->xt, 0, h->nV, 1, h->partE,
@@ -3015,6 +3069,7 @@ int dotmi_eval_elem_hessians(dotmi_handle *h, const double *x, double *H)
 {
     if (!h || !x || !H) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     if (int rc = upload_tmp(h, x, h->x_trial)) return rc;
     // scratch copy so the resident He (state of the current preconditioner) is not disturbed
     double *tmp = nullptr;
@@ -3031,6 +3086,7 @@ int dotmi_refactor(dotmi_handle *h, const double *x)
 {
     if (!h) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     const double *xd = h->x;
     if (x) {
         if (int rc = upload_tmp(h, x, h->x_trial)) return rc;
@@ -3047,6 +3103,7 @@ int dotmi_apply_precond(dotmi_handle *h, const double *r, double *p)
         return DOTMI_E_NOTSPD;
     }
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     if (int rc = upload_tmp(h, r, h->q)) return rc;
     LbfgsArgs L;
     memset(&L, 0, sizeof(L));
@@ -3073,6 +3130,7 @@ int dotmi_probe_direction(dotmi_handle *h, const double *x, int32_t m, const dou
         return DOTMI_E_INVALID;
     }
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     const int n = h->n;
     const size_t bytes = sizeof(double) * n;
     // the probe works on tmpn (iterate), g_trial (gradient), x_trial (trial point): the handle's own x, g stay
@@ -3148,6 +3206,7 @@ int dotmi_spmv(dotmi_handle *h, const double *p, double *Hp)
         return DOTMI_E_INVALID;
     }
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     if (int rc = upload_tmp(h, p, h->tmpn)) return rc;
     launch_spmv_dots(h->M, h->Hval, h->tmpn, nullptr, h->Hp, 0, h->nV, h->partS, h->st);
     HIPCHECK(h, hipMemcpyAsync(Hp, h->Hp, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->st));
@@ -3177,6 +3236,7 @@ int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *Mout, 
 {
     if (!h || part < h->p0 || part >= h->p1 || !Mout) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     const int ls = part - h->p0;
     const int ns = 3 * (int)h->partVerts[part].size();
     const int nmax = h->P.nmax, ntl = nmax / 64;
@@ -3231,6 +3291,7 @@ int dotmi_bench_precond(dotmi_handle *h, int32_t reps, double *ms_per_launch, in
 {
     if (!h || reps < 1) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     launch_gemv(h->P, h->q, h->st);  // warm
     HIPCHECK(h, hipEventRecord(h->ev0, h->st));
     for (int i = 0; i < reps; ++i) launch_gemv(h->P, h->q, h->st);
@@ -3252,6 +3313,7 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
 {
     if (!h || reps < 1) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     const int n = h->n, nV = h->nV;
     const int64_t nTo = h->PT.nElem, nVo = h->v1 - h->v0, m = h->m > 0 ? h->m : h->hist;
     LbfgsArgs L = lbfgs_args(h);
@@ -3349,6 +3411,7 @@ int dotmi_bench_energy(dotmi_handle *h, int32_t reps, double *ms_per_launch, int
 {
     if (!h || reps < 1) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
+    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     int nb = 0;
     launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x, h->xt, h->v0, h->v1, 0, h->partE, &nb, h->st);
     HIPCHECK(h, hipEventRecord(h->ev0, h->st));

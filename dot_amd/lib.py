@@ -25,6 +25,7 @@ FLAG_HOST_LOOP = 8
 FLAG_TIME_PHASES = 16
 FLAG_GSDD = 32
 FLAG_NEWTON = 64
+FLAG_ASYNC_REFRESH = 128
 
 
 class Mesh(C.Structure):

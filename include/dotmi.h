@@ -122,6 +122,13 @@ enum {
                                      * line search from step 1 along p_s, refresh the gradient.  stats.iters = sweeps.
                                      * Single GPU. */
 
+#define DOTMI_FLAG_ASYNC_REFRESH 128 /* dotmi_step returns as soon as the refresh at the end of the step (element Hessians,
+                                     * assembly, factorisation: DOTTimeStepper.cpp:349-380) is ENQUEUED instead of waiting
+                                     * for it: the caller's work between two steps (moving the handles, writing output)
+                                     * overlaps it.  Its device times (ms_hessian, ms_factor) and its verdict
+                                     * (DOTMI_E_NOTSPD) are then reported by the NEXT dotmi_step -- whose loop has by then
+                                     * run on that factorisation -- or by the next call that needs the factors.  Single
+                                     * rank, device loop; ignored otherwise. */
 #define DOTMI_FLAG_NEWTON 64         /* dotmi_step runs the reference's projected Newton (`timeStepper Newton`, the base
                                      * Optimizer::fullyImplicit / solve_oneStep, Optimizer.cpp:654-749): every iteration
                                      * re-evaluates the projected Hessian at the current iterate, factorises, solves

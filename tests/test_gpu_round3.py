@@ -155,3 +155,30 @@ def test_early_backsolve_matches_the_q_based_loop(workload, nparts, steps, histo
             np.testing.assert_allclose(u, w, rtol=rtol, atol=0)
         assert np.abs(a.getResult() - b.getResult()).max() < 1e-9
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("workload,steps", [("bar17K_twist", 5), ("horse7K_stretch", 4)])
+def test_asynchronous_refresh_changes_only_when_things_are_reported(workload, steps):
+    """DOTMI_FLAG_ASYNC_REFRESH: dotmi_step returns with the end-of-step refresh (element Hessians, assembly, factorisation,
+    DOTTimeStepper.cpp:349-380) still queued, so the caller's work between two steps overlaps it.  Same kernels in the same
+    order on the same stream: positions bit-identical to the synchronous handle after every step, same iterations; the
+    refresh's device times are reported one step later (step 0 reports none, the others the refresh that prepared their
+    preconditioner); a call that reads the state in between (getResult) sees the finished step."""
+    sc, ep, n = load_workload(workload)
+    a = DOTTimeStepper(sc, ep, n, flags=dl.FLAG_ASYNC_REFRESH)
+    sc2, _, _ = load_workload(workload)
+    b = DOTTimeStepper(sc2, ep, n)
+    for k in range(steps):
+        # the scripted handles do not depend on the free vertices: both get the same targets without reading `a` back,
+        # so `a` really runs its steps back to back behind the queued refreshes
+        idx, pos = sc2.scripter.step(b.getResult(), sc2.cfg.dt)
+        a.setDirichlet(idx, pos); b.setDirichlet(idx, pos)
+        sa, sb = a.step(), b.step()
+        assert (sa.status, sa.iters, sa.ls_halvings, sa.energy_evals) == (sb.status, sb.iters, sb.ls_halvings, sb.energy_evals)
+        assert sa.E == sb.E and sa.g2 == sb.g2
+        assert (sa.ms_factor == 0.0) == (k == 0) and sb.ms_factor > 0.0
+        assert sa.ms_loop > 0.0
+        if k == steps - 2:
+            assert np.array_equal(a.getResult(), b.getResult())       # resolves the pending refresh on the way
+    assert np.array_equal(a.getResult(), b.getResult())
+    a.close(); b.close()
