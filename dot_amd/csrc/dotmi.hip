@@ -105,6 +105,7 @@ struct Tuning {
     bool tileBalance = true;  // DOTMI_TILE_BALANCE=0 every tile task at its earliest level (no second scheduling pass)
     int tileEagerMinDiag = 0; // DOTMI_TILE_EAGER_MIN_DIAG early products a diagonal tile task may keep
     int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
+    bool fuseStep = true;     // DOTMI_FUSE_STEP=0    (early order) step_forward as a launch of its own instead of inside the element pass
     bool earlyAbort = true;   // DOTMI_EARLY_ABORT=0  (ablation) speculative back-solves run to their end even when the trial is rejected
     bool earlyHostCtl = true; // DOTMI_EARLY_HOST_CTL=0 (ablation) early back-solve with the controller as a launch of its own
     int earlyBs = 1;          // DOTMI_EARLY_BACKSOLVE 0: the back-solve after the controller, on q; 1: speculatively on the trial
@@ -149,6 +150,7 @@ struct Tuning {
         t.earlyBs = std::min(2, std::max(0, geti("DOTMI_EARLY_BACKSOLVE", 1)));
         t.earlyHostCtl = geti("DOTMI_EARLY_HOST_CTL", 1) != 0;
         t.earlyAbort = geti("DOTMI_EARLY_ABORT", 1) != 0;
+        t.fuseStep = geti("DOTMI_FUSE_STEP", 1) != 0;
         return t;
     }
 };
@@ -1772,9 +1774,15 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     memset(&L0, 0, sizeof(L0));
     launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
     launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st, h->ctl);
-    launch_step_forward(n, h->x, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st, h->ctl);
     int nb = 0;
-    launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st, h->ctl);
+    if (h->tune.fuseStep) {   // the step x_trial = x_cur + alpha p inside the element pass
+        StepArgs sa{h->p, h->partS, h->alpha_dev, h->alphaMin};
+        launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st, h->ctl,
+                                &sa);
+    } else {
+        launch_step_forward(n, h->x, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st, h->ctl);
+        launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st, h->ctl);
+    }
     GatherArgs a;
     memset(&a, 0, sizeof(a));
     a.xt = h->xt;

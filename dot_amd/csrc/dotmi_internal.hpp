@@ -176,9 +176,16 @@ void launch_step_forward(int n, const double *x0, const double *p, double *x, co
                          double *alpha_out_host, hipStream_t st, const DevLoop *ctl = nullptr);
 // element pass: partial energy sums (+ inertia) and, optionally, element gradients
 // grad != 0: the per-(patch, vertex) partial gradients go to PT.gpart (read by launch_vertex_gather)
+// step (device loop only): the line-search step x_trial = x_cur + alpha p is taken inside the element pass
+// (alpha from the SpMV partials as in launch_step_forward) instead of by a launch of its own
+struct StepArgs {
+    const double *p, *spmv_partials;
+    double *alpha_out;
+    double alpha_min;
+};
 void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, double dtSq, const double *x,
                              const double *xt, int v0, int v1, int grad, double *partials, int *nblocks_out,
-                             hipStream_t st, const DevLoop *ctl = nullptr);
+                             hipStream_t st, const DevLoop *ctl = nullptr, const StepArgs *step = nullptr);
 // vertex gather of element gradients + inertia; optional L-BFGS pair + stats partials
 struct GatherArgs {
     const double *x, *xt, *g_old, *p, *alpha_dev;

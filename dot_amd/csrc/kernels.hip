@@ -52,18 +52,60 @@ __device__ __forceinline__ double wave_sum(double v)
 // vertex instead of the ~22 incident contributions of 24 bytes each that a global scatter / gather moves twice.
 // LDS: xs[3 * PV] | gs[3][4 PE] (component-major corner runs) | cptr | slot.
 // ------------------------------------------------------------------------------------------------
-template <int MAT, bool GRAD, int EPT>
+template <int MAT, bool GRAD, int EPT, bool FUSE>
 __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const double *__restrict__ mass,
                                                          const double *__restrict__ x, const double *__restrict__ xt,
                                                          int v0, int v1, double dtSq, double *__restrict__ partials,
-                                                         const DevLoop *__restrict__ ctl)
+                                                         const DevLoop *__restrict__ ctl, StepArgs sa)
 {
     extern __shared__ double lds[];
     __shared__ double sm[8];
+    __shared__ double sh_alpha;
+    // sa.p != nullptr (device loop): the line-search step x_trial = x_cur + alpha p (step_forward_kernel's statements) is
+    // taken HERE: every position this kernel reads is formed on the fly, the trial point is written by the inertia loop
+    // (which visits every vertex exactly once), and alpha comes from the SpMV partials in wave 0's prologue -- one launch
+    // and one pass over x, p less per line-search trial
+    constexpr bool fuse = FUSE;   // (a template parameter: the plain instantiation keeps its register count)
+    double *__restrict__ x_out = nullptr;
     if (ctl) {
         if (ctl->status != 0) return;
-        x = ctl->x_trial;
+        x = fuse ? ctl->x_cur : ctl->x_trial;
+        x_out = ctl->x_trial;
     }
+    double pgv[NB_RED / 64], pHpv[NB_RED / 64];
+    const bool usePart = fuse && ctl->phase == 0;   // a retry steps with the halved alpha the controller left
+    if (usePart && threadIdx.x < 64) {              // requested here, summed after this thread's other loads are out
+#pragma unroll
+        for (int u = 0; u < NB_RED / 64; ++u) {
+            pgv[u] = sa.spmv_partials[(size_t)(threadIdx.x + 64 * u) * RED_K];
+            pHpv[u] = sa.spmv_partials[(size_t)(threadIdx.x + 64 * u) * RED_K + 1];
+        }
+    }
+    bool haveAlpha = false;
+    double alpha = 0.0;
+    auto finish_alpha = [&]() {   // (all threads; one barrier)
+        if (threadIdx.x < 64) {
+            double a = ctl->alpha;
+            if (usePart) {
+                double pg = 0.0, pHp = 0.0;
+#pragma unroll
+                for (int u = 0; u < NB_RED / 64; ++u) {
+                    pg += pgv[u];
+                    pHp += pHpv[u];
+                }
+                pg = __shfl(wave_sum(pg), 0, 64);
+                pHp = __shfl(wave_sum(pHp), 0, 64);
+                a = fmax(sa.alpha_min, fmin(1.0, -pg / pHp));  // Optimizer.cpp:1085
+            }
+            if (threadIdx.x == 0) {
+                sh_alpha = a;
+                if (blockIdx.x == 0) *sa.alpha_out = a;
+            }
+        }
+        __syncthreads();
+        alpha = sh_alpha;
+        haveAlpha = true;
+    };
     constexpr int PE = 256 * EPT;
     // LDS: xs[3 PV] | gs[3][4 PE] | cptr[PV + 1 .. padded] (u16) | slot[PV] (i32)
     double *xs = lds, *gs = lds + 3 * PT.PV;
@@ -75,12 +117,13 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
     // inertia operands of this thread's first vertex: independent of the element work, requested ahead of it
     const int gstride = gridDim.x * blockDim.x;
     const int vfirst = v0 + blockIdx.x * blockDim.x + tid;
-    double ix[3] = {0, 0, 0}, ixt[3] = {0, 0, 0}, im = 0.0;
+    double ix[3] = {0, 0, 0}, ixt[3] = {0, 0, 0}, ip[3] = {0, 0, 0}, im = 0.0;
     if (vfirst < v1) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             ix[d] = x[3 * vfirst + d];
             ixt[d] = xt[3 * vfirst + d];
+            if (fuse) ip[d] = sa.p[3 * vfirst + d];
         }
         im = mass[vfirst];
     }
@@ -109,16 +152,37 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
             for (int lv = tid; lv <= nv; lv += 256) cptr[lv] = cp[lv];
             for (int lv = tid; lv < nv; lv += 256) vslot[lv] = PT.pv_slot[vb + lv];
         }
-        if (gid0 >= 0) {
-            xs[3 * tid] = x[3 * gid0];
-            xs[3 * tid + 1] = x[3 * gid0 + 1];
-            xs[3 * tid + 2] = x[3 * gid0 + 2];
-        }
-        for (int lv = tid + 256; lv < nv; lv += 256) {
-            const int gid = PT.pv_gid[vb + lv];
-            xs[3 * lv] = x[3 * gid];
-            xs[3 * lv + 1] = x[3 * gid + 1];
-            xs[3 * lv + 2] = x[3 * gid + 2];
+        if (!fuse) {
+            if (gid0 >= 0) {
+                xs[3 * tid] = x[3 * gid0];
+                xs[3 * tid + 1] = x[3 * gid0 + 1];
+                xs[3 * tid + 2] = x[3 * gid0 + 2];
+            }
+            for (int lv = tid + 256; lv < nv; lv += 256) {
+                const int gid = PT.pv_gid[vb + lv];
+                xs[3 * lv] = x[3 * gid];
+                xs[3 * lv + 1] = x[3 * gid + 1];
+                xs[3 * lv + 2] = x[3 * gid + 2];
+            }
+        } else {
+            double xv[3] = {0, 0, 0}, pv[3] = {0, 0, 0};
+            if (gid0 >= 0) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    xv[d] = x[3 * gid0 + d];
+                    pv[d] = sa.p[3 * gid0 + d];
+                }
+            }
+            if (!haveAlpha) finish_alpha();
+            if (gid0 >= 0) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) xs[3 * tid + d] = xv[d] + alpha * pv[d];
+            }
+            for (int lv = tid + 256; lv < nv; lv += 256) {
+                const int gid = PT.pv_gid[vb + lv];
+#pragma unroll
+                for (int d = 0; d < 3; ++d) xs[3 * lv + d] = x[3 * gid + d] + alpha * sa.p[3 * gid + d];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -215,13 +279,29 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
     }
     // inertia: sum_v 1/2 m_v |x_v - x~_v|^2 over this rank's vertex slice
     double ine = 0.0;
+    if (fuse && !haveAlpha) finish_alpha();   // (a workgroup without a patch)
     if (vfirst < v1) {
+        if (fuse) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                ix[d] = ix[d] + alpha * ip[d];
+                x_out[3 * vfirst + d] = ix[d];
+            }
+        }
         const double dx = ix[0] - ixt[0], dy = ix[1] - ixt[1], dz = ix[2] - ixt[2];
         ine += (dx * dx + dy * dy + dz * dz) * im / 2.0;
     }
     for (int v = vfirst + gstride; v < v1; v += gstride) {
-        const double dx = x[3 * v] - xt[3 * v], dy = x[3 * v + 1] - xt[3 * v + 1],
-                     dz = x[3 * v + 2] - xt[3 * v + 2];
+        double xv[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            xv[d] = x[3 * v + d];
+            if (fuse) {
+                xv[d] = xv[d] + alpha * sa.p[3 * v + d];
+                x_out[3 * v + d] = xv[d];
+            }
+        }
+        const double dx = xv[0] - xt[3 * v], dy = xv[1] - xt[3 * v + 1], dz = xv[2] - xt[3 * v + 2];
         ine += (dx * dx + dy * dy + dz * dz) * mass[v] / 2.0;
     }
     // both block sums through one exchange
@@ -240,8 +320,10 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
 
 void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, double dtSq, const double *x,
                              const double *xt, int v0, int v1, int grad, double *partials, int *nblocks_out,
-                             hipStream_t st, const DevLoop *ctl)
+                             hipStream_t st, const DevLoop *ctl, const StepArgs *step)
 {
+    StepArgs sa{nullptr, nullptr, nullptr, 0.0};
+    if (step && ctl) sa = *step;
     int nb = PT.nPatches;
     const int nbv = (v1 - v0 + 255) / 256;
     if (nb < nbv) nb = nbv;    // the inertia loop likes one vertex per thread on small meshes
@@ -252,8 +334,14 @@ void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, do
     const size_t shm = sizeof(double) * ((size_t)3 * PT.PV + (grad ? (size_t)12 * PT.PE : 0)) +
                        (grad ? 2 * (size_t)((PT.PV + 1 + 3) & ~3) + 4 * (size_t)PT.PV : 0);
 #define DM_LAUNCH(MATV, GRADV, EPTV)                                                                            \
-    hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV>), dim3(nb), dim3(256), shm, st, PT, M.mass, x, xt, \
-                       v0, v1, dtSq, partials, ctl)
+    do {                                                                                                            \
+        if (sa.p)                                                                                                   \
+            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, true>), dim3(nb), dim3(256), shm, st, PT, M.mass, x, \
+                               xt, v0, v1, dtSq, partials, ctl, sa);                                                \
+        else                                                                                                        \
+            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, false>), dim3(nb), dim3(256), shm, st, PT, M.mass, x, \
+                               xt, v0, v1, dtSq, partials, ctl, sa);                                                \
+    } while (0)
 #define DM_LAUNCH_E(MATV, GRADV)      \
     do {                              \
         if (ept == 1) DM_LAUNCH(MATV, GRADV, 1); \

@@ -103,7 +103,9 @@ def test_bench_kernel_entry_covers_every_kernel_class():
 @pytest.mark.parametrize("env", [{"DOTMI_PATCH_ELEMS": "512"}, {"DOTMI_TILE_THREADS": "256"},
                                  {"DOTMI_TILE_EAGER_MIN": "1000"}, {"DOTMI_TILE_EAGER_MIN": "1", "DOTMI_TILE_EAGER_CHUNK": "1"},
                                  {"DOTMI_TILE_XCD_ORDER": "0", "DOTMI_TILE_ROWS_LONG": "16"}, {"DOTMI_EARLY_BACKSOLVE": "0"},
-                                 {"DOTMI_EARLY_BACKSOLVE": "2"}])
+                                 {"DOTMI_EARLY_BACKSOLVE": "2"}, {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_FUSE_STEP": "0"},
+                                 {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_EARLY_ABORT": "0"},
+                                 {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_EARLY_HOST_CTL": "0"}])
 def test_tuning_switches_do_not_change_results(env):
     """Every tuning variable of DESIGN.md section 10 that selects another variant of a round-3 kernel / schedule: same
     iterations as the oracle, positions to 1e-9 (horse7K: FCR with SVD in the element pass, 8 subdomains, back-tracking)."""
