@@ -105,6 +105,7 @@ struct Tuning {
     bool tileBalance = true;  // DOTMI_TILE_BALANCE=0 every tile task at its earliest level (no second scheduling pass)
     int tileEagerMinDiag = 0; // DOTMI_TILE_EAGER_MIN_DIAG early products a diagonal tile task may keep
     int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
+    bool fuseDir = true;      // DOTMI_FUSE_DIR=0     (early order) build_p and spmv_dots as two launches instead of one on cached H s_j
     bool fuseStep = true;     // DOTMI_FUSE_STEP=0    (early order) step_forward as a launch of its own instead of inside the element pass
     bool earlyAbort = true;   // DOTMI_EARLY_ABORT=0  (ablation) speculative back-solves run to their end even when the trial is rejected
     bool earlyHostCtl = true; // DOTMI_EARLY_HOST_CTL=0 (ablation) early back-solve with the controller as a launch of its own
@@ -151,6 +152,7 @@ struct Tuning {
         t.earlyHostCtl = geti("DOTMI_EARLY_HOST_CTL", 1) != 0;
         t.earlyAbort = geti("DOTMI_EARLY_ABORT", 1) != 0;
         t.fuseStep = geti("DOTMI_FUSE_STEP", 1) != 0;
+        t.fuseDir = geti("DOTMI_FUSE_DIR", 1) != 0;
         return t;
     }
 };
@@ -231,6 +233,7 @@ struct dotmi_handle {
     bool earlyNow = false;    // chosen for the running step
     int prevIters = -1, prevHalv = 0;   // last step's iterations / line-search halvings (-1: no step yet)
     double *u_old = nullptr, *MY[HIST_MAX + 1] = {nullptr};
+    double *HS[HIST_MAX + 1] = {nullptr};   // H s_i of the stored pairs (fused direction kernel of the early order)
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
     double *gstage = nullptr;   // sharded element pass, device loop: [g (n) ; 0 ; E] staging buffer of the gradient all-reduce
     double *alpha_dev = nullptr;
@@ -1772,8 +1775,13 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     const int n = h->n;
     LbfgsArgs L0;
     memset(&L0, 0, sizeof(L0));
-    launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
-    launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st, h->ctl);
+    const bool fuseDir = h->tune.fuseDir;
+    if (fuseDir) {   // build_p + spmv_dots in one launch, H p from the cached H s_j
+        launch_spmv_zp(h->M, h->Hval, h->z, h->partC, h->p, h->Hp, h->partS, h->st, h->ctl);
+    } else {
+        launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
+        launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st, h->ctl);
+    }
     int nb = 0;
     if (h->tune.fuseStep) {   // the step x_trial = x_cur + alpha p inside the element pass
         StepArgs sa{h->p, h->partS, h->alpha_dev, h->alphaMin};
@@ -1791,6 +1799,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     a.iv0 = h->v0;
     a.iv1 = h->v1;
     a.make_pair = 1;
+    a.hp = fuseDir ? h->Hp : nullptr;   // H s_new = alpha H p beside s_new
     // -g_trial goes straight into the padded right-hand sides, whatever the controller will say about the trial
     a.vp_ptr = h->P.vp_ptr;
     a.vp_off = h->P.vp_off;
@@ -1908,6 +1917,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
         C.S[s] = h->S[s];
         C.Y[s] = h->Y[s];
         C.MY[s] = h->MY[s];
+        C.HS[s] = h->HS[s];
     }
     C.u_old = h->u_old;
     C.log_alpha = h->dlog;
@@ -2641,8 +2651,10 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         h->earlyBs = h->devLoop && h->tune.earlyBs != 0 && !h->dist && !h->shardElems && h->P.mt_ptr != nullptr;
         if (h->earlyBs) {
             if (int rc = dalloc(h, &h->u_old, (size_t)h->n)) return rc;
-            for (int sl = 0; sl <= h->hist; ++sl)
+            for (int sl = 0; sl <= h->hist; ++sl) {
                 if (int rc = dalloc(h, &h->MY[sl], (size_t)h->n)) return rc;
+                if (int rc = dalloc(h, &h->HS[sl], (size_t)h->n)) return rc;
+            }
         }
         h->logCap = std::min(h->iterCap, 10001) + 1;
         h->kindCap = 4096;

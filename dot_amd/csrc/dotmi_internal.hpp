@@ -157,6 +157,8 @@ struct DevLoop {
     int abortEpoch;        // `slots` value of the last slot whose trial was rejected or that ended the loop: the speculative
                            // back-solve of that slot (which knows its epoch) stops when it sees it
     double *u_old, *MY[HIST_MAX + 1];
+    // H s_i of the stored pairs (same slots as S): H p = H z + sum_j delta_j (H s_j), H s_new = alpha H p (spmv_zp_kernel)
+    double *HS[HIST_MAX + 1];
 };
 // the controller's operands when it runs as one workgroup of another launch (launch_gemv)
 struct CtlArgs {
@@ -197,6 +199,8 @@ struct GatherArgs {
     // vertex (DevParts::vp_ptr / vp_off), so no build_qpad launch stands between the gather and the back-solve
     const int *vp_ptr, *vp_off;
     double *rpad;
+    const double *hp;   // early order with the fused direction kernel: H p of the running trial; H s_new = alpha H p goes to
+                        // DevLoop::HS[slot] beside s_new
 };
 void launch_vertex_gather(const DevMesh &M, const DevPatches &PT, const GatherArgs &a, const LbfgsArgs &L,
                           double *partials, hipStream_t st, const DevLoop *ctl = nullptr);
@@ -234,6 +238,11 @@ void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, doubl
 // p = z + sum_j delta_j s_j, delta from c partials, xi and SY
 void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_partials,
                     const double *xi_host, double *p, hipStream_t st, const DevLoop *ctl = nullptr);
+// early order, one launch for build_p + spmv_dots: p = z + sum_j delta_j s_j (build_p's statements), H p = H z + sum_j
+// delta_j (H s_j) from the cached H s_j, and the partial sums of p.g and p.Hp -- the only sparse product is H z, which
+// does not wait for delta
+void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const double *c_partials, double *p, double *Hp,
+                    double *partials, hipStream_t st, const DevLoop *ctl);
 // Hp = H p on rows [v0,v1), partial sums of p.g and p.Hp
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
                       int v0, int v1, double *partials, hipStream_t st, const DevLoop *ctl = nullptr);

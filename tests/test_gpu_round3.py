@@ -104,6 +104,7 @@ def test_bench_kernel_entry_covers_every_kernel_class():
                                  {"DOTMI_TILE_EAGER_MIN": "1000"}, {"DOTMI_TILE_EAGER_MIN": "1", "DOTMI_TILE_EAGER_CHUNK": "1"},
                                  {"DOTMI_TILE_XCD_ORDER": "0", "DOTMI_TILE_ROWS_LONG": "16"}, {"DOTMI_EARLY_BACKSOLVE": "0"},
                                  {"DOTMI_EARLY_BACKSOLVE": "2"}, {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_FUSE_STEP": "0"},
+                                 {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_FUSE_DIR": "0"},
                                  {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_EARLY_ABORT": "0"},
                                  {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_EARLY_HOST_CTL": "0"}])
 def test_tuning_switches_do_not_change_results(env):
