@@ -1808,7 +1808,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size() &&
                        (h->timeCount++ % h->timeStride) == 0;
     h->slotTimed.push_back(timed ? h->evUsed : -1);
-    CtlArgs ca{h->ctl, h->partE, h->partR, h->alpha_dev, h->h_flags, nb};
+    CtlArgs ca{h->ctl, h->partE, h->partR, h->alpha_dev, h->h_flags, nb, 0};
     if (!h->tune.earlyHostCtl)   // (ablation) the controller as a launch of its own, in front of the speculative solve
         launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st);
     launch_gemv(h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr,
@@ -1950,14 +1950,21 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
         a.iv1 = h->v1;
         LbfgsArgs L0;
         memset(&L0, 0, sizeof(L0));
+        if (h->earlyNow) {   // -g_0 straight into the padded right-hand sides (their padding entries stay zero)
+            a.vp_ptr = h->P.vp_ptr;
+            a.vp_off = h->P.vp_off;
+            a.rpad = h->P.rpad;
+        }
         launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st);
-        if (!h->shardElems) {
+        if (!h->shardElems && h->earlyNow) {
+            // the first direction's solve, u = -M g_0 and z = u, with the start-of-step controller inside its launch
+            CtlArgs ca{h->ctl, h->partE, h->partR, h->alpha_dev, h->h_flags, nb, 1};
+            launch_gemv(h->P, nullptr, h->st, h->ctl, nullptr, nullptr, h->tune.earlyHostCtl ? &ca : nullptr, 1 << 30);
+            if (!h->tune.earlyHostCtl)
+                launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
+            launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl);
+        } else if (!h->shardElems) {
             launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
-            if (h->earlyNow) {   // the first direction's solve: u = -M g_0, z = u
-                launch_build_qpad(h->P, h->g, L0, nullptr, h->st, h->ctl, 1);
-                launch_gemv(h->P, nullptr, h->st, h->ctl);
-                launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl);
-            }
         } else {
             hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
                                h->gstage + n_ + 1);

@@ -166,6 +166,7 @@ struct CtlArgs {
     const double *partE, *partR, *alpha_dev;
     int *flags_host;
     int nbE;
+    int init;   // the evaluation at the start of the step (nothing to decide yet)
 };
 
 // ---- kernel launchers (kernels.hip) --------------------------------------------------------------

@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__res
     __shared__ int s_abort[3];
     // (which workgroup hosts the controller makes no difference: index 0 / 256 / 520 / last measured 47.0-47.5 us)
     if (blockIdx.x == 0) {
-        loop_control_body(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, 0);
+        loop_control_body(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init);
         return;
     }
     if (ca.ctl->status != 0) return;
@@ -1271,7 +1271,7 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
     const bool timed = ev0 && ev1;
     if (ca && spec <= 0) spec = 1;   // (callers pass the slot's epoch: > 0)
     if (ca && nN == 0)   // no launch of the 256-thread kernel to host it: the controller on its own, in front
-        launch_loop_control(ca->ctl, ca->partE, ca->nbE, ca->partR, ca->alpha_dev, ca->flags_host, st, 0);
+        launch_loop_control(ca->ctl, ca->partE, ca->nbE, ca->partR, ca->alpha_dev, ca->flags_host, st, ca->init);
     if (nW > 0) {
         if (timed)
             hipExtLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, ev0, nN > 0 ? (hipEvent_t) nullptr : ev1, 0,
