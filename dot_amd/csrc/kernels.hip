@@ -259,8 +259,9 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
         if (GRAD) {
             __syncthreads();
             // one lane per (vertex, component): a contiguous run of LDS, four entries in flight, added in run order
+            // (vertex-major: three consecutive lanes write the 24 contiguous bytes of one partial)
             for (int item = tid; item < 3 * nv; item += 256) {
-                const int d = item >= 2 * nv ? 2 : (item >= nv ? 1 : 0), lv = item - d * nv;
+                const int lv = item / 3, d = item - 3 * lv;
                 const int kb = cptr[lv], ke = cptr[lv + 1];
                 const double *run = gs + d * 4 * PE;
                 double sum = 0.0;
