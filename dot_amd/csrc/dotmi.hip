@@ -109,9 +109,10 @@ struct Tuning {
     bool fuseStep = true;     // DOTMI_FUSE_STEP=0    (early order) step_forward as a launch of its own instead of inside the element pass
     bool earlyAbort = true;   // DOTMI_EARLY_ABORT=0  (ablation) speculative back-solves run to their end even when the trial is rejected
     bool earlyHostCtl = true; // DOTMI_EARLY_HOST_CTL=0 (ablation) early back-solve with the controller as a launch of its own
-    int earlyBs = 1;          // DOTMI_EARLY_BACKSOLVE 0: the back-solve after the controller, on q; 1: speculatively on the trial
+    int earlyBs = 2;          // DOTMI_EARLY_BACKSOLVE 0: the back-solve after the controller, on q; 1: speculatively on the trial
                               //                      gradient with the controller inside its launch, in the steps where
-                              //                      that pays (run_device_loop); 2: in every step
+                              //                      the last step's counts say it pays (run_device_loop); 2 (default): in
+                              //                      every step
     static int geti(const char *name, int dflt)
     {
         const char *ev = getenv(name);
@@ -148,7 +149,7 @@ struct Tuning {
         t.tileBalance = geti("DOTMI_TILE_BALANCE", 1) != 0;
         t.tileEagerMinDiag = std::max(0, geti("DOTMI_TILE_EAGER_MIN_DIAG", 0));
         t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
-        t.earlyBs = std::min(2, std::max(0, geti("DOTMI_EARLY_BACKSOLVE", 1)));
+        t.earlyBs = std::min(2, std::max(0, geti("DOTMI_EARLY_BACKSOLVE", 2)));
         t.earlyHostCtl = geti("DOTMI_EARLY_HOST_CTL", 1) != 0;
         t.earlyAbort = geti("DOTMI_EARLY_ABORT", 1) != 0;
         t.fuseStep = geti("DOTMI_FUSE_STEP", 1) != 0;
