@@ -1816,7 +1816,15 @@ int enqueue_loop_slot_early(dotmi_handle *h)
                 h->tune.earlyHostCtl ? &ca : nullptr,
                 h->tune.earlyAbort ? (int)h->slotTimed.size() /* the slot's epoch, 1-based */ : (1 << 30) /* never stopped */);
     if (timed) h->evUsed += 2;
-    launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl);
+    if (!h->dist) {
+        launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl);
+    } else {
+        // sharded subdomains: this rank's part of the sum, the one collective of the iteration (issued in every slot,
+        // whatever the controller decided: every rank enqueues the same sequence), then the division and the history terms
+        launch_merge(h->M, h->P, L0, h->z, h->partC, 0, h->st, h->ctl);
+        if (int rc = allreduce_sum(h, h->z, n)) return rc;
+        launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, 1);
+    }
     return 0;
 }
 
@@ -1963,7 +1971,13 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
             launch_gemv(h->P, nullptr, h->st, h->ctl, nullptr, nullptr, h->tune.earlyHostCtl ? &ca : nullptr, 1 << 30);
             if (!h->tune.earlyHostCtl)
                 launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
-            launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl);
+            if (!h->dist) {
+                launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl);
+            } else {
+                launch_merge(h->M, h->P, L0, h->z, h->partC, 0, h->st, h->ctl);
+                if (int rc = allreduce_sum(h, h->z, n_)) return rc;
+                launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, 1);
+            }
         } else if (!h->shardElems) {
             launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
         } else {
@@ -2654,9 +2668,9 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         }
         h->devLoop = !h->gsdd && !h->newton && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) &&
                      h->tune.deviceLoop;
-        // one rank, merged tile partials: the back-solve of the next direction is issued on the trial gradient, beside
-        // the controller (enqueue_loop_slot)
-        h->earlyBs = h->devLoop && h->tune.earlyBs != 0 && !h->dist && !h->shardElems && h->P.mt_ptr != nullptr;
+        // replicated element pass, merged tile partials: the back-solve of the next direction is issued on the trial
+        // gradient, beside the controller (enqueue_loop_slot); sharded subdomains keep their one collective per iteration
+        h->earlyBs = h->devLoop && h->tune.earlyBs != 0 && !h->shardElems && h->P.mt_ptr != nullptr;
         if (h->earlyBs) {
             if (int rc = dalloc(h, &h->u_old, (size_t)h->n)) return rc;
             for (int sl = 0; sl <= h->hist; ++sl) {

@@ -226,8 +226,9 @@ void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, c
                        const DevLoop *ctl = nullptr, int spec = 0);
 // early back-solve: u = merge(tile partials) / dup = -M g;  M y of the newest pair = u_old - u;  z = u - sum_j xi_j M y_j
 // (+ partial dots y_i . z);  first: start of the step (no history, u_old is only set)
+// summed: z already holds the sum over all subdomains of all ranks (sharded subdomains: partial merge + all-reduce in front)
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
-                        const DevLoop *ctl);
+                        const DevLoop *ctl, int summed = 0);
 // one subdomain only (GSDD, DOTTimeStepper.cpp:507-565): psub_s = X_s^T (X_s q[dofmap_s]) for owned part `ls`, whose
 // tiles are job[0..njobs); then p = 0 except p[dofs of part ls] = psub_s  (ADMMDDTimeStepper::fill, :1646-1665)
 void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, const int2 *lwork, int nlwork, const double *q,

@@ -2149,7 +2149,7 @@ __global__ __launch_bounds__(256) void merge_tiles_kernel(int n3, const int *__r
 // like build_qpad's.  first: start of the step (no pair yet; u_old is only set).
 __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const int *__restrict__ mt_ptr,
                                                                 const int *__restrict__ mt_ent, const int *__restrict__ dup,
-                                                                const double *__restrict__ ppart, int first,
+                                                                const double *__restrict__ ppart, int first, int summed,
                                                                 double *__restrict__ z, double *__restrict__ partials,
                                                                 const DevLoop *__restrict__ ctl)
 {
@@ -2182,8 +2182,10 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
             mk[i] = (i < m && !(pairNew && i == m - 1)) ? my[i][k] : 0.0;
         }
         const double uo = first ? 0.0 : u_old[k];
-        double u = 0.0, ps = 0.0;
-        for (int e = e0; e < e1; e += MT_CH) {
+        // summed (sharded subdomains): z holds the all-reduced sum over every rank's subdomains (merge_tiles_kernel without
+        // the division, then the collective); only the division and the history terms are left
+        double u = summed ? z[k] : 0.0, ps = 0.0;
+        for (int e = summed ? e1 : e0; e < e1; e += MT_CH) {
             int off[MT_CH];
 #pragma unroll
             for (int q = 0; q < MT_CH; ++q) off[q] = (e + q < e1) ? mt_ent[e + q] : 0;
@@ -2221,10 +2223,10 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
 }
 
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
-                        const DevLoop *ctl)
+                        const DevLoop *ctl, int summed)
 {
     hipLaunchKernelGGL(merge_tiles_early_kernel, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup, P.ppart,
-                       first, z, partials, ctl);
+                       first, summed, z, partials, ctl);
 }
 
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,

@@ -257,6 +257,7 @@ def test_sharded_device_loop_is_bit_identical_to_sharded_host_loop(workload, ste
     batches (same count on every rank).  With the 1-rank RCCL communicator of DOTMI_FLAG_FORCE_DIST it must take exactly
     the decisions of the sharded host loop."""
     monkeypatch.setenv("DOTMI_SHARD_ELEMS", shard_elems)
+    monkeypatch.setenv("DOTMI_EARLY_BACKSOLVE", "0")   # the host loop's order of operations (the early order: test_gpu_round3.py)
     sc, ep, n = load_workload(workload)
     a = DOTTimeStepper(sc, ep, n, flags=dl.FLAG_FORCE_DIST)
     sc2, _, _ = load_workload(workload)

@@ -185,3 +185,28 @@ def test_asynchronous_refresh_changes_only_when_things_are_reported(workload, st
             assert np.array_equal(a.getResult(), b.getResult())       # resolves the pending refresh on the way
     assert np.array_equal(a.getResult(), b.getResult())
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 6), ("bar17K_twist", 3)])
+def test_early_order_on_the_sharded_path_matches_the_single_rank_run(workload, steps):
+    """The early back-solve with sharded subdomains (replicated element pass): partial merge of this rank's subdomains, the
+    iteration's one all-reduce, then the division by the multiplicity and the history terms (merge_tiles_early_kernel,
+    summed).  With the 1-rank communicator of DOTMI_FLAG_FORCE_DIST the sums are the single-rank ones taken in two steps:
+    same iterations and halvings, positions to 1e-9 (the multi-rank runs are in tests/test_gpu_two_ranks.py)."""
+    os.environ["DOTMI_SHARD_ELEMS"] = "0"
+    try:
+        sc, ep, n = load_workload(workload)
+        a = DOTTimeStepper(sc, ep, n, flags=dl.FLAG_FORCE_DIST)
+    finally:
+        del os.environ["DOTMI_SHARD_ELEMS"]
+    sc2, _, _ = load_workload(workload)
+    b = DOTTimeStepper(sc2, ep, n)
+    for k in range(steps):
+        for ts, s_ in ((a, sc), (b, sc2)):
+            idx, pos = s_.scripter.step(ts.getResult(), s_.cfg.dt)
+            ts.setDirichlet(idx, pos)
+        sa, sb = a.step(), b.step()
+        assert (sa.status, sa.iters, sa.ls_halvings) == (sb.status, sb.iters, sb.ls_halvings), k
+        assert sa.backsolve_stopped == sb.backsolve_stopped == sa.ls_halvings + 1      # both ran the early order
+        assert np.abs(a.getResult() - b.getResult()).max() < 1e-9
+    a.close(); b.close()
