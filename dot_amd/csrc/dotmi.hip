@@ -1784,6 +1784,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st, h->ctl);
     }
     int nb = 0;
+    // (not on meshes whose workgroups walk several patches: the prefetched operands leave no registers for it)
     if (h->tune.fuseStep) {   // the step x_trial = x_cur + alpha p inside the element pass
         StepArgs sa{h->p, h->partS, h->alpha_dev, h->alphaMin};
         launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st, h->ctl,

@@ -9,6 +9,9 @@
 namespace dotmi {
 
 constexpr int HIST_MAX = 6;     // L-BFGS pairs kept (reference uses 5, DOTTimeStepper.cpp:45)
+// workgroups of the element pass when the mesh has more patches than that: what is resident at once with the prefetching
+// instantiation's registers (Stable Neo-Hookean 158: three per CU; fixed-corotational with its SVD 190: two) x 256 CUs
+inline int elem_wg_cap(int mat) { return mat == 1 ? 768 : 512; }
 constexpr int NB_RED = 256;     // blocks of every reducing kernel (fixed => run-to-run bit-identical sums)
 constexpr int RED_K = 3 * HIST_MAX + 3;  // partial values per block
 constexpr int BS_LONG = 4096;   // longest row (columns) the single-pass back-solve kernel holds in registers

@@ -52,7 +52,19 @@ __device__ __forceinline__ double wave_sum(double v)
 // vertex instead of the ~22 incident contributions of 24 bytes each that a global scatter / gather moves twice.
 // LDS: xs[3 * PV] | gs[3][4 PE] (component-major corner runs) | cptr | slot.
 // ------------------------------------------------------------------------------------------------
-template <int MAT, bool GRAD, int EPT, bool FUSE>
+#ifdef EP_PROFILE
+// per-workgroup wall-clock stamps of the element pass (tools/prof_elem.sh): start, operands + positions in LDS, element
+// work + gradient runs in LDS, run sums + stores issued, end
+__device__ long long g_ep_prof[8192][6];
+extern "C" int dotmi_debug_ep_prof(long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ep_prof), sizeof(long long) * 6 * (size_t)n);
+}
+#define EP_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_ep_prof[blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define EP_STAMP(i) do { } while (0)
+#endif
+template <int MAT, bool GRAD, int EPT, bool FUSE, bool PIPE>
 __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const double *__restrict__ mass,
                                                          const double *__restrict__ x, const double *__restrict__ xt,
                                                          int v0, int v1, double dtSq, double *__restrict__ partials,
@@ -106,6 +118,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
         alpha = sh_alpha;
         haveAlpha = true;
     };
+    EP_STAMP(0);
     constexpr int PE = 256 * EPT;
     // LDS: xs[3 PV] | gs[3][4 PE] | cptr[PV + 1 .. padded] (u16) | slot[PV] (i32)
     double *xs = lds, *gs = lds + 3 * PT.PV;
@@ -127,64 +140,112 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
         }
         im = mass[vfirst];
     }
-    for (int p = blockIdx.x; p < PT.nPatches; p += gridDim.x) {
-        // Everything a patch needs from HBM is requested here, before the first barrier: the element operands
-        // (EPT x (8 + 72 + 24) bytes per lane, contiguous per wave), the vertex lists and the corner lists of the
-        // vertex sums.  The only dependent round trip is vertex id -> position.
-        const int nv = PT.pv_cnt[p];
-        const size_t vb = (size_t)p * PT.PV;
-        const int gid0 = tid < nv ? PT.pv_gid[vb + tid] : -1;
+    // The operands of a patch in registers.  A workgroup that owns several patches (meshes beyond elem_wg_cap() patches) requests
+    // the NEXT patch's operands and positions while it works on the current one: the ~5 us a patch waits for its two
+    // dependent round trips (vertex id -> position) are then covered by the previous patch's arithmetic and run sums.
+    struct PatchOps {
+        int nv, gid0, slot0;
+        unsigned short cp0;
         ushort4 tl[EPT], ep[EPT];
         double Ai[EPT][9], m[EPT], l[EPT], vo[EPT];
+        double xv[3], pv[3];
+    };
+    // three stages, each one dependent round trip: vertex ids (and the short lists), positions, element operands
+    auto issue_ids = [&](int p, PatchOps &o) {
+        o.nv = PT.pv_cnt[p];
+        const size_t vb = (size_t)p * PT.PV;
+        o.gid0 = tid < o.nv ? PT.pv_gid[vb + tid] : -1;
+        o.cp0 = 0;
+        o.slot0 = 0;
+        if (GRAD) {
+            if (tid <= o.nv) o.cp0 = PT.c_ptr[(size_t)p * (PT.PV + 1) + tid];
+            if (tid < o.nv) o.slot0 = PT.pv_slot[vb + tid];
+        }
+    };
+    auto issue_ops = [&](int p, PatchOps &o) {
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
             const size_t s = (size_t)p * PE + u * 256 + tid;
-            tl[u] = PT.tl[s];
-            if (GRAD) ep[u] = PT.epos[s];
+            o.tl[u] = PT.tl[s];
+            if (GRAD) o.ep[u] = PT.epos[s];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) Ai[u][k] = PT.A[(size_t)k * strideA + s];
-            m[u] = PT.mu[s];
-            l[u] = PT.lam[s];
-            vo[u] = PT.vol[s];
+            for (int k = 0; k < 9; ++k) o.Ai[u][k] = PT.A[(size_t)k * strideA + s];
+            o.m[u] = PT.mu[s];
+            o.l[u] = PT.lam[s];
+            o.vo[u] = PT.vol[s];
         }
+    };
+    auto issue_pos = [&](PatchOps &o) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) o.xv[d] = o.pv[d] = 0.0;
+        if (o.gid0 >= 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                o.xv[d] = x[3 * o.gid0 + d];
+                if (fuse) o.pv[d] = sa.p[3 * o.gid0 + d];
+            }
+        }
+    };
+    PatchOps cur, nxt;
+    int nvN = 0, gidN = -1, slotN = 0;   // ids of the patch after next
+    unsigned short cpN = 0;
+    if ((int)blockIdx.x < PT.nPatches) {
+        issue_ids(blockIdx.x, cur);
+        issue_ops(blockIdx.x, cur);
+        issue_pos(cur);
+        if (PIPE && (int)(blockIdx.x + gridDim.x) < PT.nPatches) issue_ids(blockIdx.x + gridDim.x, nxt);
+    }
+    for (int p = blockIdx.x; p < PT.nPatches; p += gridDim.x) {
+        // PIPE: the instantiation for meshes whose workgroups walk several patches (the prefetched set costs ~50 registers,
+        // which the one-patch-per-workgroup meshes keep for occupancy)
+        const int pn = p + gridDim.x, pn2 = pn + gridDim.x;
+        const bool more = PIPE && pn < PT.nPatches, more2 = PIPE && pn2 < PT.nPatches;
+        if (!PIPE && p != (int)blockIdx.x) {
+            issue_ids(p, cur);
+            issue_ops(p, cur);
+            issue_pos(cur);
+        }
+        const int nv = cur.nv;
+        const size_t vb = (size_t)p * PT.PV;
+        auto &tl = cur.tl;
+        auto &ep = cur.ep;
+        auto &Ai = cur.Ai;
+        auto &m = cur.m;
+        auto &l = cur.l;
+        auto &vo = cur.vo;
         if (GRAD) {
+            if (tid <= nv) cptr[tid] = cur.cp0;
+            if (tid < nv) vslot[tid] = cur.slot0;
             const unsigned short *cp = PT.c_ptr + (size_t)p * (PT.PV + 1);
-            for (int lv = tid; lv <= nv; lv += 256) cptr[lv] = cp[lv];
-            for (int lv = tid; lv < nv; lv += 256) vslot[lv] = PT.pv_slot[vb + lv];
+            for (int lv = tid + 256; lv <= nv; lv += 256) cptr[lv] = cp[lv];
+            for (int lv = tid + 256; lv < nv; lv += 256) vslot[lv] = PT.pv_slot[vb + lv];
         }
-        if (!fuse) {
-            if (gid0 >= 0) {
-                xs[3 * tid] = x[3 * gid0];
-                xs[3 * tid + 1] = x[3 * gid0 + 1];
-                xs[3 * tid + 2] = x[3 * gid0 + 2];
-            }
-            for (int lv = tid + 256; lv < nv; lv += 256) {
-                const int gid = PT.pv_gid[vb + lv];
-                xs[3 * lv] = x[3 * gid];
-                xs[3 * lv + 1] = x[3 * gid + 1];
-                xs[3 * lv + 2] = x[3 * gid + 2];
-            }
-        } else {
-            double xv[3] = {0, 0, 0}, pv[3] = {0, 0, 0};
-            if (gid0 >= 0) {
+        if (fuse && !haveAlpha) finish_alpha();
+        if (cur.gid0 >= 0) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    xv[d] = x[3 * gid0 + d];
-                    pv[d] = sa.p[3 * gid0 + d];
-                }
-            }
-            if (!haveAlpha) finish_alpha();
-            if (gid0 >= 0) {
+            for (int d = 0; d < 3; ++d) xs[3 * tid + d] = fuse ? cur.xv[d] + alpha * cur.pv[d] : cur.xv[d];
+        }
+        for (int lv = tid + 256; lv < nv; lv += 256) {
+            const int gid = PT.pv_gid[vb + lv];
 #pragma unroll
-                for (int d = 0; d < 3; ++d) xs[3 * tid + d] = xv[d] + alpha * pv[d];
-            }
-            for (int lv = tid + 256; lv < nv; lv += 256) {
-                const int gid = PT.pv_gid[vb + lv];
-#pragma unroll
-                for (int d = 0; d < 3; ++d) xs[3 * lv + d] = x[3 * gid + d] + alpha * sa.p[3 * gid + d];
-            }
+            for (int d = 0; d < 3; ++d) xs[3 * lv + d] = fuse ? x[3 * gid + d] + alpha * sa.p[3 * gid + d] : x[3 * gid + d];
+        }
+        // the next patch: its ids came in during the previous patch -> positions and operands now, in flight during this
+        // patch's work; the ids of the patch after it as well
+        if (more) {
+            issue_pos(nxt);
+            issue_ops(pn, nxt);
+        }
+        if (more2) {
+            PatchOps t;
+            issue_ids(pn2, t);
+            nvN = t.nv;
+            gidN = t.gid0;
+            slotN = t.slot0;
+            cpN = t.cp0;
         }
         __syncthreads();
+        EP_STAMP(1);
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
             if (tl[u].x == 0xFFFF) continue;   // padding slot of the last patch
@@ -258,6 +319,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
         }
         if (GRAD) {
             __syncthreads();
+            EP_STAMP(2);
             // one lane per (vertex, component): a contiguous run of LDS, four entries in flight, added in run order
             // (vertex-major: three consecutive lanes write the 24 contiguous bytes of one partial)
             for (int item = tid; item < 3 * nv; item += 256) {
@@ -276,7 +338,15 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
                 PT.gpart[(size_t)3 * vslot[lv] + d] = sum;
             }
         }
+        EP_STAMP(3);
         __syncthreads();   // the next patch of this workgroup reuses xs / gs
+        if (more) {
+            cur = nxt;
+            nxt.nv = nvN;
+            nxt.gid0 = gidN;
+            nxt.slot0 = slotN;
+            nxt.cp0 = cpN;
+        }
     }
     // inertia: sum_v 1/2 m_v |x_v - x~_v|^2 over this rank's vertex slice
     double ine = 0.0;
@@ -317,6 +387,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
         partials[2 * blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);      // to be scaled by dtSq by the consumer
         partials[2 * blockIdx.x + 1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
     }
+    EP_STAMP(4);
 }
 
 void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, double dtSq, const double *x,
@@ -325,9 +396,13 @@ void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, do
 {
     StepArgs sa{nullptr, nullptr, nullptr, 0.0};
     if (step && ctl) sa = *step;
-    int nb = PT.nPatches;
+    // at most elem_wg_cap() workgroups take the patches (as many as are resident at once): beyond that a workgroup walks several
+    // patches and prefetches the next one's operands (elem_patch_kernel)
+    const int cap = (step && ctl) ? 512 : elem_wg_cap(mat);   // (the instantiation with the step inside: two per CU)
+    const bool pipe = PT.nPatches > cap;
+    int nb = pipe ? cap : PT.nPatches;
     const int nbv = (v1 - v0 + 255) / 256;
-    if (nb < nbv) nb = nbv;    // the inertia loop likes one vertex per thread on small meshes
+    if (nb < nbv && !pipe) nb = nbv;    // the inertia loop likes one vertex per thread on small meshes
     if (nb > ELEM_NB_MAX) nb = ELEM_NB_MAX;
     if (nb < 1) nb = 1;
     *nblocks_out = nb;
@@ -336,12 +411,18 @@ void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, do
                        (grad ? 2 * (size_t)((PT.PV + 1 + 3) & ~3) + 4 * (size_t)PT.PV : 0);
 #define DM_LAUNCH(MATV, GRADV, EPTV)                                                                            \
     do {                                                                                                            \
-        if (sa.p)                                                                                                   \
-            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, true>), dim3(nb), dim3(256), shm, st, PT, M.mass, x, \
-                               xt, v0, v1, dtSq, partials, ctl, sa);                                                \
+        if (sa.p && pipe)                                                                                           \
+            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, true, true>), dim3(nb), dim3(256), shm, st, PT, M.mass, \
+                               x, xt, v0, v1, dtSq, partials, ctl, sa);                                             \
+        else if (sa.p)                                                                                              \
+            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, true, false>), dim3(nb), dim3(256), shm, st, PT, M.mass, \
+                               x, xt, v0, v1, dtSq, partials, ctl, sa);                                             \
+        else if (pipe)                                                                                              \
+            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, false, true>), dim3(nb), dim3(256), shm, st, PT, M.mass, \
+                               x, xt, v0, v1, dtSq, partials, ctl, sa);                                             \
         else                                                                                                        \
-            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, false>), dim3(nb), dim3(256), shm, st, PT, M.mass, x, \
-                               xt, v0, v1, dtSq, partials, ctl, sa);                                                \
+            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, false, false>), dim3(nb), dim3(256), shm, st, PT, M.mass, \
+                               x, xt, v0, v1, dtSq, partials, ctl, sa);                                             \
     } while (0)
 #define DM_LAUNCH_E(MATV, GRADV)      \
     do {                              \
