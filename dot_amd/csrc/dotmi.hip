@@ -492,8 +492,18 @@ int upload_patches(dotmi_handle *h, const HostPatches &H, DevPatches &D)
     }
     if (int rc = upload(h, &D.tl, tl)) return rc;
     if (int rc = upload(h, &D.A, A)) return rc;
-    if (int rc = upload(h, &D.mu, mu)) return rc;
-    if (int rc = upload(h, &D.lam, lam)) return rc;
+    // one material (every input deck of the reference: Mesh.cpp:741-744 fills u / lambda from one Young's modulus and
+    // Poisson ratio): the element pass takes the two numbers as kernel arguments instead of 16 bytes per tet
+    bool uniform = !h->mu.empty();
+    for (size_t e = 1; e < h->mu.size() && uniform; ++e) uniform = h->mu[e] == h->mu[0] && h->lam[e] == h->lam[0];
+    D.mu = D.lam = nullptr;
+    if (uniform) {
+        D.mu0 = h->mu[0];
+        D.lam0 = h->lam[0];
+    } else {
+        if (int rc = upload(h, &D.mu, mu)) return rc;
+        if (int rc = upload(h, &D.lam, lam)) return rc;
+    }
     if (int rc = upload(h, &D.vol, vol)) return rc;
     if (int rc = upload(h, &D.pv_gid, H.pv_gid)) return rc;
     if (int rc = upload(h, &D.pv_slot, H.pv_slot)) return rc;

@@ -40,6 +40,7 @@ struct DevPatches {
     ushort4 *tl = nullptr;        // nPatches*PE: patch-local vertex indices of a slot's corners (x == 0xFFFF: padding slot)
     double *A = nullptr;          // [9][nPatches*PE] rest-shape inverse in patch order, SoA
     double *mu = nullptr, *lam = nullptr, *vol = nullptr;   // nPatches*PE in patch order (0 on padding)
+    double mu0 = 0.0, lam0 = 0.0;   // mu == nullptr: every element has these Lame parameters (one material: 16 B per tet not read)
     int *pv_gid = nullptr, *pv_slot = nullptr, *pv_cnt = nullptr;   // nPatches*PV, nPatches*PV, nPatches
     unsigned short *c_ptr = nullptr;   // per patch (PV+1): offsets of the vertices' corner runs
     ushort4 *epos = nullptr;          // nPatches*PE: position of a slot's four corners in their vertices' runs

@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
             if (GRAD) o.ep[u] = PT.epos[s];
 #pragma unroll
             for (int k = 0; k < 9; ++k) o.Ai[u][k] = PT.A[(size_t)k * strideA + s];
-            o.m[u] = PT.mu[s];
-            o.l[u] = PT.lam[s];
+            o.m[u] = PT.mu ? PT.mu[s] : PT.mu0;
+            o.l[u] = PT.mu ? PT.lam[s] : PT.lam0;
             o.vo[u] = PT.vol[s];
         }
     };
