@@ -40,7 +40,51 @@ REFERENCE_ANCHOR = {
     "bunny5K_LTSS": {"ms_per_step": [160, 360], "iters": [11, 10, 9, 9, 9, 10, 11, 11, 12, 12]},
     "monkey18K_stiff": {"ms_per_step": [4024, 10152], "iters": [108, 85, 98, 88, 145, 135, 145, 162, 131, 126]},
 }
+FP64_MFMA_PEAK = 78.6   # TFLOP/s, MI355X FP64 matrix = vector peak (256 CUs x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+
+def compact_line(full):
+    """The driver-facing JSON line: the contract's keys plus numbers-only `roofline`, `roofline_factor`, `cpu_baseline` and a
+    one-row-per-workload summary.  Everything else (roofline_by_kernel, PMC sources, notes) is in bench_detail.json."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "ms_per_step_p50", "ms_per_step_p95", "iters_per_frame", "step_breakdown_ms")
+    out = {k: full[k] for k in keep if k in full}
+    out["data"] = "reference input mesh (fixture), scripted handles"
+    r = full["roofline"]
+    out["roofline"] = {"bound": "hbm", "kernel": "backsolve_ctl_kernel", "achieved": r["achieved"], "peak": r["peak"],
+                       "unit": "GB/s", "frac": r["frac"], "traffic": r["traffic"],
+                       "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_ms": r["avg_launch_ms"],
+                       "launches_timed": r["launches_timed"], "launches_total": r["launches_total"],
+                       "launches_stopped": r["launches_stopped"]}
+    f = full["roofline_factor"]
+    out["roofline_factor"] = {"bound": "mfma", "kernel": "tile_task_kernel", "achieved": f["achieved"], "peak": f["peak"],
+                              "unit": "TFLOP/s", "frac": f["frac"], "flop": f["flop_per_factorisation"], "avg_ms": f["avg_ms"]}
+    if "collectives" in full:
+        c = full["collectives"]
+        out["collectives"] = {k: c[k] for k in ("allreduce_calls_per_step", "payload_MB_per_step", "est_ms_per_step") if k in c}
+    if "cpu_baseline" in full:
+        c = full["cpu_baseline"]
+        cb = {k: c[k] for k in ("value", "unit", "cores", "kind", "sample") if k in c}
+        a = c.get("reference_anchor") or {}
+        if a.get("ms_per_step"):
+            cb["reference_anchor_ms"] = a["ms_per_step"]
+            cb["reference_anchor_cores"] = a.get("cores")
+        rc = c.get("reference_cholmod") or {}
+        if "factorize_ms_all_subdomains" in rc:
+            cb["reference_cholmod"] = {"factorize_ms": rc["factorize_ms_all_subdomains"], "solve_ms": rc["solve_ms_all_subdomains"],
+                                       "cores": rc["cores"], "nnz_L": rc.get("nnz_L")}
+        for k in ("variants",):
+            if k in c:
+                cb[k] = c[k]
+        out["cpu_baseline"] = cb
+    if full.get("workloads"):
+        out["workloads"] = [{"name": w["workload"], "ms_per_step": w["ms_per_step"], "iters": w["iters_per_frame"],
+                             "backsolve_frac": w["roofline"]["frac"],
+                             "factor_ms": w["step_breakdown_ms"]["subdomain_factor"],
+                             "factor_frac": (w.get("roofline_factor") or {}).get("frac")} for w in full["workloads"]]
+    out["detail"] = "bench_detail.json"
+    return out
 
 
 def main():
@@ -285,6 +329,19 @@ def main():
             "part_sizes": {"live_min": int(min(ns)), "live_mean": round(float(np.mean(ns)), 1), "live_max": int(max(ns)),
                            "padded": nmax},
         }
+        # ---- second roofline: the once-per-step factorisation against the dense FP64 matrix-core peak ----------------
+        fact_ms = float(np.mean([s.ms_factor for s in stats]))
+        fact_tf = stats[0].factor_flops / (fact_ms * 1e-3) / 1e12 if fact_ms > 0 else 0.0
+        rec["roofline_factor"] = {
+            "bound": "mfma", "kernel": "tile_task_kernel: block-sparse inverse-Cholesky of the subdomain blocks as 64x64 "
+            "tile tasks (v_mfma_f64_16x16x4_f64 from LDS), once per step",
+            "achieved": round(fact_tf, 2), "peak": FP64_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(fact_tf / FP64_MFMA_PEAK, 4),
+            "flop_per_factorisation": float(stats[0].factor_flops), "avg_ms": round(fact_ms, 4),
+            "note": "flop as executed on the tiles that can be non-zero in each subdomain (padding only inside 64-tiles)",
+            # for scale: a dense potrf + trtri on the live sizes would be (2/3) sum n_s^3 flop
+            "dense_potrf_trtri_flop_on_live_sizes": float(sum(2.0 / 3.0 * n ** 3 for n in ns)),
+            "factor_storage_bytes": rec.get("factor_storage_bytes"),
+        }
         target = ts.targetGRes
         rec["roofline_by_kernel"] = kernel_rooflines(ts, rec) if rank == 0 or world == 1 else None
         if rec["collectives"] is None:
@@ -299,21 +356,7 @@ def main():
     roofline = rec["roofline"]
     avg_ms = roofline["avg_launch_ms"]
 
-    # ---- second roofline: the once-per-step factorisation against the dense FP64 matrix-core peak ----------------
-    FP64_MFMA_PEAK = 78.6   # TFLOP/s, MI355X FP64 matrix = vector peak (256 CUs x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
-    fact_ms = float(np.mean([s.ms_factor for s in stats]))
-    fact_tf = stats[0].factor_flops / (fact_ms * 1e-3) / 1e12 if fact_ms > 0 else 0.0
-    roofline_factor = {
-        "bound": "mfma", "kernel": "tile_task_kernel: block-sparse inverse-Cholesky of the subdomain blocks as level-scheduled 64x64 "
-        "tile tasks (v_mfma_f64_16x16x4_f64 from LDS), once per step",
-        "achieved": round(fact_tf, 2), "peak": FP64_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(fact_tf / FP64_MFMA_PEAK, 4),
-        "flop_per_factorisation": float(stats[0].factor_flops), "avg_ms": round(fact_ms, 4),
-        "note": "flop as executed on the tiles that can be non-zero in each subdomain (padding only inside 64-tiles); see "
-                "profiles/r03_factor_tiles.txt",
-    }
-    # for scale: a dense potrf + trtri on the live sizes would be (2/3) sum n_s^3 flop
-    roofline_factor["dense_potrf_trtri_flop_on_live_sizes"] = float(sum(2.0 / 3.0 * n ** 3 for n in rec["_ns"]))
-    roofline_factor["factor_storage_bytes"] = rec.get("factor_storage_bytes")
+    roofline_factor = rec["roofline_factor"]
     del rec["_ns"]
 
     # ---- the other configurations BASELINE.json / north_star name, short runs (every rank takes part) --------------
@@ -388,7 +431,18 @@ def main():
                 out["cpu_baseline"]["reference_cholmod"] = reference_cholmod_leg(sc2, ep2, nparts, orc)
             except Exception as e:   # noqa: BLE001 - the leg is optional (needs oracle/_ref + the image's MKL)
                 out["cpu_baseline"]["reference_cholmod"] = {"error": f"{type(e).__name__}: {e}"}
-        print(json.dumps(out), flush=True)
+        # the full record (per-kernel rooflines, PMC sources, per-workload detail, the long explanatory strings) goes to a
+        # side file; the ONE stdout line stays below 4 KB so that the driver's parser gets all of it
+        detail_paths = [os.path.join(ROOT, "bench_detail.json")]
+        if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            detail_paths.append(os.path.join(ROOT, "gpurun_out", f"bench_detail_n{world}.json"))
+        for dp_ in detail_paths:
+            try:
+                with open(dp_, "w") as fh:
+                    json.dump(out, fh, indent=1)
+            except OSError:
+                pass
+        print(json.dumps(compact_line(out)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

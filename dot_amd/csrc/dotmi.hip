@@ -162,6 +162,7 @@ struct dotmi_handle {
     Tuning tune;
 #ifdef DOTMI_TEST_HOOKS
     int testIterDelta = 0;   // fault injection for tests/test_gpu_two_ranks.py (libdotmi_testhooks.so only)
+    int testFailRefresh = 0, testRefreshCount = 0;   // DOTMI_TEST_FAIL_REFRESH=k: the k-th factorisation reports a bad pivot
 #endif
     // configuration
     int nV = 0, nT = 0, n = 0, mat = 0, hist = 5, iterCap = 10000;
@@ -227,7 +228,6 @@ struct dotmi_handle {
     double *He = nullptr, *Hval = nullptr, *tmpn = nullptr;
     double *S[HIST_MAX + 1] = {nullptr}, *Y[HIST_MAX + 1] = {nullptr};
     // early back-solve (enqueue_loop_slot): u = -M g of the current iterate, M y_i of the stored pairs (slots as Y)
-    hipEvent_t evLoop0 = nullptr, evLoop1 = nullptr;   // device-side bracket of a step's loop (asynchronous refresh)
     bool refreshPending = false;   // DOTMI_FLAG_ASYNC_REFRESH: the last step's refresh is enqueued, not yet judged / timed
     double carryHess = 0, carryFact = 0;   // device times of a refresh resolved outside dotmi_step (reported by the next step)
     bool earlyBs = false;     // possible on this handle (buffers exist)
@@ -1552,6 +1552,9 @@ int refactor_issue(dotmi_handle *h, const double *x)
 int refactor_finish(dotmi_handle *h, double *ms_hess, double *ms_fact)
 {
     int bad = -1;
+#ifdef DOTMI_TEST_HOOKS
+    if (h->testFailRefresh > 0 && ++h->testRefreshCount == h->testFailRefresh && h->P.nParts > 0) h->h_info[0] = 7;
+#endif
     for (int i = 0; i < h->P.nParts && bad < 0; ++i)
         if (h->h_info[i] != 0) bad = i;
     if (h->world > 1) {
@@ -1610,6 +1613,20 @@ int resolve_refresh(dotmi_handle *h, double *ms_hess = nullptr, double *ms_fact 
     if (ms_fact) *ms_fact += b;
     else h->carryFact += b;
     return rc;
+}
+
+// Every entry point that reads the factors starts here: the refresh a step left running (DOTMI_FLAG_ASYNC_REFRESH) is waited
+// for and judged FIRST, then the handle's verdict is tested -- so a non-SPD subdomain found by an asynchronous refresh stops
+// the next call exactly like one found by the synchronous path
+int enter_with_factors(dotmi_handle *h)
+{
+    const int rc = resolve_refresh(h);
+    if (rc == DOTMI_E_DEVICE) return rc;
+    if (h->poisoned) {
+        if (rc != DOTMI_E_NOTSPD) h->err = "the subdomain factors are invalid (the last factorisation failed): " + h->err;
+        return DOTMI_E_NOTSPD;
+    }
+    return 0;
 }
 
 // sum over the ranks of n doubles at `dev`, in place, ordered on the handle's stream: RCCL, or the host hook
@@ -2460,8 +2477,6 @@ void dotmi_destroy(dotmi_handle *h)
     if (h->evA) hipEventDestroy(h->evA);
     for (hipEvent_t e : h->evP)
         if (e) hipEventDestroy(e);
-    if (h->evLoop0) hipEventDestroy(h->evLoop0);
-    if (h->evLoop1) hipEventDestroy(h->evLoop1);
     for (hipEvent_t e : h->tFork) hipEventDestroy(e);
     for (hipEvent_t e : h->tJoin) hipEventDestroy(e);
     if (h->stDiag) hipStreamDestroy(h->stDiag);
@@ -2534,6 +2549,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     h->tune = Tuning::from_env();
 #ifdef DOTMI_TEST_HOOKS
     h->testIterDelta = Tuning::geti("DOTMI_TEST_ITER_DELTA", 0);
+    h->testFailRefresh = Tuning::geti("DOTMI_TEST_FAIL_REFRESH", 0);
 #endif
     h->density = mesh->density;
     h->nPartsAll = mesh->nParts;
@@ -2834,11 +2850,10 @@ int dotmi_last_iter_log(const dotmi_handle *h, int32_t cap, double *alpha, doubl
 int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
 {
     if (!h) return DOTMI_E_INVALID;
-    if (h->poisoned) {
-        h->err = "the subdomain factors are invalid (the last factorisation failed): " + h->err;
-        return DOTMI_E_NOTSPD;
-    }
     HIPCHECK(h, hipSetDevice(h->device));
+    // a refresh still running from the last step is judged BEFORE anything of this step is enqueued: a step never runs on
+    // factors whose factorisation failed (what the caller did between the two steps has already overlapped the refresh)
+    if (int rc = enter_with_factors(h)) return rc;
     const double T0 = now_ms();
     const int n = h->n;
     h->m = 0;
@@ -2858,14 +2873,6 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
     for (double &v : h->phaseMs) v = 0.0;
     h->evPn = 0;
     phase_mark(h, -1);
-    const bool asyncTimed = h->refreshPending;
-    if (asyncTimed) {
-        if (!h->evLoop0) {
-            HIPCHECK(h, hipEventCreate(&h->evLoop0));
-            HIPCHECK(h, hipEventCreate(&h->evLoop1));
-        }
-        HIPCHECK(h, hipEventRecord(h->evLoop0, h->st));
-    }
     // initX(2): x += dt v + dt^2 g on free vertices (Optimizer.cpp:442-582)
     launch_init_x(h->nV, h->M.fixed, h->v, h->dt, h->gdtsq, h->x, h->st);
     LbfgsArgs L = lbfgs_args(h);
@@ -2982,17 +2989,6 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         if (++it >= h->iterCap) break;
     } while (g2 > h->targetGRes);
     double Tloop1 = now_ms();
-    double TloopDev = -1.0;
-    if (asyncTimed) {
-        // the step started behind the previous step's refresh: its loop is timed on the device (from the moment the
-        // stream reached this step's first kernel), and that refresh is judged and timed now that the stream is idle
-        HIPCHECK(h, hipEventRecord(h->evLoop1, h->st));
-        HIPCHECK(h, hipEventSynchronize(h->evLoop1));
-        float ms = 0;
-        hipEventElapsedTime(&ms, h->evLoop0, h->evLoop1);
-        TloopDev = ms;
-    }
-    if (int rc = resolve_refresh(h, &ms_hess, &ms_fact)) return rc;
     ms_hess += h->carryHess;
     ms_fact += h->carryFact;
     h->carryHess = h->carryFact = 0.0;
@@ -3031,7 +3027,7 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         st->E = lastE;
         st->g2 = g2;
         st->ms_total = now_ms() - T0;
-        st->ms_loop = TloopDev >= 0.0 ? TloopDev : Tloop1 - Tloop;
+        st->ms_loop = Tloop1 - Tloop;
         st->ms_hessian = ms_hess;
         st->ms_factor = ms_fact;
         std::vector<char> ran(h->evUsed / 2 + 1, h->devLoop ? 0 : 1);
@@ -3151,12 +3147,8 @@ int dotmi_refactor(dotmi_handle *h, const double *x)
 int dotmi_apply_precond(dotmi_handle *h, const double *r, double *p)
 {
     if (!h || !r || !p) return DOTMI_E_INVALID;
-    if (h->poisoned) {
-        h->err = "the subdomain factors are invalid (the last factorisation failed)";
-        return DOTMI_E_NOTSPD;
-    }
     HIPCHECK(h, hipSetDevice(h->device));
-    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
+    if (int rc = enter_with_factors(h)) return rc;
     if (int rc = upload_tmp(h, r, h->q)) return rc;
     LbfgsArgs L;
     memset(&L, 0, sizeof(L));
@@ -3174,16 +3166,12 @@ int dotmi_probe_direction(dotmi_handle *h, const double *x, int32_t m, const dou
                           double *q_out, double *z_out, double *p_out, double *alpha0, double *E_trial)
 {
     if (!h || !x || m < 0 || m > h->hist || (m > 0 && (!S || !Y))) return DOTMI_E_INVALID;
-    if (h->poisoned) {
-        h->err = "the subdomain factors are invalid (the last factorisation failed)";
-        return DOTMI_E_NOTSPD;
-    }
     if (h->dist) {
         h->err = "dotmi_probe_direction: single-GPU handles only";
         return DOTMI_E_INVALID;
     }
     HIPCHECK(h, hipSetDevice(h->device));
-    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
+    if (int rc = enter_with_factors(h)) return rc;
     const int n = h->n;
     const size_t bytes = sizeof(double) * n;
     // the probe works on tmpn (iterate), g_trial (gradient), x_trial (trial point): the handle's own x, g stay
@@ -3289,7 +3277,9 @@ int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *Mout, 
 {
     if (!h || part < h->p0 || part >= h->p1 || !Mout) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
-    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
+    if (inverse) {
+        if (int rc = enter_with_factors(h)) return rc;
+    } else if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
     const int ls = part - h->p0;
     const int ns = 3 * (int)h->partVerts[part].size();
     const int nmax = h->P.nmax, ntl = nmax / 64;
@@ -3344,7 +3334,7 @@ int dotmi_bench_precond(dotmi_handle *h, int32_t reps, double *ms_per_launch, in
 {
     if (!h || reps < 1) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
-    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
+    if (int rc = enter_with_factors(h)) return rc;
     launch_gemv(h->P, h->q, h->st);  // warm
     HIPCHECK(h, hipEventRecord(h->ev0, h->st));
     for (int i = 0; i < reps; ++i) launch_gemv(h->P, h->q, h->st);
@@ -3366,7 +3356,7 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
 {
     if (!h || reps < 1) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
-    if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
+    if (int rc = enter_with_factors(h)) return rc;
     const int n = h->n, nV = h->nV;
     const int64_t nTo = h->PT.nElem, nVo = h->v1 - h->v0, m = h->m > 0 ? h->m : h->hist;
     LbfgsArgs L = lbfgs_args(h);

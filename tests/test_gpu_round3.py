@@ -210,3 +210,4 @@ def test_early_order_on_the_sharded_path_matches_the_single_rank_run(workload, s
         assert sa.backsolve_stopped == sb.backsolve_stopped == sa.ls_halvings + 1      # both ran the early order
         assert np.abs(a.getResult() - b.getResult()).max() < 1e-9
     a.close(); b.close()
+
