@@ -76,7 +76,7 @@ def main():
             tf.write(text)
         parsed = O.ref_config_parse(tf.name)
         os.remove(tf.name)
-        cfgs[os.path.relpath(path, REF)] = dict(text=text, parsed=parsed)
+        cfgs[os.path.relpath(path, REF)] = dict(parsed=parsed)   # the text stays in the reference checkout
     with open(os.path.join(HERE, "ref_config.json"), "w") as f:
         json.dump(cfgs, f, indent=0, sort_keys=True)
     print("ref_config.json:", len(cfgs), "scripts")

@@ -178,24 +178,30 @@ def test_time_steps_match_oracle(name, nsteps):
 
 
 def test_stiff_monkey_with_backtracking():
-    """config 4: E = 4e5, dt = 0.04, SNH, 64 parts: ~100+ iterations and ~1.75 energy evaluations per
-    iteration -- exercises the halving path.  One step.  The iteration is chaotic at
-    rounding level over that many iterations, so parity is asserted
-    per iteration while the two runs are still rounding-close, and at the end on the quantities that
-    define the step: converged to the same tolerance, same energy to solver accuracy."""
+    """config 4: E = 4e5, dt = 0.04, SNH, 64 parts: ~100+ iterations and more halvings than iterations in step 0
+     -- exercises the halving path in a free run.  The iteration is chaotic at rounding level over that many
+    iterations, so what a FREE run can honestly assert is: the per-iteration (alpha, E) logs
+    agree while the two runs are still rounding-close -- at least the first 25 iterations, every accept / halve decision
+    among them included --, both runs end below the same tolerance, and the converged energies agree to what that
+    tolerance allows.  Whole-step agreement per iteration and per trial is asserted where it can be: teacher-forced, in
+    tests/test_gpu_round4.py::test_teacher_forced_stiff_monkey_whole_steps_every_trial."""
     sc, ep, n, ts, orc = make_pair("monkey18K_stiff")
     try:
         (st, so, xg, xo, (a, e, g2), (ao, eo, g2o)), = run_both(sc, ts, orc, 1)
-        assert st.ls_halvings > 0 and so.ls_halvings > 0
-        k = min(15, len(a), len(ao))
-        assert np.allclose(a[:k], ao[:k], rtol=1e-6, atol=0)       # same accept/halve decisions
-        assert np.allclose(e[:k], eo[:k], rtol=1e-9, atol=0)
+        assert st.ls_halvings > 100 and so.ls_halvings > 100
+        m = min(len(a), len(ao))
+        same = np.isclose(a[:m], ao[:m], rtol=1e-6, atol=0) & np.isclose(e[:m], eo[:m], rtol=1e-9, atol=0)
+        prefix = m if same.all() else int(np.argmin(same))
+        assert prefix >= 25, prefix     # same accept / halve decisions, same energies (measured: 36 of 105 iterations)
         assert st.status == 0 and so.status == 0
         assert st.g2 <= ts.targetGRes and so.g2 <= orc.target_gres
-        assert abs(st.iters - so.iters) <= max(5, so.iters // 10)
+        if prefix == m:
+            assert st.iters == so.iters and st.ls_halvings == so.ls_halvings
+        assert abs(st.iters - so.iters) <= max(5, so.iters // 10)    # (documented band of the chaotic tail)
         assert abs(st.E - so.E) <= 1e-4 * abs(so.E)
-        print("monkey: iters", st.iters, so.iters, "halvings", st.ls_halvings, so.ls_halvings, "dE/E",
-              abs(st.E - so.E) / abs(so.E), "max dx", np.abs(xg - xo).max())
+        print("monkey: iters", st.iters, so.iters, "halvings", st.ls_halvings, so.ls_halvings, "identical prefix", prefix,
+              "of", m, "iterations; dE/E", abs(st.E - so.E) / abs(so.E),
+              "max dx", np.abs(xg - xo).max())
     finally:
         ts.close(); orc.close()
 

@@ -473,13 +473,21 @@ def test_config_echo_is_byte_identical_to_the_references_saveToFile(tmp_path):
     with open(FORMATS) as f:
         G = json.load(f)["config"]
     assert len(G) >= 65
+    from tests.test_oracle_pin import reference_script_text
+    nshipped = 0
     for rel, rec in G.items():
         src, dst = tmp_path / "s.txt", tmp_path / "config.txt"
-        src.write_text(rec["text"])
+        # the fixture stores the reference writer's OUTPUT; the shipped scripts' texts are read from the reference checkout
+        text = rec["text"] if "text" in rec else reference_script_text(rel)
+        if text is None:
+            continue
+        nshipped += "text" not in rec
+        src.write_text(text)
         subprocess.check_call([exe, "100", str(src), "--echo-config", str(dst)])
         ours = dst.read_bytes()
         assert b"\nscript null\n" in ours, rel
         assert ours.replace(b"\nscript null\n", b"\nscript @SCRIPT@\n") == rec["echo"].encode(), rel
+    assert nshipped >= 60 or not os.path.isdir("/root/reference/input")
     # and the script token itself round-trips
     src.write_text("energy FCR\ntimeStepper DOT 6\nscript twistnsns\nshape input a.msh\n")
     subprocess.check_call([exe, "100", str(src), "--echo-config", str(dst)])
