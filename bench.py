@@ -400,31 +400,56 @@ def main():
             from tests import oracle_py as O
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             O.lib().dor_set_threads(threads)
-            sc2, ep2, _ = load_workload(args.workload)
-            orc = O.OracleSim(sc2.V_rest, sc2.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc2.fixed, sc2.x0,
-                              ep2, nparts, cfg.with_gravity)
             nwarm = min(args.warmup, 2)
-            times, cits = [], []
-            budget_t0 = time.perf_counter()
-            for k in range(nwarm + args.cpu_steps):
-                x = orc.state()[0]
-                idx, pos = sc2.scripter.step(x, cfg.dt)
-                orc.move(idx, pos)
-                c0 = time.perf_counter()
-                so = orc.step()
-                if k >= nwarm:
-                    times.append(time.perf_counter() - c0)
-                    cits.append(so.iters)
-                if time.perf_counter() - budget_t0 > 30.0 and len(times) >= 3:
-                    break
+
+            def cpu_leg(reference_cholmod):
+                """the oracle on `threads` host threads over a bounded sample of the workload; with reference_cholmod the
+                subdomain factorisations / solves run in the reference's own CHOLMODSolver (one object per subdomain,
+                OpenMP over the subdomains as the reference's TBB loops DOTTimeStepper.cpp:363-377, :406-431)"""
+                sc2, ep2, _ = load_workload(args.workload)
+                orc = O.OracleSim(sc2.V_rest, sc2.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc2.fixed, sc2.x0,
+                                  ep2, nparts, cfg.with_gravity)
+                if reference_cholmod:
+                    O.use_reference_cholmod(orc)
+                times, cits, tf, tsv = [], [], [], []
+                budget_t0 = time.perf_counter()
+                for k in range(nwarm + args.cpu_steps):
+                    x = orc.state()[0]
+                    idx, pos = sc2.scripter.step(x, cfg.dt)
+                    orc.move(idx, pos)
+                    c0 = time.perf_counter()
+                    so = orc.step()
+                    if k >= nwarm:
+                        times.append(time.perf_counter() - c0)
+                        cits.append(so.iters)
+                        tf.append(so.ms_factor)
+                        tsv.append(so.ms_backsolve)
+                    if time.perf_counter() - budget_t0 > (15.0 if reference_cholmod else 30.0) and len(times) >= 3:
+                        break
+                return sc2, ep2, orc, times, cits, float(np.mean(tf)), float(np.mean(tsv))
+
+            sc2, ep2, orc, times, cits, tf_, ts_ = cpu_leg(False)
             out["cpu_baseline"] = {
                 "value": round(1e3 * float(np.mean(times)), 2), "unit": "ms", "cores": threads, "kind": "port",
                 "sample": f"steps {nwarm}..{nwarm + len(times) - 1} of {args.workload} (same partition, same tolerance), "
                           f"oracle/dot_oracle.c with OpenMP, iters/step {cits}",
+                "factor_ms": round(tf_, 2), "backsolve_ms": round(ts_, 2),
                 # the reference's own code cannot be built on this box (TBB); what BASELINE.md section 2 measured with it
                 "reference_anchor": dict(REFERENCE_ANCHOR.get(args.workload, {}), cores=8, source="BASELINE.md section 2: "
                                          "the reference's unmodified sources, 8 vCPU Xeon 2.1 GHz, OMP_NUM_THREADS=8, MKL sequential"),
             }
+            # second variant (VERDICT r03 next 7): the same stepping leg with the reference's CHOLMODSolver doing the linear
+            # algebra of the subdomains (oracle/_ref/librefsolver.so = src/LinSysSolver/CHOLMODSolver.cpp compiled in place)
+            if O.ref_solver_available():
+                try:
+                    _, _, orc2, times2, cits2, tf2, ts2 = cpu_leg(True)
+                    orc2.close()
+                    out["cpu_baseline"]["variants"] = [{
+                        "kind": "port+reference_cholmod", "value": round(1e3 * float(np.mean(times2)), 2), "unit": "ms",
+                        "cores": threads, "steps": len(times2), "iters_equal_port": cits2 == cits[:len(cits2)],
+                        "factor_ms": round(tf2, 2), "backsolve_ms": round(ts2, 2)}]
+                except Exception as e:   # noqa: BLE001 - optional leg (needs oracle/_ref + the image's MKL)
+                    out["cpu_baseline"]["variants"] = [{"kind": "port+reference_cholmod", "error": f"{type(e).__name__}: {e}"}]
             # the one piece of the reference that IS compiled here, timed on the same subdomains: CHOLMODSolver
             # factorize + solve (oracle/_ref/librefsolver.so = src/LinSysSolver/CHOLMODSolver.cpp on the vendored CHOLMOD)
             try:

@@ -440,6 +440,10 @@ typedef struct {
     long *rowptr;  /* scalar row start offsets in L (n+1) */
     int *first;    /* scalar row first column */
     double *L;     /* envelope storage */
+    /* external solver (dor_use_ext_solver): its object, and the local block pattern handed to it */
+    void *ext;
+    int *nbr_ptr, *nbr_idx;
+    size_t *nbr_src; /* per pattern entry: block index in Hval */
 } dor_part;
 
 #define HIST 5 /* DOTTimeStepper.cpp:45 historySize */
@@ -460,6 +464,7 @@ struct dor_sim {
     int *epart, *dup;
     int *vpart; /* optional vertex partition: subdomains = vertex sets (block Jacobi) */
     dor_part *parts;
+    dor_ext_solver ext; /* ext.create != NULL: the subdomain systems go through it */
     /* state */
     double *x, *xn, *v, *xt, *g, *p;
     /* L-BFGS */
@@ -809,6 +814,83 @@ static void solve_part(const dor_part *P, double *b /* in RCM scalar order, in/o
     }
 }
 
+/* ---- external subdomain solver (dor_use_ext_solver) ---- */
+static void ext_release(dor_sim *s)
+{
+    for (int pI = 0; pI < s->nParts; ++pI) {
+        dor_part *P = &s->parts[pI];
+        if (P->ext && s->ext.destroy) s->ext.destroy(P->ext);
+        P->ext = NULL;
+        free(P->nbr_ptr); free(P->nbr_idx); free(P->nbr_src);
+        P->nbr_ptr = P->nbr_idx = NULL;
+        P->nbr_src = NULL;
+    }
+}
+
+/* the block pattern of H_s = R_s H R_s^T in local ids (both sorted lists walked as in factor_part) + one object per part */
+static void ext_build(dor_sim *s)
+{
+    for (int pI = 0; pI < s->nParts; ++pI) {
+        dor_part *P = &s->parts[pI];
+        int n = P->nv, cnt = 0;
+        P->nbr_ptr = (int *)malloc(sizeof(int) * (n + 1));
+        for (int pass = 0; pass < 2; ++pass) {
+            cnt = 0;
+            for (int i = 0; i < n; ++i) {
+                int v = P->l2g[i], a = 0;
+                if (pass == 0) P->nbr_ptr[i] = cnt;
+                for (int k = s->adj_ptr[v]; k < s->adj_ptr[v + 1]; ++k) {
+                    int u = s->adj_idx[k];
+                    while (a < n && P->l2g[a] < u) a++;
+                    if (a >= n) break;
+                    if (P->l2g[a] != u) continue;
+                    if (pass == 1) {
+                        P->nbr_idx[cnt] = a;
+                        P->nbr_src[cnt] = (size_t)k;
+                    }
+                    cnt++;
+                }
+            }
+            if (pass == 0) {
+                P->nbr_ptr[n] = cnt;
+                P->nbr_idx = (int *)malloc(sizeof(int) * (cnt > 0 ? cnt : 1));
+                P->nbr_src = (size_t *)malloc(sizeof(size_t) * (cnt > 0 ? cnt : 1));
+            }
+        }
+        unsigned char *fx = (unsigned char *)malloc(n > 0 ? n : 1);
+        for (int i = 0; i < n; ++i) fx[i] = s->fixed[P->l2g[i]];
+        P->ext = s->ext.create(n, P->nbr_ptr, P->nbr_idx, fx);
+        free(fx);
+    }
+}
+
+static int ext_factor_part(const dor_sim *s, dor_part *P)
+{
+    int cnt = P->nbr_ptr[P->nv];
+    double *blk = (double *)malloc(sizeof(double) * 9 * (size_t)(cnt > 0 ? cnt : 1));
+    for (int e = 0; e < cnt; ++e) memcpy(blk + 9 * (size_t)e, s->Hval + 9 * P->nbr_src[e], sizeof(double) * 9);
+    int rc = s->ext.factor(P->ext, blk);
+    free(blk);
+    return rc;
+}
+
+/* b in RCM scalar order, in / out, whichever solver holds the factors */
+static void solve_part_any(const dor_sim *s, int pI, double *b)
+{
+    const dor_part *P = &s->parts[pI];
+    if (!s->ext.create) {
+        solve_part(P, b);
+        return;
+    }
+    double *loc = (double *)malloc(sizeof(double) * 3 * (P->nv > 0 ? P->nv : 1));
+    for (int i = 0; i < P->nv; ++i)
+        for (int d = 0; d < 3; ++d) loc[3 * i + d] = b[3 * P->pos[i] + d];
+    s->ext.solve(P->ext, loc);
+    for (int i = 0; i < P->nv; ++i)
+        for (int d = 0; d < 3; ++d) b[3 * P->pos[i] + d] = loc[3 * i + d];
+    free(loc);
+}
+
 /* Optimizer.cpp:613-651 computeCharNormSq, :1045 updateTargetGRes, :222-228 setRelGL2Tol */
 static double char_norm_sq(const dor_sim *s, double epsSq)
 {
@@ -994,7 +1076,7 @@ void dor_refactor(dor_sim *s, const double *x)
     int fail = 0;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int pI = 0; pI < s->nParts; ++pI)
-        if (factor_part(s, &s->parts[pI])) fail = 1;
+        if (s->ext.create ? ext_factor_part(s, &s->parts[pI]) : factor_part(s, &s->parts[pI])) fail = 1;
     if (fail) fprintf(stderr, "dot_oracle: subdomain factorisation failed (non-SPD)\n");
     s->t_factor += now_ms() - t1;
 }
@@ -1015,7 +1097,7 @@ void dor_apply_precond(dor_sim *s, const double *r, double *p)
             b[3 * pi + 1] = r[3 * v + 1];
             b[3 * pi + 2] = r[3 * v + 2];
         }
-        solve_part(P, b);
+        solve_part_any(s, pI, b);
         ps[pI] = b;
     }
     memset(p, 0, sizeof(double) * 3 * s->nV);
@@ -1168,6 +1250,7 @@ dor_sim *dor_create_v(int nV, int nT, const double *Xrest, const int *T, double 
 void dor_destroy(dor_sim *s)
 {
     if (!s) return;
+    ext_release(s);
     for (int pI = 0; pI < s->nParts; ++pI) {
         dor_part *P = &s->parts[pI];
         free(P->l2g); free(P->pos); free(P->ord); free(P->rowptr); free(P->first); free(P->L);
@@ -1360,7 +1443,7 @@ int dor_step_gsdd(dor_sim *s, dor_step_stats *st)
                 int v = P->l2g[P->ord[pi]];
                 for (int d = 0; d < 3; ++d) b[3 * pi + d] = -s->g[3 * v + d];
             }
-            solve_part(P, b);
+            solve_part_any(s, sI, b);
             memset(s->p, 0, sizeof(double) * n);
             for (int i = 0; i < P->nv; ++i) {
                 int v = P->l2g[i], pi = P->pos[i];
@@ -1536,7 +1619,26 @@ void dor_set_alpha_min(dor_sim *s, double a) { s->alphaMin = a; }
 void dor_set_fixed(dor_sim *s, const unsigned char *fixed)
 {
     memcpy(s->fixed, fixed, s->nV);
+    if (s->ext.create) { /* the pattern of the fixed rows changes with the set */
+        ext_release(s);
+        ext_build(s);
+    }
     dor_refactor(s, s->x);
+}
+
+int dor_use_ext_solver(dor_sim *s, const dor_ext_solver *api)
+{
+    ext_release(s);
+    memset(&s->ext, 0, sizeof(s->ext));
+    if (api && api->create) {
+        s->ext = *api;
+        ext_build(s);
+    }
+    double t = s->t_factor;
+    dor_refactor(s, s->xn);
+    /* (dor_refactor only reports a failure on stderr; the timing of this extra refresh is not a step's) */
+    s->t_factor = t;
+    return 0;
 }
 
 void dor_get_features(const dor_sim *s, double *A, double *vol, double *mass, double *mu, double *lam)

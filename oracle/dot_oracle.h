@@ -57,6 +57,20 @@ void dor_set_svd_batch(dor_svd_batch_fn fn);
 /* ---- simulation object ---- */
 typedef struct dor_sim dor_sim;
 
+/* optional external solver for the subdomain systems (DOTTimeStepper.cpp:363-377 factorize, :406-431 solve): bench.py's
+ * second CPU leg binds it to the reference's own CHOLMODSolver (oracle/_ref/librefsolver.so: ref_sub_*), so that the CPU
+ * baseline's linear algebra is the reference's.  One object per subdomain: create(local vertex count, CSR of the local
+ * neighbours of every local vertex incl. itself -- ascending local ids --, fixed flags) once; factor(blocks) with the
+ * 3 x 3 row-major blocks of H_s in that CSR order after every refresh; solve(b) in place, local vertex order. */
+typedef struct {
+    void *(*create)(int nv, const int *nbr_ptr, const int *nbr_idx, const unsigned char *fixed);
+    int (*factor)(void *h, const double *blocks);
+    void (*solve)(void *h, double *b);
+    void (*destroy)(void *h);
+} dor_ext_solver;
+/* api == NULL: back to the built-in envelope Cholesky.  Re-factors at the current x.  returns 0, or 1 if a factorisation failed */
+int dor_use_ext_solver(dor_sim *s, const dor_ext_solver *api);
+
 typedef struct {
     int iters;         /* L-BFGS iterations this step (innerIterAmt delta) */
     int ls_halvings;   /* numOfLineSearch delta */

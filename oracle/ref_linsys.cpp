@@ -19,6 +19,21 @@
 
 using Solver = DOT::CHOLMODSolver<Eigen::VectorXi, Eigen::VectorXd>;
 
+// a view into the reference solver's protected members (this driver's code; the class itself is the reference's)
+struct SolverView : Solver {
+    bool has(int r, int c) const { return r < (int)IJ2aI.size() && IJ2aI[r].find(c) != IJ2aI[r].end(); }
+    double nnzL() const { return cm.lnz; }   // cholmod_common::lnz of the last analyze
+};
+
+// one subdomain system kept alive across time steps (DOTTimeStepper keeps linSysSolver_subdomain[s] the same way:
+// set_pattern + analyze_pattern once in the constructor, setCoeff + factorize per refresh, solve per L-BFGS iteration)
+struct SubSystem {
+    SolverView solver;
+    int nv = 0;
+    std::vector<int> nbr_ptr, nbr_idx;
+    Eigen::VectorXd rhs, res;
+};
+
 namespace {
 // pattern + coefficients of a (sub-)mesh into the reference's solver object
 void assemble(Solver &solver, int nV, int nT, const int *T, const unsigned char *fixed, const double *He, const double *mass)
@@ -91,9 +106,66 @@ int ref_linsys_time(int nV, int nT, const int *T, const unsigned char *fixed, co
         best = std::min(best, now_ms() - t0);
     }
     out[1] = nsolve > 0 ? best : 0.0;
-    out[2] = 0.0;
+    out[2] = static_cast<const SolverView &>(solver).nnzL();
     return 0;
 }
+
+// ---- persistent subdomain systems for the oracle's external-solver hook (dor_use_ext_solver, oracle/dot_oracle.h) ----------
+// nbr: CSR over the local vertices of their neighbours INSIDE the subdomain, itself included, ascending local ids -- the block
+// pattern of H_s = R_s H R_s^T.  The reference builds the same pattern from the subdomain mesh's vNeighbor
+// (ADMMDDTimeStepper.cpp:88-262 -> LinSysSolver::set_pattern, LinSysSolver.hpp:37-135).
+void *ref_sub_create(int nv, const int *nbr_ptr, const int *nbr_idx, const unsigned char *fixed)
+{
+    SubSystem *S = new SubSystem;
+    S->nv = nv;
+    S->nbr_ptr.assign(nbr_ptr, nbr_ptr + nv + 1);
+    S->nbr_idx.assign(nbr_idx, nbr_idx + nbr_ptr[nv]);
+    std::vector<std::set<int>> vNeighbor(nv);
+    std::set<int> fixedVert;
+    for (int i = 0; i < nv; ++i) {
+        for (int k = nbr_ptr[i]; k < nbr_ptr[i + 1]; ++k)
+            if (nbr_idx[k] != i) vNeighbor[i].insert(nbr_idx[k]);
+        if (fixed[i]) fixedVert.insert(i);
+    }
+    S->solver.set_type(1, 2);
+    S->solver.set_pattern(vNeighbor, fixedVert);
+    S->solver.analyze_pattern();
+    S->rhs.resize(3 * nv);
+    return S;
+}
+
+// blocks: 9 doubles (row-major 3 x 3) per pattern entry, in the CSR order of ref_sub_create.  The solver stores the upper
+// triangle of the free rows / columns and a unit diagonal for the fixed ones (set_pattern); entries outside that are skipped
+// (they are zeros / the unit diagonal in the assembled global matrix the blocks come from).  returns 1 when factorize fails
+int ref_sub_factor(void *h, const double *blocks)
+{
+    SubSystem *S = static_cast<SubSystem *>(h);
+    S->solver.setZero();
+    for (int i = 0; i < S->nv; ++i)
+        for (int k = S->nbr_ptr[i]; k < S->nbr_ptr[i + 1]; ++k) {
+            const int j = S->nbr_idx[k];
+            if (j < i) continue;
+            const double *b = blocks + 9 * (size_t)k;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    const int row = 3 * i + r, col = 3 * j + c;
+                    if (row <= col && S->solver.has(row, col)) S->solver.setCoeff(row, col, b[3 * r + c]);
+                }
+        }
+    return S->solver.factorize() ? 1 : 0;
+}
+
+void ref_sub_solve(void *h, double *b)
+{
+    SubSystem *S = static_cast<SubSystem *>(h);
+    std::memcpy(S->rhs.data(), b, sizeof(double) * 3 * S->nv);
+    S->solver.solve(S->rhs, S->res);
+    std::memcpy(b, S->res.data(), sizeof(double) * 3 * S->nv);
+}
+
+double ref_sub_nnzL(void *h) { return static_cast<SubSystem *>(h)->solver.nnzL(); }
+
+void ref_sub_destroy(void *h) { delete static_cast<SubSystem *>(h); }
 
 // T: nT*4, fixed: nV, He: nT*144 row-major element Hessians (already projected, dt^2 vol included), mass: nV
 // rhs, x: n = 3 nV.  Outputs: sol = A^-1 rhs, Ax = A x, and (if dense != NULL) the n*n matrix the solver holds.

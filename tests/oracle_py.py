@@ -334,8 +334,29 @@ def _load_refsolver():
     return _refsolver
 
 
+class ExtSolverAPI(C.Structure):
+    """dor_ext_solver (oracle/dot_oracle.h)"""
+    _fields_ = [("create", C.c_void_p), ("factor", C.c_void_p), ("solve", C.c_void_p), ("destroy", C.c_void_p)]
+
+
+def use_reference_cholmod(sim, on=True):
+    """Route the subdomain factorisations and solves of an OracleSim through the reference's own CHOLMODSolver, one
+    object per subdomain kept across the steps (oracle/_ref/librefsolver.so: ref_sub_*, oracle/ref_linsys.cpp) -- or back
+    to the built-in envelope Cholesky."""
+    L = lib()
+    L.dor_use_ext_solver.argtypes = [C.c_void_p, C.c_void_p]
+    L.dor_use_ext_solver.restype = C.c_int
+    if not on:
+        return L.dor_use_ext_solver(sim.h, None)
+    R = _load_refsolver()
+    api = ExtSolverAPI(*(C.cast(getattr(R, n), C.c_void_p) for n in ("ref_sub_create", "ref_sub_factor", "ref_sub_solve",
+                                                                      "ref_sub_destroy")))
+    return L.dor_use_ext_solver(sim.h, C.byref(api))
+
+
 def ref_linsys_time(T, fixed, He, mass, nfact=3, nsolve=10):
-    """(ms per numeric factorisation, ms per solve, 0) of the reference's CHOLMODSolver on the matrix of this (sub-)mesh"""
+    """(ms per numeric factorisation, ms per solve, non-zeros of L) of the reference's CHOLMODSolver on the matrix of this
+    (sub-)mesh"""
     R = _load_refsolver()
     T = np.ascontiguousarray(T, dtype=np.int32)
     fixed = np.ascontiguousarray(fixed, dtype=np.uint8)

@@ -316,3 +316,33 @@ def test_published_bar17K_as_shipped_list_needs_the_references_svd_rounding():
     d = np.abs(He_own - He_ref).max(1) / np.abs(He_own).max(1)
     frac = (d > 1e-6).mean()
     assert 0.85 < frac < 0.90 and d.max() < 0.3
+
+
+# ---- round 4: the oracle stepping on the reference's own subdomain solver (bench.py's second CPU leg) -------------------
+@pytest.mark.skipif(not O.ref_solver_available(), reason="oracle/_ref/librefsolver.so or the image's MKL not present")
+@pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 3), ("synbar:12x4x4:6", 3)])
+def test_oracle_on_reference_cholmod_takes_the_same_steps(workload, steps):
+    """dor_use_ext_solver bound to the reference's CHOLMODSolver (one persistent object per subdomain: pattern + analyze
+    once, setCoeff + factorize per refresh, solve per L-BFGS iteration -- DOTTimeStepper.cpp:363-377, :406-431): the same
+    iterations and halvings as the oracle's own envelope Cholesky, positions to 1e-9, and the block solve itself to 1e-10."""
+    from tests.workloads import load_workload
+    sc, ep, n = load_workload(workload)
+    cfg = sc.cfg
+    mk = lambda: O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, n,
+                             cfg.with_gravity)
+    a, b = mk(), mk()
+    assert O.use_reference_cholmod(b) == 0
+    r = np.random.default_rng(5).standard_normal(sc.x0.shape) * (1 - sc.fixed[:, None])
+    za, zb = a.apply_precond(r), b.apply_precond(r)
+    assert np.abs(za - zb).max() <= 1e-10 * np.abs(za).max()
+    for k in range(steps):
+        idx, pos = sc.scripter.step(a.state()[0], cfg.dt)
+        a.move(idx, pos); b.move(idx, pos)
+        sa, sb = a.step(), b.step()
+        assert (sa.status, sa.iters, sa.ls_halvings) == (sb.status, sb.iters, sb.ls_halvings), k
+        assert np.abs(a.state()[0] - b.state()[0]).max() < 1e-9
+    O.use_reference_cholmod(b, False)                 # and back
+    zb = b.apply_precond(r)
+    za = a.apply_precond(r)
+    assert np.abs(za - zb).max() <= 1e-10 * np.abs(za).max()
+    a.close(); b.close()
