@@ -103,6 +103,11 @@ struct Tuning {
     bool tileXcdOrder = true; // DOTMI_TILE_XCD_ORDER=0 tile tasks of a level longest first instead of grouped per XCD
     int tileEagerMin = 0;     // DOTMI_TILE_EAGER_MIN early products a critical-path tile task may keep
     bool tileBalance = true;  // DOTMI_TILE_BALANCE=0 every tile task at its earliest level (no second scheduling pass)
+    int tileFlow = -1;        // DOTMI_TILE_FLOW      1: the factorisation as ONE launch of persistent workgroups with per-task
+                              //                         dependencies (tile_flow_kernel) instead of one launch per level; 0: never;
+                              //                         default: where a level holds fewer tasks than the GPU holds workgroups
+    int tileFlowWg = 0;       // DOTMI_TILE_FLOW_WG   workgroups of that launch (0: two per CU)
+    int tileFlowWaitMs = 2000;   // DOTMI_TILE_FLOW_WAIT_MS  a task that waits longer for one of its dependencies gives up (error)
     int tileEagerMinDiag = 0; // DOTMI_TILE_EAGER_MIN_DIAG early products a diagonal tile task may keep
     int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
     bool fuseDir = true;      // DOTMI_FUSE_DIR=0     (early order) build_p and spmv_dots as two launches instead of one on cached H s_j
@@ -147,6 +152,9 @@ struct Tuning {
         t.tileXcdOrder = geti("DOTMI_TILE_XCD_ORDER", 1) != 0;
         t.tileEagerMin = std::max(0, geti("DOTMI_TILE_EAGER_MIN", 0));
         t.tileBalance = geti("DOTMI_TILE_BALANCE", 1) != 0;
+        t.tileFlow = geti("DOTMI_TILE_FLOW", -1);
+        t.tileFlowWg = geti("DOTMI_TILE_FLOW_WG", 0);
+        t.tileFlowWaitMs = std::max(1, geti("DOTMI_TILE_FLOW_WAIT_MS", 2000));
         t.tileEagerMinDiag = std::max(0, geti("DOTMI_TILE_EAGER_MIN_DIAG", 0));
         t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
         t.earlyBs = std::min(2, std::max(0, geti("DOTMI_EARLY_BACKSOLVE", 2)));
@@ -218,6 +226,9 @@ struct dotmi_handle {
     int nTclear = 0;
     std::vector<int> tlevelStart, tlevelDiag;
     bool tileSplit = false;
+    bool tileFlow = false;            // dataflow factorisation (tile_flow_kernel)
+    int *tdepPtr = nullptr, *tdepIdx = nullptr, *tdone = nullptr, *tnext = nullptr;
+    int tileEpoch = 0, nTtasks = 0, tileFlowWg = 0;
     hipStream_t stDiag = nullptr;              // side stream of the diagonal-block tasks
     std::vector<hipEvent_t> tFork, tJoin;      // per level
     double tileFlops = 0;
@@ -932,6 +943,33 @@ int build_device_mesh(dotmi_handle *h)
         h->tlevelStart = S.levelStart;
         h->tlevelDiag = S.levelDiag;
         h->tileSplit = h->tune.tileSplit >= 0 ? h->tune.tileSplit != 0 : P.nParts > 64;
+        h->nTtasks = (int)S.tasks.size();
+        // Dataflow or levels (profiles/r04_factor_flow.txt): per task the dataflow launch pays a ticket, a look at its
+        // dependencies' flags and write-through stores, and it runs the level kernel's 77 KB workgroups -- it wins where the
+        // levels are launches of less than one round of workgroups, i.e. the chain of dependent tasks paces the phase
+        // (bunny5K / 8 subdomains: 217 tasks per level, 0.57 -> 0.41 ms), and loses where the levels are several rounds
+        // (bar17K / 32: 1000 per level, 1.11 -> 1.21 ms; 1 M tets: 15 -> 23 ms).
+        const size_t nLevels = std::max<size_t>(S.levelStart.size() - 1, 1);
+        h->tileFlow = !S.tasks.empty() &&
+                      (h->tune.tileFlow > 0 || (h->tune.tileFlow < 0 && S.tasks.size() / nLevels <= 256 && h->world == 1));
+        if (h->tileFlow) {
+            std::vector<int> depPtr, depIdx;
+            build_tile_deps(S.tasks, S.prods, depPtr, depIdx);
+            if (depIdx.empty()) depIdx.push_back(0);
+            if (int rc = upload(h, &h->tdepPtr, depPtr)) return rc;
+            if (int rc = upload(h, &h->tdepIdx, depIdx)) return rc;
+            if (int rc = dalloc(h, &h->tdone, S.tasks.size())) return rc;
+            if (int rc = dalloc(h, &h->tnext, 2)) return rc;
+            HIPCHECK(h, hipMemset(h->tdone, 0, sizeof(int) * S.tasks.size()));
+            HIPCHECK(h, hipMemset(h->tnext, 0, sizeof(int) * 2));
+            hipDeviceProp_t prop;
+            HIPCHECK(h, hipGetDeviceProperties(&prop, h->device));
+            h->tileFlowWg = h->tune.tileFlowWg > 0 ? h->tune.tileFlowWg : 2 * prop.multiProcessorCount;
+            h->tileSplit = false;
+            if (h->tune.fuseLog)
+                fprintf(stderr, "dotmi: tile dataflow: %zu tasks, %zu dependencies, %d workgroups\n", S.tasks.size(), depIdx.size(),
+                        h->tileFlowWg);
+        }
         if (h->tileSplit) {
             HIPCHECK(h, hipStreamCreateWithFlags(&h->stDiag, hipStreamNonBlocking));
             h->tFork.resize(S.levelDiag.size());
@@ -1421,6 +1459,12 @@ int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id, i
 // issue (or replay) the inverse-Cholesky recursion of every owned subdomain on h->st
 int issue_factor(dotmi_handle *h)
 {
+    if (h->tileMode && h->tileFlow) {
+        launch_tile_flow(h->ttasks, h->nTtasks, h->tprods, h->tdepPtr, h->tdepIdx, h->tdone, h->tnext, ++h->tileEpoch, h->info_dev,
+                         h->tileFlowWg, h->st, h->tune.tileThreads, (double)h->tune.tileFlowWaitMs);
+        h->flopCount = h->tileFlops;
+        return 0;
+    }
     if (h->tileMode) {
         // one launch per level of the static tile schedule; a launch boundary is the only synchronisation
         for (size_t l = 0; l + 1 < h->tlevelStart.size(); ++l) {
@@ -1486,7 +1530,7 @@ int run_factor(dotmi_handle *h)
 {
     if (h->graphState == 0) {
         h->graphState = -1;
-        if (h->tune.factorGraph) {
+        if (h->tune.factorGraph && !h->tileFlow) {   // (the dataflow launch carries its epoch as an argument: not replayed)
             // warm rocBLAS (kernel selection, lazy loads) outside of capture, then capture the same sequence
             h->flopCount = 0;
             if (int rc = issue_factor(h)) return rc;
@@ -1569,6 +1613,12 @@ int refactor_finish(dotmi_handle *h, double *ms_hess, double *ms_fact)
             h->poisoned = true;
             return DOTMI_E_NOTSPD;
         }
+    }
+    if (bad >= 0 && h->h_info[bad] >= (1 << 30)) {
+        h->err = "the tile factorisation's dataflow scheduler waited for a task that never finished (subdomain " +
+                 std::to_string(h->p0 + bad) + ")";
+        h->poisoned = true;
+        return DOTMI_E_DEVICE;
     }
     if (bad >= 0) {
         h->err = "subdomain " + std::to_string(h->p0 + bad) + " Hessian not positive definite (pivot " +
@@ -2338,6 +2388,49 @@ int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pat
             q[3] = pr.ldb;
         }
     }
+    return 0;
+}
+
+// host-only: the dependencies the dataflow kernel (tile_flow_kernel) waits on, for the task list dotmi_plan_tile_schedule
+// returns (same arguments, same task order): task v may run once the tasks dep_idx[dep_ptr[v] .. dep_ptr[v+1]) have finished.
+// With dep_idx == NULL only *n_deps is returned.  tests/test_tile_schedule.py executes the tasks in random orders that
+// respect exactly these edges.
+int dotmi_plan_tile_deps(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0, int32_t eager_min,
+                         int32_t eager_chunk, int64_t *dep_ptr, int64_t *dep_idx, int64_t *n_deps)
+{
+    if (nt < 1 || !live || !pattern || !c0 || !n_deps) return DOTMI_E_INVALID;
+    std::vector<long long> rtOff(nt, -1);
+    std::vector<int> rtLd(nt, 0), rtC0(nt, 0);
+    long long tot = 0;
+    for (int j = 0; j < nt; ++j) {
+        if (!live[j]) continue;
+        rtC0[j] = 64 * c0[j];
+        rtLd[j] = 64 * (j + 1) - rtC0[j];
+        rtOff[j] = tot;
+        tot += 64ll * rtLd[j];
+    }
+    double *const W = reinterpret_cast<double *>(1ull << 40);
+    double *const scratch = W + tot;
+    std::vector<uint8_t> lv(live, live + nt), pat(pattern, pattern + (size_t)nt * nt);
+    std::vector<TileTaskL> all;
+    TileSchedule S;
+    size_t sn = 0;
+    plan_subdomain_tiles(0, nt, W, rtOff.data(), rtLd.data(), rtC0.data(), lv, pat, scratch, sn, all, S.clearTiles, S.clearLd,
+                         S.flops, S.qTiles, std::max(1, eager_min), std::max(1, eager_chunk));
+    std::stable_sort(all.begin(), all.end(), [](const TileTaskL &a, const TileTaskL &b) { return a.level < b.level; });
+    for (auto &t : all) {
+        TileTask k = t.t;
+        k.first = (int)S.prods.size();
+        k.nprod = (int)t.prods.size();
+        for (auto &p : t.prods) S.prods.push_back(p);
+        S.tasks.push_back(k);
+    }
+    std::vector<int> depPtr, depIdx;
+    build_tile_deps(S.tasks, S.prods, depPtr, depIdx);
+    *n_deps = (int64_t)depIdx.size();
+    if (!dep_ptr || !dep_idx) return 0;
+    for (size_t k = 0; k < depPtr.size(); ++k) dep_ptr[k] = depPtr[k];
+    for (size_t k = 0; k < depIdx.size(); ++k) dep_idx[k] = depIdx[k];
     return 0;
 }
 

@@ -281,6 +281,8 @@ void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, h
 void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, int threads = 256);
 // the non-diagonal tasks of a level on half tiles, four workgroups per CU (tile_gemm_kernel)
 void launch_tile_gemm(const TileTask *tasks, int ntasks, const TileProd *prods, hipStream_t st);
+void launch_tile_flow(const TileTask *tasks, int ntasks, const TileProd *prods, const int *depPtr, const int *depIdx, int *done,
+                      int *next, int epoch, int *info, int nwg, hipStream_t st, int threads, double waitMs);
 void launch_clear_tiles(double *const *tiles, const int *lds_, int ntiles, hipStream_t st);
 void launch_block_copy(double *dst, int ldd, size_t sd, const double *src, int lds_, size_t ss, int rows,
                        int cols, int batch, hipStream_t st, const LeafOffs &LO = LeafOffs());

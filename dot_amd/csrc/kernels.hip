@@ -1781,6 +1781,30 @@ __device__ __forceinline__ void tile_store(double (*G)[CHOL_NB + 1], double *__r
         *reinterpret_cast<double2 *>(dst + (size_t)j * ld + k) = make_double2(G[k][j], G[k + 1][j]);
     }
 }
+// The same store WRITE-THROUGH (sc1) for the dataflow kernel: the tile leaves the XCD's L2 as it is written, so publishing
+// it needs no release fence (a buffer_wbl2 behind 32 KB of fresh lines is ~6 us), only the storing waves' vmcnt drain in
+// front of the flag.  16-byte raw buffer stores through a descriptor on the tile's (wave-uniform) origin, aux 16 = sc1.
+typedef unsigned int tile_v4u __attribute__((ext_vector_type(4)));
+template <int THREADS, bool TRANSPOSED>
+__device__ __forceinline__ void tile_store_wt(double (*G)[CHOL_NB + 1], double *__restrict__ dst, int ld, int tid)
+{
+    const unsigned long long a = reinterpret_cast<unsigned long long>(dst);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const int ldu = __builtin_amdgcn_readfirstlane(ld);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(((unsigned long long)hi << 32) | lo), 0, (63 * ldu + 64) * 8, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < TileGeom<THREADS>::NL; ++u) {
+        const int idx2 = tid + THREADS * u, j = idx2 >> 5, k = 2 * (idx2 & 31);
+        union {
+            double d[2];
+            tile_v4u v;
+        } w;
+        w.d[0] = TRANSPOSED ? G[j][k] : G[k][j];
+        w.d[1] = TRANSPOSED ? G[j][k + 1] : G[k + 1][j];
+        __builtin_amdgcn_raw_buffer_store_b128(w.v, rsrc, (j * ldu + k) * 8, 0, 16);
+    }
+}
 template <int THREADS, bool TRANS_A>
 __device__ __forceinline__ void mfma_acc_tile(mfma_v4d (&acc)[TileGeom<THREADS>::NT], double (*La)[CHOL_NB + 1],
                                               double (*Lb)[CHOL_NB + 1], double sign, int tid)
@@ -1799,14 +1823,15 @@ __device__ __forceinline__ void mfma_acc_tile(mfma_v4d (&acc)[TileGeom<THREADS>:
     }
 }
 
-template <int THREADS>
-__global__ __launch_bounds__(THREADS, 2) void tile_task_kernel(const TileTask *__restrict__ tasks,
-                                                               const TileProd *__restrict__ prods, int *__restrict__ info)
+// one tile task on the workgroup's LDS tiles (the body of both the level kernel and the dataflow kernel below)
+template <int THREADS, bool COH = false>
+__device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd *__restrict__ prods, int *__restrict__ info,
+                                               double (*La)[CHOL_NB + 1], double (*Lb)[CHOL_NB + 1], double (*T32)[33],
+                                               double (*T16)[17])
 {
     constexpr int NB = CHOL_NB, LD = NB + 1, NT = TileGeom<THREADS>::NT;
-    __shared__ double La[NB][LD], Lb[NB][LD], T32[32][33], T16[16][17];
-    const TileTask t = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+    auto TL = [](const double *src, int ld, int tid_) { return tile_load<THREADS>(src, (size_t)ld, tid_); };
     const int rb = 16 * (w & 3), cb = 16 * NT * (w >> 2);   // this wave's rows / first column of the accumulator tiles
     const bool fact = t.form == TF_FACT;   // C -= A^T B on H tiles;  else C += A B
     const TileProd *pl = prods + t.first;
@@ -1815,13 +1840,13 @@ __global__ __launch_bounds__(THREADS, 2) void tile_task_kernel(const TileTask *_
     for (int q = 0; q < NT; ++q) acc[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
     BlkT<THREADS> ra, rbk;
     if (t.nprod > 0) {
-        ra = tile_load<THREADS>(t.p0.a, t.p0.lda, tid);
-        if (t.p0.b != t.p0.a) rbk = tile_load<THREADS>(t.p0.b, t.p0.ldb, tid);
+        ra = TL(t.p0.a, t.p0.lda, tid);
+        if (t.p0.b != t.p0.a) rbk = TL(t.p0.b, t.p0.ldb, tid);
     } else if (t.post == TP_ROW) {
-        ra = tile_load<THREADS>(t.q, t.ldq, tid);
+        ra = TL(t.q, t.ldq, tid);
     }
     if (t.init) {
-        tile_to_lds<THREADS>(tile_load<THREADS>(t.c, t.ldc, tid), La, tid);
+        tile_to_lds<THREADS>(TL(t.c, t.ldc, tid), La, tid);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < NT; ++q)
@@ -1835,10 +1860,10 @@ __global__ __launch_bounds__(THREADS, 2) void tile_task_kernel(const TileTask *_
         if (!same) tile_to_lds<THREADS>(rbk, Lb, tid);
         __syncthreads();
         if (p + 1 < t.nprod) {
-            ra = tile_load<THREADS>(pl[p + 1].a, pl[p + 1].lda, tid);
-            if (pl[p + 1].b != pl[p + 1].a) rbk = tile_load<THREADS>(pl[p + 1].b, pl[p + 1].ldb, tid);
+            ra = TL(pl[p + 1].a, pl[p + 1].lda, tid);
+            if (pl[p + 1].b != pl[p + 1].a) rbk = TL(pl[p + 1].b, pl[p + 1].ldb, tid);
         } else if (t.post == TP_ROW) {
-            ra = tile_load<THREADS>(t.q, t.ldq, tid);   // Q_kk for the final multiplication
+            ra = TL(t.q, t.ldq, tid);   // Q_kk for the final multiplication
         }
         if (fact) mfma_acc_tile<THREADS, true>(acc, La, same ? La : Lb, -1.0, tid);
         else mfma_acc_tile<THREADS, false>(acc, La, Lb, 1.0, tid);
@@ -1851,7 +1876,8 @@ __global__ __launch_bounds__(THREADS, 2) void tile_task_kernel(const TileTask *_
 #pragma unroll
             for (int r = 0; r < 4; ++r) La[rb + lk + 4 * r][cb + 16 * q + lr] = sg * acc[q][r];
         __syncthreads();
-        tile_store<THREADS>(La, t.c, t.ldc, tid);
+        if constexpr (COH) tile_store_wt<THREADS, false>(La, t.c, t.ldc, tid);
+        else tile_store<THREADS>(La, t.c, t.ldc, tid);
         return;
     }
     // G = updated H tile -> LDS
@@ -1873,17 +1899,92 @@ __global__ __launch_bounds__(THREADS, 2) void tile_task_kernel(const TileTask *_
 #pragma unroll
             for (int r = 0; r < 4; ++r) Lb[rb + lk + 4 * r][cb + 16 * q + lr] = acc[q][r];
         __syncthreads();
-        tile_store<THREADS>(Lb, t.c, t.ldc, tid);
+        if constexpr (COH) tile_store_wt<THREADS, false>(Lb, t.c, t.ldc, tid);
+        else tile_store<THREADS>(Lb, t.c, t.ldc, tid);
         return;
     }
     __syncthreads();
     const int bad = block_chol_inv<64>(La, Lb, 0, T32, T16, tid);
     // Q_jj = X^T: column i of the stored tile, row k <- X(i,k) (zero for k > i: the strictly lower part is cleared)
-    for (int idx = tid; idx < NB * NB; idx += THREADS) {
-        const int i = idx / NB, k = idx % NB;
-        t.c[(size_t)i * t.ldc + k] = Lb[i][k];
+    if constexpr (COH) {
+        tile_store_wt<THREADS, true>(Lb, t.c, t.ldc, tid);
+    } else {
+        for (int idx = tid; idx < NB * NB; idx += THREADS) {
+            const int i = idx / NB, k = idx % NB;
+            t.c[(size_t)i * t.ldc + k] = Lb[i][k];
+        }
     }
     if (tid == 0 && bad) atomicMax(info + t.sub, t.pivotBase + bad);
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 2) void tile_task_kernel(const TileTask *__restrict__ tasks,
+                                                               const TileProd *__restrict__ prods, int *__restrict__ info)
+{
+    constexpr int NB = CHOL_NB, LD = NB + 1;
+    __shared__ double La[NB][LD], Lb[NB][LD], T32[32][33], T16[16][17];
+    const TileTask t = tasks[blockIdx.x];
+    tile_task_body<THREADS>(t, prods, info, La, Lb, T32, T16);
+}
+
+// Dataflow form of the same factorisation (DOTMI_TILE_FLOW): ONE launch of persistent workgroups that
+// pull the tasks of the whole schedule, in its (topological) order, from a counter and wait -- per task -- only for the
+// tasks whose tiles it touches (build_tile_deps, tile_factor.hpp), so the levels overlap: a workgroup that has finished a
+// task of level l goes on with the next unissued task whatever the other workgroups of level l are doing, and a diagonal
+// task starts the moment its own row tiles are there.  done[v] == epoch <=> task v of this factorisation has finished
+// (the epoch grows by one per factorisation, so nothing is cleared); next[epoch & 1] is the ticket counter, the other one
+// is reset for the next launch by whoever draws ticket 0.  Tickets are drawn in order and a task only waits for tasks with
+// smaller tickets, all of which are held by workgroups that are running: no deadlock whatever the grid size.  Sums keep
+// their fixed order (a tile is still written by one task at a time): results equal to the level kernel's bit for bit.
+// A wait that exceeds ~2 s (never, unless a kernel before it failed) flags the subdomain and goes on, so the launch ends.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 2) void tile_flow_kernel(const TileTask *__restrict__ tasks,
+                                                               const TileProd *__restrict__ prods, int ntasks,
+                                                               const int *__restrict__ depPtr, const int *__restrict__ depIdx,
+                                                               int *__restrict__ done, int *__restrict__ next, int epoch,
+                                                               long long waitTicks, int *__restrict__ info)
+{
+    constexpr int NB = CHOL_NB, LD = NB + 1;
+    __shared__ double La[NB][LD], Lb[NB][LD], T32[32][33], T16[16][17];
+    __shared__ int s_ticket;
+    const int tid = threadIdx.x;
+    int *const ctr = next + (epoch & 1);
+    // (the ticket for the next task is drawn by the thread that publishes the finished one, in ONE divergent region that a
+    // barrier follows: two regions `if (tid == 0)` on either side of the loop's back edge get threaded into one path by the
+    // compiler, after which the other lanes of wave 0 spin through the loop without lane 0 -- seen in the ISA, hangs)
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        __syncthreads();
+        const int ti = s_ticket;
+        if (ti >= ntasks) return;
+        const TileTask t = tasks[ti];
+        const int d0 = depPtr[ti], d1 = depPtr[ti + 1];
+        if (tid < 64) {   // ONE wave polls (one flag per lane), relaxed, with a sleep between the looks
+            for (int d = d0 + tid; d < d1; d += 64) {
+                const int *flag = done + depIdx[d];
+                const long long tStart = wall_clock64();
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - tStart > waitTicks) {   // 100 MHz counter
+                        atomicMax(info + t.sub, 1 << 30);
+                        break;
+                    }
+                }
+            }
+            // ONE acquire after the last flag has been seen (the barrier hands it on).  (sc1 tile loads and no fence
+            // measured 3 % faster on bunny5K; the fence is the form the guide's hand-off recipe validates, kept.)
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        tile_task_body<THREADS, true>(t, prods, info, La, Lb, T32, T16);   // (result tile stored write-through)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its part of the result tile has left
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(done + ti, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ti == 0) __hip_atomic_store(next + ((epoch + 1) & 1), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ticket = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // The product / row / inverse tasks (everything but TP_DIAG) on HALF tiles: LDS holds 32 x 64 of A and of B at a time
@@ -2031,6 +2132,18 @@ void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods,
     if (ntasks <= 0) return;
     if (threads == 512) hipLaunchKernelGGL(tile_task_kernel<512>, dim3(ntasks), dim3(512), 0, st, tasks, prods, info);
     else hipLaunchKernelGGL(tile_task_kernel<256>, dim3(ntasks), dim3(256), 0, st, tasks, prods, info);
+}
+void launch_tile_flow(const TileTask *tasks, int ntasks, const TileProd *prods, const int *depPtr, const int *depIdx, int *done,
+                      int *next, int epoch, int *info, int nwg, hipStream_t st, int threads, double waitMs)
+{
+    if (ntasks <= 0) return;
+    const int grid = std::min(ntasks, nwg);
+    const long long waitTicks = (long long)(waitMs * 1e5);
+    // always the 512-thread form: the 256-thread instantiation needs 256 VGPRs plus scratch and measured a wrong factor on
+    // horse7K (same non-SPD pivot in every run: not a race; not pursued, DOTMI_TILE_THREADS only selects the level kernel's form)
+    (void)threads;
+    hipLaunchKernelGGL(tile_flow_kernel<512>, dim3(grid), dim3(512), 0, st, tasks, prods, ntasks, depPtr, depIdx, done, next, epoch,
+                       waitTicks, info);
 }
 void launch_tile_gemm(const TileTask *tasks, int ntasks, const TileProd *prods, hipStream_t st)
 {

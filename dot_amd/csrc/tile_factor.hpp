@@ -380,4 +380,55 @@ inline void finish_tile_schedule(std::vector<TileTaskL> &all, TileSchedule &S, b
     }
 }
 
+// ---- dependencies of the ordered task list, for the dataflow kernel (tile_flow_kernel, kernels.hip) ------------------------
+// The level schedule above synchronises with launch boundaries: every task of level l waits for ALL tasks of level l - 1.
+// The dataflow kernel hands the same tasks, in the same (topological) order, to persistent workgroups and lets each wait
+// only for the tasks whose tiles it touches: per tile, a reader comes after the last writer, a writer after the previous
+// writer and after every reader since then (the rule of the second scheduling pass above).  dep[depPtr[v] .. depPtr[v+1])
+// = the tasks task v waits for, all with smaller indices; an edge u -> v is dropped when u is already a predecessor of
+// another predecessor of v (it has finished by then).
+inline void build_tile_deps(const std::vector<TileTask> &tasks, const std::vector<TileProd> &prods, std::vector<int> &depPtr,
+                            std::vector<int> &depIdx)
+{
+    struct Acc {
+        int writer = -1;
+        std::vector<int> readers;
+    };
+    std::unordered_map<const double *, Acc> acc;
+    acc.reserve(tasks.size() * 2);
+    const int n = (int)tasks.size();
+    std::vector<std::vector<int>> pred(n);
+    for (int v = 0; v < n; ++v) {
+        const TileTask &T = tasks[v];
+        auto rd = [&](const double *x) {
+            Acc &a = acc[x];
+            if (a.writer >= 0) pred[v].push_back(a.writer);
+            a.readers.push_back(v);
+        };
+        for (int p = T.first; p < T.first + T.nprod; ++p) {
+            rd(prods[p].a);
+            if (prods[p].b != prods[p].a) rd(prods[p].b);
+        }
+        if (T.q) rd(T.q);
+        Acc &c = acc[T.c];
+        if (c.writer >= 0) pred[v].push_back(c.writer);
+        for (int r : c.readers)
+            if (r != v) pred[v].push_back(r);
+        c.writer = v;
+        c.readers.clear();
+        std::sort(pred[v].begin(), pred[v].end());
+        pred[v].erase(std::unique(pred[v].begin(), pred[v].end()), pred[v].end());
+    }
+    depPtr.assign(1, 0);
+    depIdx.clear();
+    std::vector<int> mark(n, -1);
+    for (int v = 0; v < n; ++v) {
+        for (int w : pred[v])
+            for (int u : pred[w]) mark[u] = v;
+        for (int u : pred[v])
+            if (mark[u] != v) depIdx.push_back(u);
+        depPtr.push_back((int)depIdx.size());
+    }
+}
+
 }  // namespace dotmi

@@ -214,6 +214,11 @@ int dotmi_plan_patches(int32_t nV, int32_t nT, const int32_t *T, const double *X
 int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0, int32_t eager_min,
                              int32_t eager_chunk, int64_t *tasks, int64_t *prods, int64_t *n_tasks, int64_t *n_prods,
                              int64_t *n_levels, int64_t *storage, int64_t *scratch_base, int64_t *row_off, int32_t *row_ld);
+/* (host only) the dependencies of that task list for the dataflow form of the factorisation (DOTMI_TILE_FLOW, one launch of
+ * persistent workgroups; tile_flow_kernel): task v waits for dep_idx[dep_ptr[v] .. dep_ptr[v+1]).  Same arguments and task
+ * order as dotmi_plan_tile_schedule; dep_idx == NULL returns the count only. */
+int dotmi_plan_tile_deps(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0, int32_t eager_min,
+                         int32_t eager_chunk, int64_t *dep_ptr, int64_t *dep_idx, int64_t *n_deps);
 int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xrest, const int32_t *epart,
                       int32_t nParts, int32_t p0, int32_t p1, int32_t levels, int32_t min_split,
                       int32_t node_cap, int32_t *nodes, int32_t *n_nodes, int32_t *nmax, int32_t *pos);

@@ -182,3 +182,130 @@ def test_schedule_of_a_dense_block_and_of_random_patterns():
         np.fill_diagonal(pat, 1)
         worst, _, _ = run_schedule(nt, np.ones(nt, dtype=np.uint8), pat, np.zeros(nt, dtype=np.int32), 3, 2, seed=10 + seed)
         assert worst < 1e-9, (seed, worst)
+
+
+def plan_deps(nt, live, pat, c0, eager_min, eager_chunk, ntasks):
+    L = C.CDLL(dl.LIB_PATH)
+    f = L.dotmi_plan_tile_deps
+    u8, i32, i64 = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    f.argtypes = [C.c_int32, u8, u8, i32, C.c_int32, C.c_int32, i64, i64, i64]
+    live = np.ascontiguousarray(live, dtype=np.uint8)
+    pat = np.ascontiguousarray(pat, dtype=np.uint8)
+    c0 = np.ascontiguousarray(c0, dtype=np.int32)
+    nd = C.c_int64()
+    assert f(nt, live.ctypes.data_as(u8), pat.ctypes.data_as(u8), c0.ctypes.data_as(i32), eager_min, eager_chunk, None, None,
+             C.byref(nd)) == 0
+    ptr = np.zeros(ntasks + 1, dtype=np.int64)
+    idx = np.zeros(max(nd.value, 1), dtype=np.int64)
+    assert f(nt, live.ctypes.data_as(u8), pat.ctypes.data_as(u8), c0.ctypes.data_as(i32), eager_min, eager_chunk,
+             ptr.ctypes.data_as(i64), idx.ctypes.data_as(i64), C.byref(nd)) == 0
+    return ptr, idx[:nd.value]
+
+
+def run_dataflow(nt, live, pat, c0, eager_min, eager_chunk, seed, orders=3):
+    """The tasks executed ONE AT A TIME, IN PLACE, in random orders that respect only the edges of dotmi_plan_tile_deps
+    (what the persistent workgroups of tile_flow_kernel wait for): every such order must give the inverse factor -- a
+    missing read-after-write, write-after-read or write-after-write edge shows up as a wrong or NaN tile."""
+    tasks, prods, nlev, storage, roff, rld = plan(nt, live, pat, c0, eager_min, eager_chunk)
+    order0 = np.argsort(tasks[:, 0], kind="stable")          # the order of dotmi_plan_tile_deps
+    tasks = tasks[order0]
+    ptr, idx = plan_deps(nt, live, pat, c0, eager_min, eager_chunk, len(tasks))
+    assert ptr[-1] == len(idx)
+    for v in range(len(tasks)):
+        assert all(u < v for u in idx[ptr[v]:ptr[v + 1]])   # topological: a task only waits for earlier tickets
+    rng = np.random.default_rng(seed)
+    n = 64 * nt
+    H = np.zeros((n, n))
+    for i in range(nt):
+        for j in range(i, nt):
+            if pat[i, j] and live[i] and live[j]:
+                H[64 * i:64 * i + 64, 64 * j:64 * j + 64] = rng.standard_normal((64, 64)) * 0.05
+    H = np.triu(H) + np.triu(H, 1).T
+    H += np.diag(np.abs(H).sum(1) + 1.0)
+    for j in range(nt):
+        if not live[j]:
+            H[64 * j:64 * j + 64, :] = 0
+            H[:, 64 * j:64 * j + 64] = 0
+            H[64 * j:64 * j + 64, 64 * j:64 * j + 64] = np.eye(64)
+    Q = np.linalg.inv(np.linalg.cholesky(H).T)
+    nscr = int(tasks[:, 6].max() // 4096 + 2)
+    succ = [[] for _ in tasks]
+    for v in range(len(tasks)):
+        for u in idx[ptr[v]:ptr[v + 1]]:
+            succ[u].append(v)
+    worst = 0.0
+    for rep in range(orders):
+        M = np.full(storage + 4096 * nscr, np.nan)
+
+        def tile(off, ld):
+            return np.lib.stride_tricks.as_strided(M[off:], shape=(64, 64), strides=(8, 8 * ld))
+        for j in range(nt):
+            if live[j]:
+                for i in range(int(c0[j]), j + 1):
+                    if pat[i, j] or i == j:
+                        tile(roff[j] + 64 * i - 64 * c0[j], rld[j])[:, :] = H[64 * i:64 * i + 64, 64 * j:64 * j + 64]
+        left = np.array([ptr[v + 1] - ptr[v] for v in range(len(tasks))])
+        ready = [v for v in range(len(tasks)) if left[v] == 0]
+        done = 0
+        while ready:
+            # rep 0: latest ready task first (the most adversarial simple order), then random picks
+            k = len(ready) - 1 if rep == 0 else int(rng.integers(len(ready)))
+            t = ready.pop(k)
+            _, form, init, post, nprod, first, coff, qoff, ldc, ldq = tasks[t]
+            acc = tile(coff, ldc).copy() if init else np.zeros((64, 64))
+            for p in range(first, first + nprod):
+                a, b, lda, ldb = prods[p]
+                acc = acc - tile(a, lda).T @ tile(b, ldb) if form == TF_FACT else acc + tile(a, lda) @ tile(b, ldb)
+            if post == TP_DIAG:
+                out = np.linalg.inv(np.linalg.cholesky(acc).T)
+            elif post == TP_ROW:
+                out = tile(qoff, ldq).T @ acc
+            elif post == TP_NEG:
+                out = -acc
+            else:
+                out = acc
+            tile(coff, ldc)[:, :] = out
+            done += 1
+            for w in succ[t]:
+                left[w] -= 1
+                if left[w] == 0:
+                    ready.append(w)
+        assert done == len(tasks)
+        for j in range(nt):
+            if not live[j]:
+                continue
+            for i in range(int(c0[j]), j + 1):
+                got = tile(roff[j] + 64 * i - 64 * c0[j], rld[j])
+                ref = Q[64 * i:64 * i + 64, 64 * j:64 * j + 64]
+                if i == j:
+                    worst = max(worst, np.abs(np.triu(got) - ref).max())
+                elif np.abs(ref).max() > 0:
+                    assert np.isfinite(got).all()
+                    worst = max(worst, np.abs(got - ref).max())
+    return worst, len(idx), len(tasks)
+
+
+@pytest.mark.parametrize("eager", [(1000, 1), (2, 1), (4, 4)])
+def test_dataflow_dependencies_of_a_two_level_dissection(eager):
+    rng = np.random.default_rng(1)
+    nt = 14
+    pat, c0 = nd_pattern(nt, [(0, 3), (3, 5), (6, 8), (8, 11)], [(5, 6, 0), (11, 12, 6), (12, 14, 0)], rng)
+    live = np.ones(nt, dtype=np.uint8)
+    live[3] = 0
+    pat[3, :] = 0; pat[:, 3] = 0
+    worst, ndeps, ntask = run_dataflow(nt, live, pat, c0, eager[0], eager[1], seed=4)
+    assert worst < 1e-10, worst
+    assert ndeps < 12 * ntask          # the transitive edges are dropped: a handful of flags per task
+
+
+def test_dataflow_dependencies_of_dense_and_random_patterns():
+    rng = np.random.default_rng(6)
+    pat = np.triu(np.ones((6, 6), dtype=np.uint8))
+    worst, _, _ = run_dataflow(6, np.ones(6, dtype=np.uint8), pat, np.zeros(6, dtype=np.int32), 2, 1, seed=7)
+    assert worst < 1e-10
+    for seed in range(4):
+        nt = int(rng.integers(4, 10))
+        pat = np.triu((rng.random((nt, nt)) < 0.35).astype(np.uint8))
+        np.fill_diagonal(pat, 1)
+        worst, _, _ = run_dataflow(nt, np.ones(nt, dtype=np.uint8), pat, np.zeros(nt, dtype=np.int32), 3, 2, seed=20 + seed)
+        assert worst < 1e-9, (seed, worst)
