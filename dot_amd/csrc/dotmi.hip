@@ -951,7 +951,7 @@ int build_device_mesh(dotmi_handle *h)
         // (bar17K / 32: 1000 per level, 1.11 -> 1.21 ms; 1 M tets: 15 -> 23 ms).
         const size_t nLevels = std::max<size_t>(S.levelStart.size() - 1, 1);
         h->tileFlow = !S.tasks.empty() &&
-                      (h->tune.tileFlow > 0 || (h->tune.tileFlow < 0 && S.tasks.size() / nLevels <= 256 && h->world == 1));
+                      (h->tune.tileFlow > 0 || (h->tune.tileFlow < 0 && S.tasks.size() / nLevels <= 512));
         if (h->tileFlow) {
             std::vector<int> depPtr, depIdx;
             build_tile_deps(S.tasks, S.prods, depPtr, depIdx);
