@@ -148,12 +148,17 @@ def main():
             K = rec["kernels"]
 
             def pick(cls, must=None, total=False):
-                inst = {k: v for k, v in K.get(cls, {}).items() if "hbm_bytes_per_launch" in v and (must is None or must in k)}
+                import re
+                inst = {k: v for k, v in K.get(cls, {}).items()
+                        if "hbm_bytes_per_launch" in v and (must is None or re.search(must, k))}
                 if not inst:
                     return None
                 vals = [v["hbm_bytes_per_launch"] for v in inst.values()]
                 return int(sum(vals)) if total else int(vals[0])
-            out = {"elem_energy_grad": pick("elem_pass", "true,"), "elem_energy": pick("elem_pass", "false,"),
+            # elem_patch_kernel<MAT, GRAD, EPT, FUSE (step inside), PIPE>
+            out = {"elem_energy_grad": pick("elem_pass", r"<\d, true, \d, false,"), "elem_energy": pick("elem_pass", r"<\d, false,"),
+                   "elem_step": pick("elem_pass", r"<\d, true, \d, true,"), "gather_early": pick("vertex_gather", "<true>"),
+                   "spmv_zp": pick("spmv_zp"), "merge_early": pick("merge_early"),
                    "vertex_gather": pick("vertex_gather", "<false>"), "spmv_dots": pick("spmv_dots"),
                    "backsolve": pick("backsolve", total=True), "merge": pick("merge", "<false>"),
                    "build_qpad": pick("build_qpad", "<false>"), "build_p": pick("build_p", "<false>"),

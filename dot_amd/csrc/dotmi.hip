@@ -3461,6 +3461,7 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
     }
     int nb = 0;
     int64_t bytes = 0;
+    bool live = false;   // the kernel form reads the device loop's state
     std::function<void()> run;
     GatherArgs a;
     memset(&a, 0, sizeof(a));
@@ -3527,8 +3528,62 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
             else launch_assemble(h->M, h->He, h->Hval, h->st);
         };
         break;
+    // ---- the forms the device loop's early order really launches.  They read the loop state on the
+    // device, so the state the last step left there (history full, buffer roles, xi / delta) is switched back to "running,
+    // new direction" for the duration of the measurement and restored afterwards; none of them advances it (only the
+    // controller does), so every repetition does the same work.  They overwrite loop-internal vectors (p, z, the trial
+    // point and gradient, the free pair slot, the padded right-hand sides), all of which the next step rewrites.
+    case DOTMI_BENCH_SPMV_ZP:            // 72 nnzb + z, g read, p, Hp written, m pairs of (s_j, H s_j) read
+        bytes = 72 * (int64_t)h->M.nnzb + 8 * (int64_t)n * (4 + 2 * L.m);
+        live = true;
+        run = [&] { launch_spmv_zp(h->M, h->Hval, h->z, h->partC, h->p, h->Hp, h->partS, h->st, h->ctl); };
+        break;
+    case DOTMI_BENCH_MERGE_EARLY:        // tile partials + u_old read / written, z written, M y_new written, m x (y_j, M y_j) read
+        bytes = 8 * (int64_t)h->mergeEntries + 8 * (int64_t)n * (4 + 2 * L.m);
+        live = true;
+        run = [&] { launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl); };
+        break;
+    case DOTMI_BENCH_ELEM_STEP: {        // the element pass with the line-search step inside: + p read, trial point written
+        bytes = 112 * nTo + 56 * nVo + 48 * (int64_t)nV;
+        live = true;
+        run = [&] {
+            StepArgs sa{h->p, h->partS, h->alpha_dev, h->alphaMin};
+            launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st, h->ctl,
+                                    h->tune.fuseStep ? &sa : nullptr);
+        };
+        break;
+    }
+    case DOTMI_BENCH_GATHER_EARLY: {     // + H p read, H s_new written, -g into the padded right-hand sides of every holder
+        long long held = 0;
+        for (int v = 0; v < nV; ++v) held += h->dup[v];
+        bytes = 80 * (int64_t)nV + (int64_t)(6 + 2 * L.m) * 8 * n + 24 * held;
+        live = true;
+        a.x = nullptr;
+        a.g_old = nullptr;
+        a.g_new = nullptr;
+        a.s_new = nullptr;
+        a.y_new = nullptr;
+        a.hp = h->tune.fuseDir ? h->Hp : nullptr;
+        a.vp_ptr = h->P.vp_ptr;
+        a.vp_off = h->P.vp_off;
+        a.rpad = h->P.rpad;
+        run = [&] { launch_vertex_gather(h->M, h->PT, a, L, h->partR, h->st, h->ctl); };
+        break;
+    }
     default:
         return DOTMI_E_INVALID;
+    }
+    DevLoop saved;
+    if (live) {
+        if (!h->earlyBs || h->prevSlots < 0 || !h->P.vp_ptr) {
+            h->err = "the in-loop kernel forms need a handle that has run a step of the device loop's early order";
+            return DOTMI_E_INVALID;
+        }
+        HIPCHECK(h, hipMemcpy(&saved, h->ctl, sizeof(DevLoop), hipMemcpyDeviceToHost));
+        DevLoop live_ctl = saved;
+        live_ctl.status = 0;
+        live_ctl.phase = 0;
+        HIPCHECK(h, hipMemcpy(h->ctl, &live_ctl, sizeof(DevLoop), hipMemcpyHostToDevice));
     }
     run();   // warm
     HIPCHECK(h, hipEventRecord(h->ev0, h->st));
@@ -3536,8 +3591,14 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
     HIPCHECK(h, hipEventRecord(h->ev1, h->st));
     HIPCHECK(h, hipEventSynchronize(h->ev1));
     HIPCHECK(h, hipGetLastError());
+    if (live) HIPCHECK(h, hipMemcpy(h->ctl, &saved, sizeof(DevLoop), hipMemcpyHostToDevice));
     float ms = 0;
     HIPCHECK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if (kind == DOTMI_BENCH_ELEM_HESSIAN || kind == DOTMI_BENCH_ASSEMBLE) {
+        // these two rewrote the element / global Hessians at the CURRENT positions; the factors (and the alpha_0 of the next
+        // step) belong to the positions of the last refresh -- bring everything back in line
+        if (int rc = refactor(h, h->x, nullptr, nullptr)) return rc;
+    }
     if (ms_per_launch) *ms_per_launch = ms / reps;
     if (bytes_per_launch) *bytes_per_launch = bytes;
     return 0;

@@ -302,7 +302,13 @@ enum dotmi_bench_kind {
     DOTMI_BENCH_STEP_FORWARD = 8,     /* x_trial = x + alpha p */
     DOTMI_BENCH_ELEM_HESSIAN = 9,     /* projected 12x12 element Hessians (once per step) */
     DOTMI_BENCH_ASSEMBLE = 10,        /* global block-CSR assembly (once per step) */
-    DOTMI_BENCH_COUNT = 11
+    /* the forms the device loop's early order launches (they read the loop state the last step left on the device; the
+     * handle must have run a step): */
+    DOTMI_BENCH_SPMV_ZP = 11,         /* build_p + SpMV + dots in one launch on cached H s_j */
+    DOTMI_BENCH_MERGE_EARLY = 12,     /* tile partials -> u, M y_new, z, y_i . z */
+    DOTMI_BENCH_ELEM_STEP = 13,       /* element pass that takes the line-search step itself */
+    DOTMI_BENCH_GATHER_EARLY = 14,    /* vertex pass that also writes -g into the padded right-hand sides and H s_new */
+    DOTMI_BENCH_COUNT = 15
 };
 int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_per_launch, int64_t *bytes_per_launch);
 
