@@ -56,7 +56,8 @@ def compact_line(full):
                        "unit": "GB/s", "frac": r["frac"], "traffic": r["traffic"],
                        "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_ms": r["avg_launch_ms"],
                        "launches_timed": r["launches_timed"], "launches_total": r["launches_total"],
-                       "launches_stopped": r["launches_stopped"]}
+                       "launches_stopped": r["launches_stopped"], "launches_held": r.get("launches_held", 0),
+                       "launches_held_rejected": r.get("launches_held_rejected", 0)}
     f = full["roofline_factor"]
     out["roofline_factor"] = {"bound": "mfma", "kernel": "tile_task_kernel", "achieved": f["achieved"], "peak": f["peak"],
                               "unit": "TFLOP/s", "frac": f["frac"], "flop": f["flop_per_factorisation"], "avg_ms": f["avg_ms"]}
@@ -311,6 +312,10 @@ def main():
             # DESIGN.md section 5) -- they are not among the timed launches
             "launches_timed": int(pre_n), "launches_total": int(sum(s.backsolve_launches for s in stats)),
             "launches_stopped": int(sum(s.backsolve_stopped for s in stats)),
+            # held: slots whose tiles waited for the controller's verdict (the trial was expected to be rejected);
+            # held_rejected: those of them that were rejected and left without streaming (part of launches_stopped)
+            "launches_held": int(sum(s.backsolve_held for s in stats)),
+            "launches_held_rejected": int(sum(s.backsolve_held_rejected for s in stats)),
             "share_of_step_time": round(avg_ms * sum(s.backsolve_launches for s in stats) / (1e3 * elapsed), 3),
         }
         w = np.array(walls) * 1e3

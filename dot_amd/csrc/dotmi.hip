@@ -113,6 +113,8 @@ struct Tuning {
     bool fuseDir = true;      // DOTMI_FUSE_DIR=0     (early order) build_p and spmv_dots as two launches instead of one on cached H s_j
     bool fuseStep = true;     // DOTMI_FUSE_STEP=0    (early order) step_forward as a launch of its own instead of inside the element pass
     bool earlyAbort = true;   // DOTMI_EARLY_ABORT=0  (ablation) speculative back-solves run to their end even when the trial is rejected
+    bool earlySharded = true; // DOTMI_EARLY_SHARDED=0 the q-based order on the sharded element pass (N > 1, >= 400 k tets)
+    bool earlyHold = true;    // DOTMI_EARLY_HOLD=0   the back-solve of a trial that is expected to be rejected still starts speculatively
     bool earlyHostCtl = true; // DOTMI_EARLY_HOST_CTL=0 (ablation) early back-solve with the controller as a launch of its own
     int earlyBs = 2;          // DOTMI_EARLY_BACKSOLVE 0: the back-solve after the controller, on q; 1: speculatively on the trial
                               //                      gradient with the controller inside its launch, in the steps where
@@ -160,6 +162,8 @@ struct Tuning {
         t.earlyBs = std::min(2, std::max(0, geti("DOTMI_EARLY_BACKSOLVE", 2)));
         t.earlyHostCtl = geti("DOTMI_EARLY_HOST_CTL", 1) != 0;
         t.earlyAbort = geti("DOTMI_EARLY_ABORT", 1) != 0;
+        t.earlyHold = geti("DOTMI_EARLY_HOLD", 1) != 0;
+        t.earlySharded = geti("DOTMI_EARLY_SHARDED", 1) != 0;
         t.fuseStep = geti("DOTMI_FUSE_STEP", 1) != 0;
         t.fuseDir = geti("DOTMI_FUSE_DIR", 1) != 0;
         return t;
@@ -226,6 +230,8 @@ struct dotmi_handle {
     int nTclear = 0;
     std::vector<int> tlevelStart, tlevelDiag;
     bool tileSplit = false;
+    int predState[10] = {0, 0, 1, 1, 1, 1, 1, 1, 1, 1};   // DevLoop::predHist / predCtr between the steps
+    int heldSlots = 0, heldRejected = 0;                  // held back-solves of the last step (DevLoop::holdNext)
     bool tileFlow = false;            // dataflow factorisation (tile_flow_kernel)
     int *tdepPtr = nullptr, *tdepIdx = nullptr, *tdone = nullptr, *tnext = nullptr;
     int tileEpoch = 0, nTtasks = 0, tileFlowWg = 0;
@@ -248,6 +254,7 @@ struct dotmi_handle {
     double *HS[HIST_MAX + 1] = {nullptr};   // H s_i of the stored pairs (fused direction kernel of the early order)
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
     double *gstage = nullptr;   // sharded element pass, device loop: [g (n) ; 0 ; E] staging buffer of the gradient all-reduce
+    double *zstage = nullptr;   // sharded subdomains, early order: this rank's undivided partial merge, all-reduced in place
     double *alpha_dev = nullptr;
     int *info_dev = nullptr, *h_info = nullptr;  // per owned part: failing pivot (device / pinned copy)
     int4 *clearSeg = nullptr;                    // row segments (row, first column, columns, -) cleared before a refill
@@ -1854,20 +1861,31 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     LbfgsArgs L0;
     memset(&L0, 0, sizeof(L0));
     const bool fuseDir = h->tune.fuseDir;
+    const bool se = h->shardElems;   // sharded element pass: this rank's rows of H, its elements; three collectives per slot
     if (fuseDir) {   // build_p + spmv_dots in one launch, H p from the cached H s_j
-        launch_spmv_zp(h->M, h->Hval, h->z, h->partC, h->p, h->Hp, h->partS, h->st, h->ctl);
+        launch_spmv_zp(h->M, h->Hval, h->z, h->partC, h->p, h->Hp, h->partS, h->st, h->ctl, se ? h->v0 : 0, se ? h->v1 : -1);
     } else {
         launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
         launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st, h->ctl);
     }
+    const double *spart = h->partS;
+    if (se) {
+        // this rank's rows of p.g and p.Hp -> two scalars -> summed over the ranks (row 0 of partG; rows >= 1 stay zero).
+        // It cannot ride on the z all-reduce in front of it: p.Hp is quadratic in the reduced vector
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partS, NB_RED, RED_K, 2, 0.0, 0.0, 0, h->partG);
+        if (int rc = allreduce_sum(h, h->partG, 2)) return rc;
+        spart = h->partG;
+    }
     int nb = 0;
     // (not on meshes whose workgroups walk several patches: the prefetched operands leave no registers for it)
-    if (h->tune.fuseStep) {   // the step x_trial = x_cur + alpha p inside the element pass
-        StepArgs sa{h->p, h->partS, h->alpha_dev, h->alphaMin};
+    // (sharded element pass: the fused form writes the trial point only on this rank's vertex slice -- its inertia loop --,
+    // so the step stays a launch of its own there)
+    if (h->tune.fuseStep && !se) {   // the step x_trial = x_cur + alpha p inside the element pass
+        StepArgs sa{h->p, spart, h->alpha_dev, h->alphaMin};
         launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st, h->ctl,
                                 &sa);
     } else {
-        launch_step_forward(n, h->x, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st, h->ctl);
+        launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st, h->ctl);
         launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st, h->ctl);
     }
     GatherArgs a;
@@ -1883,13 +1901,33 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     a.vp_ptr = h->P.vp_ptr;
     a.vp_off = h->P.vp_off;
     a.rpad = h->P.rpad;
-    launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st, h->ctl);
+    const double *ctlE = h->partE;
+    if (!se) {
+        launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st, h->ctl);
+    } else {
+        // this rank's partial gradient and energy to the staging buffer [g (n) ; 0 ; E_local], one all-reduce, then the pair,
+        // its statistics, -g into the right-hand sides and H s_new from the SUM (pair_stats)
+        GatherArgs ag = a;
+        ag.make_pair = 0;
+        ag.stage = 1;
+        ag.g_new = h->gstage;
+        ag.hp = nullptr;
+        ag.vp_ptr = ag.vp_off = nullptr;
+        ag.rpad = nullptr;
+        launch_vertex_gather(h->M, h->PT, ag, L0, h->partR, h->st, h->ctl);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
+                           h->gstage + n + 1);
+        if (int rc = allreduce_sum(h, h->gstage, (size_t)n + 2)) return rc;
+        launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
+        ctlE = h->gstage + n;   // the controller reads the energy as one block (0, E)
+        nb = 1;
+    }
     const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size() &&
                        (h->timeCount++ % h->timeStride) == 0;
     h->slotTimed.push_back(timed ? h->evUsed : -1);
-    CtlArgs ca{h->ctl, h->partE, h->partR, h->alpha_dev, h->h_flags, nb, 0};
+    CtlArgs ca{h->ctl, ctlE, h->partR, h->alpha_dev, h->h_flags, nb, 0};
     if (!h->tune.earlyHostCtl)   // (ablation) the controller as a launch of its own, in front of the speculative solve
-        launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st);
+        launch_loop_control(h->ctl, ctlE, nb, h->partR, h->alpha_dev, h->h_flags, h->st);
     launch_gemv(h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr,
                 h->tune.earlyHostCtl ? &ca : nullptr,
                 h->tune.earlyAbort ? (int)h->slotTimed.size() /* the slot's epoch, 1-based */ : (1 << 30) /* never stopped */);
@@ -1899,9 +1937,11 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     } else {
         // sharded subdomains: this rank's part of the sum, the one collective of the iteration (issued in every slot,
         // whatever the controller decided: every rank enqueues the same sequence), then the division and the history terms
-        launch_merge(h->M, h->P, L0, h->z, h->partC, 0, h->st, h->ctl);
-        if (int rc = allreduce_sum(h, h->z, n)) return rc;
-        launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, 1);
+        // (the sum travels in a staging buffer: in a slot whose merge is gated off -- retry, past the end -- the collective
+        // still runs, on stale scratch, and z is left alone)
+        launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl);
+        if (int rc = allreduce_sum(h, h->zstage, n)) return rc;
+        launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage);
     }
     return 0;
 }
@@ -2007,6 +2047,10 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
         C.HS[s] = h->HS[s];
     }
     C.u_old = h->u_old;
+    C.holdEnable = h->tune.earlyHold && h->tune.earlyAbort ? 1 : 0;
+    // the forecast carries over from the last step (a function of the handle's own history)
+    memcpy(C.predHist, h->predState, sizeof(int) * 2);
+    memcpy(&C.predCtr[0][0], h->predState + 2, sizeof(int) * 8);
     C.log_alpha = h->dlog;
     C.log_E = h->dlog + h->logCap;
     C.log_g2 = h->dlog + 2 * (size_t)h->logCap;
@@ -2052,9 +2096,9 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
             if (!h->dist) {
                 launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl);
             } else {
-                launch_merge(h->M, h->P, L0, h->z, h->partC, 0, h->st, h->ctl);
-                if (int rc = allreduce_sum(h, h->z, n_)) return rc;
-                launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, 1);
+                launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl);
+                if (int rc = allreduce_sum(h, h->zstage, n_)) return rc;
+                launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage);
             }
         } else if (!h->shardElems) {
             launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
@@ -2065,7 +2109,20 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
             HIPCHECK(h, hipMemcpyAsync(h->g, h->gstage, sizeof(double) * n_, hipMemcpyDeviceToDevice, h->st));
             const double *vecs[1] = {h->g};
             launch_multidot(n_, h->g, vecs, 1, h->partR, h->st);   // |g|^2
-            launch_loop_control(h->ctl, h->gstage + n_, 1, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
+            if (!h->earlyNow) {
+                launch_loop_control(h->ctl, h->gstage + n_, 1, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
+            } else {
+                // early order on the sharded element pass: -g_0 (the summed gradient) into this rank's right-hand sides, the
+                // first direction's solve with the start-of-step controller inside its launch, the sum over the ranks, z = u
+                launch_build_qpad(h->P, h->g, L0, nullptr, h->st, nullptr);
+                CtlArgs ca{h->ctl, h->gstage + n_, h->partR, h->alpha_dev, h->h_flags, 1, 1};
+                launch_gemv(h->P, nullptr, h->st, h->ctl, nullptr, nullptr, h->tune.earlyHostCtl ? &ca : nullptr, 1 << 30);
+                if (!h->tune.earlyHostCtl)
+                    launch_loop_control(h->ctl, h->gstage + n_, 1, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
+                launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl);
+                if (int rc = allreduce_sum(h, h->zstage, n_)) return rc;
+                launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage);
+            }
         }
     }
     int enq = 0;
@@ -2149,6 +2206,10 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     h->prevSlots = C.slots;
     h->prevIters = C.iter;
     h->prevHalv = C.halvings;
+    memcpy(h->predState, C.predHist, sizeof(int) * 2);
+    memcpy(h->predState + 2, &C.predCtr[0][0], sizeof(int) * 8);
+    h->heldSlots = C.heldSlots;
+    h->heldRejected = C.heldRejected;
     *failed = C.status == 3;
     *lastE = C.E_cur;
     *g2 = C.g2_cur;
@@ -2790,7 +2851,12 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
                      h->tune.deviceLoop;
         // replicated element pass, merged tile partials: the back-solve of the next direction is issued on the trial
         // gradient, beside the controller (enqueue_loop_slot); sharded subdomains keep their one collective per iteration
-        h->earlyBs = h->devLoop && h->tune.earlyBs != 0 && !h->shardElems && h->P.mt_ptr != nullptr;
+        // (round 4: also with the sharded element pass -- the scatter of -g and H s_new then happen in pair_stats, behind the
+        // gradient's all-reduce; DOTMI_EARLY_SHARDED=0 keeps the q-based order there)
+        h->earlyBs = h->devLoop && h->tune.earlyBs != 0 && (!h->shardElems || h->tune.earlySharded) && h->P.mt_ptr != nullptr;
+        if (h->earlyBs && h->tune.fuseStep && !h->shardElems) h->PT.wgCap = 512;   // the trials' grouping of the energy partials, everywhere
+        if (h->dist)
+            if (int rc = dalloc(h, &h->zstage, (size_t)h->n)) return rc;
         if (h->earlyBs) {
             if (int rc = dalloc(h, &h->u_old, (size_t)h->n)) return rc;
             for (int sl = 0; sl <= h->hist; ++sl) {
@@ -3138,6 +3204,8 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         st->factor_flops = h->factorFlops;
         st->backsolve_launches = it;
         st->backsolve_stopped = (h->devLoop && h->earlyNow) ? (h->numLineSearch - ls0) + 1 : 0;
+        st->backsolve_held = (h->devLoop && h->earlyNow) ? h->heldSlots : 0;
+        st->backsolve_held_rejected = (h->devLoop && h->earlyNow) ? h->heldRejected : 0;
         for (int k = 0; k + 1 < h->evArUsed; k += 2) {
             float ms = 0;
             hipEventElapsedTime(&ms, h->evAr[k], h->evAr[k + 1]);

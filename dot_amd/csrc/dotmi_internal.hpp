@@ -37,6 +37,8 @@ struct DevMesh {
 // ---- element patches of the element pass (patches.hpp) ---------------------------------------------
 struct DevPatches {
     int nPatches = 0, PE = 0, PV = 0, nSlots = 0, nElem = 0;
+    int wgCap = 0;                // > 0: every instantiation of the element pass uses at most this many workgroups on this handle
+                                  // (one grouping of the energy partials for the start-of-step evaluation and the trials)
     ushort4 *tl = nullptr;        // nPatches*PE: patch-local vertex indices of a slot's corners (x == 0xFFFF: padding slot)
     double *A = nullptr;          // [9][nPatches*PE] rest-shape inverse in patch order, SoA
     double *mu = nullptr, *lam = nullptr, *vol = nullptr;   // nPatches*PE in patch order (0 on padding)
@@ -160,6 +162,16 @@ struct DevLoop {
     int pairNew;           // the controller's last accept stored a pair (its M y goes to MY[order[m - 1]])
     int abortEpoch;        // `slots` value of the last slot whose trial was rejected or that ended the loop: the speculative
                            // back-solve of that slot (which knows its epoch) stops when it sees it
+    // Held back-solves (round 4): the tiles of a slot whose trial is EXPECTED to be rejected do not start streaming beside
+    // the controller; they wait for its verdict (holdVerdict = 2 * slot + (rejected or last iterate)) and leave at once
+    // when it is a rejection.  The expectation is what happened to the last trial of the same kind (first trial of an
+    // iteration / retry after a halving), kept by the controller; holdNext is its forecast for the slot that follows.
+    int holdEnable, holdNext, holdVerdict, padHold;
+    int heldSlots, heldRejected;   // slots whose tiles were told to wait / of those, rejected (statistics)
+    // two-level forecast per kind of trial (0: first trial of an iteration, 1: retry): the last two outcomes of the kind
+    // select one of four saturating counters (0 .. 3, >= 2 forecasts a rejection) -- a plain "same as last time" is wrong
+    // every time on the alternating pattern stiff steps show (measured: profiles/r04_hold.txt)
+    int predHist[2], predCtr[2][4];
     double *u_old, *MY[HIST_MAX + 1];
     // H s_i of the stored pairs (same slots as S): H p = H z + sum_j delta_j (H s_j), H s_new = alpha H p (spmv_zp_kernel)
     double *HS[HIST_MAX + 1];
@@ -230,9 +242,9 @@ void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, c
                        const DevLoop *ctl = nullptr, int spec = 0);
 // early back-solve: u = merge(tile partials) / dup = -M g;  M y of the newest pair = u_old - u;  z = u - sum_j xi_j M y_j
 // (+ partial dots y_i . z);  first: start of the step (no history, u_old is only set)
-// summed: z already holds the sum over all subdomains of all ranks (sharded subdomains: partial merge + all-reduce in front)
+// zsum: the all-reduced sum (over all ranks' subdomains) of the undivided partial merges, in a staging buffer
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
-                        const DevLoop *ctl, int summed = 0);
+                        const DevLoop *ctl, const double *zsum = nullptr);
 // one subdomain only (GSDD, DOTTimeStepper.cpp:507-565): psub_s = X_s^T (X_s q[dofmap_s]) for owned part `ls`, whose
 // tiles are job[0..njobs); then p = 0 except p[dofs of part ls] = psub_s  (ADMMDDTimeStepper::fill, :1646-1665)
 void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, const int2 *lwork, int nlwork, const double *q,
@@ -247,8 +259,9 @@ void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_
 // early order, one launch for build_p + spmv_dots: p = z + sum_j delta_j s_j (build_p's statements), H p = H z + sum_j
 // delta_j (H s_j) from the cached H s_j, and the partial sums of p.g and p.Hp -- the only sparse product is H z, which
 // does not wait for delta
+// rows [v0, v1) only for the product and the dots (sharded rows); v1 < 0: every row
 void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const double *c_partials, double *p, double *Hp,
-                    double *partials, hipStream_t st, const DevLoop *ctl);
+                    double *partials, hipStream_t st, const DevLoop *ctl, int v0 = 0, int v1 = -1);
 // Hp = H p on rows [v0,v1), partial sums of p.g and p.Hp
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
                       int v0, int v1, double *partials, hipStream_t st, const DevLoop *ctl = nullptr);

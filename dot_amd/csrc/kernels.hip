@@ -398,7 +398,8 @@ void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, do
     if (step && ctl) sa = *step;
     // at most elem_wg_cap() workgroups take the patches (as many as are resident at once): beyond that a workgroup walks several
     // patches and prefetches the next one's operands (elem_patch_kernel)
-    const int cap = (step && ctl) ? 512 : elem_wg_cap(mat);   // (the instantiation with the step inside: two per CU)
+    // (the instantiation with the step inside: two per CU; a handle whose loop uses it fixes 512 for all of them, PT.wgCap)
+    const int cap = PT.wgCap > 0 ? PT.wgCap : ((step && ctl) ? 512 : elem_wg_cap(mat));
     const bool pipe = PT.nPatches > cap;
     int nb = pipe ? cap : PT.nPatches;
     const int nbv = (v1 - v0 + 255) / 256;
@@ -689,6 +690,10 @@ __global__ __launch_bounds__(256) void pair_stats_kernel(int n, GatherArgs a, Lb
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
     const double alpha = *a.alpha_dev;
     const int stride = gridDim.x * blockDim.x;
+    double *__restrict__ hs_new = nullptr;
+    if constexpr (DEV) {
+        if (a.hp) hs_new = ctl->HS[ctl->slot];
+    }
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
         const double gn = gsrc ? gsrc[k] : a.g_new[k];
         if (gsrc) a.g_new[k] = gn;
@@ -696,6 +701,13 @@ __global__ __launch_bounds__(256) void pair_stats_kernel(int n, GatherArgs a, Lb
         const double yn = gn - a.g_old[k];
         a.s_new[k] = sn;
         a.y_new[k] = yn;
+        // early order on the sharded element pass: what vertex_gather does on one rank happens here, on the SUMMED gradient --
+        // -g into the padded right-hand sides of this rank's subdomains that hold the vertex, H s_new = alpha H p
+        if (a.rpad) {
+            const int v = k / 3, dd = k - 3 * v;
+            for (int c = a.vp_ptr[v]; c < a.vp_ptr[v + 1]; ++c) a.rpad[a.vp_off[c] + dd] = -gn;
+        }
+        if (hs_new) hs_new[k] = alpha * a.hp[k];
         pair_stats_accum(k, gn, sn, yn, Lr, acc);
     }
     write_partials(acc, RED_K, partials, sm);
@@ -1162,6 +1174,24 @@ __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__res
         return;
     }
     if (ca.ctl->status != 0) return;
+    if (epoch < (1 << 30) && ca.ctl->holdNext) {
+        // the trial is expected to be rejected (DevLoop::holdNext): wait for the controller's verdict instead of streaming
+        // the factors beside it -- a rejection then costs the controller's ~7 us, not a stopped back-solve's ~20.  (A
+        // workgroup that starts after the controller has stored its forecast for the NEXT slot reads that one: the verdict
+        // is out by then, so it neither waits nor decides anything else than the abort test would.)
+        if (threadIdx.x == 0) {
+            const long long t0 = wall_clock64();
+            int v;
+            while (((v = __hip_atomic_load(&ca.ctl->holdVerdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) < epoch) {
+                __builtin_amdgcn_s_sleep(16);
+                if (wall_clock64() - t0 > 200000000ll) break;   // 2 s: go on speculatively (the result is only used if valid)
+            }
+            s_abort[2] = ((v >> 1) >= epoch && (v & 1)) ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_abort[2]) return;
+        __syncthreads();
+    }
     backsolve_block<256>(blockIdx.x - 1, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm,
                          epoch < (1 << 30) ? &ca.ctl->abortEpoch : nullptr, epoch, s_abort);
 }
@@ -2343,7 +2373,8 @@ __global__ __launch_bounds__(256) void merge_tiles_kernel(int n3, const int *__r
 // like build_qpad's.  first: start of the step (no pair yet; u_old is only set).
 __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const int *__restrict__ mt_ptr,
                                                                 const int *__restrict__ mt_ent, const int *__restrict__ dup,
-                                                                const double *__restrict__ ppart, int first, int summed,
+                                                                const double *__restrict__ ppart, int first,
+                                                                const double *__restrict__ zsum,
                                                                 double *__restrict__ z, double *__restrict__ partials,
                                                                 const DevLoop *__restrict__ ctl)
 {
@@ -2376,10 +2407,11 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
             mk[i] = (i < m && !(pairNew && i == m - 1)) ? my[i][k] : 0.0;
         }
         const double uo = first ? 0.0 : u_old[k];
-        // summed (sharded subdomains): z holds the all-reduced sum over every rank's subdomains (merge_tiles_kernel without
-        // the division, then the collective); only the division and the history terms are left
-        double u = summed ? z[k] : 0.0, ps = 0.0;
-        for (int e = summed ? e1 : e0; e < e1; e += MT_CH) {
+        // zsum (sharded subdomains): the all-reduced sum over every rank's subdomains (merge_tiles_kernel without the division
+        // into a staging buffer, then the collective -- on the staging buffer, so that a slot whose merge is gated off leaves z
+        // alone); only the division and the history terms are left
+        double u = zsum ? zsum[k] : 0.0, ps = 0.0;
+        for (int e = zsum ? e1 : e0; e < e1; e += MT_CH) {
             int off[MT_CH];
 #pragma unroll
             for (int q = 0; q < MT_CH; ++q) off[q] = (e + q < e1) ? mt_ent[e + q] : 0;
@@ -2417,10 +2449,10 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
 }
 
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
-                        const DevLoop *ctl, int summed)
+                        const DevLoop *ctl, const double *zsum)
 {
     hipLaunchKernelGGL(merge_tiles_early_kernel, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup, P.ppart,
-                       first, summed, z, partials, ctl);
+                       first, zsum, z, partials, ctl);
 }
 
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
@@ -2597,7 +2629,8 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const in
 // lane group, pair j on lane j), (H p)_v = (H z)_v + sum_j delta_j (H s_j)[v] with the H s_j cached beside the s_j (H is fixed
 // during a step; H s_new = alpha H p is written by the vertex gather).  delta comes from the y_i . z partials in wave 0's
 // prologue (requested first, finished behind the column loop).  Device loop only.
-__global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, const int *__restrict__ adj_ptr, const int *__restrict__ adj_idx,
+__global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, int v0, int v1, const int *__restrict__ adj_ptr,
+                                                      const int *__restrict__ adj_idx,
                                                       const double *__restrict__ Hval, const double *__restrict__ z,
                                                       const double *__restrict__ c_partials, int c_blocks,
                                                       double *__restrict__ p, double *__restrict__ Hp,
@@ -2672,8 +2705,12 @@ __global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, const int *__restr
 #pragma unroll
             for (int d = 0; d < 3; ++d) a[u][d] = zv[u][d] = gg[u][d] = sv[u][d] = hv[u][d] = 0.0;
             if (v < nV) {
-                kb[u] = adj_ptr[v];
-                nk[u] = adj_ptr[v + 1] - kb[u];
+                // sharded rows (N > 1 with the sharded element pass): p for every vertex, the product and the two dots only on
+                // this rank's rows [v0, v1) -- the others' H p (and cached H s_j) are never read
+                if (v >= v0 && v < v1) {
+                    kb[u] = adj_ptr[v];
+                    nk[u] = adj_ptr[v + 1] - kb[u];
+                }
                 // the row's own operands do not depend on the column loop: requested first.  Lane j of the row's group
                 // takes pair j of the history (HIST_MAX <= 8 lanes)
                 if (sub == 0) {
@@ -2733,12 +2770,13 @@ __global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, const int *__restr
             }
             if (sub == 0 && v < nV) {
 #pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    p[3 * v + d] = pv[d];
-                    Hp[3 * v + d] = hp[d];
+                for (int d = 0; d < 3; ++d) p[3 * v + d] = pv[d];
+                if (v >= v0 && v < v1) {
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) Hp[3 * v + d] = hp[d];
+                    pHp += pv[0] * hp[0] + pv[1] * hp[1] + pv[2] * hp[2];
+                    pg += pv[0] * gg[u][0] + pv[1] * gg[u][1] + pv[2] * gg[u][2];
                 }
-                pHp += pv[0] * hp[0] + pv[1] * hp[1] + pv[2] * hp[2];
-                pg += pv[0] * gg[u][0] + pv[1] * gg[u][1] + pv[2] * gg[u][2];
             }
         }
     }
@@ -2757,9 +2795,10 @@ __global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, const int *__restr
 }
 
 void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const double *c_partials, double *p, double *Hp,
-                    double *partials, hipStream_t st, const DevLoop *ctl)
+                    double *partials, hipStream_t st, const DevLoop *ctl, int v0, int v1)
 {
-    hipLaunchKernelGGL(spmv_zp_kernel, dim3(NB_RED), dim3(256), 0, st, M.nV, M.adj_ptr, M.adj_idx, Hval, z, c_partials,
+    if (v1 < 0) v1 = M.nV;
+    hipLaunchKernelGGL(spmv_zp_kernel, dim3(NB_RED), dim3(256), 0, st, M.nV, v0, v1, M.adj_ptr, M.adj_idx, Hval, z, c_partials,
                        NB_RED, p, Hp, partials, ctl);
 }
 
@@ -2918,11 +2957,21 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
         C.evals++;
         if (C.slots < C.kindCap) C.slot_kind[C.slots] = C.phase == 0 ? 1 : 2;
         C.slots++;
+        const int kind = C.phase == 0 ? 0 : 1;   // first trial of an iteration / retry after a halving
+        C.heldSlots += C.holdNext;
         if (E > C.E_cur && alpha > 0.0) {
             // back-tracking (c1 = 0, lower bound 0)
             // a speculative back-solve on this trial's gradient may be running beside this workgroup: tell it to stop
             C.abortEpoch = C.slots;
             __hip_atomic_store(&ctl->abortEpoch, C.slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            C.holdVerdict = 2 * C.slots + 1;   // ... and one that has been waiting for the verdict to leave
+            __hip_atomic_store(&ctl->holdVerdict, C.holdVerdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            {
+                int &ctr = C.predCtr[kind][C.predHist[kind] & 3];
+                ctr = min(3, ctr + 1);
+                C.predHist[kind] = ((C.predHist[kind] << 1) | 1) & 3;
+            }
+            C.heldRejected += C.holdNext;
             alpha /= 2.0;
             C.halvings++;
             if (alpha == 0.0) {
@@ -2946,11 +2995,19 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
             C.E_cur = E;
             const double g2 = R[0];
             C.g2_cur = g2;
-            if (C.iter + 1 >= C.iterCap || !(g2 > C.tol)) {
+            const bool last = C.iter + 1 >= C.iterCap || !(g2 > C.tol);
+            if (last) {
                 // the loop ends with this iterate: a speculative back-solve for the next direction (running beside this
                 // workgroup) may stop -- said before the history update below
                 C.abortEpoch = C.slots;
                 __hip_atomic_store(&ctl->abortEpoch, C.slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            C.holdVerdict = 2 * C.slots + (last ? 1 : 0);   // a held back-solve may start now (or leave)
+            __hip_atomic_store(&ctl->holdVerdict, C.holdVerdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            {
+                int &ctr = C.predCtr[kind][C.predHist[kind] & 3];
+                ctr = max(0, ctr - 1);
+                C.predHist[kind] = (C.predHist[kind] << 1) & 3;
             }
             // The history update and the first half of the two-loop below are the host loop's statements
             // (dotmi_step) with every array held in registers: all loops are unrolled to HIST_MAX with guards, so
@@ -3072,6 +3129,11 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
                 }
             }
         }
+    }
+    // forecast for the slot that follows: hold its back-solve if its kind's counter for the current pattern says "rejected"
+    if (t == 0 && !init) {
+        const int nk = C.phase == 0 ? 0 : 1;
+        C.holdNext = (C.holdEnable && C.status == 0 && C.predCtr[nk][C.predHist[nk] & 3] >= 2) ? 1 : 0;
     }
     __syncthreads();
     {

@@ -54,7 +54,8 @@ class StepStats(C.Structure):
                 ("factor_flops", C.c_double), ("ms_phase", C.c_double * 14),
                 ("collective_calls", C.c_int64), ("collective_bytes", C.c_int64), ("ms_collective", C.c_double),
                 ("collective_timed", C.c_int64), ("collective_timed_bytes", C.c_int64),
-                ("backsolve_launches", C.c_int64), ("backsolve_stopped", C.c_int64)]
+                ("backsolve_launches", C.c_int64), ("backsolve_stopped", C.c_int64),
+                ("backsolve_held", C.c_int64), ("backsolve_held_rejected", C.c_int64)]
 
 
 # enum dotmi_bench_kind (include/dotmi.h)

@@ -170,6 +170,10 @@ typedef struct {
     int64_t backsolve_stopped;      /* speculative back-solves the controller stopped: ls_halvings + 1 in a step whose device
                                        loop issued them on the trial gradient (DESIGN.md section 5,
                                        DOTMI_EARLY_BACKSOLVE), else 0 */
+    int64_t backsolve_held;         /* slots whose back-solve waited for the controller's verdict instead of streaming beside it
+                                       (the trial was expected to be rejected: a two-level forecast from the outcomes of the earlier trials of its kind) */
+    int64_t backsolve_held_rejected; /* ... and were rejected: these left without reading a factor (they are part of
+                                       backsolve_stopped) */
 } dotmi_step_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

@@ -187,13 +187,17 @@ def test_asynchronous_refresh_changes_only_when_things_are_reported(workload, st
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("shard_elems", ["0", "1"])
 @pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 6), ("bar17K_twist", 3)])
-def test_early_order_on_the_sharded_path_matches_the_single_rank_run(workload, steps):
-    """The early back-solve with sharded subdomains (replicated element pass): partial merge of this rank's subdomains, the
-    iteration's one all-reduce, then the division by the multiplicity and the history terms (merge_tiles_early_kernel,
-    summed).  With the 1-rank communicator of DOTMI_FLAG_FORCE_DIST the sums are the single-rank ones taken in two steps:
-    same iterations and halvings, positions to 1e-9 (the multi-rank runs are in tests/test_gpu_two_ranks.py)."""
-    os.environ["DOTMI_SHARD_ELEMS"] = "0"
+def test_early_order_on_the_sharded_path_matches_the_single_rank_run(workload, steps, shard_elems):
+    """The early back-solve with sharded subdomains: partial merge of this rank's subdomains into a staging buffer, the
+    all-reduce of that buffer, then the division by the multiplicity and the history terms (merge_tiles_early_kernel, zsum).
+    shard_elems 1 (round 4): the element pass, the rows of H and the refresh are sharded too -- p.g / p.Hp go through a
+    two-scalar all-reduce into the element pass that takes the step, the partial gradient through [g ; 0 ; E], and
+    pair_stats writes -g into the right-hand sides and H s_new from the sum.  With the 1-rank communicator of
+    DOTMI_FLAG_FORCE_DIST the sums are the single-rank ones taken in two steps: same iterations and halvings, positions to
+    1e-9 (the multi-rank runs are in tests/test_gpu_two_ranks.py)."""
+    os.environ["DOTMI_SHARD_ELEMS"] = shard_elems
     try:
         sc, ep, n = load_workload(workload)
         a = DOTTimeStepper(sc, ep, n, flags=dl.FLAG_FORCE_DIST)
