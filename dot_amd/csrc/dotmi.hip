@@ -80,9 +80,13 @@ struct Tuning {
     int ndLevels = -1;        // DOTMI_ND_LEVELS      depth of the nested dissection (-1: nd_default_levels)
     int ndMin = 768;          // DOTMI_ND_MIN         smallest region (scalars) that is still split
     int tileRows = 0;         // DOTMI_TILE_ROWS      rows per back-solve tile (0: 64, or 32 for few subdomains)
-    int tileRowsLong = 64;    // DOTMI_TILE_ROWS_LONG rows per back-solve tile when the rows have more than 1536 columns
+    int tileRowsLong = 0;     // DOTMI_TILE_ROWS_LONG rows per back-solve tile when the rows have more than 1536 columns (0: as the
+                              //                      other rows, or ~256 KB tiles where few subdomains leave the launch bound by
+                              //                      its longest tile)
     bool splitBs = true;      // DOTMI_SPLIT_BS=0     one back-solve launch instead of wide / narrow tiles apart
     bool mergeTiles = true;   // DOTMI_MERGE_TILES=0  reduce_partial_p + merge instead of merge_tiles_kernel
+    int splitMerge = -1;      // DOTMI_SPLIT_MERGE    1 / 0: the merge as reduce_partial_p + a gather from psub (the early order included) /
+                              //                      as one walk over the tile partials; default: split from 400 k scalar dofs
     bool fuseLeaves = true;   // DOTMI_FUSE_LEAVES=0  one GEMM chain per leaf instead of equal-size leaves together
     bool fuseLog = false;     // DOTMI_FUSE_LOG       print the fused-leaf units
     bool splitRoot = true;    // DOTMI_ND_SPLIT_ROOT=0  the root's triangular products on one branch
@@ -132,9 +136,11 @@ struct Tuning {
         if (t.ndLevels < -1) t.ndLevels = 0;
         t.ndMin = std::max(128, geti("DOTMI_ND_MIN", 768));
         if (const char *ev = getenv("DOTMI_TILE_ROWS")) t.tileRows = std::min(64, std::max(8, atoi(ev) / 8 * 8));
-        t.tileRowsLong = std::min(64, std::max(8, geti("DOTMI_TILE_ROWS_LONG", 64) / 8 * 8));
+        t.tileRowsLong = geti("DOTMI_TILE_ROWS_LONG", 0);
+        if (t.tileRowsLong > 0) t.tileRowsLong = std::min(64, std::max(8, t.tileRowsLong / 8 * 8));
         t.splitBs = geti("DOTMI_SPLIT_BS", 1) != 0;
         t.mergeTiles = geti("DOTMI_MERGE_TILES", 1) != 0;
+        t.splitMerge = geti("DOTMI_SPLIT_MERGE", -1);
         t.fuseLeaves = geti("DOTMI_FUSE_LEAVES", 1) != 0;
         t.fuseLog = getenv("DOTMI_FUSE_LOG") != nullptr;
         t.splitRoot = geti("DOTMI_ND_SPLIT_ROOT", 1) != 0;
@@ -650,7 +656,8 @@ int build_device_mesh(dotmi_handle *h)
     std::vector<int> dofmap((size_t)P.nParts * P.nmax, -1);
     // rows per back-solve tile: 64, or 32 when 64-row tiles would not give every CU two workgroups (few subdomains:
     // the launch is then bound by the pass chain of a workgroup, which halves)
-    int tileRows = ((long long)P.nParts * P.nmax / 64 < 2 * 256) ? 32 : 64;
+    const bool fewTiles = (long long)P.nParts * P.nmax / 64 < 2 * 256;
+    int tileRows = fewTiles ? 32 : 64;
     if (h->tune.tileRows > 0) tileRows = h->tune.tileRows;
     std::vector<int4> tiles;
     std::vector<std::vector<int2>> ranges(P.nParts);
@@ -688,8 +695,16 @@ int build_device_mesh(dotmi_handle *h)
             // a tile stays inside one 64-row block of the factor storage (RowTile): the first tile of a region ends
             // at the next multiple of 64
             // rows of more than 1536 columns (the separators of the upper tree levels) can take fewer rows per tile
-            // (DOTMI_TILE_ROWS_LONG): measured, no gain -- profiles/r03_factor_tiles.txt section E
-            const int trows = (ro + used - cb > 1536) ? std::min(tileRows, h->tune.tileRowsLong) : tileRows;
+            // (DOTMI_TILE_ROWS_LONG).  Where every CU has its two workgroups anyway (bar17K: 1116 tiles) that buys nothing
+            // (profiles/r03_factor_tiles.txt section E); with few subdomains the launch lasts as long as its longest tile
+            // (bunny5K / 8: a 32-row tile of the root separator is 512 KB at ~30 GB/s per workgroup), so those rows get
+            // tiles of ~256 KB: 16 rows at 2000 columns, 8 at 3000 (round 4: bunny5K 23.0 -> 16.8 us, horse7K 46.5 -> 31.8)
+            const int len = ro + used - cb;
+            int trows = tileRows;
+            if (len > 1536) {
+                if (h->tune.tileRowsLong > 0) trows = std::min(tileRows, h->tune.tileRowsLong);
+                else if (fewTiles) trows = std::min(tileRows, std::max(8, (32768 / len) / 8 * 8));
+            }
             for (int r0 = ro, rows = 0; r0 < ro + used; r0 += rows) {
                 rows = std::min(std::min(trows, ro + used - r0), 64 - (r0 & 63));
                 tiles.push_back(make_int4(ls, r0, b | (rows << 16), cb));
@@ -878,8 +893,14 @@ int build_device_mesh(dotmi_handle *h)
         P.mt_ptr = nullptr;
         P.mt_ent = nullptr;
         const long long ppartN = (long long)P.nParts * P.nbmax * P.nmax;
-        if (h->tune.mergeTiles && ppartN < (1ll << 31) && !(h->flags & DOTMI_FLAG_GSDD)) {
-            std::vector<int> mp((size_t)3 * nV + 1, 0), ment;
+        // Big meshes: the walk over a dof's ~20 tile partials is a walk over scattered 8-byte words and 4-byte list entries
+        // (1 M tets: 75 us per iteration at 0.26 of the HBM peak); the two-launch form reads the partials coalesced in the
+        // subdomains' own order and gathers one 24-byte triple per (vertex, subdomain).  Small meshes keep the one launch.
+        P.splitMerge = h->tune.splitMerge >= 0 ? (h->tune.splitMerge != 0) : (3ll * nV >= 400000 || ppartN >= (1ll << 31));
+        const bool lists = h->tune.mergeTiles && !P.splitMerge && ppartN < (1ll << 31) && !(h->flags & DOTMI_FLAG_GSDD);
+        if (h->tune.mergeTiles && !(h->flags & DOTMI_FLAG_GSDD)) {
+            std::vector<int> mp(lists ? (size_t)3 * nV + 1 : 0, 0), ment;
+            long long count = 0;
             for (int v = 0; v < nV; ++v)
                 for (int d = 0; d < 3; ++d) {
                     for (int k = vp_ptr[v]; k < vp_ptr[v + 1]; ++k) {
@@ -887,16 +908,23 @@ int build_device_mesh(dotmi_handle *h)
                         bool first = true;
                         for (size_t b = 0; b < ranges[ls].size(); ++b)
                             if (col >= ranges[ls][b].x && col < ranges[ls][b].y) {
-                                const int off = (int)(((long long)ls * P.nbmax + (long long)b) * P.nmax + col);
-                                ment.push_back(first ? ~off : off);
+                                ++count;
+                                if (lists) {
+                                    const int off = (int)(((long long)ls * P.nbmax + (long long)b) * P.nmax + col);
+                                    ment.push_back(first ? ~off : off);
+                                }
                                 first = false;
                             }
                     }
-                    mp[(size_t)3 * v + d + 1] = (int)ment.size();
+                    if (lists) mp[(size_t)3 * v + d + 1] = (int)ment.size();
                 }
-            if (int rc = upload(h, &P.mt_ptr, mp)) return rc;
-            if (int rc = upload(h, &P.mt_ent, ment)) return rc;
-            h->mergeEntries = (long long)ment.size();
+            if (lists) {
+                if (int rc = upload(h, &P.mt_ptr, mp)) return rc;
+                if (int rc = upload(h, &P.mt_ent, ment)) return rc;
+            }
+            h->mergeEntries = count;   // tile partials one merge reads (either form)
+        } else {
+            P.splitMerge = 0;
         }
     }
     if (int rc = upload(h, &P.dup, h->dup)) return rc;
@@ -2853,7 +2881,8 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         // gradient, beside the controller (enqueue_loop_slot); sharded subdomains keep their one collective per iteration
         // (round 4: also with the sharded element pass -- the scatter of -g and H s_new then happen in pair_stats, behind the
         // gradient's all-reduce; DOTMI_EARLY_SHARDED=0 keeps the q-based order there)
-        h->earlyBs = h->devLoop && h->tune.earlyBs != 0 && (!h->shardElems || h->tune.earlySharded) && h->P.mt_ptr != nullptr;
+        h->earlyBs = h->devLoop && h->tune.earlyBs != 0 && (!h->shardElems || h->tune.earlySharded) &&
+                     (h->P.mt_ptr != nullptr || h->P.splitMerge);
         if (h->earlyBs && h->tune.fuseStep && !h->shardElems) h->PT.wgCap = 512;   // the trials' grouping of the energy partials, everywhere
         if (h->dist)
             if (int rc = dalloc(h, &h->zstage, (size_t)h->n)) return rc;

@@ -95,6 +95,8 @@ struct DevParts {
     // the same merge straight from the tile partials: per global scalar dof (CSR mt_ptr over 3 nV) the offsets into ppart
     // that make up its value, subdomain after subdomain; the first entry of a subdomain is stored complemented (~off)
     int *mt_ptr, *mt_ent;
+    int splitMerge;         // big meshes: no such lists -- reduce_partial_p (coalesced, in the subdomains' own order) leaves psub
+                            // and the merge kernels gather from it through vp_ptr / vp_off (round 4: 1 M tets, loop -2 ms)
     int *dup;               // nV (global multiplicity, DOTTimeStepper.cpp:47-56)
     // dense fill list
     int nfill;

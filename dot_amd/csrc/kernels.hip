@@ -2375,6 +2375,8 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
                                                                 const int *__restrict__ mt_ent, const int *__restrict__ dup,
                                                                 const double *__restrict__ ppart, int first,
                                                                 const double *__restrict__ zsum,
+                                                                const int *__restrict__ vp_ptr, const int *__restrict__ vp_off,
+                                                                const double *__restrict__ psub,
                                                                 double *__restrict__ z, double *__restrict__ partials,
                                                                 const DevLoop *__restrict__ ctl)
 {
@@ -2398,8 +2400,16 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
     const int stride = gridDim.x * blockDim.x;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += stride) {
-        const int e0 = mt_ptr[k], e1 = mt_ptr[k + 1];
-        const int d = dup[k / 3];
+        const int vtx = k / 3;
+        int e0 = 0, e1 = 0, c0 = 0, c1 = 0;
+        if (psub) {
+            c0 = vp_ptr[vtx];
+            c1 = vp_ptr[vtx + 1];
+        } else if (!zsum) {
+            e0 = mt_ptr[k];
+            e1 = mt_ptr[k + 1];
+        }
+        const int d = dup[vtx];
         double yk[HIST_MAX], mk[HIST_MAX];
 #pragma unroll
         for (int i = 0; i < HIST_MAX; ++i) {
@@ -2411,7 +2421,20 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
         // into a staging buffer, then the collective -- on the staging buffer, so that a slot whose merge is gated off leaves z
         // alone); only the division and the history terms are left
         double u = zsum ? zsum[k] : 0.0, ps = 0.0;
-        for (int e = zsum ? e1 : e0; e < e1; e += MT_CH) {
+        if (psub && !zsum) {
+            // split form (big meshes): the subdomains' own sums are in psub (reduce_partial_p_kernel); same additions in the
+            // same order as the list walk below -- tiles of a subdomain first, then the subdomains
+            const int dd = k - 3 * vtx;
+            for (int c = c0; c < c1; c += 4) {
+                double w[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[q] = (c + q < c1) ? psub[vp_off[c + q] + dd] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c + q < c1) u += w[q];
+            }
+        }
+        for (int e = e0; e < e1; e += MT_CH) {
             int off[MT_CH];
 #pragma unroll
             for (int q = 0; q < MT_CH; ++q) off[q] = (e + q < e1) ? mt_ent[e + q] : 0;
@@ -2451,8 +2474,10 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
                         const DevLoop *ctl, const double *zsum)
 {
+    const bool split = !P.mt_ptr;
     hipLaunchKernelGGL(merge_tiles_early_kernel, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup, P.ppart,
-                       first, zsum, z, partials, ctl);
+                       first, zsum, split ? P.vp_ptr : nullptr, split ? P.vp_off : nullptr,
+                       split ? (const double *)P.psub : nullptr, z, partials, ctl);
 }
 
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
