@@ -181,3 +181,93 @@ def test_teacher_forced_stiff_monkey_whole_steps_every_trial(step, min_iters, mi
     assert err["z"].max() < 1e-8 and err["p"].max() < 1e-8
     assert err["alpha0"].max() < 1e-8 and err["E"].max() < 1e-12 and err["E_halved"].max() < 1e-12
     ts.close(); orc.close()
+
+
+def _steps_with_env(workload, steps, env, parts=()):
+    """runs `steps` scripted steps with the environment set while the handle is created (the tuning variables are read once,
+    in dotmi_create); returns per-step (iterations, halvings, evals), the final positions and the inverse factors of `parts`"""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        sc, ep, n = load_workload(workload)
+        ts = DOTTimeStepper(sc, ep, n)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    rows, held = [], 0
+    for _ in range(steps):
+        idx, pos = sc.scripter.step(ts.getResult(), sc.cfg.dt)
+        ts.setDirichlet(idx, pos)
+        st = ts.step()
+        rows.append((st.status, st.iters, st.ls_halvings, st.energy_evals))
+        held += st.backsolve_held
+    X = [ts.partMatrix(p, inverse=True)[0] for p in parts]
+    x = ts.getResult().copy()
+    ts.close()
+    return rows, x, X, held
+
+
+@pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 3), ("bar17K_twist", 2)])
+def test_dataflow_factorisation_gives_the_level_schedules_factors_bit_for_bit(workload, steps):
+    """DOTMI_TILE_FLOW (round 4): ONE launch of persistent workgroups that pull the tile tasks in schedule order and wait
+    per task for the tasks whose tiles it touches (tile_flow_kernel) instead of one launch per level.  Every tile is
+    still written by one task at a time and every sum keeps its order, so the inverse factors -- and with them the steps --
+    are the level kernel's bit for bit, on a workload where the dataflow form is the default (bunny5K: 217 tasks per
+    level) and on one where it is not (bar17K: 1000 per level, forced here)."""
+    a = _steps_with_env(workload, steps, {"DOTMI_TILE_FLOW": "0"}, parts=(0, 3))
+    b = _steps_with_env(workload, steps, {"DOTMI_TILE_FLOW": "1"}, parts=(0, 3))
+    assert a[0] == b[0]
+    assert np.array_equal(a[1], b[1])
+    for Xa, Xb in zip(a[2], b[2]):
+        assert np.array_equal(Xa, Xb)
+
+
+def test_held_back_solves_change_no_decision_and_no_digit():
+    """DOTMI_EARLY_HOLD (round 4): the tiles of a slot whose trial the controller expects to be rejected wait for the
+    verdict instead of streaming the factors beside it.  Only WHEN the back-solve runs changes, not what it computes:
+    stiff monkey (about one halving per iteration), same iterations / halvings / energy evaluations and bit-identical
+    positions with the forecast on and off -- and the forecast does hold launches on this workload."""
+    a = _steps_with_env("monkey18K_stiff", 2, {"DOTMI_EARLY_HOLD": "0"})
+    b = _steps_with_env("monkey18K_stiff", 2, {"DOTMI_EARLY_HOLD": "1"})
+    assert a[0] == b[0]
+    assert np.array_equal(a[1], b[1])
+    assert a[3] == 0 and b[3] > 20
+
+
+def test_long_row_tiles_of_few_subdomain_layouts_keep_the_oracles_iterations():
+    """Round 4: with few subdomains the back-solve gives rows longer than 1536 columns ~256 KB tiles (8 or 16 rows instead of
+    32).  More tiles per column change the order of the partial sums only: bunny5K / 8 still takes the oracle's iterations
+    and lands within 1e-9 of its positions (the default path: this is what test_time_steps_match_oracle runs); here the
+    explicit settings 8 and 32 are held against each other."""
+    a = _steps_with_env("bunny5K_LTSS", 4, {"DOTMI_TILE_ROWS_LONG": "8"})
+    b = _steps_with_env("bunny5K_LTSS", 4, {"DOTMI_TILE_ROWS_LONG": "32"})
+    assert a[0] == b[0]
+    assert np.abs(a[1] - b[1]).max() < 1e-9
+
+
+def test_in_loop_kernel_forms_are_priced_on_the_live_state_without_disturbing_it():
+    """dotmi_bench_kernel kinds 11-14 (round 4) launch the kernels of the device loop's early order -- spmv_zp, merge_early,
+    the element pass that takes the step, the gather that scatters -g -- on the loop state the last step left on the device.
+    They must report a time and a byte count, and the next steps must be exactly those of a handle that was never
+    benched (they only touch vectors the next step rewrites; the Hessian / assembly kinds re-issue the refresh)."""
+    import ctypes as C
+    sc, ep, n = load_workload("bunny5K_LTSS")
+    a = DOTTimeStepper(sc, ep, n)
+    sc2, _, _ = load_workload("bunny5K_LTSS")
+    b = DOTTimeStepper(sc2, ep, n)
+    L = dl.load()
+    for k in range(3):
+        for ts, s_ in ((a, sc), (b, sc2)):
+            idx, pos = s_.scripter.step(ts.getResult(), s_.cfg.dt)
+            ts.setDirichlet(idx, pos)
+        sa, sb = a.step(), b.step()
+        assert (sa.iters, sa.ls_halvings) == (sb.iters, sb.ls_halvings)
+        assert np.array_equal(a.getResult(), b.getResult())
+        for kind, name in enumerate(dl.BENCH_KERNELS):
+            ms, nb = C.c_double(), C.c_int64()
+            assert L.dotmi_bench_kernel(a._h, kind, 3, C.byref(ms), C.byref(nb)) == 0, name
+            assert ms.value > 0 and nb.value > 0, name
+    a.close(); b.close()
