@@ -228,7 +228,12 @@ def main():
                         "the pattern of H_s); the reference runs them concurrently under TBB"}
 
     def run_workload(name, steps, warmup):
-        """-> (record, per-step stats, scene, timestepper is closed)"""
+        """-> (record, per-step stats, scene, timestepper is closed).  A trailing "+owner" (N > 1) runs the workload with
+        DOTMI_FLAG_OWNER_EXCHANGE: interface-only vector collectives, owner-summed dot products"""
+        owner = name.endswith("+owner")
+        label = name
+        if owner:
+            name = name[:-len("+owner")]
         sc, ep, nparts = load_workload(name)
         cfg = sc.cfg
         # one rank: dotmi_step returns with the end-of-step refresh queued (DOTMI_FLAG_ASYNC_REFRESH), so moving the handles
@@ -236,7 +241,8 @@ def main():
         # refresh is inside it.  BENCH_SYNC_REFRESH=1 keeps the synchronous return.
         async_refresh = world == 1 and os.environ.get("BENCH_SYNC_REFRESH", "0") != "1"
         ts = DOTTimeStepper(sc, ep, nparts, device=local_rank, rank=rank, world=world, comm_id=fresh_comm_id(),
-                            flags=dl.FLAG_TIME_BACKSOLVE | (dl.FLAG_ASYNC_REFRESH if async_refresh else 0))
+                            flags=dl.FLAG_TIME_BACKSOLVE | (dl.FLAG_ASYNC_REFRESH if async_refresh else 0) |
+                            (dl.FLAG_OWNER_EXCHANGE if owner and world > 1 else 0))
         # scripted (Dirichlet) vertices are never moved by the solver: the scripter keeps their positions itself, as
         # the reference's host mesh does, instead of reading all positions back every step
         cached = cfg.script != "rubberBandPull"
@@ -320,7 +326,7 @@ def main():
         }
         w = np.array(walls) * 1e3
         rec = {
-            "workload": name, "nV": int(sc.V_rest.shape[0]), "nT": int(sc.T.shape[0]), "energy": cfg.energy,
+            "workload": label, "nV": int(sc.V_rest.shape[0]), "nT": int(sc.T.shape[0]), "energy": cfg.energy,
             "subdomains": int(nparts), "dt": cfg.dt, "script": cfg.script, "steps": steps, "warmup": warmup,
             "ms_per_step": round(1e3 * elapsed / steps, 3), "ms_per_step_p50": round(float(np.percentile(w, 50)), 3),
             "ms_per_step_p95": round(float(np.percentile(w, 95)), 3),
@@ -372,10 +378,15 @@ def main():
     # ---- the other configurations BASELINE.json / north_star name, short runs (every rank takes part) --------------
     extra = []
     if args.extra_workloads and args.extra_workloads != "none":
-        for name in args.extra_workloads.split(","):
+        names = args.extra_workloads.split(",")
+        if world > 1:
+            # N > 1: the two configurations meant to scale also under the owner exchange (interface-only collectives), next to
+            # the replicated-vector sharding, so that a multi-GPU run measures both
+            names += [n_ + "+owner" for n_ in names if n_.startswith("synbar") or "@r" in n_]
+        for name in names:
             if name == args.workload:
                 continue
-            st_, wu_ = EXTRA_STEPS.get(name, (6, 2))
+            st_, wu_ = EXTRA_STEPS.get(name.replace("+owner", ""), (6, 2))
             r2 = run_workload(name, st_, wu_)[0]
             r2.pop("_ns", None)
             extra.append(r2)

@@ -261,6 +261,18 @@ struct dotmi_handle {
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
     double *gstage = nullptr;   // sharded element pass, device loop: [g (n) ; 0 ; E] staging buffer of the gradient all-reduce
     double *zstage = nullptr;   // sharded subdomains, early order: this rank's undivided partial merge, all-reduced in place
+    // owner exchange (DOTMI_FLAG_OWNER_EXCHANGE)
+    bool owner = false;
+    std::vector<int32_t> firstPart;        // parts of rank r: [firstPart[r], firstPart[r + 1])
+    uint8_t *ownMask = nullptr, *heldMask = nullptr;   // nV: this rank owns the vertex / holds it in one of its subdomains
+    int *ifaceIdx = nullptr;               // the vertices held by more than one rank (the same list on every rank), ascending
+    int nIface = 0;
+    double *xpack = nullptr;               // 3 nIface + 8 doubles: the packed entries (+ E) that travel
+    double *massOwn = nullptr;             // nV: lumped mass on the owned vertices, 0 elsewhere
+    double *HvalOwn = nullptr;             // block-CSR values of this rank's OWN elements' part of H (+ massOwn): alpha_0's p.Hp
+    int *ownBlkPtr = nullptr, *ownBlkEnt = nullptr;   // contribution lists of that assembly (over hessBlk)
+    double *partGR = nullptr, *partGC = nullptr;      // all-reduced statistics / y_i.z in row 0 of a zeroed partial array
+    DevMesh Mown;                          // the mesh with massOwn for mass (element pass of the owner exchange)
     double *alpha_dev = nullptr;
     int *info_dev = nullptr, *h_info = nullptr;  // per owned part: failing pivot (device / pinned copy)
     int4 *clearSeg = nullptr;                    // row segments (row, first column, columns, -) cleared before a refill
@@ -636,6 +648,7 @@ int build_device_mesh(dotmi_handle *h)
         dotmi_plan_shards(nP, ps.data(), h->world, first.data());
         h->p0 = first[h->rank];
         h->p1 = first[h->rank + 1];
+        h->firstPart = first;
     }
     DevParts &P = h->P;
     P.nParts = h->p1 - h->p0;
@@ -1136,28 +1149,38 @@ int build_device_mesh(dotmi_handle *h)
     // slice [v0, v1) of the SpMV.  Their blocks are sums over the elements incident to the row vertex, so the elements
     // needed are the rank's own plus the halo that touches its interface vertices -- recomputed locally instead of
     // exchanging 1152 bytes per element (DOTTimeStepper.cpp:349-380, :574-616 run on every rank's share).
-    h->shardHess = h->shardElems && (h->tune.shardHess >= 0 ? h->tune.shardHess != 0 : true);
+    h->shardHess = h->shardElems && (h->owner || (h->tune.shardHess >= 0 ? h->tune.shardHess != 0 : true));
     h->nHessElems = nT;
     if (h->shardHess) {
         std::vector<uint8_t> needV(nV, 0);
         for (int pI = h->p0; pI < h->p1; ++pI)
             for (int v : h->partVerts[pI]) needV[v] = 1;
-        for (int v = h->v0; v < h->v1; ++v) needV[v] = 1;
+        if (!h->owner)
+            for (int v = h->v0; v < h->v1; ++v) needV[v] = 1;
         std::vector<int> el, e2c(nT, -1);
         for (int e = 0; e < nT; ++e)
             if (needV[h->T[4 * e]] || needV[h->T[4 * e + 1]] || needV[h->T[4 * e + 2]] || needV[h->T[4 * e + 3]]) {
                 e2c[e] = (int)el.size();
                 el.push_back(e);
             }
-        std::vector<int> bl, bptr(1, 0), bent;
+        std::vector<int> bl, bptr(1, 0), bent, optr(1, 0), oent;
         for (int v = 0; v < nV; ++v) {
             if (!needV[v]) continue;
             for (int k = adj_ptr[v]; k < adj_ptr[v + 1]; ++k) {
                 bl.push_back(k);
-                for (int i = blk_ptr[k]; i < blk_ptr[k + 1]; ++i)
-                    bent.push_back((e2c[blk_ent[i] >> 4] << 4) | (blk_ent[i] & 15));   // every contributor touches v: listed
+                for (int i = blk_ptr[k]; i < blk_ptr[k + 1]; ++i) {
+                    const int e = blk_ent[i] >> 4;
+                    bent.push_back((e2c[e] << 4) | (blk_ent[i] & 15));   // every contributor touches v: listed
+                    if (h->owner && h->epart[e] >= h->p0 && h->epart[e] < h->p1) oent.push_back(bent.back());
+                }
                 bptr.push_back((int)bent.size());
+                optr.push_back((int)oent.size());
             }
+        }
+        if (h->owner) {
+            if (oent.empty()) oent.push_back(-1);
+            if (int rc = upload(h, &h->ownBlkPtr, optr)) return rc;
+            if (int rc = upload(h, &h->ownBlkEnt, oent)) return rc;
         }
         h->nHessElems = (int)el.size();
         h->nHessBlk = (int)bl.size();
@@ -1181,6 +1204,44 @@ int build_device_mesh(dotmi_handle *h)
         } else {
             h->PT = h->PTall;
         }
+    }
+    if (h->owner) {
+        // who holds / owns a vertex: a rank HOLDS the vertices of its subdomains (= of its elements); the lowest rank that
+        // holds a vertex OWNS it (its inertia term, its share of every dot product).  Vertices held by two or more ranks
+        // are the only ones whose entries travel inside the loop.
+        std::vector<int> holders(nV, 0), last(nV, -1), ownerR(nV, -1);
+        for (int r = 0; r < h->world; ++r)
+            for (int pI = h->firstPart[r]; pI < h->firstPart[r + 1]; ++pI)
+                for (int v : h->partVerts[pI])
+                    if (last[v] != r) {
+                        last[v] = r;
+                        holders[v]++;
+                        if (ownerR[v] < 0) ownerR[v] = r;
+                    }
+        std::vector<uint8_t> own(nV, 0), held(nV, 0);
+        std::vector<int> iface;
+        std::vector<double> mo(nV, 0.0);
+        for (int pI = h->p0; pI < h->p1; ++pI)
+            for (int v : h->partVerts[pI]) held[v] = 1;
+        for (int v = 0; v < nV; ++v) {
+            own[v] = ownerR[v] == h->rank || (ownerR[v] < 0 && h->rank == 0);
+            if (own[v]) mo[v] = h->mass[v];
+            if (holders[v] >= 2) iface.push_back(v);
+        }
+        h->nIface = (int)iface.size();
+        if (iface.empty()) iface.push_back(0);
+        if (int rc = upload(h, &h->ownMask, own)) return rc;
+        if (int rc = upload(h, &h->heldMask, held)) return rc;
+        if (int rc = upload(h, &h->ifaceIdx, iface)) return rc;
+        if (int rc = upload(h, &h->massOwn, mo)) return rc;
+        if (int rc = dalloc(h, &h->xpack, (size_t)3 * h->nIface + 8)) return rc;
+        // the element pass' inertia term 1/2 m |x - x~|^2 by ownership too: the same kernel over every vertex with the
+        // owner's share of the mass (positions outside the held vertices stay where the warm start put them)
+        h->Mown = h->M;
+        h->Mown.mass = h->massOwn;
+        if (h->tune.fuseLog)
+            fprintf(stderr, "dotmi: owner exchange: rank %d holds %d of %d vertices, %d are held by more than one rank\n", h->rank,
+                    (int)std::count(held.begin(), held.end(), 1), nV, h->nIface);
     }
     return 0;
 }
@@ -1602,6 +1663,10 @@ int refactor_issue(dotmi_handle *h, const double *x)
     if (h->shardHess) {
         launch_elem_hessians(h->M, h->mat, h->dtSq, x, h->He, h->st, h->hessElems, h->nHessElems);
         launch_assemble(h->M, h->He, h->Hval, h->st, h->hessBlk, h->nHessBlk, h->hessBlkPtr, h->hessBlkEnt);
+        // owner exchange: this rank's own elements' part of the same rows (+ the mass of the vertices it owns): the
+        // operator behind alpha_0's p.Hp -- the parts of all ranks add up to H, and no row needs a vertex the rank does not hold
+        if (h->owner)
+            launch_assemble(h->M, h->He, h->HvalOwn, h->st, h->hessBlk, h->nHessBlk, h->ownBlkPtr, h->ownBlkEnt, h->massOwn);
     } else {
         launch_elem_hessians(h->M, h->mat, h->dtSq, x, h->He, h->st);
         launch_assemble(h->M, h->He, h->Hval, h->st);
@@ -1874,6 +1939,23 @@ void sum_stats(const dotmi_handle *h, int nvals, double *R)
     for (int j = 0; j < nvals; ++j) R[j] = chunked_sum(NB_RED, [&](int b) { return h->h_partR[(size_t)b * RED_K + j]; });
 }
 
+// owner exchange: sum over the ranks of the entries of `vec` at the vertices held by more than one rank (packed, summed, put
+// back) -- plus `ntail` scalars at `tailp` that ride along
+int exchange_iface(dotmi_handle *h, double *vec, double *tailp, int ntail)
+{
+    launch_pack_iface(h->nIface, h->ifaceIdx, vec, h->xpack, tailp, ntail, h->st);
+    if (int rc = allreduce_sum(h, h->xpack, (size_t)3 * h->nIface + ntail)) return rc;
+    launch_unpack_iface(h->nIface, h->ifaceIdx, h->xpack, h->heldMask, vec, tailp, ntail, h->st);
+    return 0;
+}
+// owner exchange: the first `ncols` columns of a partial array summed over its rows and over the ranks into row 0 of `dst`
+// (whose other rows stay zero: consumers sum the rows of a partial array)
+int allreduce_columns(dotmi_handle *h, const double *partials, int ncols, double *dst)
+{
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, partials, NB_RED, RED_K, ncols, 0.0, 0.0, 0, dst);
+    return allreduce_sum(h, dst, (size_t)ncols);
+}
+
 // One slot of the device-resident loop: the nine kernels of an L-BFGS iteration (or, when the controller
 // asked for a retry, only the three of a line-search trial -- the others return at once) and the controller.
 // Early back-solve (one rank, h->earlyBs): the preconditioner M is fixed during a step and linear, so the solve for the
@@ -1890,7 +1972,10 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     memset(&L0, 0, sizeof(L0));
     const bool fuseDir = h->tune.fuseDir;
     const bool se = h->shardElems;   // sharded element pass: this rank's rows of H, its elements; three collectives per slot
-    if (fuseDir) {   // build_p + spmv_dots in one launch, H p from the cached H s_j
+    const bool ow = h->owner;        // owner exchange: only the entries of shared vertices travel, dots are owner-summed scalars
+    if (ow) {
+        launch_spmv_zp(h->M, h->HvalOwn, h->z, h->partGC, h->p, h->Hp, h->partS, h->st, h->ctl, 0, -1, h->heldMask, h->ownMask);
+    } else if (fuseDir) {   // build_p + spmv_dots in one launch, H p from the cached H s_j
         launch_spmv_zp(h->M, h->Hval, h->z, h->partC, h->p, h->Hp, h->partS, h->st, h->ctl, se ? h->v0 : 0, se ? h->v1 : -1);
     } else {
         launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
@@ -1914,7 +1999,8 @@ int enqueue_loop_slot_early(dotmi_handle *h)
                                 &sa);
     } else {
         launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st, h->ctl);
-        launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st, h->ctl);
+        launch_elem_energy_grad(ow ? h->Mown : h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, ow ? 0 : h->v0, ow ? h->nV : h->v1,
+                                1, h->partE, &nb, h->st, h->ctl);
     }
     GatherArgs a;
     memset(&a, 0, sizeof(a));
@@ -1924,7 +2010,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     a.iv0 = h->v0;
     a.iv1 = h->v1;
     a.make_pair = 1;
-    a.hp = fuseDir ? h->Hp : nullptr;   // H s_new = alpha H p beside s_new
+    a.hp = (fuseDir || ow) ? h->Hp : nullptr;   // H s_new = alpha H p beside s_new
     // -g_trial goes straight into the padded right-hand sides, whatever the controller will say about the trial
     a.vp_ptr = h->P.vp_ptr;
     a.vp_off = h->P.vp_off;
@@ -1942,20 +2028,30 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         ag.hp = nullptr;
         ag.vp_ptr = ag.vp_off = nullptr;
         ag.rpad = nullptr;
+        ag.ownMask = ow ? h->ownMask : nullptr;
         launch_vertex_gather(h->M, h->PT, ag, L0, h->partR, h->st, h->ctl);
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
                            h->gstage + n + 1);
-        if (int rc = allreduce_sum(h, h->gstage, (size_t)n + 2)) return rc;
+        if (!ow) {
+            if (int rc = allreduce_sum(h, h->gstage, (size_t)n + 2)) return rc;
+        } else {
+            // the gradient is complete on the vertices only this rank holds; the shared ones (and E) are summed
+            if (int rc = exchange_iface(h, h->gstage, h->gstage + n + 1, 1)) return rc;
+            a.ownMask = h->ownMask;   // pair_stats: the statistics over the owned vertices ...
+        }
         launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
+        if (ow)   // ... summed over the ranks before the controller reads them
+            if (int rc = allreduce_columns(h, h->partR, RED_K, h->partGR)) return rc;
         ctlE = h->gstage + n;   // the controller reads the energy as one block (0, E)
         nb = 1;
     }
+    const double *ctlR = ow ? h->partGR : h->partR;
     const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size() &&
                        (h->timeCount++ % h->timeStride) == 0;
     h->slotTimed.push_back(timed ? h->evUsed : -1);
-    CtlArgs ca{h->ctl, ctlE, h->partR, h->alpha_dev, h->h_flags, nb, 0};
+    CtlArgs ca{h->ctl, ctlE, ctlR, h->alpha_dev, h->h_flags, nb, 0};
     if (!h->tune.earlyHostCtl)   // (ablation) the controller as a launch of its own, in front of the speculative solve
-        launch_loop_control(h->ctl, ctlE, nb, h->partR, h->alpha_dev, h->h_flags, h->st);
+        launch_loop_control(h->ctl, ctlE, nb, ctlR, h->alpha_dev, h->h_flags, h->st);
     launch_gemv(h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr,
                 h->tune.earlyHostCtl ? &ca : nullptr,
                 h->tune.earlyAbort ? (int)h->slotTimed.size() /* the slot's epoch, 1-based */ : (1 << 30) /* never stopped */);
@@ -1968,8 +2064,17 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         // (the sum travels in a staging buffer: in a slot whose merge is gated off -- retry, past the end -- the collective
         // still runs, on stale scratch, and z is left alone)
         launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl);
-        if (int rc = allreduce_sum(h, h->zstage, n)) return rc;
-        launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage);
+        if (!ow) {
+            if (int rc = allreduce_sum(h, h->zstage, n)) return rc;
+            launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage);
+        } else {
+            // zstage: this rank's subdomains' sum, zero on the vertices it does not hold; only the shared vertices' entries
+            // are summed over the ranks.  z is then whole on the held vertices and zero elsewhere -- and so is everything
+            // the loop forms from it.  The y_i . z of the owned vertices travel as five scalars.
+            if (int rc = exchange_iface(h, h->zstage, nullptr, 0)) return rc;
+            launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage, h->ownMask);
+            if (int rc = allreduce_columns(h, h->partC, HIST_MAX, h->partGC)) return rc;
+        }
     }
     return 0;
 }
@@ -2098,18 +2203,20 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     {
         // energy and gradient at the start of the step, reduced by the controller (no host round trip)
         int nb = 0;
-        launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st);
+        launch_elem_energy_grad(h->owner ? h->Mown : h->M, h->PT, h->mat, h->dtSq, h->x, h->xt, h->owner ? 0 : h->v0,
+                                h->owner ? h->nV : h->v1, 1, h->partE, &nb, h->st);
         GatherArgs a;
         memset(&a, 0, sizeof(a));
-            a.x = h->x;
+        a.x = h->x;
         a.xt = h->xt;
         a.g_new = h->shardElems ? h->gstage : h->g;
         a.make_pair = 0;
         a.iv0 = h->v0;
         a.iv1 = h->v1;
+        a.ownMask = h->owner ? h->ownMask : nullptr;
         LbfgsArgs L0;
         memset(&L0, 0, sizeof(L0));
-        if (h->earlyNow) {   // -g_0 straight into the padded right-hand sides (their padding entries stay zero)
+        if (h->earlyNow && !h->shardElems) {   // -g_0 straight into the padded right-hand sides (their padding entries stay zero)
             a.vp_ptr = h->P.vp_ptr;
             a.vp_off = h->P.vp_off;
             a.rpad = h->P.rpad;
@@ -2133,23 +2240,40 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
         } else {
             hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
                                h->gstage + n_ + 1);
-            if (int rc = allreduce_sum(h, h->gstage, (size_t)n_ + 2)) return rc;
+            const double *ctlR = h->partR;
+            if (!h->owner) {
+                if (int rc = allreduce_sum(h, h->gstage, (size_t)n_ + 2)) return rc;
+            } else {
+                if (int rc = exchange_iface(h, h->gstage, h->gstage + n_ + 1, 1)) return rc;
+            }
             HIPCHECK(h, hipMemcpyAsync(h->g, h->gstage, sizeof(double) * n_, hipMemcpyDeviceToDevice, h->st));
-            const double *vecs[1] = {h->g};
-            launch_multidot(n_, h->g, vecs, 1, h->partR, h->st);   // |g|^2
+            if (!h->owner) {
+                const double *vecs[1] = {h->g};
+                launch_multidot(n_, h->g, vecs, 1, h->partR, h->st);   // |g|^2
+            } else {
+                launch_masked_norm2(n_, h->g, h->ownMask, h->partR, h->st);   // over the owned vertices, then over the ranks
+                if (int rc = allreduce_columns(h, h->partR, 1, h->partGR)) return rc;
+                ctlR = h->partGR;
+            }
             if (!h->earlyNow) {
                 launch_loop_control(h->ctl, h->gstage + n_, 1, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
             } else {
                 // early order on the sharded element pass: -g_0 (the summed gradient) into this rank's right-hand sides, the
                 // first direction's solve with the start-of-step controller inside its launch, the sum over the ranks, z = u
                 launch_build_qpad(h->P, h->g, L0, nullptr, h->st, nullptr);
-                CtlArgs ca{h->ctl, h->gstage + n_, h->partR, h->alpha_dev, h->h_flags, 1, 1};
+                CtlArgs ca{h->ctl, h->gstage + n_, ctlR, h->alpha_dev, h->h_flags, 1, 1};
                 launch_gemv(h->P, nullptr, h->st, h->ctl, nullptr, nullptr, h->tune.earlyHostCtl ? &ca : nullptr, 1 << 30);
                 if (!h->tune.earlyHostCtl)
-                    launch_loop_control(h->ctl, h->gstage + n_, 1, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
+                    launch_loop_control(h->ctl, h->gstage + n_, 1, ctlR, h->alpha_dev, h->h_flags, h->st, 1);
                 launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl);
-                if (int rc = allreduce_sum(h, h->zstage, n_)) return rc;
-                launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage);
+                if (!h->owner) {
+                    if (int rc = allreduce_sum(h, h->zstage, n_)) return rc;
+                    launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage);
+                } else {
+                    if (int rc = exchange_iface(h, h->zstage, nullptr, 0)) return rc;
+                    launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage, h->ownMask);
+                    if (int rc = allreduce_columns(h, h->partC, HIST_MAX, h->partGC)) return rc;
+                }
             }
         }
     }
@@ -2772,6 +2896,14 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     RBCHECK(h, rocblas_set_stream(h->blas, h->st));
     h->dist = h->world > 1 || (h->flags & DOTMI_FLAG_FORCE_DIST);
     h->shardElems = h->dist && (h->tune.shardElems >= 0 ? h->tune.shardElems != 0 : h->nT >= 400000);
+    h->owner = h->dist && (h->flags & DOTMI_FLAG_OWNER_EXCHANGE);
+    if (h->owner) {
+        if (h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES | DOTMI_FLAG_GSDD | DOTMI_FLAG_NEWTON)) {
+            h->err = "DOTMI_FLAG_OWNER_EXCHANGE: device loop only";
+            return DOTMI_E_INVALID;
+        }
+        h->shardElems = true;   // own elements, own rows, own share of the refresh
+    }
     h->arCb = prm->allreduce;
     h->arCtx = prm->allreduce_ctx;
     if (h->dist && !h->arCb) {
@@ -2852,8 +2984,12 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     }
     if (int rc = dalloc(h, &h->He, (size_t)144 * std::max(h->nHessElems, 1))) return rc;
     if (int rc = dalloc(h, &h->Hval, (size_t)9 * h->M.nnzb)) return rc;
+    if (h->owner) {
+        if (int rc = dalloc(h, &h->HvalOwn, (size_t)9 * h->M.nnzb)) return rc;
+        HIPCHECK(h, hipMemsetAsync(h->HvalOwn, 0, sizeof(double) * 9 * h->M.nnzb, h->st));
+    }
     if (int rc = dalloc(h, &h->partE, (size_t)2 * ELEM_NB_MAX)) return rc;
-    double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG};
+    double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG, &h->partGR, &h->partGC};
     for (double **pp : parts) {
         if (int rc = dalloc(h, pp, (size_t)NB_RED * RED_K)) return rc;
         HIPCHECK(h, hipMemsetAsync(*pp, 0, sizeof(double) * NB_RED * RED_K, h->st));
@@ -2883,6 +3019,10 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         // gradient's all-reduce; DOTMI_EARLY_SHARDED=0 keeps the q-based order there)
         h->earlyBs = h->devLoop && h->tune.earlyBs != 0 && (!h->shardElems || h->tune.earlySharded) &&
                      (h->P.mt_ptr != nullptr || h->P.splitMerge);
+        if (h->owner && !(h->earlyBs && h->tune.fuseDir)) {
+            h->err = "DOTMI_FLAG_OWNER_EXCHANGE needs the device loop's early order with the fused direction kernel";
+            return DOTMI_E_INVALID;
+        }
         if (h->earlyBs && h->tune.fuseStep && !h->shardElems) h->PT.wgCap = 512;   // the trials' grouping of the energy partials, everywhere
         if (h->dist)
             if (int rc = dalloc(h, &h->zstage, (size_t)h->n)) return rc;
@@ -3176,6 +3316,13 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         h->log_g2.push_back(g2);
         if (++it >= h->iterCap) break;
     } while (g2 > h->targetGRes);
+    if (h->owner) {
+        // owner exchange: the loop kept the positions of the vertices this rank holds; every rank's positions are made whole
+        // again here, once per step (the owners' entries, zeros elsewhere, summed) -- the refresh reads the halo elements'
+        // vertices, dotmi_get_state everything
+        launch_mask_owned(h->n, h->x, h->ownMask, h->st);
+        if (int rc = allreduce_sum(h, h->x, (size_t)h->n)) return rc;
+    }
     double Tloop1 = now_ms();
     ms_hess += h->carryHess;
     ms_fact += h->carryFact;
@@ -3612,6 +3759,7 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
         run = [&] { launch_step_forward(n, h->x, h->p, h->x_trial, h->partS, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st); };
         break;
     case DOTMI_BENCH_ELEM_HESSIAN:       // 112 nT in, 1152 nT out
+        if (h->world > 1) return DOTMI_E_INVALID;   // (the refresh re-issued below ends in a collective: not from one rank alone)
         bytes = (int64_t)(112 + 1152) * h->nHessElems;
         run = [&] {
             if (h->shardHess) launch_elem_hessians(h->M, h->mat, h->dtSq, h->x, h->He, h->st, h->hessElems, h->nHessElems);
@@ -3619,6 +3767,7 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
         };
         break;
     case DOTMI_BENCH_ASSEMBLE:           // 1152 nT in, 72 nnzb out
+        if (h->world > 1) return DOTMI_E_INVALID;
         bytes = (int64_t)1152 * h->nHessElems + 72 * (int64_t)(h->shardHess ? h->nHessBlk : h->M.nnzb);
         run = [&] {
             if (h->shardHess) launch_assemble(h->M, h->He, h->Hval, h->st, h->hessBlk, h->nHessBlk, h->hessBlkPtr, h->hessBlkEnt);

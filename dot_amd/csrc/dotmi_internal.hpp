@@ -220,6 +220,9 @@ struct GatherArgs {
     double *rpad;
     const double *hp;   // early order with the fused direction kernel: H p of the running trial; H s_new = alpha H p goes to
                         // DevLoop::HS[slot] beside s_new
+    // owner exchange (DOTMI_FLAG_OWNER_EXCHANGE): this rank adds the inertia term of the vertices it OWNS (instead of a slice
+    // [iv0, iv1)) and pair_stats sums its statistics over them only (every vertex counted once over the ranks)
+    const uint8_t *ownMask;
 };
 void launch_vertex_gather(const DevMesh &M, const DevPatches &PT, const GatherArgs &a, const LbfgsArgs &L,
                           double *partials, hipStream_t st, const DevLoop *ctl = nullptr);
@@ -245,8 +248,17 @@ void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, c
 // early back-solve: u = merge(tile partials) / dup = -M g;  M y of the newest pair = u_old - u;  z = u - sum_j xi_j M y_j
 // (+ partial dots y_i . z);  first: start of the step (no history, u_old is only set)
 // zsum: the all-reduced sum (over all ranks' subdomains) of the undivided partial merges, in a staging buffer
+// ownMask (owner exchange): the y_i . z partials over the vertices this rank owns only
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
-                        const DevLoop *ctl, const double *zsum = nullptr);
+                        const DevLoop *ctl, const double *zsum = nullptr, const uint8_t *ownMask = nullptr);
+// owner exchange: the entries of the vertices held by more than one rank, packed / unpacked (idx: their vertex ids);
+// tail: `ntail` further scalars copied from / to tailp behind the packed entries
+void launch_pack_iface(int nI, const int *idx, const double *src, double *pack, const double *tailp, int ntail, hipStream_t st);
+void launch_unpack_iface(int nI, const int *idx, const double *pack, const uint8_t *heldMask, double *dst, double *tailp, int ntail,
+                         hipStream_t st);
+// |v|^2 over the owned vertices -> column 0 of the partial rows;  v := own ? v : 0 (in place)
+void launch_masked_norm2(int n, const double *v, const uint8_t *ownMask, double *partials, hipStream_t st);
+void launch_mask_owned(int n, double *v, const uint8_t *ownMask, hipStream_t st);
 // one subdomain only (GSDD, DOTTimeStepper.cpp:507-565): psub_s = X_s^T (X_s q[dofmap_s]) for owned part `ls`, whose
 // tiles are job[0..njobs); then p = 0 except p[dofs of part ls] = psub_s  (ADMMDDTimeStepper::fill, :1646-1665)
 void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, const int2 *lwork, int nlwork, const double *q,
@@ -262,8 +274,11 @@ void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_
 // delta_j (H s_j) from the cached H s_j, and the partial sums of p.g and p.Hp -- the only sparse product is H z, which
 // does not wait for delta
 // rows [v0, v1) only for the product and the dots (sharded rows); v1 < 0: every row
+// rowMask / ownMask (owner exchange): the product on the rows of the vertices this rank holds (with ITS elements' part of H),
+// p.Hp over them, p.g over the vertices it owns
 void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const double *c_partials, double *p, double *Hp,
-                    double *partials, hipStream_t st, const DevLoop *ctl, int v0 = 0, int v1 = -1);
+                    double *partials, hipStream_t st, const DevLoop *ctl, int v0 = 0, int v1 = -1,
+                    const uint8_t *rowMask = nullptr, const uint8_t *ownMask = nullptr);
 // Hp = H p on rows [v0,v1), partial sums of p.g and p.Hp
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
                       int v0, int v1, double *partials, hipStream_t st, const DevLoop *ctl = nullptr);
@@ -277,8 +292,9 @@ void launch_loop_control(DevLoop *ctl, const double *partE, int nbE, const doubl
 // contribution lists blk_ptr / blk_ent then index by list position and name rows of that compact He
 void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *x, double *He,
                           hipStream_t st, const int *elist = nullptr, int nList = 0);
+// mass != null: the diagonal term comes from this array instead of the lumped masses (owner exchange: the owner's share)
 void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st, const int *blist = nullptr,
-                     int nList = 0, const int *blk_ptr = nullptr, const int *blk_ent = nullptr);
+                     int nList = 0, const int *blk_ptr = nullptr, const int *blk_ent = nullptr, const double *mass = nullptr);
 void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st);
 void launch_clear_segments(const DevParts &P, const int4 *seg, int nseg, hipStream_t st);
 // Leaves of the dissection tree that have the same padded size are factorised together: one launch / one batched GEMM

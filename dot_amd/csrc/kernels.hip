@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
                     const int2 r = pp_rng[v];
                     kb[u] = r.x;
                     ke[u] = r.y;
-                    if (v >= a.iv0 && v < a.iv1) ine[u] = mass[v] * (a.x[k] - a.xt[k]);
+                    if (a.ownMask ? a.ownMask[v] != 0 : (v >= a.iv0 && v < a.iv1)) ine[u] = mass[v] * (a.x[k] - a.xt[k]);
                 }
                 if (a.make_pair) {
                     gold[u] = a.g_old[k];
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void pair_stats_kernel(int n, GatherArgs a, Lb
             for (int c = a.vp_ptr[v]; c < a.vp_ptr[v + 1]; ++c) a.rpad[a.vp_off[c] + dd] = -gn;
         }
         if (hs_new) hs_new[k] = alpha * a.hp[k];
-        pair_stats_accum(k, gn, sn, yn, Lr, acc);
+        if (!a.ownMask || a.ownMask[k / 3]) pair_stats_accum(k, gn, sn, yn, Lr, acc);
     }
     write_partials(acc, RED_K, partials, sm);
 }
@@ -2377,6 +2377,7 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
                                                                 const double *__restrict__ zsum,
                                                                 const int *__restrict__ vp_ptr, const int *__restrict__ vp_off,
                                                                 const double *__restrict__ psub,
+                                                                const uint8_t *__restrict__ ownMask,
                                                                 double *__restrict__ z, double *__restrict__ partials,
                                                                 const DevLoop *__restrict__ ctl)
 {
@@ -2464,20 +2465,81 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
         for (int j = HIST_MAX - 1; j >= 0; --j)
             if (j < m) zk -= xi[j] * ((pairNew && j == m - 1) ? myn : mk[j]);
         z[k] = zk;
+        if (!ownMask || ownMask[vtx]) {
 #pragma unroll
-        for (int i = 0; i < HIST_MAX; ++i)
-            if (i < m) acc[i] += yk[i] * zk;
+            for (int i = 0; i < HIST_MAX; ++i)
+                if (i < m) acc[i] += yk[i] * zk;
+        }
     }
     write_partials(acc, HIST_MAX, partials, sm);
 }
 
+// ---- owner exchange (DOTMI_FLAG_OWNER_EXCHANGE): only the entries of vertices held by more than one rank travel ----------------
+__global__ __launch_bounds__(256) void pack_iface_kernel(int nI, const int *__restrict__ idx, const double *__restrict__ src,
+                                                         double *__restrict__ pack, const double *__restrict__ tailp, int ntail)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 3 * nI) pack[t] = src[3 * idx[t / 3] + t % 3];
+    else if (t < 3 * nI + ntail) pack[t] = tailp[t - 3 * nI];
+}
+// (only the vertices THIS rank holds take the sum: a vertex shared by two other ranks stays zero here)
+__global__ __launch_bounds__(256) void unpack_iface_kernel(int nI, const int *__restrict__ idx, const double *__restrict__ pack,
+                                                           const uint8_t *__restrict__ heldMask, double *__restrict__ dst,
+                                                           double *__restrict__ tailp, int ntail)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < 3 * nI) {
+        const int v = idx[t / 3];
+        if (heldMask[v]) dst[3 * v + t % 3] = pack[t];
+    } else if (t < 3 * nI + ntail) {
+        tailp[t - 3 * nI] = pack[t];
+    }
+}
+void launch_pack_iface(int nI, const int *idx, const double *src, double *pack, const double *tailp, int ntail, hipStream_t st)
+{
+    const int tot = 3 * nI + ntail;
+    if (tot > 0) hipLaunchKernelGGL(pack_iface_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, nI, idx, src, pack, tailp, ntail);
+}
+void launch_unpack_iface(int nI, const int *idx, const double *pack, const uint8_t *heldMask, double *dst, double *tailp, int ntail,
+                         hipStream_t st)
+{
+    const int tot = 3 * nI + ntail;
+    if (tot > 0)
+        hipLaunchKernelGGL(unpack_iface_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, nI, idx, pack, heldMask, dst, tailp, ntail);
+}
+__global__ __launch_bounds__(256) void masked_norm2_kernel(int n, const double *__restrict__ v, const uint8_t *__restrict__ ownMask,
+                                                           double *__restrict__ partials)
+{
+    __shared__ double sm[4 * RED_K];
+    double acc[RED_K];
+#pragma unroll
+    for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
+    const int stride = gridDim.x * blockDim.x;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
+        if (ownMask[k / 3]) acc[0] += v[k] * v[k];
+    write_partials(acc, 1, partials, sm);
+}
+void launch_masked_norm2(int n, const double *v, const uint8_t *ownMask, double *partials, hipStream_t st)
+{
+    hipLaunchKernelGGL(masked_norm2_kernel, dim3(NB_RED), dim3(256), 0, st, n, v, ownMask, partials);
+}
+__global__ __launch_bounds__(256) void mask_owned_kernel(int n, double *__restrict__ v, const uint8_t *__restrict__ ownMask)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n && !ownMask[k / 3]) v[k] = 0.0;
+}
+void launch_mask_owned(int n, double *v, const uint8_t *ownMask, hipStream_t st)
+{
+    hipLaunchKernelGGL(mask_owned_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, v, ownMask);
+}
+
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
-                        const DevLoop *ctl, const double *zsum)
+                        const DevLoop *ctl, const double *zsum, const uint8_t *ownMask)
 {
     const bool split = !P.mt_ptr;
     hipLaunchKernelGGL(merge_tiles_early_kernel, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup, P.ppart,
                        first, zsum, split ? P.vp_ptr : nullptr, split ? P.vp_off : nullptr,
-                       split ? (const double *)P.psub : nullptr, z, partials, ctl);
+                       split ? (const double *)P.psub : nullptr, ownMask, z, partials, ctl);
 }
 
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
@@ -2654,7 +2716,8 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const in
 // lane group, pair j on lane j), (H p)_v = (H z)_v + sum_j delta_j (H s_j)[v] with the H s_j cached beside the s_j (H is fixed
 // during a step; H s_new = alpha H p is written by the vertex gather).  delta comes from the y_i . z partials in wave 0's
 // prologue (requested first, finished behind the column loop).  Device loop only.
-__global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, int v0, int v1, const int *__restrict__ adj_ptr,
+__global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, int v0, int v1, const uint8_t *__restrict__ rowMask,
+                                                      const uint8_t *__restrict__ ownMask, const int *__restrict__ adj_ptr,
                                                       const int *__restrict__ adj_idx,
                                                       const double *__restrict__ Hval, const double *__restrict__ z,
                                                       const double *__restrict__ c_partials, int c_blocks,
@@ -2732,7 +2795,7 @@ __global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, int v0, int v1, co
             if (v < nV) {
                 // sharded rows (N > 1 with the sharded element pass): p for every vertex, the product and the two dots only on
                 // this rank's rows [v0, v1) -- the others' H p (and cached H s_j) are never read
-                if (v >= v0 && v < v1) {
+                if (rowMask ? rowMask[v] != 0 : (v >= v0 && v < v1)) {
                     kb[u] = adj_ptr[v];
                     nk[u] = adj_ptr[v + 1] - kb[u];
                 }
@@ -2796,11 +2859,11 @@ __global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, int v0, int v1, co
             if (sub == 0 && v < nV) {
 #pragma unroll
                 for (int d = 0; d < 3; ++d) p[3 * v + d] = pv[d];
-                if (v >= v0 && v < v1) {
+                if (rowMask ? rowMask[v] != 0 : (v >= v0 && v < v1)) {
 #pragma unroll
                     for (int d = 0; d < 3; ++d) Hp[3 * v + d] = hp[d];
                     pHp += pv[0] * hp[0] + pv[1] * hp[1] + pv[2] * hp[2];
-                    pg += pv[0] * gg[u][0] + pv[1] * gg[u][1] + pv[2] * gg[u][2];
+                    if (!ownMask || ownMask[v]) pg += pv[0] * gg[u][0] + pv[1] * gg[u][1] + pv[2] * gg[u][2];
                 }
             }
         }
@@ -2820,11 +2883,12 @@ __global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, int v0, int v1, co
 }
 
 void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const double *c_partials, double *p, double *Hp,
-                    double *partials, hipStream_t st, const DevLoop *ctl, int v0, int v1)
+                    double *partials, hipStream_t st, const DevLoop *ctl, int v0, int v1, const uint8_t *rowMask,
+                    const uint8_t *ownMask)
 {
     if (v1 < 0) v1 = M.nV;
-    hipLaunchKernelGGL(spmv_zp_kernel, dim3(NB_RED), dim3(256), 0, st, M.nV, v0, v1, M.adj_ptr, M.adj_idx, Hval, z, c_partials,
-                       NB_RED, p, Hp, partials, ctl);
+    hipLaunchKernelGGL(spmv_zp_kernel, dim3(NB_RED), dim3(256), 0, st, M.nV, v0, v1, rowMask, ownMask, M.adj_ptr, M.adj_idx, Hval,
+                       z, c_partials, NB_RED, p, Hp, partials, ctl);
 }
 
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
@@ -3379,13 +3443,13 @@ __global__ __launch_bounds__(256) void assemble_kernel(int nnzb, const int *__re
 }
 
 void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st, const int *blist, int nList,
-                     const int *blk_ptr, const int *blk_ent)
+                     const int *blk_ptr, const int *blk_ent, const double *mass)
 {
     const long long tot = (long long)(blist ? nList : M.nnzb) * 9;
     if (tot <= 0) return;
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (int)(tot / 9),
-                       blist ? blk_ptr : M.blk_ptr, blist ? blk_ent : M.blk_ent, M.blk_row, M.adj_idx, M.fixed, M.mass, He,
-                       blist, Hval);
+                       blist ? blk_ptr : M.blk_ptr, blist ? blk_ent : M.blk_ent, M.blk_row, M.adj_idx, M.fixed,
+                       mass ? mass : M.mass, He, blist, Hval);
 }
 
 // dense principal sub-matrices: W_s[(3i+r)*lda + 3j+c] = H[l2g_i, l2g_j][r][c]

@@ -26,6 +26,7 @@ FLAG_TIME_PHASES = 16
 FLAG_GSDD = 32
 FLAG_NEWTON = 64
 FLAG_ASYNC_REFRESH = 128
+FLAG_OWNER_EXCHANGE = 256
 
 
 class Mesh(C.Structure):

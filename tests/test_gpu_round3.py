@@ -187,7 +187,7 @@ def test_asynchronous_refresh_changes_only_when_things_are_reported(workload, st
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("shard_elems", ["0", "1"])
+@pytest.mark.parametrize("shard_elems", ["0", "1", "owner"])
 @pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 6), ("bar17K_twist", 3)])
 def test_early_order_on_the_sharded_path_matches_the_single_rank_run(workload, steps, shard_elems):
     """The early back-solve with sharded subdomains: partial merge of this rank's subdomains into a staging buffer, the
@@ -197,10 +197,12 @@ def test_early_order_on_the_sharded_path_matches_the_single_rank_run(workload, s
     pair_stats writes -g into the right-hand sides and H s_new from the sum.  With the 1-rank communicator of
     DOTMI_FLAG_FORCE_DIST the sums are the single-rank ones taken in two steps: same iterations and halvings, positions to
     1e-9 (the multi-rank runs are in tests/test_gpu_two_ranks.py)."""
-    os.environ["DOTMI_SHARD_ELEMS"] = shard_elems
+    # "owner" (round 4): DOTMI_FLAG_OWNER_EXCHANGE on the 1-rank RCCL communicator -- packed (here: empty) interface vectors,
+    # the scalar all-reduces of 2 / 5 / 21 doubles, the partial operator of alpha_0, the positions made whole per step
+    os.environ["DOTMI_SHARD_ELEMS"] = "1" if shard_elems == "owner" else shard_elems
     try:
         sc, ep, n = load_workload(workload)
-        a = DOTTimeStepper(sc, ep, n, flags=dl.FLAG_FORCE_DIST)
+        a = DOTTimeStepper(sc, ep, n, flags=dl.FLAG_FORCE_DIST | (dl.FLAG_OWNER_EXCHANGE if shard_elems == "owner" else 0))
     finally:
         del os.environ["DOTMI_SHARD_ELEMS"]
     sc2, _, _ = load_workload(workload)
