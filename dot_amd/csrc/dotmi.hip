@@ -3744,7 +3744,11 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
         break;
     case DOTMI_BENCH_MERGE:              // z write + the tile partials that make it up + m history vectors (y_i . z)
         bytes = 8 * (int64_t)n * (2 + L.m) + 8 * (int64_t)h->mergeEntries;
-        run = [&] { launch_merge(h->M, h->P, L, h->z, h->partC, 1 | 2, h->st); };
+        // (split form, big meshes: the coalesced reduce of the tile partials is the first half of the merge)
+        run = [&] {
+            if (!h->P.mt_ptr) launch_reduce_partial(h->P, h->st);
+            launch_merge(h->M, h->P, L, h->z, h->partC, 1 | 2, h->st);
+        };
         break;
     case DOTMI_BENCH_BUILD_QPAD:         // g + m history vectors read, padded right-hand sides written
         bytes = 8 * (int64_t)n * (1 + L.m) + 8 * (int64_t)h->P.nParts * h->P.nmax;
@@ -3787,7 +3791,10 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
     case DOTMI_BENCH_MERGE_EARLY:        // tile partials + u_old read / written, z written, M y_new written, m x (y_j, M y_j) read
         bytes = 8 * (int64_t)h->mergeEntries + 8 * (int64_t)n * (4 + 2 * L.m);
         live = true;
-        run = [&] { launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl); };
+        run = [&] {
+            if (!h->P.mt_ptr) launch_reduce_partial(h->P, h->st, h->ctl);
+            launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl);
+        };
         break;
     case DOTMI_BENCH_ELEM_STEP: {        // the element pass with the line-search step inside: + p read, trial point written
         bytes = 112 * nTo + 56 * nVo + 48 * (int64_t)nV;

@@ -247,6 +247,7 @@ void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, c
                        const DevLoop *ctl = nullptr, int spec = 0);
 // early back-solve: u = merge(tile partials) / dup = -M g;  M y of the newest pair = u_old - u;  z = u - sum_j xi_j M y_j
 // (+ partial dots y_i . z);  first: start of the step (no history, u_old is only set)
+void launch_reduce_partial(const DevParts &P, hipStream_t st, const DevLoop *ctl = nullptr);
 // zsum: the all-reduced sum (over all ranks' subdomains) of the undivided partial merges, in a staging buffer
 // ownMask (owner exchange): the y_i . z partials over the vertices this rank owns only
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,

@@ -1414,9 +1414,14 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
         hipLaunchKernelGGL((backsolve_long_kernel<1>), dim3(P.nlwork), dim3(BSL_THREADS), 0, st, P.ltile, P.lwork, P.dofmap,
                            P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl, spec);
     }
-    if (!P.mt_ptr)   // merge_tiles_kernel sums the tile partials itself
-        hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.trange,
-                           P.ppart, P.nmax, P.nbmax, P.psub, ctl, 0);
+    if (!P.mt_ptr) launch_reduce_partial(P, st, ctl);   // (merge_tiles_kernel sums the tile partials itself)
+}
+// the tile partials of every owned subdomain summed in the subdomains' own order (coalesced) -> psub
+void launch_reduce_partial(const DevParts &P, hipStream_t st, const DevLoop *ctl)
+{
+    if (P.nParts > 0)
+        hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.trange, P.ppart,
+                           P.nmax, P.nbmax, P.psub, ctl, 0);
 }
 
 // p[dofmap_s[k]] = psub_s[k] on the live positions of part s (p was cleared by the caller)

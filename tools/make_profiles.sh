@@ -6,6 +6,7 @@ out=/root/repo/gpurun_out
 mkdir -p $out
 timeout 900 python /root/repo/bench.py > $out/${tag}_bench.log 2>&1
 grep '^{' $out/${tag}_bench.log | tail -1 > $out/${tag}_bench.json
+cp bench_detail.json $out/${tag}_bench_detail.json 2>/dev/null || cp /root/repo/bench_detail.json $out/${tag}_bench_detail.json
 for wl in bar17K_twist bunny5K_LTSS synbar:140x35x35:256; do
   slug=$(echo $wl | tr ':x@' '___')
   steps=20; [ "$slug" != "${slug#synbar}" ] && steps=6
