@@ -267,6 +267,9 @@ struct dotmi_handle {
     uint8_t *ownMask = nullptr, *heldMask = nullptr;   // nV: this rank owns the vertex / holds it in one of its subdomains
     int *ifaceIdx = nullptr;               // the vertices held by more than one rank (the same list on every rank), ascending
     int nIface = 0;
+    int *heldList = nullptr;               // the held vertices, ascending: the loop's vector kernels visit only these
+    int nHeld = 0;
+    VList held() const { return owner ? VList{heldList, nHeld} : VList(); }
     double *xpack = nullptr;               // 3 nIface + 8 doubles: the packed entries (+ E) that travel
     double *massOwn = nullptr;             // nV: lumped mass on the owned vertices, 0 elsewhere
     double *HvalOwn = nullptr;             // block-CSR values of this rank's OWN elements' part of H (+ massOwn): alpha_0's p.Hp
@@ -1230,6 +1233,12 @@ int build_device_mesh(dotmi_handle *h)
         }
         h->nIface = (int)iface.size();
         if (iface.empty()) iface.push_back(0);
+        std::vector<int> hl;
+        for (int v = 0; v < nV; ++v)
+            if (held[v]) hl.push_back(v);
+        h->nHeld = (int)hl.size();
+        if (hl.empty()) hl.push_back(0);
+        if (int rc = upload(h, &h->heldList, hl)) return rc;
         if (int rc = upload(h, &h->ownMask, own)) return rc;
         if (int rc = upload(h, &h->heldMask, held)) return rc;
         if (int rc = upload(h, &h->ifaceIdx, iface)) return rc;
@@ -1974,7 +1983,8 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     const bool se = h->shardElems;   // sharded element pass: this rank's rows of H, its elements; three collectives per slot
     const bool ow = h->owner;        // owner exchange: only the entries of shared vertices travel, dots are owner-summed scalars
     if (ow) {
-        launch_spmv_zp(h->M, h->HvalOwn, h->z, h->partGC, h->p, h->Hp, h->partS, h->st, h->ctl, 0, -1, h->heldMask, h->ownMask);
+        launch_spmv_zp(h->M, h->HvalOwn, h->z, h->partGC, h->p, h->Hp, h->partS, h->st, h->ctl, 0, -1, h->heldMask, h->ownMask,
+                       h->held());
     } else if (fuseDir) {   // build_p + spmv_dots in one launch, H p from the cached H s_j
         launch_spmv_zp(h->M, h->Hval, h->z, h->partC, h->p, h->Hp, h->partS, h->st, h->ctl, se ? h->v0 : 0, se ? h->v1 : -1);
     } else {
@@ -1998,7 +2008,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st, h->ctl,
                                 &sa);
     } else {
-        launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st, h->ctl);
+        launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st, h->ctl, h->held());
         launch_elem_energy_grad(ow ? h->Mown : h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, ow ? 0 : h->v0, ow ? h->nV : h->v1,
                                 1, h->partE, &nb, h->st, h->ctl);
     }
@@ -2029,6 +2039,8 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         ag.vp_ptr = ag.vp_off = nullptr;
         ag.rpad = nullptr;
         ag.ownMask = ow ? h->ownMask : nullptr;
+        ag.vlist = ow ? h->heldList : nullptr;
+        ag.nlist = ow ? h->nHeld : 0;
         launch_vertex_gather(h->M, h->PT, ag, L0, h->partR, h->st, h->ctl);
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
                            h->gstage + n + 1);
@@ -2038,6 +2050,8 @@ int enqueue_loop_slot_early(dotmi_handle *h)
             // the gradient is complete on the vertices only this rank holds; the shared ones (and E) are summed
             if (int rc = exchange_iface(h, h->gstage, h->gstage + n + 1, 1)) return rc;
             a.ownMask = h->ownMask;   // pair_stats: the statistics over the owned vertices ...
+            a.vlist = h->heldList;
+            a.nlist = h->nHeld;
         }
         launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
         if (ow)   // ... summed over the ranks before the controller reads them
@@ -2063,7 +2077,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         // whatever the controller decided: every rank enqueues the same sequence), then the division and the history terms
         // (the sum travels in a staging buffer: in a slot whose merge is gated off -- retry, past the end -- the collective
         // still runs, on stale scratch, and z is left alone)
-        launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl);
+        launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl, h->held());
         if (!ow) {
             if (int rc = allreduce_sum(h, h->zstage, n)) return rc;
             launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage);
@@ -2072,7 +2086,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
             // are summed over the ranks.  z is then whole on the held vertices and zero elsewhere -- and so is everything
             // the loop forms from it.  The y_i . z of the owned vertices travel as five scalars.
             if (int rc = exchange_iface(h, h->zstage, nullptr, 0)) return rc;
-            launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage, h->ownMask);
+            launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage, h->ownMask, h->held());
             if (int rc = allreduce_columns(h, h->partC, HIST_MAX, h->partGC)) return rc;
         }
     }
@@ -2214,6 +2228,11 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
         a.iv0 = h->v0;
         a.iv1 = h->v1;
         a.ownMask = h->owner ? h->ownMask : nullptr;
+        a.vlist = h->owner ? h->heldList : nullptr;
+        a.nlist = h->owner ? h->nHeld : 0;
+        // owner exchange: the loop only touches the held vertices' entries; the trial buffer starts as a copy of the iterate
+        // (the two swap roles on every accepted trial and must agree off the held set)
+        if (h->owner) HIPCHECK(h, hipMemcpyAsync(h->x_trial, h->x, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->st));
         LbfgsArgs L0;
         memset(&L0, 0, sizeof(L0));
         if (h->earlyNow && !h->shardElems) {   // -g_0 straight into the padded right-hand sides (their padding entries stay zero)
@@ -2265,13 +2284,13 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
                 launch_gemv(h->P, nullptr, h->st, h->ctl, nullptr, nullptr, h->tune.earlyHostCtl ? &ca : nullptr, 1 << 30);
                 if (!h->tune.earlyHostCtl)
                     launch_loop_control(h->ctl, h->gstage + n_, 1, ctlR, h->alpha_dev, h->h_flags, h->st, 1);
-                launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl);
+                launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl, h->held());
                 if (!h->owner) {
                     if (int rc = allreduce_sum(h, h->zstage, n_)) return rc;
                     launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage);
                 } else {
                     if (int rc = exchange_iface(h, h->zstage, nullptr, 0)) return rc;
-                    launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage, h->ownMask);
+                    launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage, h->ownMask, h->held());
                     if (int rc = allreduce_columns(h, h->partC, HIST_MAX, h->partGC)) return rc;
                 }
             }
@@ -3024,8 +3043,10 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
             return DOTMI_E_INVALID;
         }
         if (h->earlyBs && h->tune.fuseStep && !h->shardElems) h->PT.wgCap = 512;   // the trials' grouping of the energy partials, everywhere
-        if (h->dist)
+        if (h->dist) {
             if (int rc = dalloc(h, &h->zstage, (size_t)h->n)) return rc;
+            HIPCHECK(h, hipMemsetAsync(h->zstage, 0, sizeof(double) * h->n, h->st));   // (owner exchange: stays zero off the held set)
+        }
         if (h->earlyBs) {
             if (int rc = dalloc(h, &h->u_old, (size_t)h->n)) return rc;
             for (int sl = 0; sl <= h->hist; ++sl) {

@@ -178,6 +178,12 @@ struct DevLoop {
     // H s_i of the stored pairs (same slots as S): H p = H z + sum_j delta_j (H s_j), H s_new = alpha H p (spmv_zp_kernel)
     double *HS[HIST_MAX + 1];
 };
+// owner exchange: the vertices a rank holds -- the vector kernels of the loop then visit only these (everything else is zero
+// and stays zero); v == nullptr: every vertex
+struct VList {
+    const int *v = nullptr;
+    int n = 0;
+};
 // the controller's operands when it runs as one workgroup of another launch (launch_gemv)
 struct CtlArgs {
     DevLoop *ctl;
@@ -194,7 +200,7 @@ struct CtlArgs {
 // x = x0 + alpha * p; alpha = alpha_scale * clamp(-pg/pHp) from SpMV partials when use_partials
 void launch_step_forward(int n, const double *x0, const double *p, double *x, const double *spmv_partials,
                          double alpha_host, int use_partials, double alpha_min, double *alpha_out,
-                         double *alpha_out_host, hipStream_t st, const DevLoop *ctl = nullptr);
+                         double *alpha_out_host, hipStream_t st, const DevLoop *ctl = nullptr, VList vl = VList());
 // element pass: partial energy sums (+ inertia) and, optionally, element gradients
 // grad != 0: the per-(patch, vertex) partial gradients go to PT.gpart (read by launch_vertex_gather)
 // step (device loop only): the line-search step x_trial = x_cur + alpha p is taken inside the element pass
@@ -223,6 +229,8 @@ struct GatherArgs {
     // owner exchange (DOTMI_FLAG_OWNER_EXCHANGE): this rank adds the inertia term of the vertices it OWNS (instead of a slice
     // [iv0, iv1)) and pair_stats sums its statistics over them only (every vertex counted once over the ranks)
     const uint8_t *ownMask;
+    const int *vlist;   // owner exchange: the held vertices (the gather and pair_stats visit only these); nullptr: all
+    int nlist;
 };
 void launch_vertex_gather(const DevMesh &M, const DevPatches &PT, const GatherArgs &a, const LbfgsArgs &L,
                           double *partials, hipStream_t st, const DevLoop *ctl = nullptr);
@@ -251,7 +259,7 @@ void launch_reduce_partial(const DevParts &P, hipStream_t st, const DevLoop *ctl
 // zsum: the all-reduced sum (over all ranks' subdomains) of the undivided partial merges, in a staging buffer
 // ownMask (owner exchange): the y_i . z partials over the vertices this rank owns only
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
-                        const DevLoop *ctl, const double *zsum = nullptr, const uint8_t *ownMask = nullptr);
+                        const DevLoop *ctl, const double *zsum = nullptr, const uint8_t *ownMask = nullptr, VList vl = VList());
 // owner exchange: the entries of the vertices held by more than one rank, packed / unpacked (idx: their vertex ids);
 // tail: `ntail` further scalars copied from / to tailp behind the packed entries
 void launch_pack_iface(int nI, const int *idx, const double *src, double *pack, const double *tailp, int ntail, hipStream_t st);
@@ -266,7 +274,7 @@ void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, con
                       int n, double *p, hipStream_t st);
 // z = merge(psub) / dup  (+ partial dots y_i . z)
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
-                  int with_dots, hipStream_t st, const DevLoop *ctl = nullptr);
+                  int with_dots, hipStream_t st, const DevLoop *ctl = nullptr, VList vl = VList());
 // partial dots y_i . z only (multi-GPU path after all-reduce)
 // p = z + sum_j delta_j s_j, delta from c partials, xi and SY
 void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_partials,
@@ -279,7 +287,7 @@ void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_
 // p.Hp over them, p.g over the vertices it owns
 void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const double *c_partials, double *p, double *Hp,
                     double *partials, hipStream_t st, const DevLoop *ctl, int v0 = 0, int v1 = -1,
-                    const uint8_t *rowMask = nullptr, const uint8_t *ownMask = nullptr);
+                    const uint8_t *rowMask = nullptr, const uint8_t *ownMask = nullptr, VList vl = VList());
 // Hp = H p on rows [v0,v1), partial sums of p.g and p.Hp
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
                       int v0, int v1, double *partials, hipStream_t st, const DevLoop *ctl = nullptr);

@@ -33,6 +33,10 @@ namespace dotmi {
 // ------------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------------
+// held-vertex lists (dotmi_internal.hpp VList): logical index -> vertex / scalar dof
+__device__ __forceinline__ int vl_count3(const VList &L, int n3) { return L.v ? 3 * L.n : n3; }
+__device__ __forceinline__ int vl_dof(const VList &L, int i) { return L.v ? 3 * L.v[i / 3] + i % 3 : i; }
+__device__ __forceinline__ int vl_vtx(const VList &L, int j) { return L.v ? L.v[j] : j; }
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -562,16 +566,18 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
 #pragma unroll
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
     const double alpha = a.make_pair ? *a.alpha_dev : 0.0;
-    const int n = 3 * nV, G = gridDim.x * blockDim.x;
+    const VList vl{a.vlist, a.nlist};   // owner exchange: only the held vertices are visited
+    const int n = vl_count3(vl, 3 * nV), G = gridDim.x * blockDim.x;
     constexpr int R = GATHER_R;
     for (int kbase = blockIdx.x * blockDim.x + threadIdx.x; kbase < n; kbase += R * G) {
         double gn[R], ine[R], gold[R], pk[R], si[R][HIST_MAX], yi[R][HIST_MAX];
-        int kb[R], ke[R], dd[R], cb[R], ce[R];
+        int kb[R], ke[R], dd[R], cb[R], ce[R], kk[R];
         bool live[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            const int k = kbase + u * G;
-            live[u] = k < n;
+            live[u] = kbase + u * G < n;
+            const int k = live[u] ? vl_dof(vl, kbase + u * G) : 0;
+            kk[u] = k;
             gn[u] = ine[u] = gold[u] = pk[u] = 0.0;
             kb[u] = ke[u] = dd[u] = cb[u] = ce[u] = 0;
             if (live[u]) {
@@ -625,7 +631,7 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             if (!live[u]) continue;
-            const int k = kbase + u * G;
+            const int k = kk[u];
             const double g = gn[u] + ine[u];
             a.g_new[k] = g;
 #pragma unroll
@@ -694,7 +700,10 @@ __global__ __launch_bounds__(256) void pair_stats_kernel(int n, GatherArgs a, Lb
     if constexpr (DEV) {
         if (a.hp) hs_new = ctl->HS[ctl->slot];
     }
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) {
+    const VList vl{a.vlist, a.nlist};
+    const int cnt = vl_count3(vl, n);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
+        const int k = vl_dof(vl, i);
         const double gn = gsrc ? gsrc[k] : a.g_new[k];
         if (gsrc) a.g_new[k] = gn;
         const double sn = alpha * a.p[k];
@@ -2233,7 +2242,7 @@ __global__ __launch_bounds__(256) void merge_kernel(int nV, const int *__restric
                                                     const double *__restrict__ psub, LbfgsArgs L,
                                                     int with_dots, int divide, double *__restrict__ z,
                                                     double *__restrict__ partials,
-                                                    const DevLoop *__restrict__ ctl)
+                                                    const DevLoop *__restrict__ ctl, VList vl)
 {
     __shared__ double sm[4 * RED_K];
     if constexpr (DEV) {
@@ -2247,7 +2256,9 @@ __global__ __launch_bounds__(256) void merge_kernel(int nV, const int *__restric
 #pragma unroll
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
     const int stride = gridDim.x * blockDim.x;
-    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nV; v += stride) {
+    const int nvis = vl.v ? vl.n : nV;
+    for (int jv = blockIdx.x * blockDim.x + threadIdx.x; jv < nvis; jv += stride) {
+        const int v = vl_vtx(vl, jv);
         double z0 = 0, z1 = 0, z2 = 0;
         const int k0 = vp_ptr[v], k1 = vp_ptr[v + 1];
         // everything that does not depend on the slot list is requested before it is walked
@@ -2313,7 +2324,7 @@ __global__ __launch_bounds__(256) void merge_tiles_kernel(int n3, const int *__r
                                                           const int *__restrict__ mt_ent, const int *__restrict__ dup,
                                                           const double *__restrict__ ppart, LbfgsArgs L, int with_dots,
                                                           int divide, double *__restrict__ z,
-                                                          double *__restrict__ partials, const DevLoop *__restrict__ ctl)
+                                                          double *__restrict__ partials, const DevLoop *__restrict__ ctl, VList vl)
 {
     __shared__ double sm[4 * RED_K];
     if constexpr (DEV) {
@@ -2327,7 +2338,9 @@ __global__ __launch_bounds__(256) void merge_tiles_kernel(int n3, const int *__r
 #pragma unroll
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
     const int stride = gridDim.x * blockDim.x;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += stride) {
+    const int cnt = vl_count3(vl, n3);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
+        const int k = vl_dof(vl, i);
         const int e0 = mt_ptr[k], e1 = mt_ptr[k + 1];
         const int d = divide ? dup[k / 3] : 1;
         double yk[HIST_MAX];
@@ -2382,7 +2395,7 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
                                                                 const double *__restrict__ zsum,
                                                                 const int *__restrict__ vp_ptr, const int *__restrict__ vp_off,
                                                                 const double *__restrict__ psub,
-                                                                const uint8_t *__restrict__ ownMask,
+                                                                const uint8_t *__restrict__ ownMask, VList vl,
                                                                 double *__restrict__ z, double *__restrict__ partials,
                                                                 const DevLoop *__restrict__ ctl)
 {
@@ -2405,7 +2418,9 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
 #pragma unroll
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
     const int stride = gridDim.x * blockDim.x;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n3; k += stride) {
+    const int cnt = vl_count3(vl, n3);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
+        const int k = vl_dof(vl, i);
         const int vtx = k / 3;
         int e0 = 0, e1 = 0, c0 = 0, c1 = 0;
         if (psub) {
@@ -2539,33 +2554,33 @@ void launch_mask_owned(int n, double *v, const uint8_t *ownMask, hipStream_t st)
 }
 
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
-                        const DevLoop *ctl, const double *zsum, const uint8_t *ownMask)
+                        const DevLoop *ctl, const double *zsum, const uint8_t *ownMask, VList vl)
 {
     const bool split = !P.mt_ptr;
     hipLaunchKernelGGL(merge_tiles_early_kernel, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup, P.ppart,
                        first, zsum, split ? P.vp_ptr : nullptr, split ? P.vp_off : nullptr,
-                       split ? (const double *)P.psub : nullptr, ownMask, z, partials, ctl);
+                       split ? (const double *)P.psub : nullptr, ownMask, vl, z, partials, ctl);
 }
 
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
-                  int with_dots, hipStream_t st, const DevLoop *ctl)
+                  int with_dots, hipStream_t st, const DevLoop *ctl, VList vl)
 {
     if (P.mt_ptr) {   // (launch_gemv left the tile partials in ppart and skipped the reduce)
         if (ctl)
             hipLaunchKernelGGL(merge_tiles_kernel<true>, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup,
-                               P.ppart, L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl);
+                               P.ppart, L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl, vl);
         else
             hipLaunchKernelGGL(merge_tiles_kernel<false>, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup,
-                               P.ppart, L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl);
+                               P.ppart, L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl, vl);
         return;
     }
     // with_dots: bit0 = accumulate y_i.z partials, bit1 = divide by dup
     if (ctl)
         hipLaunchKernelGGL(merge_kernel<true>, dim3(NB_RED), dim3(256), 0, st, M.nV, P.vp_ptr, P.vp_off, P.dup, P.psub,
-                           L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl);
+                           L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl, vl);
     else
         hipLaunchKernelGGL(merge_kernel<false>, dim3(NB_RED), dim3(256), 0, st, M.nV, P.vp_ptr, P.vp_off, P.dup, P.psub,
-                           L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl);
+                           L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl, vl);
 }
 
 // Sharded subdomains: z holds the all-reduced SUM over every subdomain; z_v /= dup_v and the partial dots c_i = y_i . z,
@@ -2727,7 +2742,7 @@ __global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, int v0, int v1, co
                                                       const double *__restrict__ Hval, const double *__restrict__ z,
                                                       const double *__restrict__ c_partials, int c_blocks,
                                                       double *__restrict__ p, double *__restrict__ Hp,
-                                                      double *__restrict__ partials, const DevLoop *__restrict__ ctl)
+                                                      double *__restrict__ partials, const DevLoop *__restrict__ ctl, VList vl)
 {
     __shared__ double sm[8];
     __shared__ double delta[HIST_MAX];
@@ -2787,13 +2802,16 @@ __global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, int v0, int v1, co
             hist_hs = ctl->HS[ctl->order[j]];
         }
     // (the trip count is the same for every thread of a workgroup: finish_delta's barrier sits inside the first trip)
-    for (int base = blockIdx.x * 32; base < nV; base += R * ngroups) {
+    const int nrows = vl.v ? vl.n : nV;   // owner exchange: the rows of the held vertices only (p is zero elsewhere)
+    for (int base = blockIdx.x * 32; base < nrows; base += R * ngroups) {
         const int vbase = base + (threadIdx.x >> 3);
         double a[R][3], zv[R][3], gg[R][3], sv[R][3], hv[R][3];   // sv / hv: pair number `sub` of the history (lanes 0 .. m-1)
-        int kb[R], nk[R], nkmax = 0;
+        int kb[R], nk[R], vv[R], nkmax = 0;
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            const int v = vbase + u * ngroups;
+            const int jv = vbase + u * ngroups;
+            const int v = jv < nrows ? vl_vtx(vl, jv) : nV;
+            vv[u] = v;
             kb[u] = nk[u] = 0;
 #pragma unroll
             for (int d = 0; d < 3; ++d) a[u][d] = zv[u][d] = gg[u][d] = sv[u][d] = hv[u][d] = 0.0;
@@ -2853,7 +2871,7 @@ __global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, int v0, int v1, co
         if (!haveDelta) finish_delta();
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-            const int v = vbase + u * ngroups;
+            const int v = vv[u];
             // (H p)_v = sum over the group of [its columns' part of (H z)_v + delta_j (H s_j)_v];  p_v = z_v + sum_j delta_j s_j[v]
             double pv[3], hp[3];
 #pragma unroll
@@ -2889,11 +2907,11 @@ __global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, int v0, int v1, co
 
 void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const double *c_partials, double *p, double *Hp,
                     double *partials, hipStream_t st, const DevLoop *ctl, int v0, int v1, const uint8_t *rowMask,
-                    const uint8_t *ownMask)
+                    const uint8_t *ownMask, VList vl)
 {
     if (v1 < 0) v1 = M.nV;
     hipLaunchKernelGGL(spmv_zp_kernel, dim3(NB_RED), dim3(256), 0, st, M.nV, v0, v1, rowMask, ownMask, M.adj_ptr, M.adj_idx, Hval,
-                       z, c_partials, NB_RED, p, Hp, partials, ctl);
+                       z, c_partials, NB_RED, p, Hp, partials, ctl, vl);
 }
 
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
@@ -2910,7 +2928,7 @@ __global__ __launch_bounds__(256) void step_forward_kernel(int n, const double *
                                                            double alpha_host, int use_partials,
                                                            double alpha_min, double *__restrict__ alpha_out,
                                                            double *__restrict__ alpha_out_host,
-                                                           const DevLoop *__restrict__ ctl)
+                                                           const DevLoop *__restrict__ ctl, VList vl)
 {
     __shared__ double sh_alpha;
     if (ctl) {
@@ -2943,17 +2961,22 @@ __global__ __launch_bounds__(256) void step_forward_kernel(int n, const double *
     __syncthreads();
     const double alpha = sh_alpha;
     const int stride = gridDim.x * blockDim.x;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride) x[k] = x0[k] + alpha * p[k];
+    const int cnt = vl_count3(vl, n);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
+        const int k = vl_dof(vl, i);
+        x[k] = x0[k] + alpha * p[k];
+    }
 }
 
 void launch_step_forward(int n, const double *x0, const double *p, double *x, const double *spmv_partials,
                          double alpha_host, int use_partials, double alpha_min, double *alpha_out,
-                         double *alpha_out_host, hipStream_t st, const DevLoop *ctl)
+                         double *alpha_out_host, hipStream_t st, const DevLoop *ctl, VList vl)
 {
-    int nb = (n + 255) / 256;
+    int nb = ((vl.v ? 3 * vl.n : n) + 255) / 256;
     if (nb > 1024) nb = 1024;
+    if (nb < 1) nb = 1;
     hipLaunchKernelGGL(step_forward_kernel, dim3(nb), dim3(256), 0, st, n, x0, p, x, spmv_partials,
-                       alpha_host, use_partials, alpha_min, alpha_out, alpha_out_host, ctl);
+                       alpha_host, use_partials, alpha_min, alpha_out, alpha_out_host, ctl, vl);
 }
 
 // ------------------------------------------------------------------------------------------------
