@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dot_amd.workloads import load_workload
 from dot_amd.timestepper import DOTTimeStepper
-sc, ep, n = load_workload("bar17K_twist")
+sc, ep, n = load_workload(sys.argv[1] if len(sys.argv) > 1 else "bar17K_twist")
 ts = DOTTimeStepper(sc, ep, n)
 T = {k: 0.0 for k in ("getResult", "script", "setDirichlet", "step_wall", "step_ms_total", "loop", "hess", "fact")}
 N = 20
