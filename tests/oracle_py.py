@@ -304,12 +304,31 @@ def ref():
     return _ref
 
 
-def use_reference_svd(on: bool):
+_ref_nofma = None
+
+
+def ref_nofma_available():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "librefpin_nofma.so"))
+
+
+def ref_nofma():
+    """the same reference sources compiled with -ffp-contract=off (oracle/Makefile)"""
+    global _ref_nofma
+    if _ref_nofma is None:
+        R = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "librefpin_nofma.so"))
+        R.ref_svd.argtypes = [C.c_int, c_dp, c_dp, c_dp, c_dp]
+        R.ref_svd.restype = C.c_int
+        _ref_nofma = R
+    return _ref_nofma
+
+
+def use_reference_svd(on: bool, contracted: bool = True):
     """Route every simulation-level SVD of the oracle through the reference's own AVX kernel (librefpin.so:ref_svd,
-    Utils/SVD_EFTYCHIOS compiled in place) -- or back to dor_svd3."""
+    Utils/SVD_EFTYCHIOS compiled in place; contracted=False: the build without FMA contraction) -- or back to dor_svd3."""
     L = lib()
     L.dor_set_svd_batch.argtypes = [C.c_void_p]
-    L.dor_set_svd_batch(C.cast(ref().ref_svd, C.c_void_p) if on else None)
+    R = ref() if contracted else ref_nofma()
+    L.dor_set_svd_batch(C.cast(R.ref_svd, C.c_void_p) if on else None)
 
 
 _refsolver = None

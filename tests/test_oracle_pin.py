@@ -318,6 +318,54 @@ def test_published_bar17K_as_shipped_list_needs_the_references_svd_rounding():
     assert 0.85 < frac < 0.90 and d.max() < 0.3
 
 
+@pytest.mark.skipif(not (O.ref_available() and O.ref_nofma_available()), reason="oracle/_ref not built (needs /root/reference)")
+def test_the_published_list_belongs_to_the_fma_contraction_of_the_reference_build():
+    """Round 4: why no device mode "follows the reference's SVD sequence".  The reference's SVD kernel is
+    written as separate _mm256_mul_pd / _mm256_add_pd; its CMake flags (-O3 -mavx2 -mfma) let GCC contract them into 1087
+    vfmadd instructions.  The SAME kernel compiled with -ffp-contract=off -- the operation sequence as written, which is what a
+    device restatement of the source would compute -- agrees with the contracted build on the bits of sigma for only about
+    half of near-identity inputs, moves a fifth of the rest-state element Hessians, and takes 8 iterations on step 0 of the
+    shipped bar17K script where the contracted build takes the published 9.  The published lists are therefore a property
+    of one compiler's contraction choices; reproducing them on the device means mirroring those 1087 placements."""
+    rng = np.random.default_rng(0)
+    n = 8192
+    F = np.tile(np.eye(3).ravel(), (n, 1)) + rng.standard_normal((n, 9)) * 1.1e-16
+    S = {}
+    for name, R in (("fma", O.ref()), ("nofma", O.ref_nofma())):
+        U, Sg, V = np.zeros((n, 9)), np.zeros((n, 3)), np.zeros((n, 9))
+        assert R.ref_svd(n, dp(F), dp(U), dp(Sg), dp(V)) == 0
+        S[name] = Sg
+        A = np.einsum("nij,nj,nkj->nik", U.reshape(n, 3, 3), Sg, V.reshape(n, 3, 3))
+        assert np.abs(A - F.reshape(n, 3, 3)).max() < 1e-9          # both are SVDs of F
+    same = np.all(S["fma"] == S["nofma"], axis=1).mean()
+    assert 0.3 < same < 0.8, same                                    # measured 0.56
+    from tests.workloads import load_workload
+
+    def first_step(contracted):
+        sc, ep, npart = load_workload("bar17K_twist", 6)
+        sc.cfg.energy = "FCR"
+        cfg = sc.cfg
+        O.use_reference_svd(True, contracted=contracted)
+        try:
+            sim = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, npart,
+                              cfg.with_gravity)
+            He = np.zeros((sc.T.shape[0], 144))
+            O.lib().dor_eval_elem_hessians(sim.h, dp(np.ascontiguousarray(sc.x0)), dp(He))
+            idx, pos = sc.scripter.step(sim.state()[0], cfg.dt)
+            sim.move(idx, pos)
+            it = sim.step().iters
+            sim.close()
+        finally:
+            O.use_reference_svd(False)
+        return it, He
+
+    it_fma, He_fma = first_step(True)
+    it_nofma, He_nofma = first_step(False)
+    assert it_fma == 9 and it_nofma == 8       # BASELINE.md section 2 publishes 9
+    d = np.abs(He_fma - He_nofma).max(1) / np.abs(He_fma).max(1)
+    assert 0.1 < (d > 1e-6).mean() < 0.35      # measured 0.204
+
+
 # ---- round 4: the oracle stepping on the reference's own subdomain solver (bench.py's second CPU leg) -------------------
 @pytest.mark.skipif(not O.ref_solver_available(), reason="oracle/_ref/librefsolver.so or the image's MKL not present")
 @pytest.mark.parametrize("workload,steps", [("bunny5K_LTSS", 3), ("synbar:12x4x4:6", 3)])
