@@ -164,6 +164,13 @@ def main():
                    "backsolve": pick("backsolve", total=True), "merge": pick("merge", "<false>"),
                    "build_qpad": pick("build_qpad", "<false>"), "build_p": pick("build_p", "<false>"),
                    "step_forward": pick("step_forward"), "elem_hessian": pick("elem_hessian"), "assemble": pick("assemble")}
+            # big meshes (split merge): the coalesced reduce of the tile partials is the first half of either merge form
+            rp = pick("reduce_partial")
+            if rp:
+                if out.get("merge_early"):
+                    out["merge_early"] += rp
+                if not out.get("merge") and pick("merge_split"):
+                    out["merge"] = pick("merge_split") + rp
             return {k: v for k, v in out.items() if v}, os.path.relpath(f, ROOT)
         return {}, None
 

@@ -13,7 +13,7 @@ done
 python - "$wl" /root/repo/gpurun_out/${tag}_pmc_${slug}.json <<'PY'
 import csv, glob, json, sys, collections
 CLASSES = [("elem_patch_kernel", "elem_pass"), ("vertex_gather_kernel", "vertex_gather"), ("spmv_dots_kernel", "spmv_dots"),
-           ("backsolve_kernel", "backsolve"), ("merge_tiles_kernel", "merge"), ("merge_tiles_early_kernel", "merge_early"),
+           ("backsolve_kernel", "backsolve"), ("merge_tiles_kernel", "merge"), ("merge_tiles_early_kernel", "merge_early"), ("merge_kernel", "merge_split"), ("reduce_partial_p_kernel", "reduce_partial"),
            ("spmv_zp_kernel", "spmv_zp"), ("build_qpad_kernel", "build_qpad"),
            ("build_p_kernel", "build_p"), ("step_forward_kernel", "step_forward"), ("elem_hessian_kernel", "elem_hessian"),
            ("assemble_kernel", "assemble"), ("tile_task_kernel", "tile_task"), ("dense_fill_kernel", "dense_fill")]
