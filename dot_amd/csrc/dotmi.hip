@@ -968,8 +968,12 @@ int build_device_mesh(dotmi_handle *h)
         }
         // eager partial updates shorten the launches of a latency-bound factorisation (few subdomains) and cost tile
         // traffic in a throughput-bound one (measured: profiles/r03_factor_tiles.txt)
-        const int eagerMin = h->tune.tileEagerMin > 0 ? h->tune.tileEagerMin : (P.nParts <= 64 ? 4 : 8);
-        const int eagerChunk = h->tune.tileEagerChunk > 0 ? h->tune.tileEagerChunk : (P.nParts <= 64 ? 4 : 8);
+        // (round 4: with very few tile columns in total -- bunny5K: 8 x 32 -- the chain of dependent tasks is all there is, and
+        // the dataflow launch runs finer eager tasks at no barrier cost: 2 / 2 there, factor 0.43 -> 0.39 ms; horse7K, 8 x 47,
+        // keeps 4 / 4)
+        const bool tiny = (long long)P.nParts * nt <= 320;
+        const int eagerMin = h->tune.tileEagerMin > 0 ? h->tune.tileEagerMin : (tiny ? 2 : P.nParts <= 64 ? 4 : 8);
+        const int eagerChunk = h->tune.tileEagerChunk > 0 ? h->tune.tileEagerChunk : (tiny ? 2 : P.nParts <= 64 ? 4 : 8);
         TileSchedule S;
         for (int pass = 0; pass < 2; ++pass) {
             std::vector<TileTaskL> all;
