@@ -83,7 +83,11 @@ def compact_line(full):
         out["workloads"] = [{"name": w["workload"], "ms_per_step": w["ms_per_step"], "iters": w["iters_per_frame"],
                              "backsolve_frac": w["roofline"]["frac"],
                              "factor_ms": w["step_breakdown_ms"]["subdomain_factor"],
-                             "factor_frac": (w.get("roofline_factor") or {}).get("frac")} for w in full["workloads"]]
+                             "factor_frac": (w.get("roofline_factor") or {}).get("frac"),
+                             **({"allreduce_per_step": w["collectives"]["allreduce_calls_per_step"],
+                                 "payload_MB_per_step": w["collectives"]["payload_MB_per_step"]} if "collectives" in w else {})}
+                            if "error" not in w else {"name": w["workload"], "error": w["error"][:120]}
+                            for w in full["workloads"]]
     out["detail"] = "bench_detail.json"
     return out
 
@@ -394,7 +398,13 @@ def main():
             if name == args.workload:
                 continue
             st_, wu_ = EXTRA_STEPS.get(name.replace("+owner", ""), (6, 2))
-            r2 = run_workload(name, st_, wu_)[0]
+            try:
+                r2 = run_workload(name, st_, wu_)[0]
+            except Exception as e:   # noqa: BLE001  (an extra workload must not cost the line its headline)
+                if name.endswith("+owner"):
+                    extra.append({"workload": name, "error": repr(e)})
+                    continue
+                raise
             r2.pop("_ns", None)
             extra.append(r2)
 
