@@ -1867,6 +1867,17 @@ __device__ __forceinline__ void mfma_acc_tile(mfma_v4d (&acc)[TileGeom<THREADS>:
     }
 }
 
+#ifdef DIAG_PROFILE
+__device__ long long g_diag_prof[4096][8];
+__device__ int g_diag_prof_n;
+extern "C" int dotmi_debug_diag_prof(long long *out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_diag_prof), sizeof(long long) * 8 * (size_t)n);
+}
+#define DPROF(k) do { if (slot >= 0 && threadIdx.x == 0) g_diag_prof[slot][k] = wall_clock64(); } while (0)
+#else
+#define DPROF(k) do { } while (0)
+#endif
 // one tile task on the workgroup's LDS tiles (the body of both the level kernel and the dataflow kernel below)
 template <int THREADS, bool COH = false>
 __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd *__restrict__ prods, int *__restrict__ info,
@@ -1876,6 +1887,14 @@ __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd
     constexpr int NB = CHOL_NB, LD = NB + 1, NT = TileGeom<THREADS>::NT;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
     auto TL = [](const double *src, int ld, int tid_) { return tile_load<THREADS>(src, (size_t)ld, tid_); };
+#ifdef DIAG_PROFILE
+    __shared__ int s_slot;
+    if (threadIdx.x == 0) s_slot = (t.post == TP_DIAG || t.post == TP_ROW) ? atomicAdd(&g_diag_prof_n, 1) : -1;
+    __syncthreads();
+    const int slot = (s_slot >= 0 && s_slot < 4096) ? s_slot : -1;
+    if (slot >= 0 && threadIdx.x == 0) { g_diag_prof[slot][6] = t.post; g_diag_prof[slot][7] = t.nprod; }
+    DPROF(0);
+#endif
     const int rb = 16 * (w & 3), cb = 16 * NT * (w >> 2);   // this wave's rows / first column of the accumulator tiles
     const bool fact = t.form == TF_FACT;   // C -= A^T B on H tiles;  else C += A B
     const TileProd *pl = prods + t.first;
@@ -1898,6 +1917,7 @@ __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd
             for (int r = 0; r < 4; ++r) acc[q][r] = La[rb + lk + 4 * r][cb + 16 * q + lr];
         __syncthreads();
     }
+    DPROF(1);
     for (int p = 0; p < t.nprod; ++p) {
         const bool same = pl[p].b == pl[p].a;
         tile_to_lds<THREADS>(ra, La, tid);
@@ -1924,6 +1944,7 @@ __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd
         else tile_store<THREADS>(La, t.c, t.ldc, tid);
         return;
     }
+    DPROF(2);
     // G = updated H tile -> LDS
     double (*G)[LD] = t.post == TP_ROW ? Lb : La;
 #pragma unroll
@@ -1943,12 +1964,16 @@ __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd
 #pragma unroll
             for (int r = 0; r < 4; ++r) Lb[rb + lk + 4 * r][cb + 16 * q + lr] = acc[q][r];
         __syncthreads();
+        DPROF(3);
         if constexpr (COH) tile_store_wt<THREADS, false>(Lb, t.c, t.ldc, tid);
         else tile_store<THREADS>(Lb, t.c, t.ldc, tid);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DPROF(4);
         return;
     }
     __syncthreads();
     const int bad = block_chol_inv<64>(La, Lb, 0, T32, T16, tid);
+    DPROF(3);
     // Q_jj = X^T: column i of the stored tile, row k <- X(i,k) (zero for k > i: the strictly lower part is cleared)
     if constexpr (COH) {
         tile_store_wt<THREADS, true>(Lb, t.c, t.ldc, tid);
@@ -1959,6 +1984,10 @@ __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd
         }
     }
     if (tid == 0 && bad) atomicMax(info + t.sub, t.pivotBase + bad);
+#ifdef DIAG_PROFILE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DPROF(4);
+#endif
 }
 
 template <int THREADS>
