@@ -1956,6 +1956,7 @@ void sum_stats(const dotmi_handle *h, int nvals, double *R)
 // back) -- plus `ntail` scalars at `tailp` that ride along
 int exchange_iface(dotmi_handle *h, double *vec, double *tailp, int ntail)
 {
+    if (3 * h->nIface + ntail == 0) return 0;   // (no vertex is shared -- one rank --: the same on every rank, nothing to send)
     launch_pack_iface(h->nIface, h->ifaceIdx, vec, h->xpack, tailp, ntail, h->st);
     if (int rc = allreduce_sum(h, h->xpack, (size_t)3 * h->nIface + ntail)) return rc;
     launch_unpack_iface(h->nIface, h->ifaceIdx, h->xpack, h->heldMask, vec, tailp, ntail, h->st);
