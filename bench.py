@@ -240,7 +240,7 @@ def main():
 
     def run_workload(name, steps, warmup):
         """-> (record, per-step stats, scene, timestepper is closed).  A trailing "+owner" (N > 1) runs the workload with
-        DOTMI_FLAG_OWNER_EXCHANGE: interface-only vector collectives, owner-summed dot products"""
+        DOTMI_FLAG_OWNER_EXCHANGE: interface-only vector collectives, the dot products in their tails"""
         owner = name.endswith("+owner")
         label = name
         if owner:

@@ -85,6 +85,8 @@ struct Tuning {
                               //                      its longest tile)
     bool splitBs = true;      // DOTMI_SPLIT_BS=0     one back-solve launch instead of wide / narrow tiles apart
     bool mergeTiles = true;   // DOTMI_MERGE_TILES=0  reduce_partial_p + merge instead of merge_tiles_kernel
+    int ownerPack = 1;        // DOTMI_OWNER_PACK     owner exchange: the dot products ride in the vector packets (3 collectives per
+                              //                      accepted iteration) / 0: as scalar all-reduces of their own (5)
     int splitMerge = -1;      // DOTMI_SPLIT_MERGE    1 / 0: the merge as reduce_partial_p + a gather from psub (the early order included) /
                               //                      as one walk over the tile partials; default: split from 400 k scalar dofs
     bool fuseLeaves = true;   // DOTMI_FUSE_LEAVES=0  one GEMM chain per leaf instead of equal-size leaves together
@@ -141,6 +143,7 @@ struct Tuning {
         t.splitBs = geti("DOTMI_SPLIT_BS", 1) != 0;
         t.mergeTiles = geti("DOTMI_MERGE_TILES", 1) != 0;
         t.splitMerge = geti("DOTMI_SPLIT_MERGE", -1);
+        t.ownerPack = geti("DOTMI_OWNER_PACK", 1);
         t.fuseLeaves = geti("DOTMI_FUSE_LEAVES", 1) != 0;
         t.fuseLog = getenv("DOTMI_FUSE_LOG") != nullptr;
         t.splitRoot = geti("DOTMI_ND_SPLIT_ROOT", 1) != 0;
@@ -265,12 +268,16 @@ struct dotmi_handle {
     bool owner = false;
     std::vector<int32_t> firstPart;        // parts of rank r: [firstPart[r], firstPart[r + 1])
     uint8_t *ownMask = nullptr, *heldMask = nullptr;   // nV: this rank owns the vertex / holds it in one of its subdomains
+    uint8_t *vkind = nullptr;              // nV: bit 0 = owned by this rank, bit 1 = held by more than one rank
+    int *sharedList = nullptr;             // the vertices this rank holds together with other ranks, ascending
+    int nShared = 0;
+    VList shared() const { return VList{sharedList, nShared}; }
     int *ifaceIdx = nullptr;               // the vertices held by more than one rank (the same list on every rank), ascending
     int nIface = 0;
     int *heldList = nullptr;               // the held vertices, ascending: the loop's vector kernels visit only these
     int nHeld = 0;
     VList held() const { return owner ? VList{heldList, nHeld} : VList(); }
-    double *xpack = nullptr;               // 3 nIface + 8 doubles: the packed entries (+ E) that travel
+    double *xpack = nullptr;               // 3 nIface + 8 + RED_K doubles: the packed entries (+ E, + the statistics) that travel
     double *massOwn = nullptr;             // nV: lumped mass on the owned vertices, 0 elsewhere
     double *HvalOwn = nullptr;             // block-CSR values of this rank's OWN elements' part of H (+ massOwn): alpha_0's p.Hp
     int *ownBlkPtr = nullptr, *ownBlkEnt = nullptr;   // contribution lists of that assembly (over hessBlk)
@@ -1245,9 +1252,20 @@ int build_device_mesh(dotmi_handle *h)
         if (int rc = upload(h, &h->heldList, hl)) return rc;
         if (int rc = upload(h, &h->ownMask, own)) return rc;
         if (int rc = upload(h, &h->heldMask, held)) return rc;
+        {
+            std::vector<uint8_t> kind(nV);
+            for (int v = 0; v < nV; ++v) kind[v] = (uint8_t)((own[v] ? 1 : 0) | (holders[v] >= 2 ? 2 : 0));
+            if (int rc = upload(h, &h->vkind, kind)) return rc;
+            std::vector<int> sh;
+            for (int v = 0; v < nV; ++v)
+                if (held[v] && holders[v] >= 2) sh.push_back(v);
+            h->nShared = (int)sh.size();
+            if (sh.empty()) sh.push_back(0);
+            if (int rc = upload(h, &h->sharedList, sh)) return rc;
+        }
         if (int rc = upload(h, &h->ifaceIdx, iface)) return rc;
         if (int rc = upload(h, &h->massOwn, mo)) return rc;
-        if (int rc = dalloc(h, &h->xpack, (size_t)3 * h->nIface + 8)) return rc;
+        if (int rc = dalloc(h, &h->xpack, (size_t)3 * h->nIface + 8 + RED_K)) return rc;
         // the element pass' inertia term 1/2 m |x - x~|^2 by ownership too: the same kernel over every vertex with the
         // owner's share of the mass (positions outside the held vertices stay where the warm start put them)
         h->Mown = h->M;
@@ -1970,6 +1988,33 @@ int allreduce_columns(dotmi_handle *h, const double *partials, int ncols, double
     return allreduce_sum(h, dst, (size_t)ncols);
 }
 
+// owner exchange, packed form.  The gradient's packet: [3 nIface entries | E | ncols statistics]; `partials` holds the sums this
+// rank took BEFORE the exchange (pair_stats with pre = 1, or the |g|^2 of the vertices only it holds at the start of a step:
+// ncols = 1); the summed ones land in row 0 of partGR with the shared entries' squares added to |g|^2.
+int exchange_gradient_packed(dotmi_handle *h, int n, const double *partials, int ncols)
+{
+    const int n3 = 3 * h->nIface;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, partials, NB_RED, RED_K, ncols, 0.0, 0.0, 0,
+                       h->xpack + n3 + 1);
+    launch_pack_iface(h->nIface, h->ifaceIdx, h->gstage, h->xpack, h->gstage + n + 1, 1, h->st);
+    if (int rc = allreduce_sum(h, h->xpack, (size_t)n3 + 1 + ncols)) return rc;
+    launch_unpack_iface(h->nIface, h->ifaceIdx, h->xpack, h->heldMask, h->gstage, h->gstage + n + 1, 1, h->st);
+    launch_iface_tail(n3, h->xpack, h->xpack + n3 + 1, ncols, h->partGR, h->st);
+    return 0;
+}
+// The merged back-solve's packet: [3 nIface entries | HIST_MAX sums y_i . z] (merge_early with pre = 1 left this rank's share
+// in partC); the sums land in row 0 of partGC.
+int exchange_solve_packed(dotmi_handle *h)
+{
+    const int n3 = 3 * h->nIface;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partC, NB_RED, RED_K, HIST_MAX, 0.0, 0.0, 0,
+                       h->xpack + n3);
+    launch_pack_iface(h->nIface, h->ifaceIdx, h->zstage, h->xpack, nullptr, 0, h->st);
+    if (int rc = allreduce_sum(h, h->xpack, (size_t)n3 + HIST_MAX)) return rc;
+    launch_unpack_iface(h->nIface, h->ifaceIdx, h->xpack, h->heldMask, h->zstage, h->partGC, HIST_MAX, h->st);
+    return 0;
+}
+
 // One slot of the device-resident loop: the nine kernels of an L-BFGS iteration (or, when the controller
 // asked for a retry, only the three of a line-search trial -- the others return at once) and the controller.
 // Early back-solve (one rank, h->earlyBs): the preconditioner M is fixed during a step and linear, so the solve for the
@@ -2049,18 +2094,36 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         launch_vertex_gather(h->M, h->PT, ag, L0, h->partR, h->st, h->ctl);
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
                            h->gstage + n + 1);
+        const bool packed = ow && h->tune.ownerPack;
         if (!ow) {
             if (int rc = allreduce_sum(h, h->gstage, (size_t)n + 2)) return rc;
-        } else {
-            // the gradient is complete on the vertices only this rank holds; the shared ones (and E) are summed
-            if (int rc = exchange_iface(h, h->gstage, h->gstage + n + 1, 1)) return rc;
-            a.ownMask = h->ownMask;   // pair_stats: the statistics over the owned vertices ...
+            launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
+        } else if (packed) {
+            // The gradient is complete on the vertices only this rank holds: the pair, the right-hand sides and the statistics
+            // are formed there BEFORE the exchange, together with this rank's share of the sums over the shared vertices --
+            // those are linear in the gradient -- which ride in the packet's tail; after the exchange only the shared
+            // vertices are left (|g|^2 over them: from the summed packet, iface_tail_kernel)
+            a.ownMask = h->ownMask;
             a.vlist = h->heldList;
             a.nlist = h->nHeld;
-        }
-        launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
-        if (ow)   // ... summed over the ranks before the controller reads them
+            a.kind = h->vkind;
+            a.pre = 1;
+            launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
+            if (int rc = exchange_gradient_packed(h, n, h->partR, RED_K)) return rc;
+            a.vlist = h->sharedList;
+            a.nlist = h->nShared;
+            a.pre = 0;
+            if (h->nShared > 0) launch_pair_stats(n, a, L0, nullptr, h->st, h->gstage, h->ctl);
+        } else {
+            // (DOTMI_OWNER_PACK=0) the shared entries (and E) are summed, then the statistics over the owned vertices travel as
+            // a collective of their own
+            if (int rc = exchange_iface(h, h->gstage, h->gstage + n + 1, 1)) return rc;
+            a.ownMask = h->ownMask;
+            a.vlist = h->heldList;
+            a.nlist = h->nHeld;
+            launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
             if (int rc = allreduce_columns(h, h->partR, RED_K, h->partGR)) return rc;
+        }
         ctlE = h->gstage + n;   // the controller reads the energy as one block (0, E)
         nb = 1;
     }
@@ -2090,9 +2153,18 @@ int enqueue_loop_slot_early(dotmi_handle *h)
             // zstage: this rank's subdomains' sum, zero on the vertices it does not hold; only the shared vertices' entries
             // are summed over the ranks.  z is then whole on the held vertices and zero elsewhere -- and so is everything
             // the loop forms from it.  The y_i . z of the owned vertices travel as five scalars.
-            if (int rc = exchange_iface(h, h->zstage, nullptr, 0)) return rc;
-            launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage, h->ownMask, h->held());
-            if (int rc = allreduce_columns(h, h->partC, HIST_MAX, h->partGC)) return rc;
+            if (h->tune.ownerPack) {
+                // ... inside the packet: z, u_old, M y_new on the vertices only this rank holds and its share of the y_i . z
+                // of the shared ones before the exchange, the shared vertices afterwards
+                launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage, h->ownMask, h->held(), h->vkind, 1);
+                if (int rc = exchange_solve_packed(h)) return rc;
+                if (h->nShared > 0)
+                    launch_merge_early(h->M, h->P, h->z, nullptr, 0, h->st, h->ctl, h->zstage, h->ownMask, h->shared());
+            } else {
+                if (int rc = exchange_iface(h, h->zstage, nullptr, 0)) return rc;
+                launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage, h->ownMask, h->held());
+                if (int rc = allreduce_columns(h, h->partC, HIST_MAX, h->partGC)) return rc;
+            }
         }
     }
     return 0;
@@ -2267,6 +2339,12 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
             const double *ctlR = h->partR;
             if (!h->owner) {
                 if (int rc = allreduce_sum(h, h->gstage, (size_t)n_ + 2)) return rc;
+            } else if (h->tune.ownerPack) {
+                // |g|^2 over the owned vertices no other rank holds rides with the packet, the shared entries' squares are
+                // added from the summed packet
+                launch_masked_norm2(n_, h->gstage, h->vkind, h->partR, h->st, 1);
+                if (int rc = exchange_gradient_packed(h, n_, h->partR, 1)) return rc;
+                ctlR = h->partGR;
             } else {
                 if (int rc = exchange_iface(h, h->gstage, h->gstage + n_ + 1, 1)) return rc;
             }
@@ -2274,7 +2352,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
             if (!h->owner) {
                 const double *vecs[1] = {h->g};
                 launch_multidot(n_, h->g, vecs, 1, h->partR, h->st);   // |g|^2
-            } else {
+            } else if (!h->tune.ownerPack) {
                 launch_masked_norm2(n_, h->g, h->ownMask, h->partR, h->st);   // over the owned vertices, then over the ranks
                 if (int rc = allreduce_columns(h, h->partR, 1, h->partGR)) return rc;
                 ctlR = h->partGR;
@@ -2295,8 +2373,13 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
                     launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage);
                 } else {
                     if (int rc = exchange_iface(h, h->zstage, nullptr, 0)) return rc;
-                    launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage, h->ownMask, h->held());
-                    if (int rc = allreduce_columns(h, h->partC, HIST_MAX, h->partGC)) return rc;
+                    if (h->tune.ownerPack) {   // (no pair yet: no y_i . z to sum)
+                        launch_merge_early(h->M, h->P, h->z, nullptr, 1, h->st, h->ctl, h->zstage, h->ownMask, h->held());
+                        HIPCHECK(h, hipMemsetAsync(h->partGC, 0, sizeof(double) * HIST_MAX, h->st));
+                    } else {
+                        launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage, h->ownMask, h->held());
+                        if (int rc = allreduce_columns(h, h->partC, HIST_MAX, h->partGC)) return rc;
+                    }
                 }
             }
         }

@@ -231,6 +231,11 @@ struct GatherArgs {
     const uint8_t *ownMask;
     const int *vlist;   // owner exchange: the held vertices (the gather and pair_stats visit only these); nullptr: all
     int nlist;
+    // owner exchange with the statistics in the gradient's packet: pair_stats BEFORE the exchange (pre = 1) does its whole work
+    // on the vertices only this rank holds and takes its share of the linear sums on the shared ones (kind bit 1); after the
+    // exchange it runs over the shared vertices alone, without sums
+    const uint8_t *kind;
+    int pre;
 };
 void launch_vertex_gather(const DevMesh &M, const DevPatches &PT, const GatherArgs &a, const LbfgsArgs &L,
                           double *partials, hipStream_t st, const DevLoop *ctl = nullptr);
@@ -258,15 +263,20 @@ void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, c
 void launch_reduce_partial(const DevParts &P, hipStream_t st, const DevLoop *ctl = nullptr);
 // zsum: the all-reduced sum (over all ranks' subdomains) of the undivided partial merges, in a staging buffer
 // ownMask (owner exchange): the y_i . z partials over the vertices this rank owns only
+// kind, pre (owner exchange with the y_i . z in the packet): before the exchange the whole work on the vertices only this rank
+// holds and its share of y_i . z on the shared ones (kind bit 1); afterwards a launch over the shared vertices, partials = nullptr
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
-                        const DevLoop *ctl, const double *zsum = nullptr, const uint8_t *ownMask = nullptr, VList vl = VList());
+                        const DevLoop *ctl, const double *zsum = nullptr, const uint8_t *ownMask = nullptr, VList vl = VList(),
+                        const uint8_t *kind = nullptr, int pre = 0);
 // owner exchange: the entries of the vertices held by more than one rank, packed / unpacked (idx: their vertex ids);
 // tail: `ntail` further scalars copied from / to tailp behind the packed entries
 void launch_pack_iface(int nI, const int *idx, const double *src, double *pack, const double *tailp, int ntail, hipStream_t st);
 void launch_unpack_iface(int nI, const int *idx, const double *pack, const uint8_t *heldMask, double *dst, double *tailp, int ntail,
                          hipStream_t st);
 // |v|^2 over the owned vertices -> column 0 of the partial rows;  v := own ? v : 0 (in place)
-void launch_masked_norm2(int n, const double *v, const uint8_t *ownMask, double *partials, hipStream_t st);
+void launch_masked_norm2(int n, const double *v, const uint8_t *ownMask, double *partials, hipStream_t st, int exact = 0);
+// owner exchange with the scalars in the vector packets: the summed tail, |g|^2 completed from the summed entries
+void launch_iface_tail(int n3, const double *pack, const double *tail, int ntail, double *dst, hipStream_t st);
 void launch_mask_owned(int n, double *v, const uint8_t *ownMask, hipStream_t st);
 // one subdomain only (GSDD, DOTTimeStepper.cpp:507-565): psub_s = X_s^T (X_s q[dofmap_s]) for owned part `ls`, whose
 // tiles are job[0..njobs); then p = 0 except p[dofs of part ls] = psub_s  (ADMMDDTimeStepper::fill, :1646-1665)

@@ -704,6 +704,28 @@ __global__ __launch_bounds__(256) void pair_stats_kernel(int n, GatherArgs a, Lb
     const int cnt = vl_count3(vl, n);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
         const int k = vl_dof(vl, i);
+        if (a.pre && (a.kind[k / 3] & 2)) {
+            // Owner exchange, BEFORE the gradient's packet travels, at a vertex other ranks hold too: gsrc has this rank's part
+            // of the gradient there.  All statistics but |g|^2 are linear in the gradient -- (partial gradient) . v summed over
+            // the ranks is the whole product -- so this rank's share goes into the packet's tail; the terms without the new
+            // gradient are the owner's.  The vertex' pair, right-hand side entries and H s are formed after the exchange (a
+            // second launch over the shared vertices, partials == nullptr); |g|^2 there comes from the summed packet
+            // (iface_tail_kernel).
+            const double w = (a.kind[k / 3] & 1) ? 1.0 : 0.0;
+            const double gp = gsrc[k], sn = alpha * a.p[k];
+            const double yp = gp - w * a.g_old[k];
+            acc[1] += yp * sn;
+            acc[2] += sn * gp;
+#pragma unroll
+            for (int j = 0; j < HIST_MAX; ++j)
+                if (j < Lr.m) {
+                    const double si = Lr.s[j][k], yi = Lr.y[j][k];
+                    acc[3 + j] += si * yp;
+                    acc[3 + HIST_MAX + j] += w * (sn * yi);
+                    acc[3 + 2 * HIST_MAX + j] += si * gp;
+                }
+            continue;
+        }
         const double gn = gsrc ? gsrc[k] : a.g_new[k];
         if (gsrc) a.g_new[k] = gn;
         const double sn = alpha * a.p[k];
@@ -717,9 +739,9 @@ __global__ __launch_bounds__(256) void pair_stats_kernel(int n, GatherArgs a, Lb
             for (int c = a.vp_ptr[v]; c < a.vp_ptr[v + 1]; ++c) a.rpad[a.vp_off[c] + dd] = -gn;
         }
         if (hs_new) hs_new[k] = alpha * a.hp[k];
-        if (!a.ownMask || a.ownMask[k / 3]) pair_stats_accum(k, gn, sn, yn, Lr, acc);
+        if (partials && (!a.ownMask || a.ownMask[k / 3])) pair_stats_accum(k, gn, sn, yn, Lr, acc);
     }
-    write_partials(acc, RED_K, partials, sm);
+    if (partials) write_partials(acc, RED_K, partials, sm);   // (nullptr: the statistics came with the packet, stats_pre_kernel)
 }
 
 void launch_pair_stats(int n, const GatherArgs &a, const LbfgsArgs &L, double *partials, hipStream_t st,
@@ -2425,6 +2447,7 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
                                                                 const int *__restrict__ vp_ptr, const int *__restrict__ vp_off,
                                                                 const double *__restrict__ psub,
                                                                 const uint8_t *__restrict__ ownMask, VList vl,
+                                                                const uint8_t *__restrict__ kind, int pre,
                                                                 double *__restrict__ z, double *__restrict__ partials,
                                                                 const DevLoop *__restrict__ ctl)
 {
@@ -2451,6 +2474,30 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
         const int k = vl_dof(vl, i);
         const int vtx = k / 3;
+        if (pre && (kind[vtx] & 2)) {
+            // Owner exchange, BEFORE the merged solve's packet travels, at a vertex other ranks hold too (zsum = this rank's
+            // subdomains' part).  With u = (sum over the ranks)/multiplicity the loop below forms
+            //   z = (1 + xi_new) u - xi_new u_old - sum_{j stored before} xi_j M y_j,
+            // so y_i . z = (1 + xi_new) sum_ranks y_i . (part/multiplicity) - [owner] y_i . (xi_new u_old + sum_j xi_j M y_j):
+            // this rank's share goes into the packet's tail, the vertex' z / u_old / M y_new are formed after the exchange (a
+            // second launch over the shared vertices, partials == nullptr)
+            const int d = dup[vtx];
+            const double xin = pairNew ? xi[m - 1] : 0.0;
+            double up = zsum[k];
+            if (d > 1) up /= d;
+            double t = (1.0 + xin) * up;
+            if (kind[vtx] & 1) {
+                double r = pairNew ? xin * u_old[k] : 0.0;
+#pragma unroll
+                for (int j = HIST_MAX - 1; j >= 0; --j)
+                    if (j < m && !(pairNew && j == m - 1)) r += xi[j] * my[j][k];
+                t -= r;
+            }
+#pragma unroll
+            for (int j = 0; j < HIST_MAX; ++j)
+                if (j < m) acc[j] += Lr.y[j][k] * t;
+            continue;
+        }
         int e0 = 0, e1 = 0, c0 = 0, c1 = 0;
         if (psub) {
             c0 = vp_ptr[vtx];
@@ -2514,13 +2561,13 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
         for (int j = HIST_MAX - 1; j >= 0; --j)
             if (j < m) zk -= xi[j] * ((pairNew && j == m - 1) ? myn : mk[j]);
         z[k] = zk;
-        if (!ownMask || ownMask[vtx]) {
+        if (partials && (!ownMask || ownMask[vtx])) {
 #pragma unroll
             for (int i = 0; i < HIST_MAX; ++i)
                 if (i < m) acc[i] += yk[i] * zk;
         }
     }
-    write_partials(acc, HIST_MAX, partials, sm);
+    if (partials) write_partials(acc, HIST_MAX, partials, sm);   // (nullptr: the y_i . z came with the packet, yz_pre_kernel)
 }
 
 // ---- owner exchange (DOTMI_FLAG_OWNER_EXCHANGE): only the entries of vertices held by more than one rank travel ----------------
@@ -2557,7 +2604,7 @@ void launch_unpack_iface(int nI, const int *idx, const double *pack, const uint8
         hipLaunchKernelGGL(unpack_iface_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, nI, idx, pack, heldMask, dst, tailp, ntail);
 }
 __global__ __launch_bounds__(256) void masked_norm2_kernel(int n, const double *__restrict__ v, const uint8_t *__restrict__ ownMask,
-                                                           double *__restrict__ partials)
+                                                           int exact, double *__restrict__ partials)
 {
     __shared__ double sm[4 * RED_K];
     double acc[RED_K];
@@ -2565,12 +2612,12 @@ __global__ __launch_bounds__(256) void masked_norm2_kernel(int n, const double *
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
     const int stride = gridDim.x * blockDim.x;
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += stride)
-        if (ownMask[k / 3]) acc[0] += v[k] * v[k];
+        if (exact ? ownMask[k / 3] == exact : ownMask[k / 3] != 0) acc[0] += v[k] * v[k];
     write_partials(acc, 1, partials, sm);
 }
-void launch_masked_norm2(int n, const double *v, const uint8_t *ownMask, double *partials, hipStream_t st)
+void launch_masked_norm2(int n, const double *v, const uint8_t *ownMask, double *partials, hipStream_t st, int exact)
 {
-    hipLaunchKernelGGL(masked_norm2_kernel, dim3(NB_RED), dim3(256), 0, st, n, v, ownMask, partials);
+    hipLaunchKernelGGL(masked_norm2_kernel, dim3(NB_RED), dim3(256), 0, st, n, v, ownMask, exact, partials);
 }
 __global__ __launch_bounds__(256) void mask_owned_kernel(int n, double *__restrict__ v, const uint8_t *__restrict__ ownMask)
 {
@@ -2582,13 +2629,31 @@ void launch_mask_owned(int n, double *v, const uint8_t *ownMask, hipStream_t st)
     hipLaunchKernelGGL(mask_owned_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, v, ownMask);
 }
 
+// ---- owner exchange: the scalars ride in the vector packets ----------------------------------------------------------------
+// (the sums a rank takes BEFORE the exchange are in pair_stats_kernel / merge_tiles_early_kernel, `pre` branches)
+// after the exchange: dst[0..ntail) = the packet's summed tail, dst[0] += the squares of the packet's summed vector entries
+__global__ __launch_bounds__(256) void iface_tail_kernel(int n3, const double *__restrict__ pack, const double *__restrict__ tail,
+                                                         int ntail, double *__restrict__ dst)
+{
+    __shared__ double sm[4];
+    double a = 0.0;
+    for (int t = threadIdx.x; t < n3; t += 256) a += pack[t] * pack[t];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x < ntail) dst[threadIdx.x] = tail[threadIdx.x] + (threadIdx.x == 0 ? (sm[0] + sm[1]) + (sm[2] + sm[3]) : 0.0);
+}
+void launch_iface_tail(int n3, const double *pack, const double *tail, int ntail, double *dst, hipStream_t st)
+{
+    hipLaunchKernelGGL(iface_tail_kernel, dim3(1), dim3(256), 0, st, n3, pack, tail, ntail, dst);
+}
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
-                        const DevLoop *ctl, const double *zsum, const uint8_t *ownMask, VList vl)
+                        const DevLoop *ctl, const double *zsum, const uint8_t *ownMask, VList vl, const uint8_t *kind, int pre)
 {
     const bool split = !P.mt_ptr;
     hipLaunchKernelGGL(merge_tiles_early_kernel, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup, P.ppart,
                        first, zsum, split ? P.vp_ptr : nullptr, split ? P.vp_off : nullptr,
-                       split ? (const double *)P.psub : nullptr, ownMask, vl, z, partials, ctl);
+                       split ? (const double *)P.psub : nullptr, ownMask, vl, kind, pre, z, partials, ctl);
 }
 
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,

@@ -139,8 +139,8 @@ enum {
 #define DOTMI_FLAG_OWNER_EXCHANGE 256 /* N > 1 (or DOTMI_FLAG_FORCE_DIST), device loop: owner-computes exchange.  Every rank keeps the
                                       * loop's vectors valid on the vertices of ITS subdomains only (zero elsewhere); the two
                                       * vector all-reduces of an iteration carry just the entries of vertices held by more than one
-                                      * rank (packed; interior entries never travel), every dot product is summed over the vertices a
-                                      * rank owns and all-reduced as a handful of scalars, alpha_0's p.Hp uses each rank's own
+                                      * rank (packed; interior entries never travel), the dot products ride in the tails of those
+                                      * packets (each vertex counted once over the ranks), alpha_0's p.Hp uses each rank's own
                                       * elements' part of H, and the positions are made whole again once per step.  Implies the
                                       * sharded element pass and refresh.  Same iterations as one GPU; tests/test_gpu_two_ranks.py */
 
