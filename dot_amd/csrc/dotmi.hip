@@ -1990,16 +1990,16 @@ int allreduce_columns(dotmi_handle *h, const double *partials, int ncols, double
 
 // owner exchange, packed form.  The gradient's packet: [3 nIface entries | E | ncols statistics]; `partials` holds the sums this
 // rank took BEFORE the exchange (pair_stats with pre = 1, or the |g|^2 of the vertices only it holds at the start of a step:
-// ncols = 1); the summed ones land in row 0 of partGR with the shared entries' squares added to |g|^2.
-int exchange_gradient_packed(dotmi_handle *h, int n, const double *partials, int ncols)
+// ncols = 1) and partE the element pass' energy partials -- both are summed by the pack's workgroup 0 straight into the tail.
+// The summed statistics land in row 0 of partGR with the shared entries' squares added to |g|^2, E in gstage[n + 1].
+int exchange_gradient_packed(dotmi_handle *h, int n, int nbE, const double *partials, int ncols)
 {
     const int n3 = 3 * h->nIface;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, partials, NB_RED, RED_K, ncols, 0.0, 0.0, 0,
-                       h->xpack + n3 + 1);
-    launch_pack_iface(h->nIface, h->ifaceIdx, h->gstage, h->xpack, h->gstage + n + 1, 1, h->st);
+    PackRed rE{h->partE, nbE, 2, 2, 1, n3, h->dtSq, 1.0};
+    PackRed rS{partials, NB_RED, RED_K, ncols, 0, n3 + 1, 0.0, 0.0};
+    launch_pack_iface(h->nIface, h->ifaceIdx, h->gstage, h->xpack, nullptr, 0, h->st, &rE, &rS);
     if (int rc = allreduce_sum(h, h->xpack, (size_t)n3 + 1 + ncols)) return rc;
-    launch_unpack_iface(h->nIface, h->ifaceIdx, h->xpack, h->heldMask, h->gstage, h->gstage + n + 1, 1, h->st);
-    launch_iface_tail(n3, h->xpack, h->xpack + n3 + 1, ncols, h->partGR, h->st);
+    launch_unpack_iface(h->nIface, h->ifaceIdx, h->xpack, h->heldMask, h->gstage, h->gstage + n + 1, 1, h->st, h->partGR, ncols);
     return 0;
 }
 // The merged back-solve's packet: [3 nIface entries | HIST_MAX sums y_i . z] (merge_early with pre = 1 left this rank's share
@@ -2007,9 +2007,8 @@ int exchange_gradient_packed(dotmi_handle *h, int n, const double *partials, int
 int exchange_solve_packed(dotmi_handle *h)
 {
     const int n3 = 3 * h->nIface;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partC, NB_RED, RED_K, HIST_MAX, 0.0, 0.0, 0,
-                       h->xpack + n3);
-    launch_pack_iface(h->nIface, h->ifaceIdx, h->zstage, h->xpack, nullptr, 0, h->st);
+    PackRed rC{h->partC, NB_RED, RED_K, HIST_MAX, 0, n3, 0.0, 0.0};
+    launch_pack_iface(h->nIface, h->ifaceIdx, h->zstage, h->xpack, nullptr, 0, h->st, &rC);
     if (int rc = allreduce_sum(h, h->xpack, (size_t)n3 + HIST_MAX)) return rc;
     launch_unpack_iface(h->nIface, h->ifaceIdx, h->xpack, h->heldMask, h->zstage, h->partGC, HIST_MAX, h->st);
     return 0;
@@ -2092,9 +2091,10 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         ag.vlist = ow ? h->heldList : nullptr;
         ag.nlist = ow ? h->nHeld : 0;
         launch_vertex_gather(h->M, h->PT, ag, L0, h->partR, h->st, h->ctl);
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
-                           h->gstage + n + 1);
         const bool packed = ow && h->tune.ownerPack;
+        if (!packed)   // (packed: the pack sums the energy partials itself)
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
+                               h->gstage + n + 1);
         if (!ow) {
             if (int rc = allreduce_sum(h, h->gstage, (size_t)n + 2)) return rc;
             launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
@@ -2109,7 +2109,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
             a.kind = h->vkind;
             a.pre = 1;
             launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
-            if (int rc = exchange_gradient_packed(h, n, h->partR, RED_K)) return rc;
+            if (int rc = exchange_gradient_packed(h, n, nb, h->partR, RED_K)) return rc;
             a.vlist = h->sharedList;
             a.nlist = h->nShared;
             a.pre = 0;
@@ -2334,8 +2334,9 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
         } else if (!h->shardElems) {
             launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
         } else {
-            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
-                               h->gstage + n_ + 1);
+            if (!(h->owner && h->tune.ownerPack))
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
+                                   h->gstage + n_ + 1);
             const double *ctlR = h->partR;
             if (!h->owner) {
                 if (int rc = allreduce_sum(h, h->gstage, (size_t)n_ + 2)) return rc;
@@ -2343,7 +2344,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
                 // |g|^2 over the owned vertices no other rank holds rides with the packet, the shared entries' squares are
                 // added from the summed packet
                 launch_masked_norm2(n_, h->gstage, h->vkind, h->partR, h->st, 1);
-                if (int rc = exchange_gradient_packed(h, n_, h->partR, 1)) return rc;
+                if (int rc = exchange_gradient_packed(h, n_, nb, h->partR, 1)) return rc;
                 ctlR = h->partGR;
             } else {
                 if (int rc = exchange_iface(h, h->gstage, h->gstage + n_ + 1, 1)) return rc;

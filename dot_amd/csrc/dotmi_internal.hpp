@@ -270,13 +270,21 @@ void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *
                         const uint8_t *kind = nullptr, int pre = 0);
 // owner exchange: the entries of the vertices held by more than one rank, packed / unpacked (idx: their vertex ids);
 // tail: `ntail` further scalars copied from / to tailp behind the packed entries
-void launch_pack_iface(int nI, const int *idx, const double *src, double *pack, const double *tailp, int ntail, hipStream_t st);
+// red0 / red1: partial arrays whose rows workgroup 0 of the pack sums into the packet's tail (pack[dst ...]): `cols` columns of
+// `rows` rows, or (combine) s0 * column 0 + s1 * column 1 into one entry
+struct PackRed {
+    const double *part;
+    int rows, stride, cols, combine, dst;
+    double s0, s1;
+};
+void launch_pack_iface(int nI, const int *idx, const double *src, double *pack, const double *tailp, int ntail, hipStream_t st,
+                       const PackRed *red0 = nullptr, const PackRed *red1 = nullptr);
+// dst2 / ntail2: the tail behind the first one goes to dst2, with the squares of the packet's summed vector entries added to
+// dst2[0] (|g|^2 over the shared vertices)
 void launch_unpack_iface(int nI, const int *idx, const double *pack, const uint8_t *heldMask, double *dst, double *tailp, int ntail,
-                         hipStream_t st);
+                         hipStream_t st, double *dst2 = nullptr, int ntail2 = 0);
 // |v|^2 over the owned vertices -> column 0 of the partial rows;  v := own ? v : 0 (in place)
 void launch_masked_norm2(int n, const double *v, const uint8_t *ownMask, double *partials, hipStream_t st, int exact = 0);
-// owner exchange with the scalars in the vector packets: the summed tail, |g|^2 completed from the summed entries
-void launch_iface_tail(int n3, const double *pack, const double *tail, int ntail, double *dst, hipStream_t st);
 void launch_mask_owned(int n, double *v, const uint8_t *ownMask, hipStream_t st);
 // one subdomain only (GSDD, DOTTimeStepper.cpp:507-565): psub_s = X_s^T (X_s q[dofmap_s]) for owned part `ls`, whose
 // tiles are job[0..njobs); then p = 0 except p[dofs of part ls] = psub_s  (ADMMDDTimeStepper::fill, :1646-1665)

@@ -2571,18 +2571,54 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
 }
 
 // ---- owner exchange (DOTMI_FLAG_OWNER_EXCHANGE): only the entries of vertices held by more than one rank travel ----------------
+// red0 / red1: up to two partial arrays whose rows workgroup 0 sums into the packet's tail on the way (the energy's two columns
+// combined, the statistics' columns) -- the same single-wave sums as dotmi.hip's reduce_rows_kernel, without launches of their own
+__device__ __forceinline__ void pack_reduce_rows(const PackRed &r, double *__restrict__ pack)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (!r.part) return;
+    if (r.combine) {
+        if (w != 0) return;
+        double a0 = 0.0, a1 = 0.0;
+        for (int b = lane; b < r.rows; b += 64) {
+            a0 += r.part[(size_t)b * r.stride];
+            a1 += r.part[(size_t)b * r.stride + 1];
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            a0 += __shfl_down(a0, o, 64);
+            a1 += __shfl_down(a1, o, 64);
+        }
+        if (lane == 0) pack[r.dst] = r.s0 * a0 + r.s1 * a1;
+        return;
+    }
+    for (int j = w; j < r.cols; j += 4) {
+        double acc = 0.0;
+        for (int b = lane; b < r.rows; b += 64) acc += r.part[(size_t)b * r.stride + j];
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+        if (lane == 0) pack[r.dst + j] = acc;
+    }
+}
 __global__ __launch_bounds__(256) void pack_iface_kernel(int nI, const int *__restrict__ idx, const double *__restrict__ src,
-                                                         double *__restrict__ pack, const double *__restrict__ tailp, int ntail)
+                                                         double *__restrict__ pack, const double *__restrict__ tailp, int ntail,
+                                                         PackRed red0, PackRed red1)
 {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < 3 * nI) pack[t] = src[3 * idx[t / 3] + t % 3];
     else if (t < 3 * nI + ntail) pack[t] = tailp[t - 3 * nI];
+    if (blockIdx.x == 0) {
+        pack_reduce_rows(red0, pack);
+        pack_reduce_rows(red1, pack);
+    }
 }
 // (only the vertices THIS rank holds take the sum: a vertex shared by two other ranks stays zero here)
+// tail2 (gradient's packet): dst2[0 .. ntail2) = the summed tail behind the first one, dst2[0] += the squares of the packet's
+// summed vector entries -- |g|^2 over the shared vertices, the same bits on every rank (workgroup 0)
 __global__ __launch_bounds__(256) void unpack_iface_kernel(int nI, const int *__restrict__ idx, const double *__restrict__ pack,
                                                            const uint8_t *__restrict__ heldMask, double *__restrict__ dst,
-                                                           double *__restrict__ tailp, int ntail)
+                                                           double *__restrict__ tailp, int ntail, double *__restrict__ dst2,
+                                                           int ntail2)
 {
+    __shared__ double sm[4];
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t < 3 * nI) {
         const int v = idx[t / 3];
@@ -2590,18 +2626,33 @@ __global__ __launch_bounds__(256) void unpack_iface_kernel(int nI, const int *__
     } else if (t < 3 * nI + ntail) {
         tailp[t - 3 * nI] = pack[t];
     }
+    if (blockIdx.x == 0 && ntail2 > 0) {
+        double a = 0.0;
+        for (int q = threadIdx.x; q < 3 * nI; q += 256) a += pack[q] * pack[q];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x < ntail2)
+            dst2[threadIdx.x] =
+                pack[3 * nI + ntail + threadIdx.x] + (threadIdx.x == 0 ? (sm[0] + sm[1]) + (sm[2] + sm[3]) : 0.0);
+    }
 }
-void launch_pack_iface(int nI, const int *idx, const double *src, double *pack, const double *tailp, int ntail, hipStream_t st)
+void launch_pack_iface(int nI, const int *idx, const double *src, double *pack, const double *tailp, int ntail, hipStream_t st,
+                       const PackRed *red0, const PackRed *red1)
 {
     const int tot = 3 * nI + ntail;
-    if (tot > 0) hipLaunchKernelGGL(pack_iface_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, nI, idx, src, pack, tailp, ntail);
+    const PackRed none{nullptr, 0, 0, 0, 0, 0, 0.0, 0.0};
+    if (tot > 0 || red0 || red1)
+        hipLaunchKernelGGL(pack_iface_kernel, dim3(std::max(1, (tot + 255) / 256)), dim3(256), 0, st, nI, idx, src, pack, tailp,
+                           ntail, red0 ? *red0 : none, red1 ? *red1 : none);
 }
 void launch_unpack_iface(int nI, const int *idx, const double *pack, const uint8_t *heldMask, double *dst, double *tailp, int ntail,
-                         hipStream_t st)
+                         hipStream_t st, double *dst2, int ntail2)
 {
     const int tot = 3 * nI + ntail;
-    if (tot > 0)
-        hipLaunchKernelGGL(unpack_iface_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, nI, idx, pack, heldMask, dst, tailp, ntail);
+    if (tot > 0 || ntail2 > 0)
+        hipLaunchKernelGGL(unpack_iface_kernel, dim3(std::max(1, (tot + 255) / 256)), dim3(256), 0, st, nI, idx, pack, heldMask, dst,
+                           tailp, ntail, dst2, ntail2);
 }
 __global__ __launch_bounds__(256) void masked_norm2_kernel(int n, const double *__restrict__ v, const uint8_t *__restrict__ ownMask,
                                                            int exact, double *__restrict__ partials)
@@ -2629,24 +2680,6 @@ void launch_mask_owned(int n, double *v, const uint8_t *ownMask, hipStream_t st)
     hipLaunchKernelGGL(mask_owned_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, v, ownMask);
 }
 
-// ---- owner exchange: the scalars ride in the vector packets ----------------------------------------------------------------
-// (the sums a rank takes BEFORE the exchange are in pair_stats_kernel / merge_tiles_early_kernel, `pre` branches)
-// after the exchange: dst[0..ntail) = the packet's summed tail, dst[0] += the squares of the packet's summed vector entries
-__global__ __launch_bounds__(256) void iface_tail_kernel(int n3, const double *__restrict__ pack, const double *__restrict__ tail,
-                                                         int ntail, double *__restrict__ dst)
-{
-    __shared__ double sm[4];
-    double a = 0.0;
-    for (int t = threadIdx.x; t < n3; t += 256) a += pack[t] * pack[t];
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
-    __syncthreads();
-    if (threadIdx.x < ntail) dst[threadIdx.x] = tail[threadIdx.x] + (threadIdx.x == 0 ? (sm[0] + sm[1]) + (sm[2] + sm[3]) : 0.0);
-}
-void launch_iface_tail(int n3, const double *pack, const double *tail, int ntail, double *dst, hipStream_t st)
-{
-    hipLaunchKernelGGL(iface_tail_kernel, dim3(1), dim3(256), 0, st, n3, pack, tail, ntail, dst);
-}
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
                         const DevLoop *ctl, const double *zsum, const uint8_t *ownMask, VList vl, const uint8_t *kind, int pre)
 {
