@@ -2075,8 +2075,30 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     a.vp_off = h->P.vp_off;
     a.rpad = h->P.rpad;
     const double *ctlE = h->partE;
+    const bool packed = ow && h->tune.ownerPack;
     if (!se) {
         launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st, h->ctl);
+    } else if (packed) {
+        // Owner exchange, the statistics in the gradient's packet.  The gradient is complete on the vertices only this rank
+        // holds: the gather forms the pair, the right-hand sides and the statistics there as on one GPU; on the shared vertices
+        // it leaves this rank's part of the gradient in the staging buffer and its share of the sums -- those are linear in the
+        // gradient -- in the partials, which ride in the packet's tail (summed by the pack's workgroup 0, like E).  After the
+        // exchange only the shared vertices are left (|g|^2 over them: from the summed packet, in the unpack)
+        GatherArgs ag = a;
+        ag.ownMask = h->ownMask;
+        ag.vlist = h->heldList;
+        ag.nlist = h->nHeld;
+        ag.kind = h->vkind;
+        ag.pre = 1;
+        ag.gshare = h->gstage;
+        launch_vertex_gather(h->M, h->PT, ag, L0, h->partR, h->st, h->ctl);
+        if (int rc = exchange_gradient_packed(h, n, nb, h->partR, RED_K)) return rc;
+        ag.vlist = h->sharedList;
+        ag.nlist = h->nShared;
+        ag.pre = 0;
+        if (h->nShared > 0) launch_pair_stats(n, ag, L0, nullptr, h->st, h->gstage, h->ctl);
+        ctlE = h->gstage + n;   // the controller reads the energy as one block (0, E)
+        nb = 1;
     } else {
         // this rank's partial gradient and energy to the staging buffer [g (n) ; 0 ; E_local], one all-reduce, then the pair,
         // its statistics, -g into the right-hand sides and H s_new from the SUM (pair_stats)
@@ -2091,29 +2113,11 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         ag.vlist = ow ? h->heldList : nullptr;
         ag.nlist = ow ? h->nHeld : 0;
         launch_vertex_gather(h->M, h->PT, ag, L0, h->partR, h->st, h->ctl);
-        const bool packed = ow && h->tune.ownerPack;
-        if (!packed)   // (packed: the pack sums the energy partials itself)
-            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
-                               h->gstage + n + 1);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
+                           h->gstage + n + 1);
         if (!ow) {
             if (int rc = allreduce_sum(h, h->gstage, (size_t)n + 2)) return rc;
             launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
-        } else if (packed) {
-            // The gradient is complete on the vertices only this rank holds: the pair, the right-hand sides and the statistics
-            // are formed there BEFORE the exchange, together with this rank's share of the sums over the shared vertices --
-            // those are linear in the gradient -- which ride in the packet's tail; after the exchange only the shared
-            // vertices are left (|g|^2 over them: from the summed packet, iface_tail_kernel)
-            a.ownMask = h->ownMask;
-            a.vlist = h->heldList;
-            a.nlist = h->nHeld;
-            a.kind = h->vkind;
-            a.pre = 1;
-            launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
-            if (int rc = exchange_gradient_packed(h, n, nb, h->partR, RED_K)) return rc;
-            a.vlist = h->sharedList;
-            a.nlist = h->nShared;
-            a.pre = 0;
-            if (h->nShared > 0) launch_pair_stats(n, a, L0, nullptr, h->st, h->gstage, h->ctl);
         } else {
             // (DOTMI_OWNER_PACK=0) the shared entries (and E) are summed, then the statistics over the owned vertices travel as
             // a collective of their own
@@ -2145,7 +2149,8 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         // whatever the controller decided: every rank enqueues the same sequence), then the division and the history terms
         // (the sum travels in a staging buffer: in a slot whose merge is gated off -- retry, past the end -- the collective
         // still runs, on stale scratch, and z is left alone)
-        launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl, h->held());
+        if (!(ow && h->tune.ownerPack))   // (packed owner exchange: merge_early merges the tiles itself)
+            launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl, h->held());
         if (!ow) {
             if (int rc = allreduce_sum(h, h->zstage, n)) return rc;
             launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage);
@@ -2154,9 +2159,11 @@ int enqueue_loop_slot_early(dotmi_handle *h)
             // are summed over the ranks.  z is then whole on the held vertices and zero elsewhere -- and so is everything
             // the loop forms from it.  The y_i . z of the owned vertices travel as five scalars.
             if (h->tune.ownerPack) {
-                // ... inside the packet: z, u_old, M y_new on the vertices only this rank holds and its share of the y_i . z
-                // of the shared ones before the exchange, the shared vertices afterwards
-                launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage, h->ownMask, h->held(), h->vkind, 1);
+                // ... inside the packet: merge_early merges this rank's tiles itself -- z, u_old, M y_new and the y_i . z on the
+                // vertices only this rank holds, its part of the sum (to zstage) and its share of the y_i . z on the shared
+                // ones --, then the exchange, then the shared vertices
+                launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, nullptr, h->ownMask, h->held(), h->vkind, 1,
+                                   h->zstage);
                 if (int rc = exchange_solve_packed(h)) return rc;
                 if (h->nShared > 0)
                     launch_merge_early(h->M, h->P, h->z, nullptr, 0, h->st, h->ctl, h->zstage, h->ownMask, h->shared());

@@ -231,11 +231,12 @@ struct GatherArgs {
     const uint8_t *ownMask;
     const int *vlist;   // owner exchange: the held vertices (the gather and pair_stats visit only these); nullptr: all
     int nlist;
-    // owner exchange with the statistics in the gradient's packet: pair_stats BEFORE the exchange (pre = 1) does its whole work
-    // on the vertices only this rank holds and takes its share of the linear sums on the shared ones (kind bit 1); after the
-    // exchange it runs over the shared vertices alone, without sums
+    // owner exchange with the statistics in the gradient's packet (pre = 1): on the vertices only this rank holds the gather does
+    // its whole work (the gradient is complete there); on the shared ones (kind bit 1) this rank's part of the gradient goes to
+    // `gshare` and its share of the sums that are linear in the gradient to the partials; pair_stats visits them after the exchange
     const uint8_t *kind;
     int pre;
+    double *gshare;
 };
 void launch_vertex_gather(const DevMesh &M, const DevPatches &PT, const GatherArgs &a, const LbfgsArgs &L,
                           double *partials, hipStream_t st, const DevLoop *ctl = nullptr);
@@ -263,11 +264,13 @@ void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, c
 void launch_reduce_partial(const DevParts &P, hipStream_t st, const DevLoop *ctl = nullptr);
 // zsum: the all-reduced sum (over all ranks' subdomains) of the undivided partial merges, in a staging buffer
 // ownMask (owner exchange): the y_i . z partials over the vertices this rank owns only
-// kind, pre (owner exchange with the y_i . z in the packet): before the exchange the whole work on the vertices only this rank
-// holds and its share of y_i . z on the shared ones (kind bit 1); afterwards a launch over the shared vertices, partials = nullptr
+// kind, pre, zshare (owner exchange with the y_i . z in the packet; zsum = nullptr: the kernel merges this rank's tiles itself):
+// before the exchange the whole work on the vertices only this rank holds; on the shared ones (kind bit 1) this rank's part of the
+// sum goes to zshare and its share of y_i . z to the partials; afterwards a launch over the shared vertices (zsum = the unpacked
+// sums, partials = nullptr)
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
                         const DevLoop *ctl, const double *zsum = nullptr, const uint8_t *ownMask = nullptr, VList vl = VList(),
-                        const uint8_t *kind = nullptr, int pre = 0);
+                        const uint8_t *kind = nullptr, int pre = 0, double *zshare = nullptr);
 // owner exchange: the entries of the vertices held by more than one rank, packed / unpacked (idx: their vertex ids);
 // tail: `ntail` further scalars copied from / to tailp behind the packed entries
 // red0 / red1: partial arrays whose rows workgroup 0 of the pack sums into the packet's tail (pack[dst ...]): `cols` columns of

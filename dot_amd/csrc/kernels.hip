@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
     constexpr int R = GATHER_R;
     for (int kbase = blockIdx.x * blockDim.x + threadIdx.x; kbase < n; kbase += R * G) {
         double gn[R], ine[R], gold[R], pk[R], si[R][HIST_MAX], yi[R][HIST_MAX];
-        int kb[R], ke[R], dd[R], cb[R], ce[R], kk[R];
+        int kb[R], ke[R], dd[R], cb[R], ce[R], kk[R], kd[R];
         bool live[R];
 #pragma unroll
         for (int u = 0; u < R; ++u) {
@@ -579,11 +579,12 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
             const int k = live[u] ? vl_dof(vl, kbase + u * G) : 0;
             kk[u] = k;
             gn[u] = ine[u] = gold[u] = pk[u] = 0.0;
-            kb[u] = ke[u] = dd[u] = cb[u] = ce[u] = 0;
+            kb[u] = ke[u] = dd[u] = cb[u] = ce[u] = kd[u] = 0;
             if (live[u]) {
                 const int v = k / 3;
                 dd[u] = k - 3 * v;
-                if (a.rpad) {
+                if (a.pre) kd[u] = a.kind[v];
+                if (a.rpad && !(kd[u] & 2)) {
                     cb[u] = a.vp_ptr[v];
                     ce[u] = a.vp_ptr[v + 1];
                 }
@@ -633,6 +634,27 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
             if (!live[u]) continue;
             const int k = kk[u];
             const double g = gn[u] + ine[u];
+            if (kd[u] & 2) {
+                // Owner exchange with the statistics in the gradient's packet (a.pre), at a vertex other ranks hold too: g is
+                // this rank's PART of the gradient there -- it goes to the buffer the packet is filled from, and this rank's
+                // share of the sums that are linear in the gradient to the partials (all but |g|^2: the sum over the ranks of
+                // (part) . v is the whole product; the terms without the new gradient are the owner's).  The vertex' pair,
+                // right-hand side entries and H s are formed after the exchange (pair_stats over the shared vertices).
+                a.gshare[k] = g;
+                const double w = (kd[u] & 1) ? 1.0 : 0.0;
+                const double sn = alpha * pk[u];
+                const double yp = g - w * gold[u];
+                acc[1] += yp * sn;
+                acc[2] += sn * g;
+#pragma unroll
+                for (int i = 0; i < HIST_MAX; ++i)
+                    if (i < Lr.m) {
+                        acc[3 + i] += si[u][i] * yp;
+                        acc[3 + HIST_MAX + i] += w * (sn * yi[u][i]);
+                        acc[3 + 2 * HIST_MAX + i] += si[u][i] * g;
+                    }
+                continue;
+            }
             a.g_new[k] = g;
 #pragma unroll
             for (int c = 0; c < VC; ++c)
@@ -704,28 +726,6 @@ __global__ __launch_bounds__(256) void pair_stats_kernel(int n, GatherArgs a, Lb
     const int cnt = vl_count3(vl, n);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
         const int k = vl_dof(vl, i);
-        if (a.pre && (a.kind[k / 3] & 2)) {
-            // Owner exchange, BEFORE the gradient's packet travels, at a vertex other ranks hold too: gsrc has this rank's part
-            // of the gradient there.  All statistics but |g|^2 are linear in the gradient -- (partial gradient) . v summed over
-            // the ranks is the whole product -- so this rank's share goes into the packet's tail; the terms without the new
-            // gradient are the owner's.  The vertex' pair, right-hand side entries and H s are formed after the exchange (a
-            // second launch over the shared vertices, partials == nullptr); |g|^2 there comes from the summed packet
-            // (iface_tail_kernel).
-            const double w = (a.kind[k / 3] & 1) ? 1.0 : 0.0;
-            const double gp = gsrc[k], sn = alpha * a.p[k];
-            const double yp = gp - w * a.g_old[k];
-            acc[1] += yp * sn;
-            acc[2] += sn * gp;
-#pragma unroll
-            for (int j = 0; j < HIST_MAX; ++j)
-                if (j < Lr.m) {
-                    const double si = Lr.s[j][k], yi = Lr.y[j][k];
-                    acc[3 + j] += si * yp;
-                    acc[3 + HIST_MAX + j] += w * (sn * yi);
-                    acc[3 + 2 * HIST_MAX + j] += si * gp;
-                }
-            continue;
-        }
         const double gn = gsrc ? gsrc[k] : a.g_new[k];
         if (gsrc) a.g_new[k] = gn;
         const double sn = alpha * a.p[k];
@@ -2448,6 +2448,7 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
                                                                 const double *__restrict__ psub,
                                                                 const uint8_t *__restrict__ ownMask, VList vl,
                                                                 const uint8_t *__restrict__ kind, int pre,
+                                                                double *__restrict__ zshare,
                                                                 double *__restrict__ z, double *__restrict__ partials,
                                                                 const DevLoop *__restrict__ ctl)
 {
@@ -2474,30 +2475,6 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
         const int k = vl_dof(vl, i);
         const int vtx = k / 3;
-        if (pre && (kind[vtx] & 2)) {
-            // Owner exchange, BEFORE the merged solve's packet travels, at a vertex other ranks hold too (zsum = this rank's
-            // subdomains' part).  With u = (sum over the ranks)/multiplicity the loop below forms
-            //   z = (1 + xi_new) u - xi_new u_old - sum_{j stored before} xi_j M y_j,
-            // so y_i . z = (1 + xi_new) sum_ranks y_i . (part/multiplicity) - [owner] y_i . (xi_new u_old + sum_j xi_j M y_j):
-            // this rank's share goes into the packet's tail, the vertex' z / u_old / M y_new are formed after the exchange (a
-            // second launch over the shared vertices, partials == nullptr)
-            const int d = dup[vtx];
-            const double xin = pairNew ? xi[m - 1] : 0.0;
-            double up = zsum[k];
-            if (d > 1) up /= d;
-            double t = (1.0 + xin) * up;
-            if (kind[vtx] & 1) {
-                double r = pairNew ? xin * u_old[k] : 0.0;
-#pragma unroll
-                for (int j = HIST_MAX - 1; j >= 0; --j)
-                    if (j < m && !(pairNew && j == m - 1)) r += xi[j] * my[j][k];
-                t -= r;
-            }
-#pragma unroll
-            for (int j = 0; j < HIST_MAX; ++j)
-                if (j < m) acc[j] += Lr.y[j][k] * t;
-            continue;
-        }
         int e0 = 0, e1 = 0, c0 = 0, c1 = 0;
         if (psub) {
             c0 = vp_ptr[vtx];
@@ -2552,6 +2529,28 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
                 }
         }
         u += ps;
+        if (pre && (kind[vtx] & 2)) {
+            // Owner exchange with the y_i . z in the packet, BEFORE it travels, at a vertex other ranks hold too: u is this
+            // rank's subdomains' PART of the sum -- it goes to the buffer the packet is filled from.  With U = (sum over the
+            // ranks)/multiplicity the lines below form  z = (1 + xi_new) U - xi_new u_old - sum_{j stored before} xi_j M y_j,
+            // so  y_i . z = (1 + xi_new) sum_ranks y_i . (part/multiplicity) - [owner] y_i . (xi_new u_old + sum_j xi_j M y_j):
+            // this rank's share goes to the partials, the vertex' z / u_old / M y_new are formed after the exchange (a second
+            // launch over the shared vertices, partials == nullptr)
+            zshare[k] = u;
+            const double xin = pairNew ? xi[m - 1] : 0.0;
+            double t = (1.0 + xin) * (d > 1 ? u / d : u);
+            if (kind[vtx] & 1) {
+                double r = pairNew ? xin * uo : 0.0;
+#pragma unroll
+                for (int j = HIST_MAX - 1; j >= 0; --j)
+                    if (j < m && !(pairNew && j == m - 1)) r += xi[j] * mk[j];
+                t -= r;
+            }
+#pragma unroll
+            for (int j = 0; j < HIST_MAX; ++j)
+                if (j < m) acc[j] += yk[j] * t;
+            continue;
+        }
         if (d > 1) u /= d;
         u_old[k] = u;
         const double myn = uo - u;   // M y of the pair the controller has just stored
@@ -2681,12 +2680,13 @@ void launch_mask_owned(int n, double *v, const uint8_t *ownMask, hipStream_t st)
 }
 
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
-                        const DevLoop *ctl, const double *zsum, const uint8_t *ownMask, VList vl, const uint8_t *kind, int pre)
+                        const DevLoop *ctl, const double *zsum, const uint8_t *ownMask, VList vl, const uint8_t *kind, int pre,
+                        double *zshare)
 {
     const bool split = !P.mt_ptr;
     hipLaunchKernelGGL(merge_tiles_early_kernel, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup, P.ppart,
                        first, zsum, split ? P.vp_ptr : nullptr, split ? P.vp_off : nullptr,
-                       split ? (const double *)P.psub : nullptr, ownMask, vl, kind, pre, z, partials, ctl);
+                       split ? (const double *)P.psub : nullptr, ownMask, vl, kind, pre, zshare, z, partials, ctl);
 }
 
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,

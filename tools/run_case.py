@@ -1,7 +1,7 @@
 """per-step stats of a workload on the GPU:  python tools/run_case.py <workload> [nparts] [steps] [energy]
 (env RUN_CASE_FLAGS = dotmi flag bits, e.g. 4 = DOTMI_FLAG_FORCE_DIST: the sharded sequencing on a 1-rank communicator)"""
 import os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from dot_amd.workloads import load_workload
 from dot_amd.timestepper import DOTTimeStepper
