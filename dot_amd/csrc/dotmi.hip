@@ -2052,10 +2052,12 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     // (not on meshes whose workgroups walk several patches: the prefetched operands leave no registers for it)
     // (sharded element pass: the fused form writes the trial point only on this rank's vertex slice -- its inertia loop --,
     // so the step stays a launch of its own there)
-    if (h->tune.fuseStep && !se) {   // the step x_trial = x_cur + alpha p inside the element pass
+    // (owner exchange: the inertia loop runs over every vertex with the owner's share of the mass, so the fused form writes the
+    // whole trial point there too -- x + alpha 0 off the held vertices)
+    if (h->tune.fuseStep && (!se || ow)) {   // the step x_trial = x_cur + alpha p inside the element pass
         StepArgs sa{h->p, spart, h->alpha_dev, h->alphaMin};
-        launch_elem_energy_grad(h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, h->v0, h->v1, 1, h->partE, &nb, h->st, h->ctl,
-                                &sa);
+        launch_elem_energy_grad(ow ? h->Mown : h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, ow ? 0 : h->v0,
+                                ow ? h->nV : h->v1, 1, h->partE, &nb, h->st, h->ctl, &sa);
     } else {
         launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st, h->ctl, h->held());
         launch_elem_energy_grad(ow ? h->Mown : h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, ow ? 0 : h->v0, ow ? h->nV : h->v1,
