@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from dot_amd import lib as dl
+from dot_amd import scene
 from dot_amd.timestepper import DOTTimeStepper
 from tests import oracle_py as O
 from tests.workloads import load_workload
@@ -271,3 +272,45 @@ def test_in_loop_kernel_forms_are_priced_on_the_live_state_without_disturbing_it
             assert L.dotmi_bench_kernel(a._h, kind, 3, C.byref(ms), C.byref(nb)) == 0, name
             assert ms.value > 0 and nb.value > 0, name
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("pack", ["1", "0"])
+def test_owner_exchange_survives_a_change_of_the_fixed_set_and_a_restart(pack):
+    """DOTMI_FLAG_OWNER_EXCHANGE on the 1-rank communicator (FORCE_DIST; no vertex is shared, so the packets are their tails):
+    dotmi_refix (rubberBandPull's release, DOTTimeStepper.cpp:185-270) and dotmi_set_state + refactor (the `restart` path,
+    Optimizer.cpp:1096-1177) rebuild the preconditioner through the owner's partial operator as well -- same iterations and
+    positions as the plain single-GPU handle, with the dot products in the packets (pack = 1) and as collectives (0)."""
+    V, T = scene.synthetic_bar(8, 3, 3)
+    cfg = scene.Config(energy="FCR", script="stretch", dt=0.025, rho=1000.0, YM=1e5, PR=0.4, handle_ratio=0.01)
+    runs = []
+    for flags in (0, dl.FLAG_FORCE_DIST | dl.FLAG_OWNER_EXCHANGE):
+        sc = scene.build_scene(cfg, V, T)
+        ep = scene.partition_rcb(sc.V_rest, sc.T, 4)
+        old = {k: os.environ.get(k) for k in ("DOTMI_OWNER_PACK", "DOTMI_SHARD_ELEMS")}
+        os.environ.update({"DOTMI_OWNER_PACK": pack, "DOTMI_SHARD_ELEMS": "1"})
+        try:
+            ts = DOTTimeStepper(sc, ep, 4, flags=flags)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        its = []
+        for _ in range(3):
+            idx, pos = sc.scripter.step(ts.getResult(), cfg.dt)
+            ts.setDirichlet(idx, pos)
+            its.append(ts.step().iters)
+        fixed2 = sc.fixed.copy()
+        fixed2[np.nonzero(sc.V_rest[:, 0] > 0.5)[0]] = 0          # release the right handle
+        ts.refix(fixed2)
+        for _ in range(3):
+            st = ts.step()
+            assert st.status == 0
+            its.append(st.iters)
+        x, v, _ = ts.getState()
+        ts.setState(x, v)                                         # restart at the saved state
+        ts.updatePrecondMtrAndFactorize()
+        for _ in range(2):
+            its.append(ts.step().iters)
+        runs.append((its, ts.getResult().copy()))
+        ts.close()
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    assert np.abs(runs[0][1] - runs[1][1]).max() < 1e-9
