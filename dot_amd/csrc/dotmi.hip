@@ -2159,7 +2159,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         } else {
             // zstage: this rank's subdomains' sum, zero on the vertices it does not hold; only the shared vertices' entries
             // are summed over the ranks.  z is then whole on the held vertices and zero elsewhere -- and so is everything
-            // the loop forms from it.  The y_i . z of the owned vertices travel as five scalars.
+            // the loop forms from it.  The five y_i . z travel ...
             if (h->tune.ownerPack) {
                 // ... inside the packet: merge_early merges this rank's tiles itself -- z, u_old, M y_new and the y_i . z on the
                 // vertices only this rank holds, its part of the sum (to zstage) and its share of the y_i . z on the shared
@@ -2169,7 +2169,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
                 if (int rc = exchange_solve_packed(h)) return rc;
                 if (h->nShared > 0)
                     launch_merge_early(h->M, h->P, h->z, nullptr, 0, h->st, h->ctl, h->zstage, h->ownMask, h->shared());
-            } else {
+            } else {   // ... (DOTMI_OWNER_PACK=0) as a collective of their own, summed over the owned vertices
                 if (int rc = exchange_iface(h, h->zstage, nullptr, 0)) return rc;
                 launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage, h->ownMask, h->held());
                 if (int rc = allreduce_columns(h, h->partC, HIST_MAX, h->partGC)) return rc;
