@@ -941,10 +941,19 @@ int build_device_mesh(dotmi_handle *h)
                     }
                     if (lists) mp[(size_t)3 * v + d + 1] = (int)ment.size();
                 }
-            if (lists) {
+            // Few subdomains with long rows in short tiles (bunny5K: 8-16 rows per tile): a column is covered by dozens of tiles,
+            // ~30 scattered partials per dof against ~10 on bar17K -- there too the coalesced within-subdomain sum first is the
+            // shorter way (bunny5K 1.395 -> 1.367 ms per step; the stiff monkey, 8 per dof, loses 3 % with it)
+            const bool longLists = h->tune.splitMerge < 0 && count >= 24ll * 3 * nV;
+            if (lists && longLists) {
+                P.splitMerge = 1;
+            } else if (lists) {
                 if (int rc = upload(h, &P.mt_ptr, mp)) return rc;
                 if (int rc = upload(h, &P.mt_ent, ment)) return rc;
             }
+            if (h->tune.fuseLog)
+                fprintf(stderr, "dotmi: merge: %.1f tile partials per dof -> %s\n", (double)count / std::max(1, 3 * nV),
+                        P.splitMerge ? "sum per subdomain, then gather (split)" : "one walk over the list");
             h->mergeEntries = count;   // tile partials one merge reads (either form)
         } else {
             P.splitMerge = 0;
