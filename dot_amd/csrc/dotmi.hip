@@ -109,6 +109,9 @@ struct Tuning {
     bool tileXcdOrder = true; // DOTMI_TILE_XCD_ORDER=0 tile tasks of a level longest first instead of grouped per XCD
     int tileEagerMin = 0;     // DOTMI_TILE_EAGER_MIN early products a critical-path tile task may keep
     bool tileBalance = true;  // DOTMI_TILE_BALANCE=0 every tile task at its earliest level (no second scheduling pass)
+    int fastDiag = -1;        // DOTMI_FAST_DIAG      1 / 0: the diagonal tile tasks' 16 x 16 bottom steps per lane on 8 x 8 quarters (10.5 us per
+                              //                      64 x 64 step instead of 15.2, one 512-thread workgroup per CU instead of two) /
+                              //                      one row per lane; -1: by the layout, like the dataflow launch
     int tileFlow = -1;        // DOTMI_TILE_FLOW      1: the factorisation as ONE launch of persistent workgroups with per-task
                               //                         dependencies (tile_flow_kernel) instead of one launch per level; 0: never;
                               //                         default: where a level holds fewer tasks than the GPU holds workgroups
@@ -164,6 +167,7 @@ struct Tuning {
         t.tileEagerMin = std::max(0, geti("DOTMI_TILE_EAGER_MIN", 0));
         t.tileBalance = geti("DOTMI_TILE_BALANCE", 1) != 0;
         t.tileFlow = geti("DOTMI_TILE_FLOW", -1);
+        t.fastDiag = geti("DOTMI_FAST_DIAG", -1);
         t.tileFlowWg = geti("DOTMI_TILE_FLOW_WG", 0);
         t.tileFlowWaitMs = std::max(1, geti("DOTMI_TILE_FLOW_WAIT_MS", 2000));
         t.tileEagerMinDiag = std::max(0, geti("DOTMI_TILE_EAGER_MIN_DIAG", 0));
@@ -242,6 +246,7 @@ struct dotmi_handle {
     int predState[10] = {0, 0, 1, 1, 1, 1, 1, 1, 1, 1};   // DevLoop::predHist / predCtr between the steps
     int heldSlots = 0, heldRejected = 0;                  // held back-solves of the last step (DevLoop::holdNext)
     bool tileFlow = false;            // dataflow factorisation (tile_flow_kernel)
+    bool fastDiag = false;            // diagonal tasks with the per-lane 8 x 8 bottom steps (block_chol_inv<N, true>)
     int *tdepPtr = nullptr, *tdepIdx = nullptr, *tdone = nullptr, *tnext = nullptr;
     int tileEpoch = 0, nTtasks = 0, tileFlowWg = 0;
     hipStream_t stDiag = nullptr;              // side stream of the diagonal-block tasks
@@ -1023,6 +1028,12 @@ int build_device_mesh(dotmi_handle *h)
         const size_t nLevels = std::max<size_t>(S.levelStart.size() - 1, 1);
         h->tileFlow = !S.tasks.empty() &&
                       (h->tune.tileFlow > 0 || (h->tune.tileFlow < 0 && S.tasks.size() / nLevels <= 512));
+        // The same layouts -- narrow levels, the chain of diagonal tasks paces the phase -- take the diagonal tasks' faster
+        // bottom steps, whose registers leave one 512-thread workgroup per CU (bunny5K 0.386 -> 0.338 ms, horse7K / 8
+        // 0.66 -> 0.605; bar17K, where the second workgroup per CU is needed, 1.12 -> 1.31 with it).  By the LAYOUT, not by
+        // the launch form, so that DOTMI_TILE_FLOW=0 / 1 give the same bits.
+        h->fastDiag = h->tune.tileThreads == 512 &&
+                      (h->tune.fastDiag > 0 || (h->tune.fastDiag < 0 && !S.tasks.empty() && S.tasks.size() / nLevels <= 512));
         if (h->tileFlow) {
             std::vector<int> depPtr, depIdx;
             build_tile_deps(S.tasks, S.prods, depPtr, depIdx);
@@ -1597,7 +1608,7 @@ int issue_factor(dotmi_handle *h)
 {
     if (h->tileMode && h->tileFlow) {
         launch_tile_flow(h->ttasks, h->nTtasks, h->tprods, h->tdepPtr, h->tdepIdx, h->tdone, h->tnext, ++h->tileEpoch, h->info_dev,
-                         h->tileFlowWg, h->st, h->tune.tileThreads, (double)h->tune.tileFlowWaitMs);
+                         h->tileFlowWg, h->st, h->tune.tileThreads, (double)h->tune.tileFlowWaitMs, h->fastDiag);
         h->flopCount = h->tileFlops;
         return 0;
     }
@@ -1606,7 +1617,7 @@ int issue_factor(dotmi_handle *h)
         for (size_t l = 0; l + 1 < h->tlevelStart.size(); ++l) {
             const int n = h->tlevelStart[l + 1] - h->tlevelStart[l];
             if (!h->tileSplit) {
-                launch_tile_level(h->ttasks + h->tlevelStart[l], n, h->tprods, h->info_dev, h->st, h->tune.tileThreads);
+                launch_tile_level(h->ttasks + h->tlevelStart[l], n, h->tprods, h->info_dev, h->st, h->tune.tileThreads, h->fastDiag);
                 continue;
             }
             // the level's diagonal-block tasks (77 KB of LDS, ~20 us each) on the side stream, its product / row / inverse
@@ -1616,12 +1627,12 @@ int issue_factor(dotmi_handle *h)
             if (nd > 0 && ng > 0) {
                 HIPCHECK(h, hipEventRecord(h->tFork[l], h->st));
                 HIPCHECK(h, hipStreamWaitEvent(h->stDiag, h->tFork[l], 0));
-                launch_tile_level(t0, nd, h->tprods, h->info_dev, h->stDiag, h->tune.tileThreads);
+                launch_tile_level(t0, nd, h->tprods, h->info_dev, h->stDiag, h->tune.tileThreads, h->fastDiag);
                 launch_tile_gemm(t0 + nd, ng, h->tprods, h->st);
                 HIPCHECK(h, hipEventRecord(h->tJoin[l], h->stDiag));
                 HIPCHECK(h, hipStreamWaitEvent(h->st, h->tJoin[l], 0));
             } else if (nd > 0) {
-                launch_tile_level(t0, nd, h->tprods, h->info_dev, h->st, h->tune.tileThreads);
+                launch_tile_level(t0, nd, h->tprods, h->info_dev, h->st, h->tune.tileThreads, h->fastDiag);
             } else {
                 launch_tile_gemm(t0, ng, h->tprods, h->st);
             }

@@ -339,11 +339,13 @@ void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipS
 void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, hipStream_t st,
                              const LeafOffs &LO = LeafOffs());
 // one level of the tile schedule (tile_factor.hpp): one workgroup per task
-void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, int threads = 256);
+// fastDiag: the diagonal tasks' 16 x 16 bottom steps in the per-lane 8 x 8 form (kernels.hip, block_chol_inv<N, FAST>; 512 threads)
+void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, int threads = 256,
+                       bool fastDiag = false);
 // the non-diagonal tasks of a level on half tiles, four workgroups per CU (tile_gemm_kernel)
 void launch_tile_gemm(const TileTask *tasks, int ntasks, const TileProd *prods, hipStream_t st);
 void launch_tile_flow(const TileTask *tasks, int ntasks, const TileProd *prods, const int *depPtr, const int *depIdx, int *done,
-                      int *next, int epoch, int *info, int nwg, hipStream_t st, int threads, double waitMs);
+                      int *next, int epoch, int *info, int nwg, hipStream_t st, int threads, double waitMs, bool fastDiag = false);
 void launch_clear_tiles(double *const *tiles, const int *lds_, int ntiles, hipStream_t st);
 void launch_block_copy(double *dst, int ldd, size_t sd, const double *src, int lds_, size_t ss, int rows,
                        int cols, int batch, hipStream_t st, const LeafOffs &LO = LeafOffs());

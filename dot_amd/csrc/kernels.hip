@@ -1580,28 +1580,149 @@ __device__ __forceinline__ void mfma_gemm_small(FA A, FB B, FS store, int tid)
     __syncthreads();
 }
 
+constexpr int LD64 = CHOL_NB + 1;
+// ---- 16 x 16 base case without cross-lane traffic -------------------------------------------------------------------------------
+// wave_chol_inv<16> above keeps one row per lane and pays two v_readlane per multiply-add: 2.9 us per block, four of them in a
+// row on the factorisation's dependent chain (tools/bench_diag.hip: 11.8 of the 15.3 us of block_chol_inv<64>).  Here the block
+// is split once more into 8 x 8 quarters and EVERY lane factors the quarter for itself: the 36 entries of its lower triangle
+// sit in the lane's registers (broadcast LDS reads), the Cholesky is straight-line code with static indices (84 multiply-adds,
+// eight reciprocal square roots), and lane c then solves L x = e_c for column c of the inverse.  The four 8 x 8 x 8 products
+// between the two quarters take one result entry per lane (R12 rests in the X12 quarter, which is zero in the end).  One
+// wavefront, LDS as the only exchange, no workgroup barrier.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// sqrt(d) and 1/sqrt(d) to double accuracy from the hardware estimate: two coupled Newton (Goldschmidt) steps and a residual
+// correction of the root
+__device__ __forceinline__ void sqrt_rsqrt(double d, double &root, double &rroot)
+{
+    const double r0 = __builtin_amdgcn_rsq(d);
+    double g = d * r0, h = 0.5 * r0;
+    double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    g = __builtin_fma(__builtin_fma(-g, g, d), h, g);
+    root = g;
+    rroot = h + h;
+}
+// the 8 x 8 block at [o, o+8): X = chol(G)^-1 into X (zero above the diagonal); returns 0 or 1 + the first bad pivot
+__device__ __forceinline__ int lane_chol_inv8(double (*G)[LD64], double (*X)[LD64], int o, int lane)
+{
+    constexpr int Q = 8;
+    double a[Q * (Q + 1) / 2];   // a[i (i+1)/2 + j] = G(i, j), j <= i
+#pragma unroll
+    for (int i = 0; i < Q; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) a[i * (i + 1) / 2 + j] = G[o + i][o + j];
+    int bad = 0;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        const double piv = a[k * (k + 1) / 2 + k];
+        if (!(piv > 0.0) && bad == 0) bad = k + 1;
+        double root, rr;
+        sqrt_rsqrt(piv, root, rr);
+        a[k * (k + 1) / 2 + k] = rr;   // (the diagonal slot keeps 1 / L_kk: the root itself is not needed again)
+#pragma unroll
+        for (int i = k + 1; i < Q; ++i) a[i * (i + 1) / 2 + k] *= rr;
+#pragma unroll
+        for (int j = k + 1; j < Q; ++j)
+#pragma unroll
+            for (int i = j; i < Q; ++i)
+                a[i * (i + 1) / 2 + j] = __builtin_fma(-a[i * (i + 1) / 2 + k], a[j * (j + 1) / 2 + k], a[i * (i + 1) / 2 + j]);
+    }
+    // lane c solves L x = e_c (every lane runs the same straight-line code; x_i = 0 for i < c comes out by itself)
+    // (column by column: x_k is final after one multiplication, the updates of the rows below it are independent of each other)
+    const int c = lane & (Q - 1);
+    double x[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) x[i] = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < Q; ++k) {
+        x[k] *= a[k * (k + 1) / 2 + k];
+#pragma unroll
+        for (int i = k + 1; i < Q; ++i) x[i] = __builtin_fma(-a[i * (i + 1) / 2 + k], x[k], x[i]);
+    }
+    if (lane < Q) {
+#pragma unroll
+        for (int i = 0; i < Q; ++i) X[o + i][o + lane] = (i >= lane) ? x[i] : 0.0;
+    }
+    return bad;
+}
+// the 16 x 16 block at [b0, b0+16) by ONE wavefront (all 64 lanes): the 2 x 2 recursion of block_chol_inv on 8 x 8 quarters
+__device__ __forceinline__ int wave_chol_inv16_lds(double (*G)[LD64], double (*X)[LD64], int b0, int lane)
+{
+    constexpr int Q = 8;
+    const int i = lane >> 3, j = lane & 7;
+    auto T = [&](int r, int c) -> double & { return X[b0 + r][b0 + Q + c]; };
+    int bad = lane_chol_inv8(G, X, b0, lane);
+    wave_lds_sync();
+    {   // R12(i,j) = sum_k X11(i,k) A12(k,j)
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) s = __builtin_fma(X[b0 + i][b0 + k], G[b0 + k][b0 + Q + j], s);
+        T(i, j) = s;
+    }
+    wave_lds_sync();
+    {   // A22(c,d) -= sum_k R12(k,c) R12(k,d)
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) s = __builtin_fma(T(k, i), T(k, j), s);
+        G[b0 + Q + i][b0 + Q + j] -= s;
+    }
+    wave_lds_sync();
+    const int b2 = lane_chol_inv8(G, X, b0 + Q, lane);
+    if (bad == 0 && b2) bad = Q + b2;
+    {   // V(c,j) = sum_k R12(k,c) X11(k,j)  -> the A11 area (free by now)
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) s = __builtin_fma(T(k, i), X[b0 + k][b0 + j], s);
+        G[b0 + i][b0 + j] = s;
+    }
+    wave_lds_sync();
+    {   // X21(i,j) = -sum_c X22(i,c) V(c,j) ;  X12 = 0
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) s = __builtin_fma(X[b0 + Q + i][b0 + Q + k], G[b0 + k][b0 + j], s);
+        X[b0 + Q + i][b0 + j] = -s;
+        X[b0 + i][b0 + Q + j] = 0.0;
+    }
+    return bad;
+}
+
 // X = chol(A)^-1 of the N x N diagonal block at [b0, b0+N) of a 64 x 64 matrix held in LDS, by one workgroup
 // of 256 threads: the same 2 x 2 recursion as chol_inv_node(), continued inside LDS -- the 16 x 16 bottom
 // steps run in the registers of wave 0 (wave_chol_inv), the products on the FP64 matrix cores (mfma_gemm_small).
 //   G: A on entry (row-major, symmetric), destroyed.   X: X(i,k) on exit, zero above the diagonal.
 //   T32 / T16: 32x33 and 16x17 scratch.   Returns 0 or 1 + index (relative to b0) of the first non-positive
 //   pivot (valid in wave 0).
-constexpr int LD64 = CHOL_NB + 1;
-template <int N>
+// FAST: the 16 x 16 bottom steps by wave_chol_inv16_lds (8 x 8 quarters factored per lane: 2.2 instead of 2.9 us, the whole
+// 64 x 64 step 10.5 instead of 15.2 us) -- at ~100 more VGPRs than the one-row-per-lane form, which costs the 512-thread tile
+// kernel its second workgroup per CU: chosen per layout (dotmi.hip: layouts whose levels are narrower than the GPU anyway)
+template <int N, bool FAST = false>
 __device__ __forceinline__ int block_chol_inv(double (*G)[LD64], double (*X)[LD64], int b0, double (*T32)[33],
                                               double (*T16)[17], int tid)
 {
     if constexpr (N == 16) {
         int bad = 0;
         if ((tid >> 6) == 0) {
-            const int lane = tid & 63;
-            double a[16], x[16];
+            if constexpr (FAST) {
+                bad = wave_chol_inv16_lds(G, X, b0, tid & 63);
+            } else {
+                const int lane = tid & 63;
+                double a[16], x[16];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) a[j] = G[b0 + (lane & 15)][b0 + j];
-            bad = wave_chol_inv<16>(a, x, lane);
-            if (lane < 16) {
+                for (int j = 0; j < 16; ++j) a[j] = G[b0 + (lane & 15)][b0 + j];
+                bad = wave_chol_inv<16>(a, x, lane);
+                if (lane < 16) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) X[b0 + i][b0 + lane] = x[i];
+                    for (int i = 0; i < 16; ++i) X[b0 + i][b0 + lane] = x[i];
+                }
             }
         }
         __syncthreads();
@@ -1612,14 +1733,14 @@ __device__ __forceinline__ int block_chol_inv(double (*G)[LD64], double (*X)[LD6
             if constexpr (H == 32) return T32[i][j];
             else return T16[i][j];
         };
-        int bad = block_chol_inv<H>(G, X, b0, T32, T16, tid);
+        int bad = block_chol_inv<H, FAST>(G, X, b0, T32, T16, tid);
         // R12(i,j) = sum_k X11(i,k) A12(k,j)
         mfma_gemm_small<H>([&](int i, int k) { return X[b0 + i][b0 + k]; }, [&](int k, int j) { return G[b0 + k][b0 + H + j]; },
                     [&](int i, int j, double v) { T(i, j) = v; }, tid);
         // A22(c,d) -= sum_k R12(k,c) R12(k,d)
         mfma_gemm_small<H>([&](int c, int k) { return T(k, c); }, [&](int k, int d) { return T(k, d); },
                     [&](int c, int d, double v) { G[b0 + H + c][b0 + H + d] -= v; }, tid);
-        const int b2 = block_chol_inv<H>(G, X, b0 + H, T32, T16, tid);
+        const int b2 = block_chol_inv<H, FAST>(G, X, b0 + H, T32, T16, tid);
         if (bad == 0 && b2) bad = H + b2;
         // V(c,j) = sum_k R12(k,c) X11(k,j)  -> the A11 area (free by now)
         mfma_gemm_small<H>([&](int c, int k) { return T(k, c); }, [&](int k, int j) { return X[b0 + k][b0 + j]; },
@@ -1901,7 +2022,7 @@ extern "C" int dotmi_debug_diag_prof(long long *out, int n)
 #define DPROF(k) do { } while (0)
 #endif
 // one tile task on the workgroup's LDS tiles (the body of both the level kernel and the dataflow kernel below)
-template <int THREADS, bool COH = false>
+template <int THREADS, bool COH = false, bool FAST = false>
 __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd *__restrict__ prods, int *__restrict__ info,
                                                double (*La)[CHOL_NB + 1], double (*Lb)[CHOL_NB + 1], double (*T32)[33],
                                                double (*T16)[17])
@@ -1994,7 +2115,7 @@ __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd
         return;
     }
     __syncthreads();
-    const int bad = block_chol_inv<64>(La, Lb, 0, T32, T16, tid);
+    const int bad = block_chol_inv<64, FAST>(La, Lb, 0, T32, T16, tid);
     DPROF(3);
     // Q_jj = X^T: column i of the stored tile, row k <- X(i,k) (zero for k > i: the strictly lower part is cleared)
     if constexpr (COH) {
@@ -2012,14 +2133,14 @@ __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd
 #endif
 }
 
-template <int THREADS>
+template <int THREADS, bool FAST = false>
 __global__ __launch_bounds__(THREADS, 2) void tile_task_kernel(const TileTask *__restrict__ tasks,
                                                                const TileProd *__restrict__ prods, int *__restrict__ info)
 {
     constexpr int NB = CHOL_NB, LD = NB + 1;
     __shared__ double La[NB][LD], Lb[NB][LD], T32[32][33], T16[16][17];
     const TileTask t = tasks[blockIdx.x];
-    tile_task_body<THREADS>(t, prods, info, La, Lb, T32, T16);
+    tile_task_body<THREADS, false, FAST>(t, prods, info, La, Lb, T32, T16);
 }
 
 // Dataflow form of the same factorisation (DOTMI_TILE_FLOW): ONE launch of persistent workgroups that
@@ -2032,7 +2153,7 @@ __global__ __launch_bounds__(THREADS, 2) void tile_task_kernel(const TileTask *_
 // smaller tickets, all of which are held by workgroups that are running: no deadlock whatever the grid size.  Sums keep
 // their fixed order (a tile is still written by one task at a time): results equal to the level kernel's bit for bit.
 // A wait that exceeds ~2 s (never, unless a kernel before it failed) flags the subdomain and goes on, so the launch ends.
-template <int THREADS>
+template <int THREADS, bool FAST = false>
 __global__ __launch_bounds__(THREADS, 2) void tile_flow_kernel(const TileTask *__restrict__ tasks,
                                                                const TileProd *__restrict__ prods, int ntasks,
                                                                const int *__restrict__ depPtr, const int *__restrict__ depIdx,
@@ -2071,7 +2192,7 @@ __global__ __launch_bounds__(THREADS, 2) void tile_flow_kernel(const TileTask *_
             if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         __syncthreads();
-        tile_task_body<THREADS, true>(t, prods, info, La, Lb, T32, T16);   // (result tile stored write-through)
+        tile_task_body<THREADS, true, FAST>(t, prods, info, La, Lb, T32, T16);   // (result tile stored write-through)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its part of the result tile has left
         __syncthreads();
         if (tid == 0) {
@@ -2222,14 +2343,17 @@ __global__ __launch_bounds__(256, 4) void tile_gemm_kernel(const TileTask *__res
     }
 }
 
-void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, int threads)
+void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, int threads,
+                       bool fastDiag)
 {
     if (ntasks <= 0) return;
-    if (threads == 512) hipLaunchKernelGGL(tile_task_kernel<512>, dim3(ntasks), dim3(512), 0, st, tasks, prods, info);
-    else hipLaunchKernelGGL(tile_task_kernel<256>, dim3(ntasks), dim3(256), 0, st, tasks, prods, info);
+    if (threads == 512 && fastDiag)
+        hipLaunchKernelGGL((tile_task_kernel<512, true>), dim3(ntasks), dim3(512), 0, st, tasks, prods, info);
+    else if (threads == 512) hipLaunchKernelGGL((tile_task_kernel<512, false>), dim3(ntasks), dim3(512), 0, st, tasks, prods, info);
+    else hipLaunchKernelGGL((tile_task_kernel<256, false>), dim3(ntasks), dim3(256), 0, st, tasks, prods, info);
 }
 void launch_tile_flow(const TileTask *tasks, int ntasks, const TileProd *prods, const int *depPtr, const int *depIdx, int *done,
-                      int *next, int epoch, int *info, int nwg, hipStream_t st, int threads, double waitMs)
+                      int *next, int epoch, int *info, int nwg, hipStream_t st, int threads, double waitMs, bool fastDiag)
 {
     if (ntasks <= 0) return;
     const int grid = std::min(ntasks, nwg);
@@ -2237,8 +2361,12 @@ void launch_tile_flow(const TileTask *tasks, int ntasks, const TileProd *prods, 
     // always the 512-thread form: the 256-thread instantiation needs 256 VGPRs plus scratch and measured a wrong factor on
     // horse7K (same non-SPD pivot in every run: not a race; not pursued, DOTMI_TILE_THREADS only selects the level kernel's form)
     (void)threads;
-    hipLaunchKernelGGL(tile_flow_kernel<512>, dim3(grid), dim3(512), 0, st, tasks, prods, ntasks, depPtr, depIdx, done, next, epoch,
-                       waitTicks, info);
+    if (fastDiag)
+        hipLaunchKernelGGL((tile_flow_kernel<512, true>), dim3(grid), dim3(512), 0, st, tasks, prods, ntasks, depPtr, depIdx, done,
+                           next, epoch, waitTicks, info);
+    else
+        hipLaunchKernelGGL((tile_flow_kernel<512, false>), dim3(grid), dim3(512), 0, st, tasks, prods, ntasks, depPtr, depIdx, done,
+                           next, epoch, waitTicks, info);
 }
 void launch_tile_gemm(const TileTask *tasks, int ntasks, const TileProd *prods, hipStream_t st)
 {
