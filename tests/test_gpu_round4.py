@@ -314,3 +314,18 @@ def test_owner_exchange_survives_a_change_of_the_fixed_set_and_a_restart(pack):
         ts.close()
     assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
     assert np.abs(runs[0][1] - runs[1][1]).max() < 1e-9
+
+
+def test_per_lane_diagonal_base_gives_the_same_factors_to_rounding():
+    """DOTMI_FAST_DIAG (round 4): the diagonal tile tasks' 16 x 16 bottom steps on 8 x 8 quarters that every lane factors for
+    itself (kernels.hip, block_chol_inv<N, FAST>; hardware rsqrt + Goldschmidt instead of sqrt and a division) against the
+    one-row-per-lane base: the inverse factors agree to rounding, the steps take the same iterations and end at the same
+    positions.  bunny5K takes the new base by its layout, bar17K the old one -- both are run both ways."""
+    for workload, steps in (("bunny5K_LTSS", 3), ("bar17K_twist", 2)):
+        r0, x0, X0, _ = _steps_with_env(workload, steps, {"DOTMI_FAST_DIAG": "0"}, parts=(0, 3))
+        r1, x1, X1, _ = _steps_with_env(workload, steps, {"DOTMI_FAST_DIAG": "1"}, parts=(0, 3))
+        assert r0 == r1, (workload, r0, r1)
+        assert np.abs(x0 - x1).max() < 1e-10
+        for A, B in zip(X0, X1):
+            assert np.abs(A - B).max() <= 1e-11 * np.abs(A).max(), (workload, np.abs(A - B).max(), np.abs(A).max())
+            assert not np.array_equal(A, B)      # (the switch did select another base)
