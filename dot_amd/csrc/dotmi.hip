@@ -109,9 +109,8 @@ struct Tuning {
     bool tileXcdOrder = true; // DOTMI_TILE_XCD_ORDER=0 tile tasks of a level longest first instead of grouped per XCD
     int tileEagerMin = 0;     // DOTMI_TILE_EAGER_MIN early products a critical-path tile task may keep
     bool tileBalance = true;  // DOTMI_TILE_BALANCE=0 every tile task at its earliest level (no second scheduling pass)
-    int fastDiag = -1;        // DOTMI_FAST_DIAG      1 / 0: the diagonal tile tasks' 16 x 16 bottom steps per lane on 8 x 8 quarters (10.5 us per
-                              //                      64 x 64 step instead of 15.2, one 512-thread workgroup per CU instead of two) /
-                              //                      one row per lane; -1: by the layout, like the dataflow launch
+    int fastDiag = 1;         // DOTMI_FAST_DIAG      1 / 0: the diagonal tile tasks' 16 x 16 bottom steps on 4 x 4 blocks every lane factors for
+                              //                      itself (12.0 us per 64 x 64 step) / one row per lane with v_readlane operands (15.3 us)
     int tileFlow = -1;        // DOTMI_TILE_FLOW      1: the factorisation as ONE launch of persistent workgroups with per-task
                               //                         dependencies (tile_flow_kernel) instead of one launch per level; 0: never;
                               //                         default: where a level holds fewer tasks than the GPU holds workgroups
@@ -167,7 +166,7 @@ struct Tuning {
         t.tileEagerMin = std::max(0, geti("DOTMI_TILE_EAGER_MIN", 0));
         t.tileBalance = geti("DOTMI_TILE_BALANCE", 1) != 0;
         t.tileFlow = geti("DOTMI_TILE_FLOW", -1);
-        t.fastDiag = geti("DOTMI_FAST_DIAG", -1);
+        t.fastDiag = geti("DOTMI_FAST_DIAG", 1);
         t.tileFlowWg = geti("DOTMI_TILE_FLOW_WG", 0);
         t.tileFlowWaitMs = std::max(1, geti("DOTMI_TILE_FLOW_WAIT_MS", 2000));
         t.tileEagerMinDiag = std::max(0, geti("DOTMI_TILE_EAGER_MIN_DIAG", 0));
@@ -1028,12 +1027,9 @@ int build_device_mesh(dotmi_handle *h)
         const size_t nLevels = std::max<size_t>(S.levelStart.size() - 1, 1);
         h->tileFlow = !S.tasks.empty() &&
                       (h->tune.tileFlow > 0 || (h->tune.tileFlow < 0 && S.tasks.size() / nLevels <= 512));
-        // The same layouts -- narrow levels, the chain of diagonal tasks paces the phase -- take the diagonal tasks' faster
-        // bottom steps, whose registers leave one 512-thread workgroup per CU (bunny5K 0.386 -> 0.338 ms, horse7K / 8
-        // 0.66 -> 0.605; bar17K, where the second workgroup per CU is needed, 1.12 -> 1.31 with it).  By the LAYOUT, not by
-        // the launch form, so that DOTMI_TILE_FLOW=0 / 1 give the same bits.
-        h->fastDiag = h->tune.tileThreads == 512 &&
-                      (h->tune.fastDiag > 0 || (h->tune.fastDiag < 0 && !S.tasks.empty() && S.tasks.size() / nLevels <= 512));
+        // the diagonal tasks' per-lane bottom steps (kernels.hip, block_chol_inv<N, FAST>): every layout (DOTMI_FAST_DIAG=0: the
+        // one-row-per-lane base of round 3); the 256-thread level kernel keeps the old base, and then so does the dataflow launch
+        h->fastDiag = h->tune.tileThreads == 512 && h->tune.fastDiag != 0;
         if (h->tileFlow) {
             std::vector<int> depPtr, depIdx;
             build_tile_deps(S.tasks, S.prods, depPtr, depIdx);

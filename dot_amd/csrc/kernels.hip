@@ -1581,14 +1581,18 @@ __device__ __forceinline__ void mfma_gemm_small(FA A, FB B, FS store, int tid)
 }
 
 constexpr int LD64 = CHOL_NB + 1;
+#ifndef DOTMI_LANE_Q
+#define DOTMI_LANE_Q 4   // side of the blocks a lane factors for itself (8: the 64 x 64 step 10.7 instead of 12.0 us, but ~100
+                         // VGPRs for the lane's triangle -- the 512-thread tile kernel 168 instead of 118 -> one workgroup per CU)
+#endif
 // ---- 16 x 16 base case without cross-lane traffic -------------------------------------------------------------------------------
 // wave_chol_inv<16> above keeps one row per lane and pays two v_readlane per multiply-add: 2.9 us per block, four of them in a
 // row on the factorisation's dependent chain (tools/bench_diag.hip: 11.8 of the 15.3 us of block_chol_inv<64>).  Here the block
-// is split once more into 8 x 8 quarters and EVERY lane factors the quarter for itself: the 36 entries of its lower triangle
-// sit in the lane's registers (broadcast LDS reads), the Cholesky is straight-line code with static indices (84 multiply-adds,
-// eight reciprocal square roots), and lane c then solves L x = e_c for column c of the inverse.  The four 8 x 8 x 8 products
-// between the two quarters take one result entry per lane (R12 rests in the X12 quarter, which is zero in the end).  One
-// wavefront, LDS as the only exchange, no workgroup barrier.
+// is split further, down to Q x Q blocks (Q = 4) that EVERY lane factors for itself: the Q (Q + 1) / 2 entries of the lower
+// triangle sit in the lane's registers (broadcast LDS reads), the Cholesky is straight-line code with static indices, and
+// lane c then solves L x = e_c for column c of the inverse.  The products between the halves of the 2 x 2 recursion (4^3, 8^3)
+// take one result entry per lane (R12 rests in the X12 block, which is zero in the end).  One wavefront, LDS as the only
+// exchange, wave-level fences, no workgroup barrier: 2.0 us per 16 x 16 block.
 __device__ __forceinline__ void wave_lds_sync()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1611,10 +1615,10 @@ __device__ __forceinline__ void sqrt_rsqrt(double d, double &root, double &rroot
     root = g;
     rroot = h + h;
 }
-// the 8 x 8 block at [o, o+8): X = chol(G)^-1 into X (zero above the diagonal); returns 0 or 1 + the first bad pivot
-__device__ __forceinline__ int lane_chol_inv8(double (*G)[LD64], double (*X)[LD64], int o, int lane)
+// the Q x Q block at [o, o+Q): X = chol(G)^-1 into X (zero above the diagonal); returns 0 or 1 + the first bad pivot
+template <int Q>
+__device__ __forceinline__ int lane_chol_inv(double (*G)[LD64], double (*X)[LD64], int o, int lane)
 {
-    constexpr int Q = 8;
     double a[Q * (Q + 1) / 2];   // a[i (i+1)/2 + j] = G(i, j), j <= i
 #pragma unroll
     for (int i = 0; i < Q; ++i)
@@ -1654,45 +1658,58 @@ __device__ __forceinline__ int lane_chol_inv8(double (*G)[LD64], double (*X)[LD6
     }
     return bad;
 }
-// the 16 x 16 block at [b0, b0+16) by ONE wavefront (all 64 lanes): the 2 x 2 recursion of block_chol_inv on 8 x 8 quarters
+// the N x N block (N = Q, 2 Q, ... <= 16) at [b0, b0+N) by ONE wavefront: the 2 x 2 recursion of block_chol_inv down to Q x Q
+// blocks that every lane factors for itself; the products between the halves take one result entry per lane
+template <int N, int Q>
+__device__ __forceinline__ int wave_chol_inv_lds(double (*G)[LD64], double (*X)[LD64], int b0, int lane)
+{
+    if constexpr (N == Q) {
+        return lane_chol_inv<Q>(G, X, b0, lane);
+    } else {
+        constexpr int H = N / 2;
+        const int i = (lane / H) % H, j = lane % H;
+        const bool on = lane < H * H;
+        auto T = [&](int r, int c) -> double & { return X[b0 + r][b0 + H + c]; };   // R12 rests in the X12 block (zero in the end)
+        int bad = wave_chol_inv_lds<H, Q>(G, X, b0, lane);
+        wave_lds_sync();
+        if (on) {   // R12(i,j) = sum_k X11(i,k) A12(k,j)
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < H; ++k) s = __builtin_fma(X[b0 + i][b0 + k], G[b0 + k][b0 + H + j], s);
+            T(i, j) = s;
+        }
+        wave_lds_sync();
+        if (on) {   // A22(c,d) -= sum_k R12(k,c) R12(k,d)
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < H; ++k) s = __builtin_fma(T(k, i), T(k, j), s);
+            G[b0 + H + i][b0 + H + j] -= s;
+        }
+        wave_lds_sync();
+        const int b2 = wave_chol_inv_lds<H, Q>(G, X, b0 + H, lane);
+        if (bad == 0 && b2) bad = H + b2;
+        wave_lds_sync();
+        if (on) {   // V(c,j) = sum_k R12(k,c) X11(k,j)  -> the A11 area (free by now)
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < H; ++k) s = __builtin_fma(T(k, i), X[b0 + k][b0 + j], s);
+            G[b0 + i][b0 + j] = s;
+        }
+        wave_lds_sync();
+        if (on) {   // X21(i,j) = -sum_c X22(i,c) V(c,j) ;  X12 = 0
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < H; ++k) s = __builtin_fma(X[b0 + H + i][b0 + H + k], G[b0 + k][b0 + j], s);
+            X[b0 + H + i][b0 + j] = -s;
+            X[b0 + i][b0 + H + j] = 0.0;
+        }
+        wave_lds_sync();
+        return bad;
+    }
+}
 __device__ __forceinline__ int wave_chol_inv16_lds(double (*G)[LD64], double (*X)[LD64], int b0, int lane)
 {
-    constexpr int Q = 8;
-    const int i = lane >> 3, j = lane & 7;
-    auto T = [&](int r, int c) -> double & { return X[b0 + r][b0 + Q + c]; };
-    int bad = lane_chol_inv8(G, X, b0, lane);
-    wave_lds_sync();
-    {   // R12(i,j) = sum_k X11(i,k) A12(k,j)
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < Q; ++k) s = __builtin_fma(X[b0 + i][b0 + k], G[b0 + k][b0 + Q + j], s);
-        T(i, j) = s;
-    }
-    wave_lds_sync();
-    {   // A22(c,d) -= sum_k R12(k,c) R12(k,d)
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < Q; ++k) s = __builtin_fma(T(k, i), T(k, j), s);
-        G[b0 + Q + i][b0 + Q + j] -= s;
-    }
-    wave_lds_sync();
-    const int b2 = lane_chol_inv8(G, X, b0 + Q, lane);
-    if (bad == 0 && b2) bad = Q + b2;
-    {   // V(c,j) = sum_k R12(k,c) X11(k,j)  -> the A11 area (free by now)
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < Q; ++k) s = __builtin_fma(T(k, i), X[b0 + k][b0 + j], s);
-        G[b0 + i][b0 + j] = s;
-    }
-    wave_lds_sync();
-    {   // X21(i,j) = -sum_c X22(i,c) V(c,j) ;  X12 = 0
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < Q; ++k) s = __builtin_fma(X[b0 + Q + i][b0 + Q + k], G[b0 + k][b0 + j], s);
-        X[b0 + Q + i][b0 + j] = -s;
-        X[b0 + i][b0 + Q + j] = 0.0;
-    }
-    return bad;
+    return wave_chol_inv_lds<16, DOTMI_LANE_Q>(G, X, b0, lane);
 }
 
 // X = chol(A)^-1 of the N x N diagonal block at [b0, b0+N) of a 64 x 64 matrix held in LDS, by one workgroup
@@ -1701,9 +1718,9 @@ __device__ __forceinline__ int wave_chol_inv16_lds(double (*G)[LD64], double (*X
 //   G: A on entry (row-major, symmetric), destroyed.   X: X(i,k) on exit, zero above the diagonal.
 //   T32 / T16: 32x33 and 16x17 scratch.   Returns 0 or 1 + index (relative to b0) of the first non-positive
 //   pivot (valid in wave 0).
-// FAST: the 16 x 16 bottom steps by wave_chol_inv16_lds (8 x 8 quarters factored per lane: 2.2 instead of 2.9 us, the whole
-// 64 x 64 step 10.5 instead of 15.2 us) -- at ~100 more VGPRs than the one-row-per-lane form, which costs the 512-thread tile
-// kernel its second workgroup per CU: chosen per layout (dotmi.hip: layouts whose levels are narrower than the GPU anyway)
+// FAST: the 16 x 16 bottom steps by wave_chol_inv16_lds (blocks factored per lane: 2.0 instead of 2.9 us, the whole 64 x 64
+// step 12.0 instead of 15.3 us, same register budget) -- the tile kernels' form; the 256-thread kernels of the recursive
+// (rocBLAS) mode keep the one-row-per-lane base
 template <int N, bool FAST = false>
 __device__ __forceinline__ int block_chol_inv(double (*G)[LD64], double (*X)[LD64], int b0, double (*T32)[33],
                                               double (*T16)[17], int tid)

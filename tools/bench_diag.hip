@@ -97,7 +97,7 @@ int main()
         run("block_chol_inv<16> (one row per lane)", dotmi::diag_bench<1>, grid, false);
         run("mfma_gemm_small<16>", dotmi::diag_bench<2>, grid, false);
         run("mfma_gemm_small<32>", dotmi::diag_bench<3>, grid, false);
-        run("block_chol_inv<64, FAST> (8 x 8 quarters per lane)", dotmi::diag_bench<5>, grid, true);
+        run("block_chol_inv<64, FAST> (blocks factored per lane)", dotmi::diag_bench<5>, grid, true);
         run("block_chol_inv<16, FAST>", dotmi::diag_bench<6>, grid, false);
     }
     return 0;
