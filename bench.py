@@ -15,7 +15,12 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
   roofline      the dominant hand-written kernel pair (subdomain back-solve), algorithmic bytes /
                 measured HIP-event time on the library's stream, against 8 TB/s
   cpu_baseline  the CPU oracle (a port of the reference algorithm, oracle/dot_oracle.c) timed on the
-                host cores of this box on a bounded sample of the same workload
+                host cores of this box on a bounded sample of the same workload -- headline leg: with the
+                reference's own CHOLMODSolver (oracle/_ref) doing the subdomain factorisations and solves;
+                variant: the port's own envelope Cholesky
+
+`python bench.py --gpus N` with N > 1 and no launcher starts its N ranks itself (torch.distributed.run on
+127.0.0.1); it refuses to run when the box has fewer GPUs, and n_gpus is checked against ncclCommCount.
 """
 import argparse
 import json
@@ -44,29 +49,69 @@ FP64_MFMA_PEAK = 78.6   # TFLOP/s, MI355X FP64 matrix = vector peak (256 CUs x 4
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
 
+def source_id():
+    """sha256 (12 hex) over the device sources the kernels are built from: PMC files carry the id of the build they were
+    measured on, and a traffic figure is only reported when it matches the build that runs"""
+    import glob
+    import hashlib
+    hsh = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dot_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dot_amd", "csrc", "*.hpp"))):
+        with open(f, "rb") as fh:
+            hsh.update(os.path.basename(f).encode())
+            hsh.update(fh.read())
+    return hsh.hexdigest()[:12]
+
+
+def plan_launch(gpus, env, device_count, argv):
+    """What `python bench.py --gpus N` has to do before anything touches a GPU -> (action, payload):
+      ("run", None)         this process is one of the N ranks (or N == 1) and goes on
+      ("reexec", [cmd...])  N > 1 and no launcher started us: start N ranks of this script under torch.distributed.run
+      ("fail", message)     the request cannot be met (fewer GPUs than ranks, launcher / --gpus mismatch)
+    n_gpus in the JSON line is then always the number of ranks that ran (and equals the size of the RCCL communicator)."""
+    if gpus < 1:
+        return "fail", f"--gpus {gpus}: need at least one GPU"
+    launched = "WORLD_SIZE" in env and "RANK" in env
+    world = int(env.get("WORLD_SIZE", "1")) if launched else 1
+    if launched and world != gpus:
+        return "fail", f"--gpus {gpus} but the launcher started WORLD_SIZE={world} ranks"
+    if device_count is not None and device_count < (1 if launched else gpus):
+        return "fail", f"--gpus {gpus} but this box has {device_count} GPU(s)"
+    if launched and device_count is not None and int(env.get("LOCAL_RANK", "0")) >= device_count:
+        return "fail", f"LOCAL_RANK {env.get('LOCAL_RANK')} but this box has {device_count} GPU(s)"
+    if gpus > 1 and not launched:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        return "reexec", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port)] + list(argv)
+    return "run", None
+
+
 def compact_line(full):
     """The driver-facing JSON line: the contract's keys plus numbers-only `roofline`, `roofline_factor`, `cpu_baseline` and a
     one-row-per-workload summary.  Everything else (roofline_by_kernel, PMC sources, notes) is in bench_detail.json."""
-    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+    keep = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data", "config", "ms_per_step_p50", "ms_per_step_p95", "iters_per_frame", "step_breakdown_ms")
     out = {k: full[k] for k in keep if k in full}
     out["data"] = "reference input mesh (fixture), scripted handles"
     r = full["roofline"]
     out["roofline"] = {"bound": "hbm", "kernel": "backsolve_ctl_kernel", "achieved": r["achieved"], "peak": r["peak"],
                        "unit": "GB/s", "frac": r["frac"], "traffic": r["traffic"],
+                       "traffic_source": r.get("traffic_source"),
                        "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_ms": r["avg_launch_ms"],
                        "launches_timed": r["launches_timed"], "launches_total": r["launches_total"],
                        "launches_stopped": r["launches_stopped"], "launches_held": r.get("launches_held", 0),
                        "launches_held_rejected": r.get("launches_held_rejected", 0)}
     f = full["roofline_factor"]
-    out["roofline_factor"] = {"bound": "mfma", "kernel": "tile_task_kernel", "achieved": f["achieved"], "peak": f["peak"],
+    out["roofline_factor"] = {"bound": "mfma", "kernel": f.get("kernel_name", "tile_task_kernel"), "achieved": f["achieved"], "peak": f["peak"],
                               "unit": "TFLOP/s", "frac": f["frac"], "flop": f["flop_per_factorisation"], "avg_ms": f["avg_ms"]}
     if "collectives" in full:
         c = full["collectives"]
         out["collectives"] = {k: c[k] for k in ("allreduce_calls_per_step", "payload_MB_per_step", "est_ms_per_step") if k in c}
     if "cpu_baseline" in full:
         c = full["cpu_baseline"]
-        cb = {k: c[k] for k in ("value", "unit", "cores", "kind", "sample") if k in c}
+        cb = {k: c[k] for k in ("value", "unit", "cores", "kind", "leg", "sample") if k in c}
         a = c.get("reference_anchor") or {}
         if a.get("ms_per_step"):
             cb["reference_anchor_ms"] = a["ms_per_step"]
@@ -113,13 +158,20 @@ def main():
     from dot_amd.workloads import WORKLOADS, load_workload
     from dot_amd.timestepper import DOTTimeStepper, comm_unique_id
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    action, payload = plan_launch(args.gpus, os.environ, torch.cuda.device_count(), sys.argv)
+    if action == "fail":
+        raise SystemExit("bench.py: " + payload)
+    if action == "reexec":
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL) and hand
+        # their output through; this process never touches a GPU
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(payload, env=env))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if "RANK" in os.environ else 1
+    rank = int(os.environ.get("RANK", "0")) if world > 1 else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -140,6 +192,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    SRC_ID = source_id()
+    stale = {}
+
     def pmc_by_kernel(workload):
         """HBM bytes per launch of every kernel class from the PMC counters (FETCH_SIZE / WRITE_SIZE need their own
         rocprofv3 passes, so they are collected separately on the same kernels + workload by tools/pmc_kernels.sh and
@@ -149,6 +204,10 @@ def main():
             with open(f) as fh:
                 rec = json.load(fh)
             if rec.get("workload") != workload or "kernels" not in rec:
+                continue
+            if rec.get("source_id") != SRC_ID:
+                # measured on another build of the kernels: not reported as this run's traffic
+                stale.setdefault(workload, os.path.relpath(f, ROOT) + f" (source_id {rec.get('source_id')}, running {SRC_ID})")
                 continue
             K = rec["kernels"]
 
@@ -183,13 +242,7 @@ def main():
         t, f = pmc_by_kernel(workload)
         if "backsolve" in t:
             return t["backsolve"], f
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_backsolve_pmc*.json")), reverse=True):
-            with open(f) as fh:
-                rec = json.load(fh)
-            if rec.get("workload") == workload:
-                return rec["hbm_bytes_per_backsolve"], os.path.relpath(f, ROOT)
-        return None, None
+        return None, ("stale: " + stale[workload]) if workload in stale else None
 
     def kernel_rooflines(ts, rec):
         """SURVEY.md section 8(d) "per kernel class": every hot kernel of the path launched back to back on this
@@ -254,6 +307,10 @@ def main():
         ts = DOTTimeStepper(sc, ep, nparts, device=local_rank, rank=rank, world=world, comm_id=fresh_comm_id(),
                             flags=dl.FLAG_TIME_BACKSOLVE | (dl.FLAG_ASYNC_REFRESH if async_refresh else 0) |
                             (dl.FLAG_OWNER_EXCHANGE if owner and world > 1 else 0))
+        # the size of the communicator as RCCL reports it: n_gpus in the line is the ranks that really cooperate
+        rr = int(dl.load().dotmi_comm_ranks(ts._h))
+        if rr != world:
+            raise SystemExit(f"bench.py: {world} ranks were started but the RCCL communicator has {rr}")
         # scripted (Dirichlet) vertices are never moved by the solver: the scripter keeps their positions itself, as
         # the reference's host mesh does, instead of reading all positions back every step
         cached = cfg.script != "rubberBandPull"
@@ -337,7 +394,7 @@ def main():
         }
         w = np.array(walls) * 1e3
         rec = {
-            "workload": label, "nV": int(sc.V_rest.shape[0]), "nT": int(sc.T.shape[0]), "energy": cfg.energy,
+            "workload": label, "rccl_ranks": rr, "nV": int(sc.V_rest.shape[0]), "nT": int(sc.T.shape[0]), "energy": cfg.energy,
             "subdomains": int(nparts), "dt": cfg.dt, "script": cfg.script, "steps": steps, "warmup": warmup,
             "ms_per_step": round(1e3 * elapsed / steps, 3), "ms_per_step_p50": round(float(np.percentile(w, 50)), 3),
             "ms_per_step_p95": round(float(np.percentile(w, 95)), 3),
@@ -360,7 +417,8 @@ def main():
         fact_ms = float(np.mean([s.ms_factor for s in stats]))
         fact_tf = stats[0].factor_flops / (fact_ms * 1e-3) / 1e12 if fact_ms > 0 else 0.0
         rec["roofline_factor"] = {
-            "bound": "mfma", "kernel": "tile_task_kernel: block-sparse inverse-Cholesky of the subdomain blocks as 64x64 "
+            "bound": "mfma", "kernel_name": {1: "tile_task_kernel", 2: "tile_flow_kernel"}.get(int(L.dotmi_factor_kind(ts._h)), "?"),
+            "kernel": "tile_task_kernel / tile_flow_kernel: block-sparse inverse-Cholesky of the subdomain blocks as 64x64 "
             "tile tasks (v_mfma_f64_16x16x4_f64 from LDS), once per step",
             "achieved": round(fact_tf, 2), "peak": FP64_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(fact_tf / FP64_MFMA_PEAK, 4),
             "flop_per_factorisation": float(stats[0].factor_flops), "avg_ms": round(fact_ms, 4),
@@ -401,7 +459,9 @@ def main():
             try:
                 r2 = run_workload(name, st_, wu_)[0]
             except Exception as e:   # noqa: BLE001  (an extra workload must not cost the line its headline)
-                if name.endswith("+owner"):
+                # N > 1: the other ranks are inside this workload's collectives -- a rank that carried on alone would leave
+                # them waiting for ever, so the error ends this rank and the launcher takes the job down
+                if name.endswith("+owner") and world == 1:
                     extra.append({"workload": name, "error": repr(e)})
                     continue
                 raise
@@ -411,7 +471,7 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "ms_per_time_step", "value": ms_per_step, "unit": "ms", "n_gpus": world,
+            "metric": "ms_per_time_step", "value": ms_per_step, "unit": "ms", "n_gpus": world, "rccl_ranks": rec["rccl_ranks"],
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "mesh fixture tests/golden/meshes (reference input mesh), scripted handles",
@@ -447,8 +507,8 @@ def main():
                 sc2, ep2, _ = load_workload(args.workload)
                 orc = O.OracleSim(sc2.V_rest, sc2.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc2.fixed, sc2.x0,
                                   ep2, nparts, cfg.with_gravity)
-                if reference_cholmod:
-                    O.use_reference_cholmod(orc)
+                if reference_cholmod and O.use_reference_cholmod(orc) != 0:
+                    raise RuntimeError("the reference CHOLMODSolver could not factorise a subdomain")
                 times, cits, tf, tsv = [], [], [], []
                 budget_t0 = time.perf_counter()
                 for k in range(nwarm + args.cpu_steps):
@@ -464,13 +524,15 @@ def main():
                         tsv.append(so.ms_backsolve)
                     if time.perf_counter() - budget_t0 > (15.0 if reference_cholmod else 30.0) and len(times) >= 3:
                         break
+                if orc.factor_failed():   # steps timed on a failed factorisation are not a baseline
+                    raise RuntimeError("a subdomain factorisation failed during the CPU leg")
                 return sc2, ep2, orc, times, cits, float(np.mean(tf)), float(np.mean(tsv))
 
             sc2, ep2, orc, times, cits, tf_, ts_ = cpu_leg(False)
             out["cpu_baseline"] = {
                 "value": round(1e3 * float(np.mean(times)), 2), "unit": "ms", "cores": threads, "kind": "port",
                 "sample": f"steps {nwarm}..{nwarm + len(times) - 1} of {args.workload} (same partition, same tolerance), "
-                          f"oracle/dot_oracle.c with OpenMP, iters/step {cits}",
+                          f"oracle/dot_oracle.c with OpenMP (own envelope Cholesky), iters/step {cits}",
                 "factor_ms": round(tf_, 2), "backsolve_ms": round(ts_, 2),
                 # the reference's own code cannot be built on this box (TBB); what BASELINE.md section 2 measured with it
                 "reference_anchor": dict(REFERENCE_ANCHOR.get(args.workload, {}), cores=8, source="BASELINE.md section 2: "
@@ -482,12 +544,22 @@ def main():
                 try:
                     _, _, orc2, times2, cits2, tf2, ts2 = cpu_leg(True)
                     orc2.close()
-                    out["cpu_baseline"]["variants"] = [{
-                        "kind": "port+reference_cholmod", "value": round(1e3 * float(np.mean(times2)), 2), "unit": "ms",
-                        "cores": threads, "steps": len(times2), "iters_equal_port": cits2 == cits[:len(cits2)],
-                        "factor_ms": round(tf2, 2), "backsolve_ms": round(ts2, 2)}]
+                    # this leg is the headline baseline: the reference's own linear algebra under the
+                    # restated stepper is the closest thing to the reference's CPU path that runs on this box; the port
+                    # with its own envelope Cholesky (factor ~60 ms instead of ~9) becomes the variant
+                    cbp = out["cpu_baseline"]
+                    port_variant = {"kind": "port", "leg": "port (own envelope Cholesky)", "value": cbp["value"], "unit": "ms", "cores": threads, "steps": len(times),
+                                    "factor_ms": cbp["factor_ms"], "backsolve_ms": cbp["backsolve_ms"]}
+                    cbp.update({
+                        "value": round(1e3 * float(np.mean(times2)), 2), "kind": "port", "leg": "port+reference_cholmod",
+                        "sample": f"steps {nwarm}..{nwarm + len(times2) - 1} of {args.workload} (same partition, same tolerance), "
+                                  f"oracle/dot_oracle.c with OpenMP over the subdomains, factorisations and solves in the "
+                                  f"reference's CHOLMODSolver (oracle/_ref, vendored CHOLMOD + MKL), iters/step {cits2}",
+                        "factor_ms": round(tf2, 2), "backsolve_ms": round(ts2, 2),
+                        "iters_equal_port": cits2 == cits[:len(cits2)]})
+                    cbp["variants"] = [port_variant]
                 except Exception as e:   # noqa: BLE001 - optional leg (needs oracle/_ref + the image's MKL)
-                    out["cpu_baseline"]["variants"] = [{"kind": "port+reference_cholmod", "error": f"{type(e).__name__}: {e}"}]
+                    out["cpu_baseline"]["variants"] = [{"kind": "port", "leg": "port+reference_cholmod", "error": f"{type(e).__name__}: {e}"}]
             # the one piece of the reference that IS compiled here, timed on the same subdomains: CHOLMODSolver
             # factorize + solve (oracle/_ref/librefsolver.so = src/LinSysSolver/CHOLMODSolver.cpp on the vendored CHOLMOD)
             try:

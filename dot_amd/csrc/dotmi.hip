@@ -171,7 +171,7 @@ struct Tuning {
         t.tileFlowWaitMs = std::max(1, geti("DOTMI_TILE_FLOW_WAIT_MS", 2000));
         t.tileEagerMinDiag = std::max(0, geti("DOTMI_TILE_EAGER_MIN_DIAG", 0));
         t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
-        t.earlyBs = std::min(2, std::max(0, geti("DOTMI_EARLY_BACKSOLVE", 2)));
+        t.earlyBs = geti("DOTMI_EARLY_BACKSOLVE", 2) != 0 ? 2 : 0;   // (1, round 3's per-step rule, now means "on")
         t.earlyHostCtl = geti("DOTMI_EARLY_HOST_CTL", 1) != 0;
         t.earlyAbort = geti("DOTMI_EARLY_ABORT", 1) != 0;
         t.earlyHold = geti("DOTMI_EARLY_HOLD", 1) != 0;
@@ -1761,9 +1761,13 @@ int refactor_finish(dotmi_handle *h, double *ms_hess, double *ms_fact)
             return DOTMI_E_NOTSPD;
         }
     }
-    if (bad >= 0 && h->h_info[bad] >= (1 << 30)) {
+    // a dataflow wait that timed out anywhere is a DEVICE failure, whatever pivot report stands in front of it
+    int stuck = -1;
+    for (int i = 0; i < h->P.nParts && stuck < 0; ++i)
+        if (h->h_info[i] >= (1 << 30)) stuck = i;
+    if (stuck >= 0) {
         h->err = "the tile factorisation's dataflow scheduler waited for a task that never finished (subdomain " +
-                 std::to_string(h->p0 + bad) + ")";
+                 std::to_string(h->p0 + stuck) + ")";
         h->poisoned = true;
         return DOTMI_E_DEVICE;
     }
@@ -2268,19 +2272,12 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
 {
     DevLoop &C = *h->h_ctl;
     memset(&C, 0, sizeof(C));
-    // Early back-solve or not, per step: it takes the controller (~9 us with its launch boundary) off every iteration and
-    // starts a back-solve for nothing per rejected trial and once at the end of the step -- the controller tells it to
-    // stop (DevLoop::abortEpoch), which costs ~20 us.  Decided from the last step's counts (a function of the handle's own
-    // history: the same from run to run).
-    // (bar17K: 27 iterations, no halving -> early, 4.09 -> 3.90 ms per step; horse7K / monkey18K halve in every second
-    // trial -> q-based, measured equal within 2 % either way; the 1 M-tet bar: the cached vectors' extra traffic eats
-    // the gain -> q-based)
+    // The early order (back-solve issued on the trial gradient, beside the controller) in every step of a handle that has its
+    // buffers: it takes the controller (~9 us with its launch boundary) off every iteration and starts a back-solve for
+    // nothing per rejected trial and once at the end of the step, which the controller tells to stop (DevLoop::abortEpoch).
+    // (Round 3's per-step rule from the previous step's counts, DOTMI_EARLY_BACKSOLVE=1, is gone: with the stop and the held
+    // launches the early order is at least as fast on every workload, and the owner exchange has no other order -- ADVICE r04.)
     h->earlyNow = h->earlyBs;
-    if (h->earlyBs && h->tune.earlyBs == 1) {
-        const double save_ms = 0.009 - 64.0 * h->n / 4e9;   // per iteration; merge_early moves ~8 vectors more
-        const double wasted_ms = 0.02;                      // a speculative back-solve until it has noticed the verdict
-        h->earlyNow = h->prevIters >= 0 && save_ms * h->prevIters > wasted_ms * (h->prevHalv + 1.0);
-    }
     C.iterCap = h->iterCap;
     C.hist = h->hist;
     C.tol = h->targetGRes;
@@ -2384,7 +2381,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
                 ctlR = h->partGR;
             }
             if (!h->earlyNow) {
-                launch_loop_control(h->ctl, h->gstage + n_, 1, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
+                launch_loop_control(h->ctl, h->gstage + n_, 1, ctlR, h->alpha_dev, h->h_flags, h->st, 1);
             } else {
                 // early order on the sharded element pass: -g_0 (the summed gradient) into this rank's right-hand sides, the
                 // first direction's solve with the start-of-step controller inside its launch, the sum over the ranks, z = u
@@ -2893,6 +2890,23 @@ int dotmi_comm_unique_id(void *out128)
     return 0;
 }
 
+int32_t dotmi_factor_kind(const dotmi_handle *h)
+{
+    if (!h) return DOTMI_E_INVALID;
+    return !h->tileMode ? 0 : h->tileFlow ? 2 : 1;
+}
+
+int32_t dotmi_comm_ranks(const dotmi_handle *h)
+{
+    if (!h) return DOTMI_E_INVALID;
+    if (h->comm) {
+        int n = 0;
+        if (ncclCommCount(h->comm, &n) != ncclSuccess) return DOTMI_E_DEVICE;
+        return n;
+    }
+    return h->arCb ? -h->world : 1;
+}
+
 void dotmi_destroy(dotmi_handle *h)
 {
     if (!h) return;
@@ -3156,7 +3170,10 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
             h->err = "DOTMI_FLAG_OWNER_EXCHANGE needs the device loop's early order with the fused direction kernel";
             return DOTMI_E_INVALID;
         }
-        if (h->earlyBs && h->tune.fuseStep && !h->shardElems) h->PT.wgCap = 512;   // the trials' grouping of the energy partials, everywhere
+        // the trials' grouping of the energy partials, everywhere: the start-of-step evaluation and the fused-step trials must
+        // sum E in the same grouping or an `E > E_cur` verdict can flip at rounding level (the owner exchange runs the fused
+        // step on its sharded element pass too)
+        if (h->earlyBs && h->tune.fuseStep && (!h->shardElems || h->owner)) h->PT.wgCap = 512;
         if (h->dist) {
             if (int rc = dalloc(h, &h->zstage, (size_t)h->n)) return rc;
             HIPCHECK(h, hipMemsetAsync(h->zstage, 0, sizeof(double) * h->n, h->st));   // (owner exchange: stays zero off the held set)

@@ -2177,6 +2177,9 @@ __global__ __launch_bounds__(THREADS, 2) void tile_flow_kernel(const TileTask *_
                                                                int *__restrict__ done, int *__restrict__ next, int epoch,
                                                                long long waitTicks, int *__restrict__ info)
 {
+    // the 256-thread form (256 VGPRs + 84 bytes of scratch) gave a wrong factor on horse7K -- the same non-SPD pivot in every
+    // run -- and was not pursued: it cannot be instantiated
+    static_assert(THREADS == 512, "tile_flow_kernel: only the 512-thread form is validated");
     constexpr int NB = CHOL_NB, LD = NB + 1;
     __shared__ double La[NB][LD], Lb[NB][LD], T32[32][33], T16[16][17];
     __shared__ int s_ticket;
@@ -2375,9 +2378,12 @@ void launch_tile_flow(const TileTask *tasks, int ntasks, const TileProd *prods, 
     if (ntasks <= 0) return;
     const int grid = std::min(ntasks, nwg);
     const long long waitTicks = (long long)(waitMs * 1e5);
-    // always the 512-thread form: the 256-thread instantiation needs 256 VGPRs plus scratch and measured a wrong factor on
-    // horse7K (same non-SPD pivot in every run: not a race; not pursued, DOTMI_TILE_THREADS only selects the level kernel's form)
-    (void)threads;
+    // always the 512-thread form (see the static_assert in the kernel); DOTMI_TILE_THREADS only selects the level kernel's form
+    if (threads != 512) {
+        static bool said = false;
+        if (!said) fprintf(stderr, "dotmi: DOTMI_TILE_THREADS=%d does not apply to the dataflow factorisation (512 threads)\n", threads);
+        said = true;
+    }
     if (fastDiag)
         hipLaunchKernelGGL((tile_flow_kernel<512, true>), dim3(grid), dim3(512), 0, st, tasks, prods, ntasks, depPtr, depIdx, done,
                            next, epoch, waitTicks, info);

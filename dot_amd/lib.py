@@ -66,11 +66,11 @@ BENCH_KERNELS = ["elem_energy_grad", "elem_energy", "vertex_gather", "spmv_dots"
                  "spmv_zp", "merge_early", "elem_step", "gather_early"]
 
 EXPORTS = [
-    "dotmi_create", "dotmi_destroy", "dotmi_last_error", "dotmi_comm_unique_id", "dotmi_set_state",
+    "dotmi_create", "dotmi_destroy", "dotmi_last_error", "dotmi_comm_unique_id", "dotmi_comm_ranks", "dotmi_set_state",
     "dotmi_get_state", "dotmi_set_dirichlet", "dotmi_refix", "dotmi_step", "dotmi_last_iter_log",
     "dotmi_target_gres", "dotmi_eval_energy", "dotmi_eval_gradient", "dotmi_eval_elem_hessians",
     "dotmi_refactor", "dotmi_apply_precond", "dotmi_spmv", "dotmi_get_features", "dotmi_part_size", "dotmi_padded_size",
-    "dotmi_part_matrix", "dotmi_factor_storage_bytes", "dotmi_probe_direction", "dotmi_bench_precond", "dotmi_bench_energy", "dotmi_bench_kernel", "dotmi_plan_shards", "dotmi_plan_layout", "dotmi_plan_tile_schedule", "dotmi_plan_tile_deps", "dotmi_plan_patches", "dotmi_plan_rank", "dotmi_partition",
+    "dotmi_part_matrix", "dotmi_factor_storage_bytes", "dotmi_factor_kind", "dotmi_probe_direction", "dotmi_bench_precond", "dotmi_bench_energy", "dotmi_bench_kernel", "dotmi_plan_shards", "dotmi_plan_layout", "dotmi_plan_tile_schedule", "dotmi_plan_tile_deps", "dotmi_plan_patches", "dotmi_plan_rank", "dotmi_partition",
 ]
 
 _lib = None
@@ -96,6 +96,8 @@ def load() -> C.CDLL:
     L.dotmi_last_error.argtypes = [H]
     L.dotmi_last_error.restype = C.c_char_p
     L.dotmi_comm_unique_id.argtypes = [C.c_void_p]
+    L.dotmi_comm_ranks.argtypes = [H]
+    L.dotmi_comm_ranks.restype = C.c_int32
     L.dotmi_set_state.argtypes = [H, c_dp, c_dp, c_dp]
     L.dotmi_get_state.argtypes = [H, c_dp, c_dp, c_dp]
     L.dotmi_set_dirichlet.argtypes = [H, C.c_int32, c_ip, c_dp]
@@ -119,6 +121,8 @@ def load() -> C.CDLL:
     L.dotmi_probe_direction.argtypes = [H, c_dp, C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.dotmi_factor_storage_bytes.argtypes = [H]
     L.dotmi_factor_storage_bytes.restype = C.c_int64
+    L.dotmi_factor_kind.argtypes = [H]
+    L.dotmi_factor_kind.restype = C.c_int32
     L.dotmi_bench_precond.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]
     L.dotmi_bench_energy.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]
     L.dotmi_bench_kernel.argtypes = [H, C.c_int32, C.c_int32, c_dp, C.POINTER(C.c_int64)]

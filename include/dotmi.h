@@ -243,6 +243,10 @@ int dotmi_partition(int32_t nV, int32_t nT, const int32_t *T, const double *X, i
 /* world>1: rank 0 calls this and ships the 128 bytes to every rank (e.g. torch.distributed
  * broadcast); all ranks pass it as params.comm_id.  */
 int dotmi_comm_unique_id(void *out128);
+/* The number of ranks in the handle's RCCL communicator as RCCL itself reports it (ncclCommCount): what a benchmark prints
+ * beside the number of processes it believes it started.  1: no communicator (single GPU); -world: the ranks cooperate
+ * through the host all-reduce hook of dotmi_params instead of RCCL. */
+int32_t dotmi_comm_ranks(const dotmi_handle *h);
 
 /* ---- state ------------------------------------------------------------------------------------ */
 /* (x, v[, x_n]) round-trip = what Optimizer::saveStatus / restart carry (Optimizer.cpp:1096-1177) */
@@ -291,6 +295,9 @@ int32_t dotmi_padded_size(const dotmi_handle *h);
 /* bytes of HBM that hold the factors X_s of this rank's subdomains (compact 64-row blocks: ~1.2x the structural
  * non-zeros dotmi_step_stats.precond_bytes counts; DOTMI_TILE_FACTOR=0: nParts x padded_size^2 x 8) */
 int64_t dotmi_factor_storage_bytes(const dotmi_handle *h);
+/* which kernel family factorises this handle's subdomains (for measurement records): 1 = tile tasks, one launch per level
+ * (tile_task_kernel), 2 = tile tasks as one dataflow launch (tile_flow_kernel) */
+int32_t dotmi_factor_kind(const dotmi_handle *h);
 int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *M, int32_t *l2g);
 
 /* ---- measurement ------------------------------------------------------------------------------ */

@@ -481,6 +481,7 @@ struct dor_sim {
     int it, failed;
     double lastE, g2, E0, g2_0;
     double t_energy, t_grad, t_solve, t_hess, t_factor;
+    int factor_failed;  /* sticky: some dor_refactor since creation (or since dor_use_ext_solver) met a non-SPD subdomain */
     int energy_evals;
 };
 
@@ -1077,7 +1078,10 @@ void dor_refactor(dor_sim *s, const double *x)
 #pragma omp parallel for schedule(dynamic, 1)
     for (int pI = 0; pI < s->nParts; ++pI)
         if (s->ext.create ? ext_factor_part(s, &s->parts[pI]) : factor_part(s, &s->parts[pI])) fail = 1;
-    if (fail) fprintf(stderr, "dot_oracle: subdomain factorisation failed (non-SPD)\n");
+    if (fail) {
+        fprintf(stderr, "dot_oracle: subdomain factorisation failed (non-SPD)\n");
+        s->factor_failed = 1;
+    }
     s->t_factor += now_ms() - t1;
 }
 
@@ -1635,11 +1639,13 @@ int dor_use_ext_solver(dor_sim *s, const dor_ext_solver *api)
         ext_build(s);
     }
     double t = s->t_factor;
+    s->factor_failed = 0;
     dor_refactor(s, s->xn);
-    /* (dor_refactor only reports a failure on stderr; the timing of this extra refresh is not a step's) */
-    s->t_factor = t;
-    return 0;
+    s->t_factor = t; /* (the timing of this extra refresh is not a step's) */
+    return s->factor_failed;
 }
+
+int dor_factor_failed(const dor_sim *s) { return s->factor_failed; }
 
 void dor_get_features(const dor_sim *s, double *A, double *vol, double *mass, double *mu, double *lam)
 {

@@ -70,6 +70,9 @@ typedef struct {
 } dor_ext_solver;
 /* api == NULL: back to the built-in envelope Cholesky.  Re-factors at the current x.  returns 0, or 1 if a factorisation failed */
 int dor_use_ext_solver(dor_sim *s, const dor_ext_solver *api);
+/* 1 if any refresh since creation / since the last dor_use_ext_solver met a subdomain matrix that could not be factorised
+ * (the steps after it ran on a stale or partial factor: a timing or parity leg must not be trusted) */
+int dor_factor_failed(const dor_sim *s);
 
 typedef struct {
     int iters;         /* L-BFGS iterations this step (innerIterAmt delta) */

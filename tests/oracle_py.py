@@ -151,6 +151,13 @@ class OracleSim:
         lib().dor_step(self.h, C.byref(st))
         return st
 
+    def factor_failed(self) -> bool:
+        """a refresh since creation (or since use_reference_cholmod) met a subdomain that could not be factorised"""
+        L = lib()
+        L.dor_factor_failed.argtypes = [C.c_void_p]
+        L.dor_factor_failed.restype = C.c_int
+        return bool(L.dor_factor_failed(self.h))
+
     def step_gsdd(self):
         st = StepStats()
         lib().dor_step_gsdd(self.h, C.byref(st))

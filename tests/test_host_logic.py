@@ -509,3 +509,56 @@ def test_info_txt_is_byte_identical_to_the_references_timer_print(tmp_path):
         args = [str(rec["nV"]), str(rec["nT"]), str(rec["iterNum"]), str(rec["inner"])] + [repr(t) for t in rec["t"]]
         subprocess.check_call([exe, "--write-info", str(dst)] + args)
         assert dst.read_bytes() == rec["text"].encode()
+
+
+# ---- bench.py: who starts the ranks -------------------------------------------------------------
+def test_bench_launch_plan_never_reports_ranks_it_did_not_start():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (or refuse), never run one rank and print N:
+    plan_launch is the whole decision, a pure function of (--gpus, environment, visible GPUs, argv)."""
+    import bench
+    argv = ["bench.py", "--gpus", "8", "--steps", "5"]
+    # one GPU asked for, no launcher: run in this process
+    assert bench.plan_launch(1, {}, 1, argv) == ("run", None)
+    assert bench.plan_launch(1, {}, 8, argv) == ("run", None)
+    # N > 1 without a launcher: re-exec under torch.distributed.run with N ranks on 127.0.0.1 and the same arguments
+    act, cmd = bench.plan_launch(8, {}, 8, argv)
+    assert act == "reexec"
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-len(argv):] == argv
+    # fewer GPUs than ranks: refuse loudly, launcher or not
+    act, msg = bench.plan_launch(8, {}, 1, argv)
+    assert act == "fail" and "8" in msg and "1 GPU" in msg
+    act, msg = bench.plan_launch(2, {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1"}, 1, argv)
+    assert act == "fail"
+    # started by the driver's launcher: go on as one of the ranks; a mismatch between --gpus and WORLD_SIZE is an error
+    assert bench.plan_launch(4, {"WORLD_SIZE": "4", "RANK": "3", "LOCAL_RANK": "3"}, 8, argv) == ("run", None)
+    assert bench.plan_launch(8, {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"}, 8, argv)[0] == "fail"
+    assert bench.plan_launch(1, {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, 8, argv)[0] == "fail"
+    assert bench.plan_launch(0, {}, 8, argv)[0] == "fail"
+    # a stale WORLD_SIZE in the environment without RANK is not a launcher
+    assert bench.plan_launch(1, {"WORLD_SIZE": "8"}, 8, argv) == ("run", None)
+
+
+def test_bench_reexec_starts_the_ranks_and_passes_their_exit_code(tmp_path):
+    """the re-exec command really starts N processes with RANK / WORLD_SIZE set (a stand-in script instead of bench.py:
+    no GPU here)"""
+    import subprocess
+    import bench
+    script = tmp_path / "fake_bench.py"
+    script.write_text("import os, sys\n"
+                      "open(os.path.join(os.path.dirname(__file__), 'rank%s' % os.environ['RANK']), 'w')"
+                      ".write(os.environ['WORLD_SIZE'] + ' ' + ' '.join(sys.argv[1:]))\n"
+                      "sys.exit(3 if os.environ['RANK'] == '1' else 0)\n")
+    act, cmd = bench.plan_launch(2, {}, 2, [str(script), "--gpus", "2"])
+    assert act == "reexec"
+    rc = subprocess.call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+    assert rc != 0                                            # rank 1's failure is the job's failure
+    assert (tmp_path / "rank0").read_text() == "2 --gpus 2"
+    assert (tmp_path / "rank1").read_text() == "2 --gpus 2"
+
+
+def test_bench_source_id_is_stable_and_pmc_files_carry_it():
+    import bench
+    a, b = bench.source_id(), bench.source_id()
+    assert a == b and len(a) == 12 and int(a, 16) >= 0

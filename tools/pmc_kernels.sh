@@ -12,6 +12,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python - "$wl" /root/repo/gpurun_out/${tag}_pmc_${slug}.json <<'PY'
 import csv, glob, json, sys, collections
+sys.path.insert(0, "/root/repo")
+from bench import source_id   # sha256 over dot_amd/csrc/*.hip, *.hpp: bench.py reports a traffic figure only for the build it runs
 CLASSES = [("elem_patch_kernel", "elem_pass"), ("vertex_gather_kernel", "vertex_gather"), ("spmv_dots_kernel", "spmv_dots"),
            ("backsolve_kernel", "backsolve"), ("merge_tiles_kernel", "merge"), ("merge_tiles_early_kernel", "merge_early"), ("merge_kernel", "merge_split"), ("reduce_partial_p_kernel", "reduce_partial"),
            ("spmv_zp_kernel", "spmv_zp"), ("build_qpad_kernel", "build_qpad"),
@@ -41,7 +43,7 @@ rec = {"_what": "rocprofv3 PMC passes (separate runs: --pmc FETCH_SIZE, then --p
        "tools/pmc_kernels.sh) of tools/kernel_bench.py (every kernel class launched 31 times back to back on the workload's resident "
        "state), one MI355X, averaged over the dispatches of a kernel instance.  Counter unit KiB; gfx950 correction per "
        "MI355X_MICROARCH.md section HBM: FETCH_SIZE doubled, WRITE_SIZE as is; Infinity-Cache hits are counted, not excluded.",
-       "workload": sys.argv[1], "kernels": out}
+       "workload": sys.argv[1], "source_id": source_id(), "kernels": out}
 json.dump(rec, open(sys.argv[2], "w"), indent=1)
 for name, ks in out.items():
     for kn, d in ks.items():
