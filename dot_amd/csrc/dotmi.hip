@@ -78,7 +78,7 @@ struct DBuf {
 // results beyond rounding.  Listed in include/dotmi.h ("Environment") and DESIGN.md section 10.
 struct Tuning {
     int ndLevels = -1;        // DOTMI_ND_LEVELS      depth of the nested dissection (-1: nd_default_levels)
-    int ndMin = 768;          // DOTMI_ND_MIN         smallest region (scalars) that is still split
+    int ndMin = ND_MIN_SPLIT; // DOTMI_ND_MIN         smallest region (scalars) that is still split
     int tileRows = 0;         // DOTMI_TILE_ROWS      rows per back-solve tile (0: 64, or 32 for few subdomains)
     int tileRowsLong = 0;     // DOTMI_TILE_ROWS_LONG rows per back-solve tile when the rows have more than 1536 columns (0: as the
                               //                      other rows, or ~256 KB tiles where few subdomains leave the launch bound by
@@ -117,6 +117,7 @@ struct Tuning {
     int tileFlowWg = 0;       // DOTMI_TILE_FLOW_WG   workgroups of that launch (0: two per CU)
     int tileFlowWaitMs = 2000;   // DOTMI_TILE_FLOW_WAIT_MS  a task that waits longer for one of its dependencies gives up (error)
     int tileEagerMinDiag = 0; // DOTMI_TILE_EAGER_MIN_DIAG early products a diagonal tile task may keep
+    int tileEagerMinRmul = -1; // DOTMI_TILE_EAGER_MIN_RMUL early products the last task of a Q tile may keep (-1: as the others; 0: none)
     int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
     bool fuseDir = true;      // DOTMI_FUSE_DIR=0     (early order) build_p and spmv_dots as two launches instead of one on cached H s_j
     bool fuseStep = true;     // DOTMI_FUSE_STEP=0    (early order) step_forward as a launch of its own instead of inside the element pass
@@ -138,7 +139,7 @@ struct Tuning {
         Tuning t;
         t.ndLevels = geti("DOTMI_ND_LEVELS", -1);
         if (t.ndLevels < -1) t.ndLevels = 0;
-        t.ndMin = std::max(128, geti("DOTMI_ND_MIN", 768));
+        t.ndMin = std::max(128, geti("DOTMI_ND_MIN", ND_MIN_SPLIT));
         if (const char *ev = getenv("DOTMI_TILE_ROWS")) t.tileRows = std::min(64, std::max(8, atoi(ev) / 8 * 8));
         t.tileRowsLong = geti("DOTMI_TILE_ROWS_LONG", 0);
         if (t.tileRowsLong > 0) t.tileRowsLong = std::min(64, std::max(8, t.tileRowsLong / 8 * 8));
@@ -170,6 +171,7 @@ struct Tuning {
         t.tileFlowWg = geti("DOTMI_TILE_FLOW_WG", 0);
         t.tileFlowWaitMs = std::max(1, geti("DOTMI_TILE_FLOW_WAIT_MS", 2000));
         t.tileEagerMinDiag = std::max(0, geti("DOTMI_TILE_EAGER_MIN_DIAG", 0));
+        t.tileEagerMinRmul = geti("DOTMI_TILE_EAGER_MIN_RMUL", -1);
         t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
         t.earlyBs = geti("DOTMI_EARLY_BACKSOLVE", 2) != 0 ? 2 : 0;   // (1, round 3's per-step rule, now means "on")
         t.earlyHostCtl = geti("DOTMI_EARLY_HOST_CTL", 1) != 0;
@@ -238,7 +240,7 @@ struct dotmi_handle {
     std::vector<long long> rtOff;   // host copy of the RowTile table (dotmi_part_matrix)
     std::vector<int> rtLd, rtC0;
     size_t wTotal = 0;
-    double *tscratch = nullptr;
+    double *W2 = nullptr;             // tile factorisation: the work buffer (H, then R), laid out like P.W (which holds Q only)
     int nTclear = 0;
     std::vector<int> tlevelStart, tlevelDiag;
     bool tileSplit = false;
@@ -673,7 +675,11 @@ int build_device_mesh(dotmi_handle *h)
     {
         std::vector<std::vector<int>> sets(P.nParts);
         for (int ls = 0; ls < P.nParts; ++ls) sets[ls] = h->partVerts[h->p0 + ls];
-        if (ndLevels < 0) ndLevels = nd_default_levels(sets);
+        if (ndLevels < 0) {   // from the sizes of ALL subdomains of the mesh: the same tree on every rank
+            int nsAll = 0;
+            for (const auto &pv : h->partVerts) nsAll = std::max(nsAll, 3 * (int)pv.size());
+            ndLevels = nd_default_levels(nsAll, (int)h->partVerts.size());
+        }
         nd_plan(sets, nV, adj_ptr, adj_idx, h->Xrest.data(), ndLevels, ndMin, h->nd, region);
     }
     P.nmax = h->nd[0].size;
@@ -994,20 +1000,22 @@ int build_device_mesh(dotmi_handle *h)
         const bool tiny = (long long)P.nParts * nt <= 320;
         const int eagerMin = h->tune.tileEagerMin > 0 ? h->tune.tileEagerMin : (tiny ? 2 : P.nParts <= 64 ? 4 : 8);
         const int eagerChunk = h->tune.tileEagerChunk > 0 ? h->tune.tileEagerChunk : (tiny ? 2 : P.nParts <= 64 ? 4 : 8);
+        // the last task of a Q tile (sum, then the multiplication with -Q_jj): up to 64 subdomains it keeps ONE early product and
+        // hands the others to a task that runs beside DIAG(j) -- the launch between two diagonal launches is then as short as
+        // before round 5 (bar17K 1.125 -> 1.077 ms); above, where every launch is several rounds of workgroups, it keeps them
+        // like any other task and saves the partial sum's round trip (1 M tets 15.5 -> 14.5 ms)
+        const int eagerMinRmul = h->tune.tileEagerMinRmul >= -1 && getenv("DOTMI_TILE_EAGER_MIN_RMUL") ? h->tune.tileEagerMinRmul
+                                                                                                          : (P.nParts <= 64 ? 1 : -1);
+        // the work buffer (H filled in, R in place of it): same layout as the factor buffer W, which only ever holds Q
+        if (int rc = dalloc(h, &h->W2, std::max<size_t>(wTotal, 64))) return rc;
         TileSchedule S;
-        for (int pass = 0; pass < 2; ++pass) {
+        {
             std::vector<TileTaskL> all;
             size_t sn = 0;
-            S = TileSchedule();
             for (int ls = 0; ls < P.nParts; ++ls)
                 plan_subdomain_tiles(ls, nt, P.W, &rtOff[(size_t)ls * nt], &rtLd[(size_t)ls * nt], &rtC0[(size_t)ls * nt],
-                                     live[ls], pat[ls], h->tscratch, sn, all, S.clearTiles, S.clearLd, S.flops, S.qTiles,
-                                     eagerMin, eagerChunk, h->tune.tileEagerMinDiag, h->tune.tileBalance);
-            S.scratchTiles = sn;
-            if (pass == 0) {
-                if (int rc = dalloc(h, &h->tscratch, std::max<size_t>(sn, 1) * TILE * TILE)) return rc;
-                continue;
-            }
+                                     live[ls], pat[ls], h->W2, sn, all, S.clearTiles, S.clearLd, S.flops, S.qTiles,
+                                     eagerMin, eagerChunk, h->tune.tileEagerMinDiag, h->tune.tileBalance, eagerMinRmul);
             finish_tile_schedule(all, S, h->tune.tileXcdOrder);
         }
         if (int rc = upload(h, &h->ttasks, S.tasks)) return rc;
@@ -1721,14 +1729,19 @@ int refactor_issue(dotmi_handle *h, const double *x)
     HIPCHECK(h, hipEventRecord(h->evA, h->st));
     // only the blocks the factorisation leaves non-zero are cleared before the refill: the leaf squares and
     // the separator panels; the (A,C) blocks and the cleared mirror panels stay zero for the handle's life
+    // tile factorisation: H goes into the WORK buffer (tile_factor.hpp); the factor buffer W was zeroed once and only ever
+    // receives tiles of Q
+    DevParts Pf = h->P;
+    if (h->tileMode) Pf.W = h->W2;
     if (h->wDirty) {
         if (h->tileMode) launch_clear_tiles(h->tclear, h->tclearLd, h->nTclear, h->st);
         else launch_clear_segments(h->P, h->clearSeg, h->nClearSeg, h->st);
     } else if (h->P.nParts > 0) {
         HIPCHECK(h, hipMemsetAsync(h->P.W, 0, h->wTotal * sizeof(double), h->st));
+        if (h->tileMode) HIPCHECK(h, hipMemsetAsync(h->W2, 0, h->wTotal * sizeof(double), h->st));
         h->wDirty = true;
     }
-    launch_dense_fill(h->P, h->Hval, h->st);
+    launch_dense_fill(Pf, h->Hval, h->st);
     HIPCHECK(h, hipEventRecord(h->ev1, h->st));
     if (h->P.nParts > 0) {
         HIPCHECK(h, hipMemsetAsync(h->info_dev, 0, sizeof(int) * h->P.nParts, h->st));
@@ -2712,7 +2725,8 @@ int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pat
     size_t pi = 0;
     for (size_t k = 0; k < all.size(); ++k) {
         const TileTask &t = all[k].t;
-        int64_t *o = tasks + 10 * k;
+        int64_t *o = tasks + 11 * k;
+        o[10] = t.o - W;
         o[0] = all[k].level;
         o[1] = t.form;
         o[2] = t.init;
@@ -2807,8 +2821,21 @@ int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xr
     }
     std::vector<NdNode> tree;
     std::vector<std::vector<std::vector<int>>> region;
-    *nmax = nd_plan(sets, nV, adj_ptr, adj_idx, Xrest, levels < 0 ? nd_default_levels(sets) : levels,
-                    min_split < 128 ? 768 : min_split, tree, region);
+    int levelsDefault = 2;
+    if (levels < 0) {   // dotmi_create's rule: from the sizes of ALL subdomains of the mesh
+        std::vector<int> cnt(nParts, 0), mark(nV, -1);
+        for (int pI = 0; pI < nParts; ++pI)
+            for (int e = 0; e < nT; ++e)
+                if (epart[e] == pI)
+                    for (int k = 0; k < 4; ++k)
+                        if (mark[T[4 * e + k]] != pI) {
+                            mark[T[4 * e + k]] = pI;
+                            cnt[pI] += 3;
+                        }
+        levelsDefault = nd_default_levels(*std::max_element(cnt.begin(), cnt.end()), nParts);
+    }
+    *nmax = nd_plan(sets, nV, adj_ptr, adj_idx, Xrest, levels < 0 ? levelsDefault : levels,
+                    min_split < 128 ? ND_MIN_SPLIT : min_split, tree, region);
     *n_nodes = (int32_t)tree.size();
     if (nodes) {
         if ((int)tree.size() > node_cap) return DOTMI_E_INVALID;

@@ -14,7 +14,7 @@ constexpr int HIST_MAX = 6;     // L-BFGS pairs kept (reference uses 5, DOTTimeS
 inline int elem_wg_cap(int mat) { return mat == 1 ? 768 : 512; }
 constexpr int NB_RED = 256;     // blocks of every reducing kernel (fixed => run-to-run bit-identical sums)
 constexpr int RED_K = 3 * HIST_MAX + 3;  // partial values per block
-constexpr int BS_LONG = 4096;   // longest row (columns) the single-pass back-solve kernel holds in registers
+constexpr int BS_LONG = 5120;   // longest row (columns) the single-pass back-solve kernel holds in registers (512 threads x 5 x 2)
 constexpr int ELEM_NB_MAX = 8192; // most workgroups (= partial energy rows) of the element pass; beyond, workgroups loop over patches
 constexpr int CHOL_NB = 64;     // base block of the recursive inverse-Cholesky (LDS resident)
 

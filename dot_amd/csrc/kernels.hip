@@ -1159,7 +1159,8 @@ __device__ __forceinline__ void backsolve_block(int jobIdx, const int4 *__restri
     } else {
         if (len <= 1024) backsolve_tile<512, 1, 32>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
         else if (len <= 2048) backsolve_tile<512, 2, 16>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
-        else backsolve_tile<512, 4, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
+        else if (len <= 4096) backsolve_tile<512, 4, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
+        else backsolve_tile<512, 5, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);   // <= BS_LONG = 5120
     }
 #ifdef BS_PROFILE
     __syncthreads();
@@ -2067,6 +2068,8 @@ __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd
         if (t.p0.b != t.p0.a) rbk = TL(t.p0.b, t.p0.ldb, tid);
     } else if (t.post == TP_ROW) {
         ra = TL(t.q, t.ldq, tid);
+    } else if (t.post == TP_RMUL) {
+        rbk = TL(t.q, t.ldq, tid);
     }
     if (t.init) {
         tile_to_lds<THREADS>(TL(t.c, t.ldc, tid), La, tid);
@@ -2088,6 +2091,8 @@ __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd
             if (pl[p + 1].b != pl[p + 1].a) rbk = TL(pl[p + 1].b, pl[p + 1].ldb, tid);
         } else if (t.post == TP_ROW) {
             ra = TL(t.q, t.ldq, tid);   // Q_kk for the final multiplication
+        } else if (t.post == TP_RMUL) {
+            rbk = TL(t.q, t.ldq, tid);  // Q_jj for the final multiplication
         }
         if (fact) mfma_acc_tile<THREADS, true>(acc, La, same ? La : Lb, -1.0, tid);
         else mfma_acc_tile<THREADS, false>(acc, La, Lb, 1.0, tid);
@@ -2100,8 +2105,30 @@ __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd
 #pragma unroll
             for (int r = 0; r < 4; ++r) La[rb + lk + 4 * r][cb + 16 * q + lr] = sg * acc[q][r];
         __syncthreads();
-        if constexpr (COH) tile_store_wt<THREADS, false>(La, t.c, t.ldc, tid);
-        else tile_store<THREADS>(La, t.c, t.ldc, tid);
+        if constexpr (COH) tile_store_wt<THREADS, false>(La, t.o, t.ldc, tid);
+        else tile_store<THREADS>(La, t.o, t.ldc, tid);
+        return;
+    }
+    if (t.post == TP_RMUL) {
+        // Q_ij = -T Q_jj:  the sum T (accumulators) becomes the A operand in LDS, element (i, k) at La[i][k]; the stored
+        // Q_jj tile (upper triangular) is the B operand, element (k, j) at Lb[k][j]
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) La[rb + lk + 4 * r][cb + 16 * q + lr] = acc[q][r];
+        tile_to_lds<THREADS>(rbk, Lb, tid);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NT; ++q) acc[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
+        mfma_acc_tile<THREADS, false>(acc, La, Lb, -1.0, tid);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) La[rb + lk + 4 * r][cb + 16 * q + lr] = acc[q][r];
+        __syncthreads();
+        if constexpr (COH) tile_store_wt<THREADS, false>(La, t.o, t.ldc, tid);
+        else tile_store<THREADS>(La, t.o, t.ldc, tid);
         return;
     }
     DPROF(2);
@@ -2125,8 +2152,8 @@ __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd
             for (int r = 0; r < 4; ++r) Lb[rb + lk + 4 * r][cb + 16 * q + lr] = acc[q][r];
         __syncthreads();
         DPROF(3);
-        if constexpr (COH) tile_store_wt<THREADS, false>(Lb, t.c, t.ldc, tid);
-        else tile_store<THREADS>(Lb, t.c, t.ldc, tid);
+        if constexpr (COH) tile_store_wt<THREADS, false>(Lb, t.o, t.ldc, tid);
+        else tile_store<THREADS>(Lb, t.o, t.ldc, tid);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DPROF(4);
         return;
@@ -2136,11 +2163,11 @@ __device__ __forceinline__ void tile_task_body(const TileTask &t, const TileProd
     DPROF(3);
     // Q_jj = X^T: column i of the stored tile, row k <- X(i,k) (zero for k > i: the strictly lower part is cleared)
     if constexpr (COH) {
-        tile_store_wt<THREADS, true>(Lb, t.c, t.ldc, tid);
+        tile_store_wt<THREADS, true>(Lb, t.o, t.ldc, tid);
     } else {
         for (int idx = tid; idx < NB * NB; idx += THREADS) {
             const int i = idx / NB, k = idx % NB;
-            t.c[(size_t)i * t.ldc + k] = Lb[i][k];
+            t.o[(size_t)i * t.ldc + k] = Lb[i][k];
         }
     }
     if (tid == 0 && bad) atomicMax(info + t.sub, t.pivotBase + bad);
@@ -2170,6 +2197,11 @@ __global__ __launch_bounds__(THREADS, 2) void tile_task_kernel(const TileTask *_
 // smaller tickets, all of which are held by workgroups that are running: no deadlock whatever the grid size.  Sums keep
 // their fixed order (a tile is still written by one task at a time): results equal to the level kernel's bit for bit.
 // A wait that exceeds ~2 s (never, unless a kernel before it failed) flags the subdomain and goes on, so the launch ends.
+// (The second launch bound is WAVES PER SIMD, not workgroups per CU: with 2 the compiler takes 211-256 VGPRs here and ONE
+// persistent 512-thread workgroup is resident per CU.  Round 5 tried 4 -- two per CU, <= 128 VGPRs: 80 spilled registers with
+// the body inlined; with the body as a noinline call 120 VGPRs and no spill, bar17K 1.128 -> 1.110 ms, monkey 0.793 -> 0.740,
+// but bunny5K 0.360 -> 0.457 (the chain of dependent tasks pays the call) and the FAST = false form failed its parity test:
+// not kept.)
 template <int THREADS, bool FAST = false>
 __global__ __launch_bounds__(THREADS, 2) void tile_flow_kernel(const TileTask *__restrict__ tasks,
                                                                const TileProd *__restrict__ prods, int ntasks,
@@ -2296,6 +2328,7 @@ __global__ __launch_bounds__(256, 4) void tile_gemm_kernel(const TileTask *__res
     for (int q = 0; q < 4; ++q) acc[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
     if (nsteps > 0) fetch(0);
     else if (t.post == TP_ROW) load_rows(t.q, t.ldq, 0, ra);
+    else if (t.post == TP_RMUL) load_rows(t.q, t.ldq, 0, rbk);
     if (t.init) {
         // the c tile through LDS into the accumulator layout (element (i, j) of acc[q][r]: i = rb + lk + 4 r, j = 16 q + lr)
         double2 c[8];
@@ -2324,8 +2357,30 @@ __global__ __launch_bounds__(256, 4) void tile_gemm_kernel(const TileTask *__res
         __syncthreads();
         if (s + 1 < nsteps) fetch(s + 1);
         else if (t.post == TP_ROW) load_rows(t.q, t.ldq, 0, ra);   // first half of Q_kk for the final multiplication
+        else if (t.post == TP_RMUL) load_rows(t.q, t.ldq, 0, rbk);  // first K half (rows 0..31) of Q_jj
         mfma_half(acc, fact ? -1.0 : 1.0);
         __syncthreads();
+    }
+    if (t.post == TP_RMUL) {
+        // Q_ij = -T Q_jj:  C(i, j) = -sum_k T(i, k) Q(k, j), K in two halves: the T half (columns 32 h .. of the accumulators, which
+        // every wave holds for its 16 rows) K-major into La[k][i], the Q half (rows 32 h .., all 64 columns) from HBM into Lb[k][j]
+        mfma_v4d acc2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc2[q] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            store_rows(rbk, Lb);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) La[16 * q + lr][rb + lk + 4 * r] = acc[2 * h + q][r];
+            __syncthreads();
+            if (h == 0) load_rows(t.q, t.ldq, 1, rbk);
+            mfma_half(acc2, -1.0);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = acc2[q];
     }
     if (t.post == TP_ROW) {
         // R_kj = Q_kk^T G:  R(i, j) = sum_k Q(k, i) G(k, j), K in two halves: the Q half from HBM, the G half from the
@@ -2359,7 +2414,7 @@ __global__ __launch_bounds__(256, 4) void tile_gemm_kernel(const TileTask *__res
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int idx2 = tid + 256 * u, j = idx2 >> 5, r = 2 * (idx2 & 31);
-        *reinterpret_cast<double2 *>(t.c + (size_t)j * t.ldc + r) = make_double2(Lf[r][j], Lf[r + 1][j]);
+        *reinterpret_cast<double2 *>(t.o + (size_t)j * t.ldc + r) = make_double2(Lf[r][j], Lf[r + 1][j]);
     }
 }
 

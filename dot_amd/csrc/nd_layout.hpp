@@ -272,15 +272,28 @@ struct NdBuilder {
 
 
 // default depth of the dissection: two levels for the ~2000-dof subdomains of the headline configurations; big
-// subdomains (`timeStepper DOT 6` on a 17k-vertex mesh: ~9800 dofs) go deeper until the leaves are ~1200 dofs
+// subdomains (`timeStepper DOT 6` on a 17k-vertex mesh: ~9800 dofs) go deeper until the leaves are ~1200 dofs.
+// Round 5: a THIRD level already from ~2900 dofs per subdomain when the mesh has at least 16 subdomains (nsmax, nParts over
+// ALL subdomains of the mesh, so that every rank of a sharded run builds the tree a single GPU builds).  The explicit inverse
+// gets ~16 % smaller (1 M tets / 256 subdomains: 4544 -> 3834 MB per back-solve, the factorisation 14.5 -> 14.0 ms, the step
+// 68.5 -> 66 ms; kingkong18K / 18 subdomains: factor 1.67 -> 1.35 ms) while the padded layout stays within the single-pass
+// back-solve kernel's BS_LONG columns; with few subdomains the launch is bound by its longest tile and the longer padded
+// rows cost more than the bytes save (horse7K / 8 subdomains: loop 2.48 -> 3.38 ms) -- there the two levels stay.
+inline int nd_default_levels(int nsmax, int nPartsMesh)
+{
+    int levels = 2;
+    for (int sz = nsmax; sz > 4800 && levels < 6; sz /= 2) ++levels;
+    if (levels == 2 && nsmax > 2900 && nPartsMesh >= 16) levels = 3;
+    return levels;
+}
 inline int nd_default_levels(const std::vector<std::vector<int>> &partVerts)
 {
     int nsmax = 0;
     for (auto &v : partVerts) nsmax = std::max(nsmax, 3 * (int)v.size());
-    int levels = 2;
-    for (int sz = nsmax; sz > 4800 && levels < 6; sz /= 2) ++levels;
-    return levels;
+    return nd_default_levels(nsmax, (int)partVerts.size());
 }
+constexpr int ND_MIN_SPLIT = 512;   // smallest region (scalars) that is still split (round 5: 768 -> 512: the 1200-dof subdomains
+                                    // of the stiff monkey get their second level -- X 165 -> 124 MB, factor 0.78 -> 0.55 ms)
 
 // layout of the given vertex sets (one per owned subdomain): tree[0] is the root, region[node][part] the
 // vertices of the node's leaf block / separator in layout order; returns the padded size (lda, multiple of 64)

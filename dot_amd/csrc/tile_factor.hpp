@@ -4,11 +4,17 @@
 // the symbolic analysis of CHOLMODSolver::analyze_pattern (:103-141) done here at tile granularity.
 //
 // Every subdomain block (nmax x nmax, column-major, nested-dissection order) is cut into 64 x 64 tiles.  With H = R^T R
-// (R upper) and Q = R^-1, the tiles of R and then of Q overwrite those of H in place:
+// (R upper) and Q = R^-1:
 //   DIAG(j)    G = H_jj - sum_m R_mj^T R_mj ;  Q_jj = chol(G)^-1
 //   ROW(k,j)   G = H_kj - sum_m R_mk^T R_mj ;  R_kj = Q_kk^T G                       (k < j)
-//   TINV(i,j)  T_ij = sum_{i <= m < j} Q_im R_mj   -> scratch                            (i < j)
-//   QFIN(i,j)  Q_ij = -T_ij Q_jj                   -> overwrites R_ij
+//   INV(i,j)   Q_ij = -(sum_{i <= m < j} Q_im R_mj) Q_jj                              (i < j)
+// Round 5: TWO buffers of the same compact layout.  H is filled into the WORK buffer, whose tiles R overwrites in place; the
+// tiles of Q go to the FACTOR buffer the back-solve streams and are never anything else.  Until round 4 Q overwrote R in
+// one buffer: the sum T_ij of INV went to a scratch tile and a task of its own (QFIN) multiplied it with -Q_jj once every
+// reader of R_ij had finished -- a third of all tasks, a fifth of the tile traffic (scratch written and read back) and two
+// launches at the end of every factorisation for one product each.  With R and Q apart nothing waits for a reader: the
+// last task of T_ij multiplies with -Q_jj itself (TP_RMUL) and stores Q_ij; its eager parts keep their partial sum in the
+// Q tile itself.
 // Only tiles that can be non-zero exist: the tile pattern of H (from the fill list) is closed under the symbolic
 // factorisation, the pattern of Q under the symbolic inversion; tiles that consist of identity padding only are
 // skipped altogether -- so the flop count follows each subdomain's own size, not the padded shared layout.
@@ -36,7 +42,8 @@ enum TilePost {
     TP_STORE = 0,   // c = acc                       (eager partial update of an H tile / of a scratch T tile)
     TP_DIAG = 1,    // c = (chol(acc)^-1)^T          (Q_jj; strictly lower part zero)
     TP_ROW = 2,     // c = Q_kk^T acc                (R_kj; q = tile of Q_kk)
-    TP_NEG = 3      // c = -acc                      (Q_ij = -T_ij Q_jj)
+    TP_NEG = 3,     // c = -acc                      (unused since round 5: was Q_ij = -T_ij Q_jj as a task of its own)
+    TP_RMUL = 4     // o = -acc Q_jj                 (Q_ij; q = tile of Q_jj)
 };
 
 struct TileProd {
@@ -48,8 +55,9 @@ struct TileTask {
     int first, sub;                // products [first, first + nprod) of the level-ordered product array; owned subdomain
     int ldc, ldq;                  // leading dimensions of the c tile and of the q tile
     int pivotBase, pad;            // TP_DIAG: scalar offset of the tile's first row (for the non-SPD report)
-    double *c;                     // the tile read (init) and written
-    double *q;                     // TP_ROW: tile of Q_kk
+    double *c;                     // the tile read (init)
+    double *q;                     // TP_ROW: tile of Q_kk;  TP_RMUL: tile of Q_jj
+    double *o;                     // the tile written (== c except for TP_DIAG: reads the work buffer's H_jj, writes the factor buffer's Q_jj)
     TileProd p0;                   // copy of the first product: its tiles are requested straight from the descriptor, one
                                    // dependent round trip earlier than through the product array
 };
@@ -62,7 +70,7 @@ struct TileSchedule {
     std::vector<double *> clearTiles; // origins of the tiles the fill writes into (cleared before the refill; fill-in tiles are
                                       // written before they are read)
     std::vector<int> clearLd;         // and their leading dimensions
-    size_t scratchTiles = 0;          // 64 x 64 scratch tiles needed (T_ij)
+    size_t scratchTiles = 0;          // 64 x 64 scratch tiles needed (none since round 5)
     double flops = 0;                 // FP64 flop of one factorisation as executed
     long long liveTiles = 0, qTiles = 0;
 };
@@ -76,17 +84,20 @@ struct TileTaskL {
     std::vector<TileProd> prods;
 };
 
-// rtOff / rtLd / rtC0: the subdomain's row blocks of the factor storage (dotmi_internal.hpp RowTile), W its base.  Tile
-// (i, j) of the column-major matrix = memory rows of block j, memory columns 64 i ...: origin W + off_j + 64 i - c0_j,
-// leading dimension ld_j.
+// rtOff / rtLd / rtC0: the subdomain's row blocks of the factor storage (dotmi_internal.hpp RowTile), W its base, W2 the base
+// of the work buffer of the same layout (H, then R).  Tile (i, j) of the column-major matrix = memory rows of block j, memory
+// columns 64 i ...: origin base + off_j + 64 i - c0_j, leading dimension ld_j.
 inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rtOff, const int *rtLd, const int *rtC0,
                                  const std::vector<uint8_t> &live, std::vector<uint8_t> pat /* by value: gets the fill */,
-                                 double *scratch, size_t &scratchNext, std::vector<TileTaskL> &out,
+                                 double *W2, size_t &scratchNext, std::vector<TileTaskL> &out,
                                  std::vector<double *> &clearTiles, std::vector<int> &clearLd, double &flops, long long &qTiles,
-                                 int eagerMin = 2, int eagerChunk = 1, int eagerMinDiag = 0, bool balance = true)
+                                 int eagerMin = 2, int eagerChunk = 1, int eagerMinDiag = 0, bool balance = true,
+                                 int eagerMinRmul = -1)
 {
     const size_t o0 = out.size();   // this subdomain's tasks are out[o0 ...)
-    auto tile = [&](int i, int j) { return W + rtOff[j] + (long long)i * TILE - rtC0[j]; };
+    auto tile = [&](int i, int j) { return W2 + rtOff[j] + (long long)i * TILE - rtC0[j]; };    // H, then R (work buffer)
+    auto qtile = [&](int i, int j) { return W + rtOff[j] + (long long)i * TILE - rtC0[j]; };    // Q (factor buffer)
+    (void)scratchNext;
     auto tld = [&](int j) { return rtLd[j]; };
     auto P = [&](int i, int j) -> uint8_t & { return pat[(size_t)i * nt + j]; };
     for (int j = 0; j < nt; ++j)
@@ -134,7 +145,8 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
     const int EAGER_MIN = eagerMin;   // early products a task on the critical path may keep (besides the last level's)
     const size_t CHUNK = (size_t)std::max(1, eagerChunk);   // early products per eager task (ties in availability stay together)
     auto emit = [&](int row, int form, int post, double *c, int ldc, double *q, int ldq, int pivotBase, std::vector<PA> &pa,
-                    int minFinal, bool initFromC) -> int {
+                    int minFinal, bool initFromC, double *dst = nullptr) -> int {
+        if (!dst) dst = c;
         std::stable_sort(pa.begin(), pa.end(), [](const PA &x, const PA &y) { return x.avail < y.avail; });
         int amax = 0;
         for (auto &x : pa) amax = std::max(amax, x.avail);
@@ -145,14 +157,17 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
         while (nEarly < pa.size() && pa[nEarly].avail + 1 < lf) ++nEarly;
         // a diagonal task is the longest of its level (~20 us of factor + invert on one workgroup) and every later task of
         // the column waits for it: it keeps no early product at all
-        if (nEarly <= (size_t)(post == TP_DIAG ? eagerMinDiag : EAGER_MIN)) nEarly = 0;
+        // (TP_RMUL: eagerMinRmul >= 0 overrides -- 0 peels every product that is ready before Q_jj into a task that runs beside
+        // DIAG(j), where the launch lasts ~26 us anyway, and leaves the multiplication with -Q_jj for the level after it)
+        const int keep = post == TP_DIAG ? eagerMinDiag : (post == TP_RMUL && eagerMinRmul >= 0) ? eagerMinRmul : EAGER_MIN;
+        if (nEarly <= (size_t)keep && !(post == TP_RMUL && eagerMinRmul == 0 && nEarly > 0)) nEarly = 0;
         bool have = initFromC;
         size_t k0 = 0;
         while (k0 < nEarly) {
-            size_t k1 = std::min(nEarly, k0 + CHUNK);
+            size_t k1 = (post == TP_RMUL && eagerMinRmul == 0 && nEarly <= (size_t)EAGER_MIN) ? nEarly : std::min(nEarly, k0 + CHUNK);
             while (k1 < nEarly && pa[k1].avail == pa[k1 - 1].avail) ++k1;
             TileTaskL E;
-            E.t = TileTask{form, have ? 1 : 0, TP_STORE, 0, 0, sub, ldc, 0, 0, 0, c, nullptr};
+            E.t = TileTask{form, have ? 1 : 0, TP_STORE, 0, 0, sub, ldc, 0, 0, 0, c, nullptr, c};
             for (size_t k = k0; k < k1; ++k) E.prods.push_back(pa[k].p);
             E.level = pa[k1 - 1].avail + 1;
             E.row = row;
@@ -162,11 +177,11 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
             k0 = k1;
         }
         TileTaskL F;
-        F.t = TileTask{form, have ? 1 : 0, post, 0, 0, sub, ldc, ldq, pivotBase, 0, c, q};
+        F.t = TileTask{form, have ? 1 : 0, post, 0, 0, sub, ldc, ldq, pivotBase, 0, c, q, dst};
         for (size_t k = nEarly; k < pa.size(); ++k) F.prods.push_back(pa[k].p);
         F.level = lf;
         F.row = row;
-        flops += 2.0 * TILE * TILE * TILE * (F.prods.size() + (post == TP_ROW ? 1 : 0)) +
+        flops += 2.0 * TILE * TILE * TILE * (F.prods.size() + ((post == TP_ROW || post == TP_RMUL) ? 1 : 0)) +
                  (post == TP_DIAG ? 2.0 / 3.0 * TILE * TILE * TILE : 0.0);
         out.push_back(std::move(F));
         return lf;
@@ -184,14 +199,14 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
                 if (Rp(m, k) && Rp(m, j))
                     pa.push_back({{tile(m, k), tile(m, j), tld(k), tld(j)}, std::max(LR(m, k), LR(m, j))});
             // a pure fill-in tile holds nothing to start from: its first task starts from zero, and nobody has to clear it
-            LR(k, j) = emit(k, TF_FACT, TP_ROW, tile(k, j), tld(j), tile(k, k), tld(k), 0, pa, lvD[k], Hp(k, j));
+            LR(k, j) = emit(k, TF_FACT, TP_ROW, tile(k, j), tld(j), qtile(k, k), tld(k), 0, pa, lvD[k], Hp(k, j));
         }
         pa.clear();
         for (int m = 0; m < j; ++m)
             if (Rp(m, j)) pa.push_back({{tile(m, j), tile(m, j), tld(j), tld(j)}, LR(m, j)});
-        lvD[j] = emit(j, TF_FACT, TP_DIAG, tile(j, j), tld(j), nullptr, 0, j * TILE, pa, 0, true);
+        lvD[j] = emit(j, TF_FACT, TP_DIAG, tile(j, j), tld(j), nullptr, 0, j * TILE, pa, 0, true, qtile(j, j));
     }
-    // levels of the inversion; lvQ(i,j) = level after which tile (i,j) holds Q_ij
+    // levels of the inversion; lvQ(i,j) = level after which tile (i,j) of the factor buffer holds Q_ij
     std::vector<int> lvQ((size_t)nt * nt, 0);
     auto LQ = [&](int i, int j) -> int & { return lvQ[(size_t)i * nt + j]; };
     for (int j = 0; j < nt; ++j)
@@ -201,8 +216,6 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
         clearTiles.push_back(tile(j, j));
         clearLd.push_back(tld(j));
         ++qTiles;
-        std::vector<int> lvT(nt, 0);
-        std::vector<double *> tsc(nt, nullptr);
         for (int i : qcol[j]) {
             if (i == j) continue;
             if (Hp(i, j)) {   // only the tiles the fill writes into are read before they are written
@@ -210,30 +223,13 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
                 clearLd.push_back(tld(j));
             }
             ++qTiles;
-            double *ts = scratch + (scratchNext++) * (size_t)TILE * TILE;
-            tsc[i] = ts;
             pa.clear();
             for (int m = i; m < j; ++m)
                 if (Qp(i, m) && Rp(m, j))
-                    pa.push_back({{tile(i, m), tile(m, j), tld(m), tld(j)}, std::max(LQ(i, m), LR(m, j))});
-            lvT[i] = emit(i, TF_INV, TP_STORE, ts, TILE, nullptr, 0, 0, pa, 0, false);
-        }
-        // QFIN(i,j) overwrites R_ij: after every reader of R_ij -- DIAG(j), ROW(k,j) for i < k < j, ROW(j,j') for j' > j,
-        // TINV(i',j) for i' <= i (their eager parts run earlier than their final tasks, whose levels are used here)
-        int runT = 0;   // max level of TINV(i', j) over i' <= i (qcol ascending)
-        for (int i : qcol[j]) {
-            if (i == j) continue;
-            runT = std::max(runT, lvT[i]);
-            int lv = std::max(runT, lvD[j]);
-            if (Rp(i, j)) {
-                for (int k = i + 1; k < j; ++k)
-                    if (Rp(i, k) && Rp(k, j)) lv = std::max(lv, LR(k, j));
-                for (int j2 = j + 1; j2 < nt; ++j2)
-                    if (Rp(i, j2) && Rp(j, j2)) lv = std::max(lv, LR(j, j2));
-            }
-            pa.clear();
-            pa.push_back({{tsc[i], tile(j, j), TILE, tld(j)}, lv});
-            LQ(i, j) = emit(i, TF_INV, TP_NEG, tile(i, j), tld(j), nullptr, 0, 0, pa, 0, false);
+                    pa.push_back({{qtile(i, m), tile(m, j), tld(m), tld(j)}, std::max(LQ(i, m), LR(m, j))});
+            // Q_ij = -(sum) Q_jj: the last task multiplies with Q_jj (ready after DIAG(j)); nothing else is waited for -- R_ij
+            // lives in the work buffer and stays there
+            LQ(i, j) = emit(i, TF_INV, TP_RMUL, qtile(i, j), tld(j), qtile(j, j), tld(j), 0, pa, lvD[j], false);
         }
     }
     if (!balance) return;
@@ -273,7 +269,8 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
             if (pr.b != pr.a) rd(pr.b);
         }
         if (T.t.q) rd(T.t.q);
-        Acc &c = acc[T.t.c];
+        if (T.t.init && T.t.c != T.t.o) rd(T.t.c);
+        Acc &c = acc[T.t.o];
         edge(c.writer, v);
         for (int r : c.readers) edge(r, v);
         c.writer = v;
@@ -410,7 +407,8 @@ inline void build_tile_deps(const std::vector<TileTask> &tasks, const std::vecto
             if (prods[p].b != prods[p].a) rd(prods[p].b);
         }
         if (T.q) rd(T.q);
-        Acc &c = acc[T.c];
+        if (T.init && T.c != T.o) rd(T.c);
+        Acc &c = acc[T.o];
         if (c.writer >= 0) pred[v].push_back(c.writer);
         for (int r : c.readers)
             if (r != v) pred[v].push_back(r);

@@ -1,7 +1,10 @@
 """The level schedule of the tile factorisation (dot_amd/csrc/tile_factor.hpp) executed in numpy on the CPU: the host-only
 entry dotmi_plan_tile_schedule returns the tasks of one block with their levels; running them level after level --
 every task of a level reading the state left by the levels before it -- must give the inverse Cholesky factor, no two
-tasks of a level may write the same tile, and no task may read a tile that another task of its level writes."""
+tasks of a level may write the same tile, and no task may read a tile that another task of its level writes.
+Round 5: two buffers of one layout -- offsets [0, storage) are the FACTOR buffer (only tiles of Q are ever written there),
+[storage, 2 storage) the WORK buffer the fill writes H into and R overwrites; a task reads its `c` tile and writes its `o`
+tile (different only for the diagonal tasks), and the last task of an off-diagonal Q tile multiplies with -Q_jj itself."""
 import ctypes as C
 
 import numpy as np
@@ -10,7 +13,7 @@ import pytest
 from dot_amd import lib as dl
 
 TF_FACT, TF_INV = 0, 1
-TP_STORE, TP_DIAG, TP_ROW, TP_NEG = 0, 1, 2, 3
+TP_STORE, TP_DIAG, TP_ROW, TP_NEG, TP_RMUL = 0, 1, 2, 3, 4
 
 
 def plan(nt, live, pat, c0, eager_min, eager_chunk):
@@ -27,7 +30,7 @@ def plan(nt, live, pat, c0, eager_min, eager_chunk):
                          p, C.byref(n[0]), C.byref(n[1]), C.byref(n[2]), C.byref(n[3]), C.byref(n[4]),
                          roff.ctypes.data_as(i64), rld.ctypes.data_as(i32))
     assert f(*args(None, None)) == 0
-    tasks = np.zeros((n[0].value, 10), dtype=np.int64)
+    tasks = np.zeros((n[0].value, 11), dtype=np.int64)
     prods = np.zeros((max(n[1].value, 1), 4), dtype=np.int64)
     assert f(*args(tasks.ctypes.data_as(i64), prods.ctypes.data_as(i64))) == 0
     return tasks, prods, n[2].value, n[3].value, roff, rld
@@ -72,21 +75,20 @@ def run_schedule(nt, live, pat, c0, eager_min, eager_chunk, seed):
             H[64 * j:64 * j + 64, :] = 0
             H[:, 64 * j:64 * j + 64] = 0
             H[64 * j:64 * j + 64, 64 * j:64 * j + 64] = np.eye(64)
-    nscr = int(tasks[:, 6].max() // 4096 + 2)
-    # everything starts as NaN: only the tiles the fill writes into (the pattern of H) are cleared and filled on the device;
-    # pure fill-in tiles and the scratch must be written before they are read
-    M = np.full(storage + 4096 * nscr, np.nan)
+    # everything starts as NaN: only the tiles the fill writes into (the pattern of H, in the work buffer) are cleared and
+    # filled on the device; pure fill-in tiles and every tile of the factor buffer must be written before they are read
+    M = np.full(2 * storage + 4096, np.nan)
 
     def tile(off, ld):      # column-major 64 x 64 view
         return np.lib.stride_tricks.as_strided(M[off:], shape=(64, 64), strides=(8, 8 * ld))
 
-    # fill: column-major element (r, c), r <= c in tile terms, lives in row block c // 64
+    # fill: column-major element (r, c), r <= c in tile terms, lives in row block c // 64 of the WORK buffer
     for j in range(nt):
         if not live[j]:
             continue
         for i in range(int(c0[j]), j + 1):
             if pat[i, j] or i == j:
-                tile(roff[j] + 64 * i - 64 * c0[j], rld[j])[:, :] = H[64 * i:64 * i + 64, 64 * j:64 * j + 64]
+                tile(storage + roff[j] + 64 * i - 64 * c0[j], rld[j])[:, :] = H[64 * i:64 * i + 64, 64 * j:64 * j + 64]
     order = np.argsort(tasks[:, 0], kind="stable")
     lv = 0
     k = 0
@@ -101,7 +103,9 @@ def run_schedule(nt, live, pat, c0, eager_min, eager_chunk, seed):
         def stile(off, ld):
             return np.lib.stride_tricks.as_strided(snap[off:], shape=(64, 64), strides=(8, 8 * ld)).copy()
         for t in group:
-            _, form, init, post, nprod, first, coff, qoff, ldc, ldq = tasks[t]
+            _, form, init, post, nprod, first, coff, qoff, ldc, ldq, ooff = tasks[t]
+            assert ooff < storage or post != TP_RMUL          # Q tiles go to the factor buffer ...
+            assert (ooff < storage) == (post in (TP_DIAG, TP_RMUL) or form == TF_INV)   # ... and nothing else does
             acc = stile(coff, ldc) if init else np.zeros((64, 64))
             if init:
                 read.add(coff)
@@ -116,21 +120,26 @@ def run_schedule(nt, live, pat, c0, eager_min, eager_chunk, seed):
             elif post == TP_ROW:
                 read.add(qoff)
                 out = stile(qoff, ldq).T @ acc
+            elif post == TP_RMUL:
+                read.add(qoff)
+                out = -acc @ np.triu(stile(qoff, ldq))
             elif post == TP_NEG:
                 out = -acc
             else:
                 out = acc
-            assert coff not in written, "two tasks of one level write the same tile"
-            written.add(coff)
-            tile(coff, ldc)[:, :] = out
+            assert ooff not in written, "two tasks of one level write the same tile"
+            written.add(ooff)
+            tile(ooff, ldc)[:, :] = out
         # a tile written in this level may only be read by the task that writes it (its own init)
         for t in group:
-            _, form, init, post, nprod, first, coff, qoff, ldc, ldq = tasks[t]
-            others = written - {coff}
+            _, form, init, post, nprod, first, coff, qoff, ldc, ldq, ooff = tasks[t]
+            others = written - {ooff}
             ops = {prods[p][0] for p in range(first, first + nprod)} | {prods[p][1] for p in range(first, first + nprod)}
-            if post == TP_ROW:
+            if post in (TP_ROW, TP_RMUL):
                 ops.add(qoff)
-            assert not (ops & others) and coff not in ops, "a task reads a tile that is written in its own level"
+            if init:
+                ops.add(coff)
+            assert not (ops & others) and ooff not in (ops - {coff}), "a task reads a tile that is written in its own level"
     # compare with the dense inverse factor: H = R^T R, Q = R^-1 (upper), stored tile (i, j) = Q[64 i.., 64 j..]
     Q = np.linalg.inv(np.linalg.cholesky(H).T)
     worst = 0.0
@@ -175,7 +184,7 @@ def test_schedule_of_a_dense_block_and_of_random_patterns():
     nt = 6
     pat = np.triu(np.ones((nt, nt), dtype=np.uint8))
     worst, nlev, _ = run_schedule(nt, np.ones(nt, dtype=np.uint8), pat, np.zeros(nt, dtype=np.int32), 2, 1, seed=3)
-    assert worst < 1e-10 and nlev == 2 * nt + 1   # 2 per tile column + the last column of the inverse
+    assert worst < 1e-10 and nlev == 2 * nt   # 2 per tile column (the last column of the inverse no longer costs a level of its own)
     for seed in range(4):
         nt = int(rng.integers(4, 10))
         pat = np.triu((rng.random((nt, nt)) < 0.35).astype(np.uint8))
@@ -228,14 +237,13 @@ def run_dataflow(nt, live, pat, c0, eager_min, eager_chunk, seed, orders=3):
             H[:, 64 * j:64 * j + 64] = 0
             H[64 * j:64 * j + 64, 64 * j:64 * j + 64] = np.eye(64)
     Q = np.linalg.inv(np.linalg.cholesky(H).T)
-    nscr = int(tasks[:, 6].max() // 4096 + 2)
     succ = [[] for _ in tasks]
     for v in range(len(tasks)):
         for u in idx[ptr[v]:ptr[v + 1]]:
             succ[u].append(v)
     worst = 0.0
     for rep in range(orders):
-        M = np.full(storage + 4096 * nscr, np.nan)
+        M = np.full(2 * storage + 4096, np.nan)
 
         def tile(off, ld):
             return np.lib.stride_tricks.as_strided(M[off:], shape=(64, 64), strides=(8, 8 * ld))
@@ -243,7 +251,7 @@ def run_dataflow(nt, live, pat, c0, eager_min, eager_chunk, seed, orders=3):
             if live[j]:
                 for i in range(int(c0[j]), j + 1):
                     if pat[i, j] or i == j:
-                        tile(roff[j] + 64 * i - 64 * c0[j], rld[j])[:, :] = H[64 * i:64 * i + 64, 64 * j:64 * j + 64]
+                        tile(storage + roff[j] + 64 * i - 64 * c0[j], rld[j])[:, :] = H[64 * i:64 * i + 64, 64 * j:64 * j + 64]
         left = np.array([ptr[v + 1] - ptr[v] for v in range(len(tasks))])
         ready = [v for v in range(len(tasks)) if left[v] == 0]
         done = 0
@@ -251,7 +259,7 @@ def run_dataflow(nt, live, pat, c0, eager_min, eager_chunk, seed, orders=3):
             # rep 0: latest ready task first (the most adversarial simple order), then random picks
             k = len(ready) - 1 if rep == 0 else int(rng.integers(len(ready)))
             t = ready.pop(k)
-            _, form, init, post, nprod, first, coff, qoff, ldc, ldq = tasks[t]
+            _, form, init, post, nprod, first, coff, qoff, ldc, ldq, ooff = tasks[t]
             acc = tile(coff, ldc).copy() if init else np.zeros((64, 64))
             for p in range(first, first + nprod):
                 a, b, lda, ldb = prods[p]
@@ -260,11 +268,13 @@ def run_dataflow(nt, live, pat, c0, eager_min, eager_chunk, seed, orders=3):
                 out = np.linalg.inv(np.linalg.cholesky(acc).T)
             elif post == TP_ROW:
                 out = tile(qoff, ldq).T @ acc
+            elif post == TP_RMUL:
+                out = -acc @ np.triu(tile(qoff, ldq))
             elif post == TP_NEG:
                 out = -acc
             else:
                 out = acc
-            tile(coff, ldc)[:, :] = out
+            tile(ooff, ldc)[:, :] = out
             done += 1
             for w in succ[t]:
                 left[w] -= 1
