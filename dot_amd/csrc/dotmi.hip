@@ -12,7 +12,6 @@
 // from one small read-back per line-search trial.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
-#include <rocblas/rocblas.h>
 
 #include <algorithm>
 #include <chrono>
@@ -83,48 +82,29 @@ struct Tuning {
     int tileRowsLong = 0;     // DOTMI_TILE_ROWS_LONG rows per back-solve tile when the rows have more than 1536 columns (0: as the
                               //                      other rows, or ~256 KB tiles where few subdomains leave the launch bound by
                               //                      its longest tile)
-    bool splitBs = true;      // DOTMI_SPLIT_BS=0     one back-solve launch instead of wide / narrow tiles apart
-    bool mergeTiles = true;   // DOTMI_MERGE_TILES=0  reduce_partial_p + merge instead of merge_tiles_kernel
-    int ownerPack = 1;        // DOTMI_OWNER_PACK     owner exchange: the dot products ride in the vector packets (3 collectives per
-                              //                      accepted iteration) / 0: as scalar all-reduces of their own (5)
     int splitMerge = -1;      // DOTMI_SPLIT_MERGE    1 / 0: the merge as reduce_partial_p + a gather from psub (the early order included) /
                               //                      as one walk over the tile partials; default: split from 400 k scalar dofs
-    bool fuseLeaves = true;   // DOTMI_FUSE_LEAVES=0  one GEMM chain per leaf instead of equal-size leaves together
     bool fuseLog = false;     // DOTMI_FUSE_LOG       print the fused-leaf units
-    bool splitRoot = true;    // DOTMI_ND_SPLIT_ROOT=0  the root's triangular products on one branch
-    bool factorGraph = true;  // DOTMI_FACTOR_GRAPH=0 direct rocBLAS calls instead of the captured hipGraph
-    bool ndParallel = true;   // DOTMI_ND_PARALLEL=0  tree nodes of one height one after the other
-    int factorStreams = 1;    // DOTMI_FACTOR_STREAMS subdomain groups factorised on streams of their own
+    bool factorGraph = true;  // DOTMI_FACTOR_GRAPH=0 the level launches of the factorisation issued directly instead of replayed as a hipGraph
     int shardElems = -1;      // DOTMI_SHARD_ELEMS    0 / 1: force the replicated / sharded element pass (-1: by size)
     int shardHess = -1;       // DOTMI_SHARD_HESS     0 / 1: force the replicated / sharded once-per-step phase
     int timeStride = 8;       // DOTMI_TIME_STRIDE    DOTMI_FLAG_TIME_BACKSOLVE brackets every n-th back-solve
-    int splitMin = 512;       // DOTMI_SPLIT_MIN      smallest block whose recursion products are split 2x2
-    int splitMinTri = 512;    // DOTMI_SPLIT_MIN_TRI  the same for the triangular products of the tree
-    bool deviceLoop = true;   // DOTMI_DEVICE_LOOP=0  host-driven L-BFGS loop (same as DOTMI_FLAG_HOST_LOOP)
     int patchElems = 0;       // DOTMI_PATCH_ELEMS    elements per patch of the element pass (0: default)
-    bool tileFactor = true;   // DOTMI_TILE_FACTOR=0  recursive rocBLAS formulation instead of the level-scheduled tile tasks
     int tileSplit = -1;       // DOTMI_TILE_SPLIT     0 / 1: one task kernel per level / diagonal and half-tile kernels side by side
                               //                      (-1: the latter above 64 subdomains, where the factorisation is throughput-bound)
-    int tileThreads = 512;    // DOTMI_TILE_THREADS   256 or 512 threads per tile task (512: two waves per SIMD share a task)
-    bool tileXcdOrder = true; // DOTMI_TILE_XCD_ORDER=0 tile tasks of a level longest first instead of grouped per XCD
     int tileEagerMin = 0;     // DOTMI_TILE_EAGER_MIN early products a critical-path tile task may keep
-    bool tileBalance = true;  // DOTMI_TILE_BALANCE=0 every tile task at its earliest level (no second scheduling pass)
     int fastDiag = 1;         // DOTMI_FAST_DIAG      1 / 0: the diagonal tile tasks' 16 x 16 bottom steps on 4 x 4 blocks every lane factors for
                               //                      itself (12.0 us per 64 x 64 step) / one row per lane with v_readlane operands (15.3 us)
     int tileFlow = -1;        // DOTMI_TILE_FLOW      1: the factorisation as ONE launch of persistent workgroups with per-task
                               //                         dependencies (tile_flow_kernel) instead of one launch per level; 0: never;
                               //                         default: where a level holds fewer tasks than the GPU holds workgroups
-    int tileFlowWg = 0;       // DOTMI_TILE_FLOW_WG   workgroups of that launch (0: two per CU)
     int tileFlowWaitMs = 2000;   // DOTMI_TILE_FLOW_WAIT_MS  a task that waits longer for one of its dependencies gives up (error)
-    int tileEagerMinDiag = 0; // DOTMI_TILE_EAGER_MIN_DIAG early products a diagonal tile task may keep
     int tileEagerMinRmul = -1; // DOTMI_TILE_EAGER_MIN_RMUL early products the last task of a Q tile may keep (-1: as the others; 0: none)
     int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
     bool fuseDir = true;      // DOTMI_FUSE_DIR=0     (early order) build_p and spmv_dots as two launches instead of one on cached H s_j
     bool fuseStep = true;     // DOTMI_FUSE_STEP=0    (early order) step_forward as a launch of its own instead of inside the element pass
     bool earlyAbort = true;   // DOTMI_EARLY_ABORT=0  (ablation) speculative back-solves run to their end even when the trial is rejected
-    bool earlySharded = true; // DOTMI_EARLY_SHARDED=0 the q-based order on the sharded element pass (N > 1, >= 400 k tets)
     bool earlyHold = true;    // DOTMI_EARLY_HOLD=0   the back-solve of a trial that is expected to be rejected still starts speculatively
-    bool earlyHostCtl = true; // DOTMI_EARLY_HOST_CTL=0 (ablation) early back-solve with the controller as a launch of its own
     int earlyBs = 2;          // DOTMI_EARLY_BACKSOLVE 0: the back-solve after the controller, on q; 1: speculatively on the trial
                               //                      gradient with the controller inside its launch, in the steps where
                               //                      the last step's counts say it pays (run_device_loop); 2 (default): in
@@ -143,41 +123,23 @@ struct Tuning {
         if (const char *ev = getenv("DOTMI_TILE_ROWS")) t.tileRows = std::min(64, std::max(8, atoi(ev) / 8 * 8));
         t.tileRowsLong = geti("DOTMI_TILE_ROWS_LONG", 0);
         if (t.tileRowsLong > 0) t.tileRowsLong = std::min(64, std::max(8, t.tileRowsLong / 8 * 8));
-        t.splitBs = geti("DOTMI_SPLIT_BS", 1) != 0;
-        t.mergeTiles = geti("DOTMI_MERGE_TILES", 1) != 0;
         t.splitMerge = geti("DOTMI_SPLIT_MERGE", -1);
-        t.ownerPack = geti("DOTMI_OWNER_PACK", 1);
-        t.fuseLeaves = geti("DOTMI_FUSE_LEAVES", 1) != 0;
         t.fuseLog = getenv("DOTMI_FUSE_LOG") != nullptr;
-        t.splitRoot = geti("DOTMI_ND_SPLIT_ROOT", 1) != 0;
         t.factorGraph = geti("DOTMI_FACTOR_GRAPH", 1) != 0;
-        t.ndParallel = geti("DOTMI_ND_PARALLEL", 1) != 0;
-        t.factorStreams = std::max(1, geti("DOTMI_FACTOR_STREAMS", 1));
         t.shardElems = geti("DOTMI_SHARD_ELEMS", -1);
         t.shardHess = geti("DOTMI_SHARD_HESS", -1);
         t.timeStride = std::max(1, geti("DOTMI_TIME_STRIDE", 8));
-        t.splitMin = std::max(128, geti("DOTMI_SPLIT_MIN", 512));
-        t.splitMinTri = std::max(128, geti("DOTMI_SPLIT_MIN_TRI", 512));
-        t.deviceLoop = geti("DOTMI_DEVICE_LOOP", 1) != 0;
         t.patchElems = std::max(0, geti("DOTMI_PATCH_ELEMS", 0));
-        t.tileFactor = geti("DOTMI_TILE_FACTOR", 1) != 0;
         t.tileSplit = geti("DOTMI_TILE_SPLIT", -1);
-        t.tileThreads = geti("DOTMI_TILE_THREADS", 512) == 256 ? 256 : 512;
-        t.tileXcdOrder = geti("DOTMI_TILE_XCD_ORDER", 1) != 0;
         t.tileEagerMin = std::max(0, geti("DOTMI_TILE_EAGER_MIN", 0));
-        t.tileBalance = geti("DOTMI_TILE_BALANCE", 1) != 0;
         t.tileFlow = geti("DOTMI_TILE_FLOW", -1);
         t.fastDiag = geti("DOTMI_FAST_DIAG", 1);
-        t.tileFlowWg = geti("DOTMI_TILE_FLOW_WG", 0);
         t.tileFlowWaitMs = std::max(1, geti("DOTMI_TILE_FLOW_WAIT_MS", 2000));
-        t.tileEagerMinDiag = std::max(0, geti("DOTMI_TILE_EAGER_MIN_DIAG", 0));
         t.tileEagerMinRmul = geti("DOTMI_TILE_EAGER_MIN_RMUL", -1);
         t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
         t.earlyBs = geti("DOTMI_EARLY_BACKSOLVE", 2) != 0 ? 2 : 0;   // (1, round 3's per-step rule, now means "on")
-        t.earlyHostCtl = geti("DOTMI_EARLY_HOST_CTL", 1) != 0;
         t.earlyAbort = geti("DOTMI_EARLY_ABORT", 1) != 0;
         t.earlyHold = geti("DOTMI_EARLY_HOLD", 1) != 0;
-        t.earlySharded = geti("DOTMI_EARLY_SHARDED", 1) != 0;
         t.fuseStep = geti("DOTMI_FUSE_STEP", 1) != 0;
         t.fuseDir = geti("DOTMI_FUSE_DIR", 1) != 0;
         return t;
@@ -215,7 +177,6 @@ struct dotmi_handle {
 
     // device
     hipStream_t st = nullptr;
-    rocblas_handle blas = nullptr;
     ncclComm_t comm = nullptr;
     void (*arCb)(void *, double *, int64_t) = nullptr;   // host all-reduce hook (dotmi_params::allreduce) instead of RCCL
     void *arCtx = nullptr;
@@ -291,11 +252,8 @@ struct dotmi_handle {
     DevMesh Mown;                          // the mesh with massOwn for mass (element pass of the owner exchange)
     double *alpha_dev = nullptr;
     int *info_dev = nullptr, *h_info = nullptr;  // per owned part: failing pivot (device / pinned copy)
-    int4 *clearSeg = nullptr;                    // row segments (row, first column, columns, -) cleared before a refill
-    int nClearSeg = 0;
     bool wDirty = false;                         // W has been through a factorisation (targeted clearing applies)
     bool poisoned = false;                       // the last factorisation failed: the factors in W are garbage
-    size_t tmp_stride = 0;
     int *didx = nullptr;
     double *dpos = nullptr;
     size_t dcap = 0;
@@ -341,44 +299,8 @@ struct dotmi_handle {
     int evPn = 0;              // boundaries recorded since the last synchronisation
     int evPslot[8] = {0};      // ms_phase slot of the interval that ENDS at boundary k (k >= 1)
     double phaseMs[DOTMI_T_COUNT] = {0};
-    // the subdomain factorisation runs as `groups` independent batches on their own streams so that the
-    // latency-bound base blocks / small GEMMs of one batch overlap the large GEMMs of another
-    struct FactorGroup {
-        int first = 0, count = 0;
-        hipStream_t st = nullptr;
-        rocblas_handle blas = nullptr;
-        hipEvent_t done = nullptr;
-        size_t tmpOff = 0;  // offset of this branch's scratch inside a part's Wtmp slice
-        // leaves of equal padded size factorised together (chol_inv_node): displacement of leaf l's diagonal block in W
-        // and of its scratch in Wtmp from the first leaf's
-        LeafOffs lw, lt;
-    };
-    std::vector<FactorGroup> groups;
-    // device pointer arrays of the fused-leaf batched GEMMs, in call order (built during the first, un-captured pass of
-    // issue_factor; every later pass -- the graph capture included -- finds them by position)
-    std::vector<double **> ptrPool;
-    size_t ptrNext = 0;
-    // the two children of a dissection node are independent: the C child runs on its own stream (a
-    // parallel branch of the captured graph), so the latency-bound diagonal-block kernels of sibling
-    // sub-trees overlap
-    struct Branch {
-        hipStream_t st = nullptr;
-        rocblas_handle blas = nullptr;
-    };
-    std::vector<Branch> branches;  // extra streams of a phase (unit k > 0 runs on branches[k-1]); empty = serial
-    // the nodes of the dissection tree by height: leaves first, the root last; nodes of one height are
-    // independent (forks and joins always go through the group's own stream -- no nested forks)
-    struct FactorUnit {
-        int node = 0;
-        int part = 0;       // see chol_inv_tree()
-        size_t tmpOff = 0;  // disjoint scratch of concurrently running units
-        hipEvent_t fork = nullptr, join = nullptr;
-        LeafOffs lw, lt;    // leaf unit: the other leaves of the same size fused into it (n > 1)
-    };
-    std::vector<std::vector<FactorUnit>> phases;
-    hipEvent_t evFill = nullptr;
-    // the factor recursion is a fixed sequence of ~250 launches on fixed pointers: captured once into a
-    // hipGraph and replayed every step (removes the host launch cost between its many small kernels)
+    // the level launches of the tile factorisation are a fixed sequence on fixed pointers: captured once into a hipGraph and
+    // replayed every step (removes the host launch cost between them)
     hipGraphExec_t factorGraph = nullptr;
     int graphState = 0;  // 0 = not tried, 1 = ready, -1 = capture unavailable -> direct launches
     std::vector<hipEvent_t> evPre;  // DOTMI_FLAG_TIME_BACKSOLVE: (start, stop) pairs around each back-solve
@@ -390,7 +312,6 @@ struct dotmi_handle {
     long long arCount = 0, arCallsStep = 0;
     double arBytesStep = 0;
     int64_t precond_bytes = 0;
-    int splitMin = 512, splitMinTri = 512;  // smallest block whose triangular products are split 2x2
     double flopCount = 0, factorFlops = 0;  // running counter of the recursion; FP64 flop of one factorisation
 };
 
@@ -399,14 +320,6 @@ struct dotmi_handle {
         hipError_t e_ = (call);                                                                   \
         if (e_ != hipSuccess) {                                                                   \
             (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
-            return DOTMI_E_DEVICE;                                                                \
-        }                                                                                         \
-    } while (0)
-#define RBCHECK(h, call)                                                                          \
-    do {                                                                                          \
-        rocblas_status s_ = (call);                                                               \
-        if (s_ != rocblas_status_success) {                                                       \
-            (h)->err = std::string(#call) + ": rocblas status " + std::to_string((int)s_);        \
             return DOTMI_E_DEVICE;                                                                \
         }                                                                                         \
     } while (0)
@@ -683,7 +596,7 @@ int build_device_mesh(dotmi_handle *h)
         nd_plan(sets, nV, adj_ptr, adj_idx, h->Xrest.data(), ndLevels, ndMin, h->nd, region);
     }
     P.nmax = h->nd[0].size;
-    h->tileMode = h->tune.tileFactor && P.nParts > 0;
+    h->tileMode = P.nParts > 0;   // (a rank without subdomains plans nothing)
     // per part: padded position of every local vertex, tiles of the back-solve, structural non-zeros
     h->partPos.assign(P.nParts, {});
     std::vector<int> dofmap((size_t)P.nParts * P.nmax, -1);
@@ -805,7 +718,6 @@ int build_device_mesh(dotmi_handle *h)
     std::stable_partition(tiles.begin(), tiles.end(), [](const int4 &t) { return t.y + (t.z >> 16) - t.w > 2560; });
     P.ntilesWide = 0;
     for (const int4 &t : tiles) P.ntilesWide += (t.y + (t.z >> 16) - t.w > 2560);
-    if (!h->tune.splitBs) P.ntilesWide = (P.maxTileLen > 2560) ? (int)tiles.size() : 0;   // one launch, as before
     P.ntiles = (int)tiles.size();
     P.nltiles = (int)ltiles.size();
     P.nlwork = (int)lwork.size();
@@ -840,9 +752,7 @@ int build_device_mesh(dotmi_handle *h)
         for (int ls = 0; ls < P.nParts; ++ls)
             for (int J = 0; J < ntl; ++J) {
                 RowTile &R = rtab[(size_t)ls * ntl + J];
-                if (!h->tileMode) {   // dense: 64 rows of the subdomain's nmax x nmax array
-                    R = RowTile{(long long)ls * P.nmax * P.nmax + (long long)J * 64 * P.nmax, P.nmax, 0};
-                } else {
+                {
                     bool live = false;
                     for (int r = 64 * J; r < 64 * J + 64 && !live; ++r) live = dofmap[(size_t)ls * P.nmax + r] >= 0;
                     if (!live) continue;   // identity padding only: nothing stored, nothing read
@@ -854,12 +764,11 @@ int build_device_mesh(dotmi_handle *h)
                 rtLd[(size_t)ls * ntl + J] = R.ld;
                 rtC0[(size_t)ls * ntl + J] = R.c0;
             }
-        if (!h->tileMode) wTotal = (size_t)P.nParts * P.nmax * P.nmax;
         // the factors are the one allocation that grows with the square of the subdomain size: refuse what cannot fit
         // instead of failing somewhere inside hipMalloc
         size_t freeB = 0, totalB = 0;
         HIPCHECK(h, hipMemGetInfo(&freeB, &totalB));
-        const double need = 8.0 * (double)wTotal * (h->tileMode ? 2.1 : 1.25);   // + scratch of the factorisation
+        const double need = 8.0 * (double)wTotal * 2.1;   // + the work buffer of the factorisation
         if (need > 0.9 * (double)freeB) {
             h->err = "the subdomain factors need " + std::to_string((long long)(need / 1e9)) + " GB (" + std::to_string(P.nParts) +
                      " subdomains, padded size " + std::to_string(P.nmax) + "), more than the free HBM: use more subdomains";
@@ -930,8 +839,8 @@ int build_device_mesh(dotmi_handle *h)
         // (1 M tets: 75 us per iteration at 0.26 of the HBM peak); the two-launch form reads the partials coalesced in the
         // subdomains' own order and gathers one 24-byte triple per (vertex, subdomain).  Small meshes keep the one launch.
         P.splitMerge = h->tune.splitMerge >= 0 ? (h->tune.splitMerge != 0) : (3ll * nV >= 400000 || ppartN >= (1ll << 31));
-        const bool lists = h->tune.mergeTiles && !P.splitMerge && ppartN < (1ll << 31) && !(h->flags & DOTMI_FLAG_GSDD);
-        if (h->tune.mergeTiles && !(h->flags & DOTMI_FLAG_GSDD)) {
+        const bool lists = !P.splitMerge && ppartN < (1ll << 31) && !(h->flags & DOTMI_FLAG_GSDD);
+        if (!(h->flags & DOTMI_FLAG_GSDD)) {
             std::vector<int> mp(lists ? (size_t)3 * nV + 1 : 0, 0), ment;
             long long count = 0;
             for (int v = 0; v < nV; ++v)
@@ -1015,8 +924,8 @@ int build_device_mesh(dotmi_handle *h)
             for (int ls = 0; ls < P.nParts; ++ls)
                 plan_subdomain_tiles(ls, nt, P.W, &rtOff[(size_t)ls * nt], &rtLd[(size_t)ls * nt], &rtC0[(size_t)ls * nt],
                                      live[ls], pat[ls], h->W2, sn, all, S.clearTiles, S.clearLd, S.flops, S.qTiles,
-                                     eagerMin, eagerChunk, h->tune.tileEagerMinDiag, h->tune.tileBalance, eagerMinRmul);
-            finish_tile_schedule(all, S, h->tune.tileXcdOrder);
+                                     eagerMin, eagerChunk, 0, true, eagerMinRmul);
+            finish_tile_schedule(all, S);
         }
         if (int rc = upload(h, &h->ttasks, S.tasks)) return rc;
         if (int rc = upload(h, &h->tprods, S.prods)) return rc;
@@ -1037,7 +946,7 @@ int build_device_mesh(dotmi_handle *h)
                       (h->tune.tileFlow > 0 || (h->tune.tileFlow < 0 && S.tasks.size() / nLevels <= 512));
         // the diagonal tasks' per-lane bottom steps (kernels.hip, block_chol_inv<N, FAST>): every layout (DOTMI_FAST_DIAG=0: the
         // one-row-per-lane base of round 3); the 256-thread level kernel keeps the old base, and then so does the dataflow launch
-        h->fastDiag = h->tune.tileThreads == 512 && h->tune.fastDiag != 0;
+        h->fastDiag = h->tune.fastDiag != 0;
         if (h->tileFlow) {
             std::vector<int> depPtr, depIdx;
             build_tile_deps(S.tasks, S.prods, depPtr, depIdx);
@@ -1050,7 +959,7 @@ int build_device_mesh(dotmi_handle *h)
             HIPCHECK(h, hipMemset(h->tnext, 0, sizeof(int) * 2));
             hipDeviceProp_t prop;
             HIPCHECK(h, hipGetDeviceProperties(&prop, h->device));
-            h->tileFlowWg = h->tune.tileFlowWg > 0 ? h->tune.tileFlowWg : 2 * prop.multiProcessorCount;
+            h->tileFlowWg = 2 * prop.multiProcessorCount;
             h->tileSplit = false;
             if (h->tune.fuseLog)
                 fprintf(stderr, "dotmi: tile dataflow: %zu tasks, %zu dependencies, %d workgroups\n", S.tasks.size(), depIdx.size(),
@@ -1068,97 +977,6 @@ int build_device_mesh(dotmi_handle *h)
             fprintf(stderr, "dotmi: tile schedule: %zu tasks, %zu products, %zu levels, %lld Q tiles, %.1f GF\n", S.tasks.size(),
                     S.prods.size(), S.levelStart.size() - 1, S.qTiles, S.flops / 1e9);
     }
-    // factorisation schedule: nodes by height; scratch of a node = R12 / U blocks of the dense recursion,
-    // [R_AS; R_CS] of a dissection node; the nodes of one height run concurrently on disjoint scratch
-    {
-        std::vector<int> height(h->nd.size(), 0);
-        int hmax = 0;
-        for (int id = (int)h->nd.size() - 1; id >= 0; --id) {  // children have larger ids than their parent
-            const NdNode &N = h->nd[id];
-            if (N.a >= 0) height[id] = 1 + std::max(height[N.a], height[N.c]);
-            hmax = std::max(hmax, height[id]);
-        }
-        // dense recursion: R12 of every level stays live while the level below runs
-        std::function<size_t(int)> dense = [&](int sz) -> size_t {
-            if (sz <= 2 * CHOL_NB) return 0;
-            const int n1 = ((sz / CHOL_NB) / 2) * CHOL_NB, n2 = sz - n1;
-            const size_t r = (size_t)n1 * n2;
-            return std::max(dense(n1), r + std::max(r, dense(n2)));
-        };
-        h->phases.assign(hmax + 1, {});
-        h->tmp_stride = 0;
-        for (int ht = 0; ht <= hmax; ++ht) {
-            size_t off = 0;
-            for (size_t id = 0; id < h->nd.size(); ++id) {
-                if (height[id] != ht) continue;
-                const NdNode &N = h->nd[id];
-                dotmi_handle::FactorUnit U;
-                U.node = (int)id;
-                U.tmpOff = off;
-                const size_t rs = (size_t)(N.offS - N.off) * N.sizeS;
-                off += (N.a < 0 ? dense(N.size) : rs + std::max(rs, dense(N.sizeS))) + 64;
-                h->phases[ht].push_back(U);
-            }
-            h->tmp_stride = std::max(h->tmp_stride, off);
-        }
-        // leaves of the same padded size are factorised together (one batched launch / pointer-array GEMM covers them in
-        // every subdomain): the first of a size class leads, the others become displacements of its operands.  (Internal
-        // nodes would additionally need identical tails all the way down; no mesh so far produced two such nodes.)
-        {
-            if (h->tune.fuseLeaves) {
-                std::vector<dotmi_handle::FactorUnit> fused;
-                for (const auto &U : h->phases[0]) {
-                    const NdNode &N = h->nd[U.node];
-                    bool merged = false;
-                    if (N.a < 0)
-                        for (auto &F : fused) {
-                            const NdNode &N0 = h->nd[F.node];
-                            if (N0.a < 0 && N0.size == N.size && F.lw.n < MAX_FUSED_LEAVES) {
-                                F.lw.d[F.lw.n] = (long long)(N.off - N0.off) * (P.nmax + 1);
-                                F.lt.d[F.lt.n] = (long long)U.tmpOff - (long long)F.tmpOff;
-                                F.lw.n++;
-                                F.lt.n++;
-                                merged = true;
-                                break;
-                            }
-                        }
-                    if (!merged) fused.push_back(U);
-                }
-                if (h->tune.fuseLog)
-                    fprintf(stderr, "dotmi: %zu leaves of the dissection in %zu units\n", h->phases[0].size(), fused.size());
-                h->phases[0] = fused;
-            }
-        }
-        // the root is alone in the last phase: its two triangular products split into their child-A and child-C
-        // halves (disjoint rows of the same scratch), which run on two branches
-        if (hmax > 0 && h->tune.splitRoot && h->phases.back().size() == 1 && h->nd[0].sizeS > 0) {
-            const dotmi_handle::FactorUnit R = h->phases.back()[0];
-            h->phases.pop_back();
-            for (int st = 0; st < 3; ++st) {
-                std::vector<dotmi_handle::FactorUnit> ph;
-                for (int part : (st == 0 ? std::vector<int>{1, 2} : st == 1 ? std::vector<int>{3} : std::vector<int>{4, 5})) {
-                    dotmi_handle::FactorUnit U = R;
-                    U.part = part;
-                    ph.push_back(U);
-                }
-                h->phases.push_back(ph);
-            }
-        }
-    }
-    {
-        // the blocks a factorisation leaves non-zero: leaf squares and separator panels (memory rows S, columns from
-        // the node's first column to the end of S)
-        std::vector<int4> segs;
-        for (const NdNode &N : h->nd) {
-            if (N.a < 0)
-                for (int r = N.off; r < N.off + N.size; ++r) segs.push_back(make_int4(r, N.off, N.size, 0));
-            else
-                for (int r = N.offS; r < N.offS + N.sizeS; ++r) segs.push_back(make_int4(r, N.off, N.offS + N.sizeS - N.off, 0));
-        }
-        h->nClearSeg = (int)segs.size();
-        if (int rc = upload(h, &h->clearSeg, segs)) return rc;
-    }
-    if (int rc = dalloc(h, &P.Wtmp, h->tileMode ? 64 : (size_t)P.nParts * h->tmp_stride)) return rc;
     if (int rc = dalloc(h, &P.ppart, (size_t)P.nParts * P.nbmax * P.nmax)) return rc;
     if (int rc = dalloc(h, &P.psub, (size_t)P.nParts * P.nmax)) return rc;
     if (int rc = dalloc(h, &P.rpad, (size_t)P.nParts * P.nmax + 8)) return rc;
@@ -1325,303 +1143,21 @@ int free_slot(const dotmi_handle *h)
     return 0;
 }
 
-// Q = R^-1 in place for every owned dense block, H = R^T R (R upper), by recursion on
-//   H = [H11 H12 ; . H22]:  Q11 = R11^-1 ; R12 = Q11^T H12 ; H22 -= R12^T R12 ;
-//                           Q22 = R22^-1 ; Q12 = -(Q11 R12) Q22
-// In column-major terms Q is upper triangular, so memory row i holds row i of X = L^-1 = Q^T, the
-// layout the single-pass back-solve kernel streams.  All off-diagonal work is FP64 GEMM (rocBLAS
-// strided-batched over the subdomains); the CHOL_NB base blocks are factored and inverted in
-// registers by chol_inv_base_kernel.  This replaces rocSOLVER potrf+potri, measured at 1-3.6 TFLOP/s
-// on these sizes against 60-70 TFLOP/s for dgemm (profiles/r01_factor_primitives.txt).  Role in the
-// reference: CHOLMODSolver::factorize (CHOLMODSolver.cpp:143) called from DOTTimeStepper.cpp:363-377.
-// C(m x n) = alpha * op(A) op(B) + beta * C for every subdomain of the group -- and, when the unit stands for several tree
-// nodes of identical shape (G.lw.n > 1), for each of them: then the batch is a pointer array over (node, subdomain), an
-// operand being displaced by G.lw.d[l] when it lives in W and by G.lt.d[l] when it lives in the scratch.
-rocblas_status gemm_group(dotmi_handle *h, const dotmi_handle::FactorGroup &G, rocblas_operation ta, rocblas_operation tb, int m,
-                          int n, int k, const double *alpha, const double *A, int la, rocblas_stride sa, const double *B, int lb,
-                          rocblas_stride sb, const double *beta, double *C, int lc, rocblas_stride sc)
-{
-    const DevParts &P = h->P;
-    const int batch = G.count, nleaf = G.lw.n;
-    h->flopCount += 2.0 * m * n * k * batch * nleaf;
-    if (nleaf == 1)
-        return rocblas_dgemm_strided_batched(G.blas, ta, tb, m, n, k, alpha, A, la, sa, B, lb, sb, beta, C, lc, sc, batch);
-    const size_t wN = (size_t)P.nParts * P.nmax * P.nmax;
-    auto delta = [&](const double *p, int l) { return (p >= P.W && p < P.W + wN) ? G.lw.d[l] : G.lt.d[l]; };
-    const int nb = batch * nleaf;
-    double **dev = nullptr;
-    if (h->ptrNext < h->ptrPool.size()) dev = h->ptrPool[h->ptrNext];
-    else {
-        std::vector<double *> host((size_t)3 * nb);
-        for (int l = 0; l < nleaf; ++l)
-            for (int b2 = 0; b2 < batch; ++b2) {
-                host[(size_t)l * batch + b2] = const_cast<double *>(A) + delta(A, l) + (size_t)b2 * sa;
-                host[(size_t)nb + l * batch + b2] = const_cast<double *>(B) + delta(B, l) + (size_t)b2 * sb;
-                host[(size_t)2 * nb + l * batch + b2] = C + delta(C, l) + (size_t)b2 * sc;
-            }
-        if (hipMalloc((void **)&dev, sizeof(double *) * host.size()) != hipSuccess) return rocblas_status_memory_error;
-        h->allocs.push_back(dev);
-        if (hipMemcpy(dev, host.data(), sizeof(double *) * host.size(), hipMemcpyHostToDevice) != hipSuccess)
-            return rocblas_status_memory_error;
-        h->ptrPool.push_back(dev);
-    }
-    h->ptrNext++;
-    return rocblas_dgemm_batched(G.blas, ta, tb, m, n, k, alpha, dev, la, dev + nb, lb, beta, dev + 2 * nb, lc, nb);
-}
-
-int chol_inv_node(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int o, int sz)
-{
-    DevParts &P = h->P;
-    const int lda = P.nmax, batch = G.count;
-    const rocblas_stride sA = (rocblas_stride)lda * lda;
-    double *Wg = P.W + (size_t)G.first * sA;
-    const int nleaf = G.lw.n;   // > 1: this call factorises the same node of several equal leaves at once
-    if (sz <= CHOL_NB) {
-        h->flopCount += 2.0 / 3.0 * 64.0 * 64.0 * 64.0 * batch * nleaf;  // factor + triangular inverse
-        launch_chol_inv_base(Wg, lda, batch, o, h->info_dev + G.first, G.st, G.lw);
-        return 0;
-    }
-    if (sz == 2 * CHOL_NB) {  // the whole two-block node in one LDS-resident launch
-        h->flopCount += 2.0 / 3.0 * 128.0 * 128.0 * 128.0 * batch * nleaf;
-        launch_chol_inv_node128(Wg, lda, batch, o, h->info_dev + G.first, G.st, G.lw);
-        return 0;
-    }
-    const int n1 = ((sz / CHOL_NB) / 2) * CHOL_NB, n2 = sz - n1;
-    if (int rc = chol_inv_node(h, G, o, n1)) return rc;
-    double *Q11 = Wg + o + (size_t)o * lda;
-    double *H12 = Wg + o + (size_t)(o + n1) * lda;
-    double *H22 = Wg + (o + n1) + (size_t)(o + n1) * lda;
-    double *H21 = Wg + (o + n1) + (size_t)o * lda;
-    double *Tb = P.Wtmp + (size_t)G.first * h->tmp_stride + G.tmpOff;
-    const int ldt = n1;
-    const rocblas_stride sT = (rocblas_stride)h->tmp_stride;
-    const double one = 1.0, zero = 0.0, mone = -1.0;
-    const rocblas_operation N = rocblas_operation_none, T = rocblas_operation_transpose;
-    // C(m x n) = alpha * op(A) op(B) + beta * C, batched over the owned subdomains
-    auto gemm = [&](rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const double *alpha,
-                    const double *A, int la, rocblas_stride sa, const double *B, int lb, rocblas_stride sb,
-                    const double *beta, double *C, int lc, rocblas_stride sc) {
-        return gemm_group(h, G, ta, tb, m, n, k, alpha, A, la, sa, B, lb, sb, beta, C, lc, sc);
-    };
-    // Q11 and Q22 are upper triangular and only the upper triangle of H22 is needed: on the big nodes
-    // each product is split 2x2 and the structurally-zero / unused quarter is skipped (3 GEMMs
-    // instead of 4 quarter-GEMMs; rocBLAS trmm/syrk are slower than the full dgemm on these sizes,
-    // profiles/r01_factor_primitives.txt).
-    const int a = ((n1 / CHOL_NB) / 2) * CHOL_NB, b = n1 - a;
-    const int c = ((n2 / CHOL_NB) / 2) * CHOL_NB, d = n2 - c;
-    const bool split = n1 >= h->splitMin && a > 0 && c > 0;
-    const double *Qaa = Q11, *Qab = Q11 + (size_t)a * lda, *Qbb = Q11 + a + (size_t)a * lda;
-    // R12 stays in this level's scratch across the recursion into H22 (which gets the scratch behind it);
-    // afterwards Q12 = -Q11 (R12 Q22) lands directly in H12 -- no staging copy.
-    double *T2 = Tb + (size_t)n1 * n2;
-    dotmi_handle::FactorGroup G2 = G;
-    G2.tmpOff = G.tmpOff + (size_t)n1 * n2;
-    if (split) {
-        // R12 = Q11^T H12 :  R_a = Qaa^T H_a ;  R_b = Qab^T H_a + Qbb^T H_b
-        RBCHECK(h, gemm(T, N, a, n2, a, &one, Qaa, lda, sA, H12, lda, sA, &zero, Tb, ldt, sT));
-        RBCHECK(h, gemm(T, N, b, n2, a, &one, Qab, lda, sA, H12, lda, sA, &zero, Tb + a, ldt, sT));
-        RBCHECK(h, gemm(T, N, b, n2, b, &one, Qbb, lda, sA, H12 + a, lda, sA, &one, Tb + a, ldt, sT));
-        // upper blocks of H22 -= R12^T R12
-        const double *Rc = Tb, *Rd = Tb + (size_t)c * ldt;
-        RBCHECK(h, gemm(T, N, c, c, n1, &mone, Rc, ldt, sT, Rc, ldt, sT, &one, H22, lda, sA));
-        RBCHECK(h, gemm(T, N, c, d, n1, &mone, Rc, ldt, sT, Rd, ldt, sT, &one, H22 + (size_t)c * lda, lda, sA));
-        RBCHECK(h, gemm(T, N, d, d, n1, &mone, Rd, ldt, sT, Rd, ldt, sT, &one, H22 + c + (size_t)c * lda, lda, sA));
-    } else {
-        RBCHECK(h, gemm(T, N, n1, n2, n1, &one, Q11, lda, sA, H12, lda, sA, &zero, Tb, ldt, sT));
-        RBCHECK(h, gemm(T, N, n2, n2, n1, &mone, Tb, ldt, sT, Tb, ldt, sT, &one, H22, lda, sA));
-    }
-    if (int rc = chol_inv_node(h, G2, o + n1, n2)) return rc;
-    if (split) {
-        // T2 = R12 Q22 :  T2_c = R_c Qcc ;  T2_d = R_c Qcd + R_d Qdd
-        const double *Qcc = H22, *Qcd = H22 + (size_t)c * lda, *Qdd = H22 + c + (size_t)c * lda;
-        const double *Rc = Tb, *Rd = Tb + (size_t)c * ldt;
-        RBCHECK(h, gemm(N, N, n1, c, c, &one, Rc, ldt, sT, Qcc, lda, sA, &zero, T2, ldt, sT));
-        RBCHECK(h, gemm(N, N, n1, d, c, &one, Rc, ldt, sT, Qcd, lda, sA, &zero, T2 + (size_t)c * ldt, ldt, sT));
-        RBCHECK(h, gemm(N, N, n1, d, d, &one, Rd, ldt, sT, Qdd, lda, sA, &one, T2 + (size_t)c * ldt, ldt, sT));
-        // Q12 = -Q11 T2 :  Q12_a = -(Qaa T2_a + Qab T2_b) ;  Q12_b = -Qbb T2_b
-        RBCHECK(h, gemm(N, N, a, n2, a, &mone, Qaa, lda, sA, T2, ldt, sT, &zero, H12, lda, sA));
-        RBCHECK(h, gemm(N, N, a, n2, b, &mone, Qab, lda, sA, T2 + a, ldt, sT, &one, H12, lda, sA));
-        RBCHECK(h, gemm(N, N, b, n2, b, &mone, Qbb, lda, sA, T2 + a, ldt, sT, &zero, H12 + a, lda, sA));
-    } else {
-        RBCHECK(h, gemm(N, N, n1, n2, n2, &one, Tb, ldt, sT, H22, lda, sA, &zero, T2, ldt, sT));
-        RBCHECK(h, gemm(N, N, n1, n2, n1, &mone, Q11, lda, sA, T2, ldt, sT, &zero, H12, lda, sA));
-    }
-    // the strictly lower block must read as zero when Q is used as a dense GEMM operand one level up
-    // and when the back-solve kernel streams whole memory rows
-    launch_block_copy(H21, lda, (size_t)sA, nullptr, 0, 0, n2, n1, batch, G.st, G.lw);
-    return 0;
-}
-
-// C = alpha * op(Q) B + beta * C for the upper-triangular inverse factor Q of a finished node of the
-// dissection tree (op = transpose when `trans`), batched over the group's subdomains.  B and C point at
-// the first row of the node's range and have `ncols` columns; B and C must not overlap.  Only the blocks
-// of Q that can be non-zero are multiplied: the (A,C) block of a dissection node and the lower triangle
-// of a dense block never enter a GEMM.
-struct TriMult {
-    dotmi_handle *h;
-    const dotmi_handle::FactorGroup &G;
-    double *Wg;
-    int lda, ncols;
-    rocblas_stride sA;
-    double alpha;
-    const double *B;
-    int ldb;
-    rocblas_stride sB;
-    double *C;
-    int ldc;
-    rocblas_stride sC;
-    bool trans;
-    // The operand couples to the separator of the node whose step this is, so it is zero above the last rows of
-    // every leaf below it: NdNode::tail rows for the root (kind 0), NdNode::tail1 rows for the leaf's parent (kind
-    // 1).  The transposed product writes, and the plain product reads, a COMPACT row layout that keeps only the rows
-    // that can be non-zero (leaf tails and separator rows); the other side keeps the padded layout of W.
-    bool compact;
-    int kind;
-    // kind 1 only holds for the leaves directly below the step's node (`direct`); anything deeper is taken dense
-    int leaf_tail(const NdNode &N, bool direct) const { return kind == 0 ? N.tail : (direct ? N.tail1 : N.size); }
-    int comp_rows(const NdNode &N, bool direct) const
-    {
-        return kind == 0 ? N.crows : ((N.a < 0 && direct) ? N.tail1 : N.size);
-    }
-
-    const double *Q(int i, int j) const { return Wg + i + (size_t)j * lda; }
-    int offB(int padded, int comp) const { return (!trans && compact) ? comp : padded; }
-    int offC(int padded, int comp) const { return (trans && compact) ? comp : padded; }
-    // C[ro..ro+m) (+)= alpha * op(Q[qi.., qj..]) * B[rb..rb+k)
-    int gemm(int m, int k, int qi, int qj, int rb, int ro, double beta) const
-    {
-        const rocblas_status st = gemm_group(
-            h, G, trans ? rocblas_operation_transpose : rocblas_operation_none, rocblas_operation_none, m, ncols, k,
-            &alpha, Q(qi, qj), lda, sA, B + rb, ldb, sB, &beta, C + ro, ldc, sC);
-        if (st != rocblas_status_success) {
-            h->err = "rocblas_dgemm_strided_batched: status " + std::to_string((int)st);
-            return DOTMI_E_DEVICE;
-        }
-        return 0;
-    }
-    // dense upper-triangular block at [o, o+sz); rb / rc = row offsets of that block inside B / C
-    int dense(int o, int sz, int rb, int rc, double beta) const
-    {
-        const int a = ((sz / CHOL_NB) / 2) * CHOL_NB, b = sz - a;
-        if (sz < h->splitMinTri || a == 0) return gemm(sz, sz, o, o, rb, rc, beta);
-        if (trans) {  // C_a = Qaa^T B_a ; C_b = Qab^T B_a + Qbb^T B_b
-            if (int e = dense(o, a, rb, rc, beta)) return e;
-            if (int e = gemm(b, a, o, o + a, rb, rc + a, beta)) return e;
-            return dense(o + a, b, rb + a, rc + a, 1.0);
-        }
-        // C_a = Qaa B_a + Qab B_b ; C_b = Qbb B_b
-        if (int e = dense(o, a, rb, rc, beta)) return e;
-        if (int e = gemm(a, b, o, o + a, rb + a, rc, 1.0)) return e;
-        return dense(o + a, b, rb + a, rc + a, beta);
-    }
-    // node `id`; rp / rq = padded / compact row offset of the node inside the operands
-    int node(int id, int rp, int rq, double beta, bool direct = true) const
-    {
-        const NdNode &N = h->nd[id];
-        if (N.a < 0) {
-            const int tl = leaf_tail(N, direct);
-            const int h0 = compact ? N.size - tl : 0;
-            const int p1 = rp + h0;  // first row of the tail (compact: rq)
-            if (h0 <= 0) return dense(N.off, N.size, offB(rp, rq), offC(rp, rq), beta);
-            // transposed: Q^T [0 ; B_b] = [0 ; Q_bb^T B_b], only the tail rows exist in the compact result
-            if (trans) return dense(N.off + h0, tl, p1, rq, beta);
-            // plain: Q [0 ; R_b] = [Q_ab R_b ; Q_bb R_b]
-            if (int e = gemm(h0, tl, N.off, N.off + h0, rq, rp, beta)) return e;
-            return dense(N.off + h0, tl, rq, p1, beta);
-        }
-        const NdNode &A = h->nd[N.a], &Cn = h->nd[N.c];
-        const int m = N.offS - N.off;  // padded rows of [A ; C]
-        if (int e = node(N.a, rp, rq, beta, false)) return e;
-        if (int e = node(N.c, rp + A.size, rq + comp_rows(A, false), beta, false)) return e;
-        if (N.sizeS == 0) return 0;
-        const int pS = rp + m, qS = rq + comp_rows(A, false) + comp_rows(Cn, false);
-        if (trans) {  // C_S = [Q_AS ; Q_CS]^T B_AC + Q_S^T B_S   (B in the padded layout)
-            if (int e = gemm(N.sizeS, m, N.off, N.offS, rp, offC(pS, qS), beta)) return e;
-            return dense(N.offS, N.sizeS, pS, offC(pS, qS), 1.0);
-        }
-        // C_AC += [Q_AS ; Q_CS] B_S ; C_S = Q_S B_S   (C in the padded layout)
-        if (int e = gemm(m, N.sizeS, N.off, N.offS, offB(pS, qS), rp, 1.0)) return e;
-        return dense(N.offS, N.sizeS, offB(pS, qS), pS, beta);
-    }
-};
-
-// inverse Cholesky factor of a node of the dissection tree:  with H = [H_A 0 H_AS ; . H_C H_CS ; . . H_S]
-//   Q_A, Q_C            (children, independent)
-//   R = blockdiag(Q_A, Q_C)^T [H_AS ; H_CS]         H_S -= R^T R
-//   U = blockdiag(Q_A, Q_C) R                        Q_S = inverse factor of the updated H_S
-//   [Q_AS ; Q_CS] = -U Q_S
-// The (A,C) block of the factor and of its inverse is structurally zero and is never touched.
-// One call does ONE node: a dense leaf, or the separator steps of a dissection node whose children are
-// finished; issue_factor() walks the tree by height and runs the nodes of one height concurrently.
-// `part`: 0 = the whole node; for a dissection node that is split over parallel branches 1 / 2 = the transposed
-// product for child A / C, 3 = the separator block itself, 4 / 5 = the final product for child A / C.
-int chol_inv_tree(dotmi_handle *h, const dotmi_handle::FactorGroup &G, int id, int part = 0)
-{
-    const NdNode &N = h->nd[id];
-    if (N.a < 0) return chol_inv_node(h, G, N.off, N.size);
-    if (N.sizeS == 0) return 0;
-    DevParts &P = h->P;
-    const NdNode &A = h->nd[N.a], &Cn = h->nd[N.c];
-    const int lda = P.nmax, batch = G.count, m = N.offS - N.off, ns = N.sizeS;
-    // R = blockdiag(Q_A, Q_C)^T H_XS is kept in compact rows (see TriMult): fewer rows in R^T R and R Q_S
-    const bool compact = true;
-    const int kind = id == 0 ? 0 : 1;
-    auto crows = [&](const NdNode &X) { return kind == 0 ? X.crows : (X.a < 0 ? X.tail1 : X.size); };  // direct children
-    const int mr = crows(A) + crows(Cn);
-    const rocblas_stride sA = (rocblas_stride)lda * lda, sT = (rocblas_stride)h->tmp_stride;
-    double *Wg = P.W + (size_t)G.first * sA;
-    double *Hxs = Wg + N.off + (size_t)N.offS * lda;   // [H_AS ; H_CS], m x ns
-    double *Hss = Wg + N.offS + (size_t)N.offS * lda;
-    double *Tb = P.Wtmp + (size_t)G.first * h->tmp_stride + G.tmpOff;
-    const double one = 1.0, zero = 0.0, mone = -1.0;
-    const rocblas_operation Nn = rocblas_operation_none, Tt = rocblas_operation_transpose;
-    if (part == 0 || part == 1 || part == 2) {
-        TriMult tm{h, G, Wg, lda, ns, sA, 1.0, Hxs, lda, sA, Tb, mr, sT, true, compact, kind};
-        if (part != 2)
-            if (int rc = tm.node(N.a, 0, 0, 0.0)) return rc;
-        if (part != 1)
-            if (int rc = tm.node(N.c, A.size, crows(A), 0.0)) return rc;
-        if (part != 0) return 0;
-    }
-    double *T2 = Tb + (size_t)mr * ns;
-    if (part == 0 || part == 3) {
-        // R^T R here, R Q_S below
-        RBCHECK(h, gemm_group(h, G, Tt, Nn, ns, ns, mr, &mone, Tb, mr, sT, Tb, mr, sT, &one, Hss, lda, sA));
-        // R stays in scratch across the factorisation of the separator block; [Q_AS ; Q_CS] = -blockdiag(Q_A, Q_C)
-        // (R Q_S) is then written straight into place
-        dotmi_handle::FactorGroup G2 = G;
-        G2.tmpOff = G.tmpOff + (size_t)mr * ns;
-        if (int rc = chol_inv_node(h, G2, N.offS, ns)) return rc;
-        RBCHECK(h, gemm_group(h, G, Nn, Nn, mr, ns, ns, &one, Tb, mr, sT, Hss, lda, sA, &zero, T2, mr, sT));
-        // rows S, columns [A C] of the lower part hold the symmetric fill of H: clear them
-        launch_block_copy(Wg + N.offS + (size_t)N.off * lda, lda, (size_t)sA, nullptr, 0, 0, ns, m, batch, G.st, G.lw);
-        if (part != 0) return 0;
-    }
-    {
-        TriMult tm{h, G, Wg, lda, ns, sA, -1.0, T2, mr, sT, Hxs, lda, sA, false, compact, kind};
-        if (part != 5)
-            if (int rc = tm.node(N.a, 0, 0, 0.0)) return rc;
-        if (part != 4)
-            if (int rc = tm.node(N.c, A.size, crows(A), 0.0)) return rc;
-    }
-    return 0;
-}
-
-// issue (or replay) the inverse-Cholesky recursion of every owned subdomain on h->st
+// issue the tile factorisation of every owned subdomain on h->st (tile_factor.hpp): one dataflow launch, or one launch per level
 int issue_factor(dotmi_handle *h)
 {
-    if (h->tileMode && h->tileFlow) {
+    if (h->tileFlow) {
         launch_tile_flow(h->ttasks, h->nTtasks, h->tprods, h->tdepPtr, h->tdepIdx, h->tdone, h->tnext, ++h->tileEpoch, h->info_dev,
-                         h->tileFlowWg, h->st, h->tune.tileThreads, (double)h->tune.tileFlowWaitMs, h->fastDiag);
+                         h->tileFlowWg, h->st, (double)h->tune.tileFlowWaitMs, h->fastDiag);
         h->flopCount = h->tileFlops;
         return 0;
     }
-    if (h->tileMode) {
+    {
         // one launch per level of the static tile schedule; a launch boundary is the only synchronisation
         for (size_t l = 0; l + 1 < h->tlevelStart.size(); ++l) {
             const int n = h->tlevelStart[l + 1] - h->tlevelStart[l];
             if (!h->tileSplit) {
-                launch_tile_level(h->ttasks + h->tlevelStart[l], n, h->tprods, h->info_dev, h->st, h->tune.tileThreads, h->fastDiag);
+                launch_tile_level(h->ttasks + h->tlevelStart[l], n, h->tprods, h->info_dev, h->st, h->fastDiag);
                 continue;
             }
             // the level's diagonal-block tasks (77 KB of LDS, ~20 us each) on the side stream, its product / row / inverse
@@ -1631,49 +1167,18 @@ int issue_factor(dotmi_handle *h)
             if (nd > 0 && ng > 0) {
                 HIPCHECK(h, hipEventRecord(h->tFork[l], h->st));
                 HIPCHECK(h, hipStreamWaitEvent(h->stDiag, h->tFork[l], 0));
-                launch_tile_level(t0, nd, h->tprods, h->info_dev, h->stDiag, h->tune.tileThreads, h->fastDiag);
+                launch_tile_level(t0, nd, h->tprods, h->info_dev, h->stDiag, h->fastDiag);
                 launch_tile_gemm(t0 + nd, ng, h->tprods, h->st);
                 HIPCHECK(h, hipEventRecord(h->tJoin[l], h->stDiag));
                 HIPCHECK(h, hipStreamWaitEvent(h->st, h->tJoin[l], 0));
             } else if (nd > 0) {
-                launch_tile_level(t0, nd, h->tprods, h->info_dev, h->st, h->tune.tileThreads, h->fastDiag);
+                launch_tile_level(t0, nd, h->tprods, h->info_dev, h->st, h->fastDiag);
             } else {
                 launch_tile_gemm(t0, ng, h->tprods, h->st);
             }
         }
-        h->flopCount = h->tileFlops;
-        return 0;
     }
-    h->ptrNext = 0;
-    HIPCHECK(h, hipEventRecord(h->evFill, h->st));
-    for (auto &G : h->groups) {
-        if (G.st != h->st) HIPCHECK(h, hipStreamWaitEvent(G.st, h->evFill, 0));
-        for (auto &phase : h->phases) {
-            const bool par = !h->branches.empty() && phase.size() > 1;
-            if (par) HIPCHECK(h, hipEventRecord(phase[0].fork, G.st));
-            for (size_t k = 0; k < phase.size(); ++k) {
-                const auto &U = phase[k];
-                dotmi_handle::FactorGroup Gk = G;
-                Gk.tmpOff = U.tmpOff;
-                Gk.lw = U.lw;
-                Gk.lt = U.lt;
-                if (par && k > 0) {
-                    Gk.st = h->branches[k - 1].st;
-                    Gk.blas = h->branches[k - 1].blas;
-                    HIPCHECK(h, hipStreamWaitEvent(Gk.st, phase[0].fork, 0));
-                }
-                if (int rc = chol_inv_tree(h, Gk, U.node, U.part)) return rc;
-                if (par && k > 0) {
-                    HIPCHECK(h, hipEventRecord(U.join, Gk.st));
-                    HIPCHECK(h, hipStreamWaitEvent(G.st, U.join, 0));
-                }
-            }
-        }
-        if (G.st != h->st) {
-            HIPCHECK(h, hipEventRecord(G.done, G.st));
-            HIPCHECK(h, hipStreamWaitEvent(h->st, G.done, 0));
-        }
-    }
+    h->flopCount = h->tileFlops;
     return 0;
 }
 
@@ -1682,7 +1187,7 @@ int run_factor(dotmi_handle *h)
     if (h->graphState == 0) {
         h->graphState = -1;
         if (h->tune.factorGraph && !h->tileFlow) {   // (the dataflow launch carries its epoch as an argument: not replayed)
-            // warm rocBLAS (kernel selection, lazy loads) outside of capture, then capture the same sequence
+            // one pass outside of capture (lazy code-object loads), then capture the same sequence
             h->flopCount = 0;
             if (int rc = issue_factor(h)) return rc;
             h->factorFlops = h->flopCount;
@@ -1734,8 +1239,7 @@ int refactor_issue(dotmi_handle *h, const double *x)
     DevParts Pf = h->P;
     if (h->tileMode) Pf.W = h->W2;
     if (h->wDirty) {
-        if (h->tileMode) launch_clear_tiles(h->tclear, h->tclearLd, h->nTclear, h->st);
-        else launch_clear_segments(h->P, h->clearSeg, h->nClearSeg, h->st);
+        launch_clear_tiles(h->tclear, h->tclearLd, h->nTclear, h->st);
     } else if (h->P.nParts > 0) {
         HIPCHECK(h, hipMemsetAsync(h->P.W, 0, h->wTotal * sizeof(double), h->st));
         if (h->tileMode) HIPCHECK(h, hipMemsetAsync(h->W2, 0, h->wTotal * sizeof(double), h->st));
@@ -2003,8 +1507,7 @@ void sum_stats(const dotmi_handle *h, int nvals, double *R)
     for (int j = 0; j < nvals; ++j) R[j] = chunked_sum(NB_RED, [&](int b) { return h->h_partR[(size_t)b * RED_K + j]; });
 }
 
-// owner exchange: sum over the ranks of the entries of `vec` at the vertices held by more than one rank (packed, summed, put
-// back) -- plus `ntail` scalars at `tailp` that ride along
+// owner exchange: the entries of the vertices held by more than one rank (and `ntail` scalars behind them) summed over the ranks
 int exchange_iface(dotmi_handle *h, double *vec, double *tailp, int ntail)
 {
     if (3 * h->nIface + ntail == 0) return 0;   // (no vertex is shared -- one rank --: the same on every rank, nothing to send)
@@ -2012,13 +1515,6 @@ int exchange_iface(dotmi_handle *h, double *vec, double *tailp, int ntail)
     if (int rc = allreduce_sum(h, h->xpack, (size_t)3 * h->nIface + ntail)) return rc;
     launch_unpack_iface(h->nIface, h->ifaceIdx, h->xpack, h->heldMask, vec, tailp, ntail, h->st);
     return 0;
-}
-// owner exchange: the first `ncols` columns of a partial array summed over its rows and over the ranks into row 0 of `dst`
-// (whose other rows stay zero: consumers sum the rows of a partial array)
-int allreduce_columns(dotmi_handle *h, const double *partials, int ncols, double *dst)
-{
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, partials, NB_RED, RED_K, ncols, 0.0, 0.0, 0, dst);
-    return allreduce_sum(h, dst, (size_t)ncols);
 }
 
 // owner exchange, packed form.  The gradient's packet: [3 nIface entries | E | ncols statistics]; `partials` holds the sums this
@@ -2110,7 +1606,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     a.vp_off = h->P.vp_off;
     a.rpad = h->P.rpad;
     const double *ctlE = h->partE;
-    const bool packed = ow && h->tune.ownerPack;
+    const bool packed = ow;   // owner exchange: the statistics ride in the gradient's packet
     if (!se) {
         launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st, h->ctl);
     } else if (packed) {
@@ -2144,25 +1640,11 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         ag.hp = nullptr;
         ag.vp_ptr = ag.vp_off = nullptr;
         ag.rpad = nullptr;
-        ag.ownMask = ow ? h->ownMask : nullptr;
-        ag.vlist = ow ? h->heldList : nullptr;
-        ag.nlist = ow ? h->nHeld : 0;
         launch_vertex_gather(h->M, h->PT, ag, L0, h->partR, h->st, h->ctl);
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
                            h->gstage + n + 1);
-        if (!ow) {
-            if (int rc = allreduce_sum(h, h->gstage, (size_t)n + 2)) return rc;
-            launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
-        } else {
-            // (DOTMI_OWNER_PACK=0) the shared entries (and E) are summed, then the statistics over the owned vertices travel as
-            // a collective of their own
-            if (int rc = exchange_iface(h, h->gstage, h->gstage + n + 1, 1)) return rc;
-            a.ownMask = h->ownMask;
-            a.vlist = h->heldList;
-            a.nlist = h->nHeld;
-            launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
-            if (int rc = allreduce_columns(h, h->partR, RED_K, h->partGR)) return rc;
-        }
+        if (int rc = allreduce_sum(h, h->gstage, (size_t)n + 2)) return rc;
+        launch_pair_stats(n, a, L0, h->partR, h->st, h->gstage, h->ctl);
         ctlE = h->gstage + n;   // the controller reads the energy as one block (0, E)
         nb = 1;
     }
@@ -2171,10 +1653,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
                        (h->timeCount++ % h->timeStride) == 0;
     h->slotTimed.push_back(timed ? h->evUsed : -1);
     CtlArgs ca{h->ctl, ctlE, ctlR, h->alpha_dev, h->h_flags, nb, 0};
-    if (!h->tune.earlyHostCtl)   // (ablation) the controller as a launch of its own, in front of the speculative solve
-        launch_loop_control(h->ctl, ctlE, nb, ctlR, h->alpha_dev, h->h_flags, h->st);
-    launch_gemv(h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr,
-                h->tune.earlyHostCtl ? &ca : nullptr,
+    launch_gemv(h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr, &ca,
                 h->tune.earlyAbort ? (int)h->slotTimed.size() /* the slot's epoch, 1-based */ : (1 << 30) /* never stopped */);
     if (timed) h->evUsed += 2;
     if (!h->dist) {
@@ -2184,7 +1663,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         // whatever the controller decided: every rank enqueues the same sequence), then the division and the history terms
         // (the sum travels in a staging buffer: in a slot whose merge is gated off -- retry, past the end -- the collective
         // still runs, on stale scratch, and z is left alone)
-        if (!(ow && h->tune.ownerPack))   // (packed owner exchange: merge_early merges the tiles itself)
+        if (!ow)   // (owner exchange: merge_early merges the tiles itself)
             launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl, h->held());
         if (!ow) {
             if (int rc = allreduce_sum(h, h->zstage, n)) return rc;
@@ -2192,21 +1671,14 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         } else {
             // zstage: this rank's subdomains' sum, zero on the vertices it does not hold; only the shared vertices' entries
             // are summed over the ranks.  z is then whole on the held vertices and zero elsewhere -- and so is everything
-            // the loop forms from it.  The five y_i . z travel ...
-            if (h->tune.ownerPack) {
-                // ... inside the packet: merge_early merges this rank's tiles itself -- z, u_old, M y_new and the y_i . z on the
-                // vertices only this rank holds, its part of the sum (to zstage) and its share of the y_i . z on the shared
-                // ones --, then the exchange, then the shared vertices
-                launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, nullptr, h->ownMask, h->held(), h->vkind, 1,
-                                   h->zstage);
-                if (int rc = exchange_solve_packed(h)) return rc;
-                if (h->nShared > 0)
-                    launch_merge_early(h->M, h->P, h->z, nullptr, 0, h->st, h->ctl, h->zstage, h->ownMask, h->shared());
-            } else {   // ... (DOTMI_OWNER_PACK=0) as a collective of their own, summed over the owned vertices
-                if (int rc = exchange_iface(h, h->zstage, nullptr, 0)) return rc;
-                launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, h->zstage, h->ownMask, h->held());
-                if (int rc = allreduce_columns(h, h->partC, HIST_MAX, h->partGC)) return rc;
-            }
+            // the loop forms from it.  The five y_i . z travel inside the packet: merge_early merges this rank's tiles itself -- z,
+            // u_old, M y_new and the y_i . z on the vertices only this rank holds, its part of the sum (to zstage) and its share
+            // of the y_i . z on the shared ones --, then the exchange, then the shared vertices
+            launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, nullptr, h->ownMask, h->held(), h->vkind, 1,
+                               h->zstage);
+            if (int rc = exchange_solve_packed(h)) return rc;
+            if (h->nShared > 0)
+                launch_merge_early(h->M, h->P, h->z, nullptr, 0, h->st, h->ctl, h->zstage, h->ownMask, h->shared());
         }
     }
     return 0;
@@ -2356,9 +1828,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
         if (!h->shardElems && h->earlyNow) {
             // the first direction's solve, u = -M g_0 and z = u, with the start-of-step controller inside its launch
             CtlArgs ca{h->ctl, h->partE, h->partR, h->alpha_dev, h->h_flags, nb, 1};
-            launch_gemv(h->P, nullptr, h->st, h->ctl, nullptr, nullptr, h->tune.earlyHostCtl ? &ca : nullptr, 1 << 30);
-            if (!h->tune.earlyHostCtl)
-                launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
+            launch_gemv(h->P, nullptr, h->st, h->ctl, nullptr, nullptr, &ca, 1 << 30);
             if (!h->dist) {
                 launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl);
             } else {
@@ -2369,29 +1839,23 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
         } else if (!h->shardElems) {
             launch_loop_control(h->ctl, h->partE, nb, h->partR, h->alpha_dev, h->h_flags, h->st, 1);
         } else {
-            if (!(h->owner && h->tune.ownerPack))
+            if (!h->owner)
                 hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(64), 0, h->st, h->partE, nb, 2, 2, h->dtSq, 1.0, 1,
                                    h->gstage + n_ + 1);
             const double *ctlR = h->partR;
             if (!h->owner) {
                 if (int rc = allreduce_sum(h, h->gstage, (size_t)n_ + 2)) return rc;
-            } else if (h->tune.ownerPack) {
+            } else {
                 // |g|^2 over the owned vertices no other rank holds rides with the packet, the shared entries' squares are
                 // added from the summed packet
                 launch_masked_norm2(n_, h->gstage, h->vkind, h->partR, h->st, 1);
                 if (int rc = exchange_gradient_packed(h, n_, nb, h->partR, 1)) return rc;
                 ctlR = h->partGR;
-            } else {
-                if (int rc = exchange_iface(h, h->gstage, h->gstage + n_ + 1, 1)) return rc;
             }
             HIPCHECK(h, hipMemcpyAsync(h->g, h->gstage, sizeof(double) * n_, hipMemcpyDeviceToDevice, h->st));
             if (!h->owner) {
                 const double *vecs[1] = {h->g};
                 launch_multidot(n_, h->g, vecs, 1, h->partR, h->st);   // |g|^2
-            } else if (!h->tune.ownerPack) {
-                launch_masked_norm2(n_, h->g, h->ownMask, h->partR, h->st);   // over the owned vertices, then over the ranks
-                if (int rc = allreduce_columns(h, h->partR, 1, h->partGR)) return rc;
-                ctlR = h->partGR;
             }
             if (!h->earlyNow) {
                 launch_loop_control(h->ctl, h->gstage + n_, 1, ctlR, h->alpha_dev, h->h_flags, h->st, 1);
@@ -2400,22 +1864,16 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
                 // first direction's solve with the start-of-step controller inside its launch, the sum over the ranks, z = u
                 launch_build_qpad(h->P, h->g, L0, nullptr, h->st, nullptr);
                 CtlArgs ca{h->ctl, h->gstage + n_, ctlR, h->alpha_dev, h->h_flags, 1, 1};
-                launch_gemv(h->P, nullptr, h->st, h->ctl, nullptr, nullptr, h->tune.earlyHostCtl ? &ca : nullptr, 1 << 30);
-                if (!h->tune.earlyHostCtl)
-                    launch_loop_control(h->ctl, h->gstage + n_, 1, ctlR, h->alpha_dev, h->h_flags, h->st, 1);
+                launch_gemv(h->P, nullptr, h->st, h->ctl, nullptr, nullptr, &ca, 1 << 30);
                 launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl, h->held());
                 if (!h->owner) {
                     if (int rc = allreduce_sum(h, h->zstage, n_)) return rc;
                     launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage);
                 } else {
                     if (int rc = exchange_iface(h, h->zstage, nullptr, 0)) return rc;
-                    if (h->tune.ownerPack) {   // (no pair yet: no y_i . z to sum)
-                        launch_merge_early(h->M, h->P, h->z, nullptr, 1, h->st, h->ctl, h->zstage, h->ownMask, h->held());
-                        HIPCHECK(h, hipMemsetAsync(h->partGC, 0, sizeof(double) * HIST_MAX, h->st));
-                    } else {
-                        launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, h->zstage, h->ownMask, h->held());
-                        if (int rc = allreduce_columns(h, h->partC, HIST_MAX, h->partGC)) return rc;
-                    }
+                    // (no pair yet: no y_i . z to sum)
+                    launch_merge_early(h->M, h->P, h->z, nullptr, 1, h->st, h->ctl, h->zstage, h->ownMask, h->held());
+                    HIPCHECK(h, hipMemsetAsync(h->partGC, 0, sizeof(double) * HIST_MAX, h->st));
                 }
             }
         }
@@ -2920,7 +2378,7 @@ int dotmi_comm_unique_id(void *out128)
 int32_t dotmi_factor_kind(const dotmi_handle *h)
 {
     if (!h) return DOTMI_E_INVALID;
-    return !h->tileMode ? 0 : h->tileFlow ? 2 : 1;
+    return h->tileFlow ? 2 : 1;
 }
 
 int32_t dotmi_comm_ranks(const dotmi_handle *h)
@@ -2940,7 +2398,6 @@ void dotmi_destroy(dotmi_handle *h)
     hipSetDevice(h->device);
     if (h->st) hipStreamSynchronize(h->st);
     if (h->comm) ncclCommDestroy(h->comm);
-    if (h->blas) rocblas_destroy_handle(h->blas);
     for (void *p : h->allocs) hipFree(p);
     if (h->arStage) hipHostFree(h->arStage);
     if (h->h_partE) hipHostFree(h->h_partE);
@@ -2963,21 +2420,6 @@ void dotmi_destroy(dotmi_handle *h)
     for (hipEvent_t e : h->evPre) hipEventDestroy(e);
     for (hipEvent_t e : h->evAr) hipEventDestroy(e);
     if (h->factorGraph) hipGraphExecDestroy(h->factorGraph);
-    for (auto &G : h->groups) {
-        if (G.blas && G.blas != h->blas) rocblas_destroy_handle(G.blas);
-        if (G.done) hipEventDestroy(G.done);
-        if (G.st && G.st != h->st) hipStreamDestroy(G.st);
-    }
-    for (auto &B : h->branches) {
-        if (B.blas) rocblas_destroy_handle(B.blas);
-        if (B.st) hipStreamDestroy(B.st);
-    }
-    for (auto &ph : h->phases)
-        for (auto &U : ph) {
-            if (U.fork) hipEventDestroy(U.fork);
-            if (U.join) hipEventDestroy(U.join);
-        }
-    if (h->evFill) hipEventDestroy(h->evFill);
     if (h->st) hipStreamDestroy(h->st);
     delete h;
 }
@@ -3066,8 +2508,6 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     h->timePhases = (h->flags & DOTMI_FLAG_TIME_PHASES) != 0;
     if (h->timePhases)
         for (auto &e : h->evP) HIPCHECK(h, hipEventCreate(&e));
-    RBCHECK(h, rocblas_create_handle(&h->blas));
-    RBCHECK(h, rocblas_set_stream(h->blas, h->st));
     h->dist = h->world > 1 || (h->flags & DOTMI_FLAG_FORCE_DIST);
     h->shardElems = h->dist && (h->tune.shardElems >= 0 ? h->tune.shardElems != 0 : h->nT >= 400000);
     h->owner = h->dist && (h->flags & DOTMI_FLAG_OWNER_EXCHANGE);
@@ -3104,47 +2544,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     }
     host_features(h);
     h->targetGRes = host_target_gres(h);
-    h->splitMin = h->tune.splitMin;
-    h->splitMinTri = h->tune.splitMinTri;
     if (int rc = build_device_mesh(h)) return rc;
-    {
-        const int ng = std::max(1, std::min(h->tune.factorStreams, std::max(1, h->P.nParts)));
-        HIPCHECK(h, hipEventCreateWithFlags(&h->evFill, hipEventDisableTiming));
-        h->groups.resize(ng);
-        for (int g = 0; g < ng; ++g) {
-            auto &G = h->groups[g];
-            G.first = (int)((long long)h->P.nParts * g / ng);
-            G.count = (int)((long long)h->P.nParts * (g + 1) / ng) - G.first;
-            if (ng == 1) {
-                G.st = h->st;  // single batch: the handle's own stream and rocBLAS handle
-                G.blas = h->blas;
-            } else {
-                HIPCHECK(h, hipStreamCreateWithFlags(&G.st, hipStreamNonBlocking));
-                HIPCHECK(h, hipEventCreateWithFlags(&G.done, hipEventDisableTiming));
-                RBCHECK(h, rocblas_create_handle(&G.blas));
-                RBCHECK(h, rocblas_set_stream(G.blas, G.st));
-            }
-        }
-    }
-
-    {
-        size_t width = 1;
-        for (auto &ph : h->phases) width = std::max(width, ph.size());
-        if (h->tune.ndParallel && h->groups.size() == 1 && h->P.nParts > 0 && width > 1) {
-            h->branches.resize(width - 1);
-            for (auto &B : h->branches) {
-                HIPCHECK(h, hipStreamCreateWithFlags(&B.st, hipStreamNonBlocking));
-                RBCHECK(h, rocblas_create_handle(&B.blas));
-                RBCHECK(h, rocblas_set_stream(B.blas, B.st));
-            }
-            for (auto &ph : h->phases)
-                for (auto &U : ph) {
-                    HIPCHECK(h, hipEventCreateWithFlags(&U.fork, hipEventDisableTiming));
-                    HIPCHECK(h, hipEventCreateWithFlags(&U.join, hipEventDisableTiming));
-                }
-        }
-    }
-
     const int n = h->n;
     double **vecs[] = {&h->x, &h->x_trial, &h->xn, &h->v, &h->xt, &h->g, &h->g_trial, &h->p, &h->q, &h->z,
                        &h->Hp, &h->tmpn};
@@ -3185,13 +2585,12 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
             h->err = "DOTMI_FLAG_GSDD: single GPU only";
             return DOTMI_E_INVALID;
         }
-        h->devLoop = !h->gsdd && !h->newton && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES)) &&
-                     h->tune.deviceLoop;
+        h->devLoop = !h->gsdd && !h->newton && !(h->flags & (DOTMI_FLAG_HOST_LOOP | DOTMI_FLAG_TIME_PHASES));
         // replicated element pass, merged tile partials: the back-solve of the next direction is issued on the trial
         // gradient, beside the controller (enqueue_loop_slot); sharded subdomains keep their one collective per iteration
         // (round 4: also with the sharded element pass -- the scatter of -g and H s_new then happen in pair_stats, behind the
         // gradient's all-reduce; DOTMI_EARLY_SHARDED=0 keeps the q-based order there)
-        h->earlyBs = h->devLoop && h->tune.earlyBs != 0 && (!h->shardElems || h->tune.earlySharded) &&
+        h->earlyBs = h->devLoop && h->tune.earlyBs != 0 &&
                      (h->P.mt_ptr != nullptr || h->P.splitMerge);
         if (h->owner && !(h->earlyBs && h->tune.fuseDir)) {
             h->err = "DOTMI_FLAG_OWNER_EXCHANGE needs the device loop's early order with the fused direction kernel";

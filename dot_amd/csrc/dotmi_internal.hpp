@@ -16,7 +16,7 @@ constexpr int NB_RED = 256;     // blocks of every reducing kernel (fixed => run
 constexpr int RED_K = 3 * HIST_MAX + 3;  // partial values per block
 constexpr int BS_LONG = 5120;   // longest row (columns) the single-pass back-solve kernel holds in registers (512 threads x 5 x 2)
 constexpr int ELEM_NB_MAX = 8192; // most workgroups (= partial energy rows) of the element pass; beyond, workgroups loop over patches
-constexpr int CHOL_NB = 64;     // base block of the recursive inverse-Cholesky (LDS resident)
+constexpr int CHOL_NB = 64;     // tile of the inverse-Cholesky factorisation (LDS resident)
 
 // ---- mesh + topology resident in HBM ------------------------------------------------------------
 struct DevMesh {
@@ -51,12 +51,11 @@ struct DevPatches {
 };
 
 // ---- factor storage -------------------------------------------------------------------------------
-// A subdomain's X_s (first H_s) is kept by 64-row blocks.  Memory row i of block J = i / 64, column c (c0 <= c <
-// 64 (J + 1)) is at W[off + (i - 64 J) * ld + (c - c0)].  Dense layout (recursive rocBLAS factorisation): every block
-// is 64 rows of the subdomain's nmax x nmax array (ld = nmax, c0 = 0).  Compact layout (tile factorisation): a block
-// only holds what its rows can have non-zero -- from the first column of the rows' tree node to the end of the
-// block's diagonal tile (ld = 64 (J + 1) - c0) --, blocks of pure padding rows hold nothing (off = -1): the
-// storage is ~1.2x the structural non-zeros the back-solve streams instead of nmax^2 per subdomain.
+// A subdomain's X_s is kept by 64-row blocks (and H_s, then R, in a work buffer of the same layout: tile_factor.hpp).  Memory
+// row i of block J = i / 64, column c (c0 <= c < 64 (J + 1)) is at W[off + (i - 64 J) * ld + (c - c0)].  A block only holds
+// what its rows can have non-zero -- from the first column of the rows' tree node to the end of the block's diagonal tile
+// (ld = 64 (J + 1) - c0) --, blocks of pure padding rows hold nothing (off = -1): the storage is ~1.2x the structural
+// non-zeros the back-solve streams instead of nmax^2 per subdomain.
 struct RowTile {
     long long off;
     int ld, c0;
@@ -70,7 +69,6 @@ struct DevParts {
     double *W;              // factor storage of the owned subdomains (RowTile): H_s, then X_s = chol(H_s)^-1 with memory
                             // row i = row i of X_s (column-major upper factor Q = R^-1 of H_s = R^T R)
     RowTile *rt;            // owned * (nmax / 64) row blocks
-    double *Wtmp;           // owned * tmp_stride scratch of the recursion
     int ntiles;             // back-solve jobs, heavy first:
     int4 *tile;             //   (part, first row, tile index within the part | rows << 16, first column)
     int ntilesWide;         // the first ntilesWide tiles have rows of more than 2560 columns (512-thread kernel)
@@ -326,29 +324,14 @@ void launch_elem_hessians(const DevMesh &M, int mat, double dtSq, const double *
 void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st, const int *blist = nullptr,
                      int nList = 0, const int *blk_ptr = nullptr, const int *blk_ent = nullptr, const double *mass = nullptr);
 void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st);
-void launch_clear_segments(const DevParts &P, const int4 *seg, int nseg, hipStream_t st);
-// Leaves of the dissection tree that have the same padded size are factorised together: one launch / one batched GEMM
-// per step of the dense recursion covers `n` leaves of every subdomain.  d[l] = displacement (in doubles) of leaf l's
-// diagonal block from the first leaf's inside a subdomain's dense block.
-constexpr int MAX_FUSED_LEAVES = 8;
-struct LeafOffs {
-    int n = 1;
-    long long d[MAX_FUSED_LEAVES] = {0, 0, 0, 0, 0, 0, 0, 0};
-};
-void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipStream_t st, const LeafOffs &LO = LeafOffs());
-void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, hipStream_t st,
-                             const LeafOffs &LO = LeafOffs());
 // one level of the tile schedule (tile_factor.hpp): one workgroup per task
 // fastDiag: the diagonal tasks' 16 x 16 bottom steps in the per-lane 8 x 8 form (kernels.hip, block_chol_inv<N, FAST>; 512 threads)
-void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, int threads = 256,
-                       bool fastDiag = false);
+void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, bool fastDiag = true);
 // the non-diagonal tasks of a level on half tiles, four workgroups per CU (tile_gemm_kernel)
 void launch_tile_gemm(const TileTask *tasks, int ntasks, const TileProd *prods, hipStream_t st);
 void launch_tile_flow(const TileTask *tasks, int ntasks, const TileProd *prods, const int *depPtr, const int *depIdx, int *done,
-                      int *next, int epoch, int *info, int nwg, hipStream_t st, int threads, double waitMs, bool fastDiag = false);
+                      int *next, int epoch, int *info, int nwg, hipStream_t st, double waitMs, bool fastDiag = true);
 void launch_clear_tiles(double *const *tiles, const int *lds_, int ntiles, hipStream_t st);
-void launch_block_copy(double *dst, int ldd, size_t sd, const double *src, int lds_, size_t ss, int rows,
-                       int cols, int batch, hipStream_t st, const LeafOffs &LO = LeafOffs());
 // small helpers
 void launch_init_x(int nV, const uint8_t *fixed, const double *v, double dt, const double *gdtsq,
                    double *x, hipStream_t st);

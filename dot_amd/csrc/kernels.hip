@@ -18,8 +18,8 @@
 //                             DOTTimeStepper.cpp:406-450 (subdomain back-solve, average by dup)
 //   loop_control_kernel       Optimizer.cpp:806-833 (line search), DOTTimeStepper.cpp:474-494 (history),
 //                             Optimizer.cpp:317-330 (stopping test) -- the host loop's control flow, on device
-//   chol_inv_base / chol_inv_node128 (+ rocBLAS dgemm from dotmi.hip)
-//                             CHOLMODSolver.cpp:143 factorize, as a block-sparse inverse-Cholesky
+//   tile_task / tile_flow / tile_gemm (schedule: tile_factor.hpp)
+//                             CHOLMODSolver.cpp:143 factorize, as a block-sparse inverse-Cholesky on 64 x 64 tiles
 //   spmv_dots / step_forward  Optimizer.cpp:1076-1093 (alpha_0), :1023-1042 (x = x0 + alpha p)
 //   elem_hessian_kernel       Energy.cpp:738-777, :1129-1270, IglUtils.hpp:466-479
 //   assemble_kernel           DOTTimeStepper.cpp:588-613, IglUtils.hpp:143-220
@@ -1493,9 +1493,8 @@ void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// dense inverse-Cholesky, base case: for one NB x NB diagonal block per wavefront compute
+// inverse-Cholesky of a diagonal tile, base case: for one NB x NB diagonal block per wavefront compute
 // L = chol(A_kk), X = L^-1 and store Q_kk = X^T (the inverse of the upper factor R_kk = L^T).
-// The off-diagonal work of the blocked recursion is FP64 GEMM (rocBLAS) -- chol_inv_node() in dotmi.hip.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double v, int srclane)
 {
@@ -1714,14 +1713,14 @@ __device__ __forceinline__ int wave_chol_inv16_lds(double (*G)[LD64], double (*X
 }
 
 // X = chol(A)^-1 of the N x N diagonal block at [b0, b0+N) of a 64 x 64 matrix held in LDS, by one workgroup
-// of 256 threads: the same 2 x 2 recursion as chol_inv_node(), continued inside LDS -- the 16 x 16 bottom
+// of 256 threads by a 2 x 2 recursion inside LDS -- the 16 x 16 bottom
 // steps run in the registers of wave 0 (wave_chol_inv), the products on the FP64 matrix cores (mfma_gemm_small).
 //   G: A on entry (row-major, symmetric), destroyed.   X: X(i,k) on exit, zero above the diagonal.
 //   T32 / T16: 32x33 and 16x17 scratch.   Returns 0 or 1 + index (relative to b0) of the first non-positive
 //   pivot (valid in wave 0).
 // FAST: the 16 x 16 bottom steps by wave_chol_inv16_lds (blocks factored per lane: 2.0 instead of 2.9 us, the whole 64 x 64
-// step 12.0 instead of 15.3 us, same register budget) -- the tile kernels' form; the 256-thread kernels of the recursive
-// (rocBLAS) mode keep the one-row-per-lane base
+// step 12.0 instead of 15.3 us, same register budget) -- the 512-thread tile kernels' form (DOTMI_FAST_DIAG=0 and the
+// 256-thread form keep the one-row-per-lane base)
 template <int N, bool FAST = false>
 __device__ __forceinline__ int block_chol_inv(double (*G)[LD64], double (*X)[LD64], int b0, double (*T32)[33],
                                               double (*T16)[17], int tid)
@@ -1774,172 +1773,9 @@ __device__ __forceinline__ int block_chol_inv(double (*G)[LD64], double (*X)[LD6
     }
 }
 
-// A 64 x 64 column-major block (leading dimension ld, 16-byte aligned) into the registers of a 256-thread workgroup:
-// eight independent 16-byte loads per thread, all in flight together (the element-by-element loop this replaces took
-// ~8 us per block: its loads were issued one iteration at a time).  blk64_to_lds stores element (k, j) to G[k][j].
-struct Blk64 {
-    double2 v[8];
-};
-__device__ __forceinline__ Blk64 blk64_load(const double *__restrict__ src, size_t ld, int tid)
-{
-    Blk64 b;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int idx2 = tid + 256 * u;          // 2048 pairs: column j = idx2 / 32, rows 2 k2, 2 k2 + 1
-        b.v[u] = *reinterpret_cast<const double2 *>(src + (size_t)(idx2 >> 5) * ld + 2 * (idx2 & 31));
-    }
-    return b;
-}
-__device__ __forceinline__ void blk64_to_lds(const Blk64 &b, double (*G)[CHOL_NB + 1], int tid)
-{
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int idx2 = tid + 256 * u, j = idx2 >> 5, k = 2 * (idx2 & 31);
-        G[k][j] = b.v[u].x;
-        G[k + 1][j] = b.v[u].y;
-    }
-}
-
-__global__ __launch_bounds__(256) void chol_inv_base_kernel(double *__restrict__ W, int nmax, int o,
-                                                            int *__restrict__ info, LeafOffs LO)
-{
-    W += LO.d[blockIdx.y];   // fused leaves: the same block of another leaf of the same size
-    constexpr int NB = CHOL_NB;
-    __shared__ double G[NB][LD64], X[NB][LD64], T32[32][33], T16[16][17];
-    double *Ws = W + (size_t)blockIdx.x * nmax * nmax + (size_t)o * nmax + o;
-    const int tid = threadIdx.x;
-    blk64_to_lds(blk64_load(Ws, nmax, tid), G, tid);   // A(i,j): column-major upper block, symmetric
-    __syncthreads();
-    const int bad = block_chol_inv<64>(G, X, 0, T32, T16, tid);
-    // store Q = X^T column-major, i.e. memory row i, position k <- X(i,k) (zero for k > i)
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int i = idx / NB, k = idx % NB;
-        Ws[(size_t)i * nmax + k] = X[i][k];
-    }
-    if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + bad);
-}
-
-void launch_chol_inv_base(double *W, int nmax, int count, int o, int *info, hipStream_t st, const LeafOffs &LO)
-{
-    hipLaunchKernelGGL(chol_inv_base_kernel, dim3(count, LO.n), dim3(256), 0, st, W, nmax, o, info, LO);
-}
-
-// 64 x 64 x 64 product on LDS operands with the FP64 matrix cores: store(i, j, sum_k A(i,k) B(k,j)).
-// Wave w owns rows [16w, 16w+16) (four 16 x 16 tiles).  v_mfma_f64_16x16x4_f64 operands: A(row = lane & 15,
-// k = lane >> 4), B(k = lane >> 4, col = lane & 15); results: col = lane & 15, row = (lane >> 4) + 4 * reg.
-// 80 LDS reads per lane instead of 512 for the 4 x 4 FMA tiling.
-template <class FA, class FB, class FS>
-__device__ __forceinline__ void mfma_gemm64(FA A, FB B, FS store, int tid)
-{
-    const int lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
-    mfma_v4d acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (mfma_v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int kk = 0; kk < 16; ++kk) {
-        const double a = A(16 * w + lr, 4 * kk + lk);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const double b = B(4 * kk + lk, 16 * t + lr);
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) store(16 * w + lk + 4 * r, 16 * t + lr, acc[t][r]);
-    __syncthreads();
-}
-
-// The whole 128 x 128 node of the recursion in one launch (one workgroup per subdomain, LDS resident):
-//   Q11 = R11^-1 ; R12 = Q11^T H12 ; H22 -= R12^T R12 ; Q22 = R22^-1 ; Q12 = -(Q11 R12) Q22 ; H21 = 0
-// The two 64 x 64 factor+invert steps are block_chol_inv<64>(); the four 64^3 products run on the FP64 matrix
-// cores from LDS (mfma_gemm64).  Replaces 2 base launches +
-// 4 tiny batched GEMMs + 2 block copies, whose launch latencies dominated the bottom of the recursion.
-#ifdef NODE128_PROFILE
-__device__ long long g_node128_prof[32];
-#define N128_MARK(i)                                                                      \
-    do {                                                                                  \
-        __syncthreads();                                                                  \
-        if (threadIdx.x == 0 && blockIdx.x == 0) g_node128_prof[i] = wall_clock64();      \
-    } while (0)
-#else
-#define N128_MARK(i)
-#endif
-__global__ __launch_bounds__(256) void chol_inv_node128_kernel(double *__restrict__ W, int nmax, int o,
-                                                               int *__restrict__ info, LeafOffs LO)
-{
-    W += LO.d[blockIdx.y];
-    constexpr int NB = CHOL_NB, LD = NB + 1;
-    __shared__ double X1[NB][LD];  // X11(i,k), later X22(i,k)
-    __shared__ double Bf[NB][LD];  // H12 -> R12 -> U -> Q12          (row index = first block index)
-    __shared__ double Gf[NB][LD];  // H11, then H22 -> H22 - R12^T R12
-    __shared__ double Tq[32][33], Tr[16][17];
-    double *Ws = W + (size_t)blockIdx.x * nmax * nmax;
-    const int tid = threadIdx.x;
-    N128_MARK(0);
-    // column-major element (r, c) of the block matrix lives at Ws[(size_t)c * nmax + r]
-    {
-        const Blk64 h11 = blk64_load(Ws + (size_t)o * nmax + o, nmax, tid);          // H11(k,j)
-        const Blk64 h12 = blk64_load(Ws + (size_t)(o + NB) * nmax + o, nmax, tid);   // H12(k,j)
-        blk64_to_lds(h11, Gf, tid);
-        blk64_to_lds(h12, Bf, tid);
-    }
-    // H22 is not needed before the first diagonal block is done: its loads stay in flight across that phase
-    const Blk64 h22 = blk64_load(Ws + (size_t)(o + NB) * nmax + o + NB, nmax, tid);
-    __syncthreads();
-    N128_MARK(1);
-    int bad = block_chol_inv<64>(Gf, X1, 0, Tq, Tr, tid);
-    N128_MARK(2);
-    if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + bad);
-    blk64_to_lds(h22, Gf, tid);                                   // H22(k,j)
-    __syncthreads();
-    N128_MARK(3);
-    // ---- R12(i,j) = sum_k X11(i,k) H12(k,j)
-    mfma_gemm64([&](int i, int k) { return X1[i][k]; }, [&](int k, int jj) { return Bf[k][jj]; },
-                [&](int i, int jj, double v) { Bf[i][jj] = v; }, tid);
-    // ---- H22(c,d) -= sum_k R12(k,c) R12(k,d)
-    mfma_gemm64([&](int c, int k) { return Bf[k][c]; }, [&](int k, int d) { return Bf[k][d]; },
-                [&](int c, int d, double v) { Gf[c][d] -= v; }, tid);
-    // ---- U(i,j) = sum_k Q11(i,k) R12(k,j) = sum_k X11(k,i) R12(k,j)
-    mfma_gemm64([&](int i, int k) { return X1[k][i]; }, [&](int k, int jj) { return Bf[k][jj]; },
-                [&](int i, int jj, double v) { Bf[i][jj] = v; }, tid);
-    N128_MARK(4);
-    // X11 is final: write it out and hand its LDS block to X22 (one 64x65 block less, 108 KB instead of 141 KB
-    // per workgroup, so a GEMM workgroup of another branch still fits next to this one on a CU)
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx / NB, c = idx % NB;
-        Ws[(size_t)(o + r) * nmax + o + c] = X1[r][c];               // Q11(c,r) = X11(r,c)
-        Ws[(size_t)(o + r) * nmax + o + NB + c] = 0.0;               // H21 block: strictly lower -> zero
-    }
-    __syncthreads();
-    N128_MARK(5);
-    // ---- X22 = chol(H22)^-1
-    bad = block_chol_inv<64>(Gf, X1, 0, Tq, Tr, tid);
-    N128_MARK(6);
-    if (tid == 0 && bad) atomicMax(info + blockIdx.x, o + NB + bad);
-    // ---- Q12(i,j) = -sum_c U(i,c) Q22(c,j) = -sum_c U(i,c) X22(j,c)
-    mfma_gemm64([&](int i, int c) { return Bf[i][c]; }, [&](int c, int jj) { return X1[jj][c]; },
-                [&](int i, int jj, double v) { Bf[i][jj] = -v; }, tid);
-    N128_MARK(7);
-    // ---- store: memory row (o+64+j) <- [Q12(:,j) | X22(j,:)]   (rows o+i were written above)
-    for (int idx = tid; idx < NB * NB; idx += 256) {
-        const int r = idx / NB, c = idx % NB;
-        Ws[(size_t)(o + NB + r) * nmax + o + c] = Bf[c][r];          // Q12(c,r)
-        Ws[(size_t)(o + NB + r) * nmax + o + NB + c] = X1[r][c];     // Q22(c,r) = X22(r,c)
-    }
-    N128_MARK(8);
-}
-
-void launch_chol_inv_node128(double *W, int nmax, int count, int o, int *info, hipStream_t st, const LeafOffs &LO)
-{
-    hipLaunchKernelGGL(chol_inv_node128_kernel, dim3(count, LO.n), dim3(256), 0, st, W, nmax, o, info, LO);
-}
-
 // ------------------------------------------------------------------------------------------------
 // Tile-level inverse-Cholesky (tile_factor.hpp): one workgroup = one tile task, one launch = one level of the
-// static schedule.  64 x 64 tiles, products on v_mfma_f64_16x16x4_f64 from LDS (layout of mfma_gemm64), the next
+// static schedule.  64 x 64 tiles, products on v_mfma_f64_16x16x4_f64 from LDS, the next
 // product's two tiles in flight (global -> registers) while the current one is multiplied; the accumulator tile
 // stays in registers over the whole product list.  Product forms: TF_FACT  C -= A^T B ;  TF_INV  C += A B.
 // ------------------------------------------------------------------------------------------------
@@ -2418,27 +2254,18 @@ __global__ __launch_bounds__(256, 4) void tile_gemm_kernel(const TileTask *__res
     }
 }
 
-void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, int threads,
-                       bool fastDiag)
+void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, bool fastDiag)
 {
     if (ntasks <= 0) return;
-    if (threads == 512 && fastDiag)
-        hipLaunchKernelGGL((tile_task_kernel<512, true>), dim3(ntasks), dim3(512), 0, st, tasks, prods, info);
-    else if (threads == 512) hipLaunchKernelGGL((tile_task_kernel<512, false>), dim3(ntasks), dim3(512), 0, st, tasks, prods, info);
-    else hipLaunchKernelGGL((tile_task_kernel<256, false>), dim3(ntasks), dim3(256), 0, st, tasks, prods, info);
+    if (fastDiag) hipLaunchKernelGGL((tile_task_kernel<512, true>), dim3(ntasks), dim3(512), 0, st, tasks, prods, info);
+    else hipLaunchKernelGGL((tile_task_kernel<512, false>), dim3(ntasks), dim3(512), 0, st, tasks, prods, info);
 }
 void launch_tile_flow(const TileTask *tasks, int ntasks, const TileProd *prods, const int *depPtr, const int *depIdx, int *done,
-                      int *next, int epoch, int *info, int nwg, hipStream_t st, int threads, double waitMs, bool fastDiag)
+                      int *next, int epoch, int *info, int nwg, hipStream_t st, double waitMs, bool fastDiag)
 {
     if (ntasks <= 0) return;
     const int grid = std::min(ntasks, nwg);
     const long long waitTicks = (long long)(waitMs * 1e5);
-    // always the 512-thread form (see the static_assert in the kernel); DOTMI_TILE_THREADS only selects the level kernel's form
-    if (threads != 512) {
-        static bool said = false;
-        if (!said) fprintf(stderr, "dotmi: DOTMI_TILE_THREADS=%d does not apply to the dataflow factorisation (512 threads)\n", threads);
-        said = true;
-    }
     if (fastDiag)
         hipLaunchKernelGGL((tile_flow_kernel<512, true>), dim3(grid), dim3(512), 0, st, tasks, prods, ntasks, depPtr, depIdx, done,
                            next, epoch, waitTicks, info);
@@ -2464,31 +2291,6 @@ __global__ __launch_bounds__(256) void clear_tiles_kernel(double *const *__restr
 void launch_clear_tiles(double *const *tiles, const int *lds_, int ntiles, hipStream_t st)
 {
     if (ntiles > 0) hipLaunchKernelGGL(clear_tiles_kernel, dim3(ntiles), dim3(256), 0, st, tiles, lds_);
-}
-
-// dst block <- src block (column-major blocks inside strided batches); zero when src == nullptr
-__global__ __launch_bounds__(256) void block_copy_kernel(double *__restrict__ dst, int ldd, size_t sd,
-                                                         const double *__restrict__ src, int lds_, size_t ss,
-                                                         int rows, int cols, int batch, LeafOffs LO)
-{
-    const int b = blockIdx.z % batch;
-    dst += LO.d[blockIdx.z / batch];   // fused leaves (only used for clearing: src == nullptr then)
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int j0 = blockIdx.y * 16 + (threadIdx.x >> 6) * 4;
-    if (i >= rows) return;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int j = j0 + u;
-        if (j < cols) dst[sd * b + (size_t)j * ldd + i] = src ? src[ss * b + (size_t)j * lds_ + i] : 0.0;
-    }
-}
-
-void launch_block_copy(double *dst, int ldd, size_t sd, const double *src, int lds_, size_t ss, int rows,
-                       int cols, int batch, hipStream_t st, const LeafOffs &LO)
-{
-    if (rows <= 0 || cols <= 0 || batch <= 0) return;
-    hipLaunchKernelGGL(block_copy_kernel, dim3((rows + 63) / 64, (cols + 15) / 16, batch * LO.n), dim3(256), 0, st,
-                       dst, ldd, sd, src, lds_, ss, rows, cols, batch, LO);
 }
 
 // z_v = (sum over parts containing v of p_s[local v]) / dup_v ; partial dots c_i = y_i . z
@@ -3830,22 +3632,6 @@ __global__ void pad_identity_kernel(int npad, const long long *__restrict__ dst,
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t < npad) W[dst[t]] = 1.0;
-}
-
-// clear row segments (memory row, first column, columns) of every owned dense block: one launch for all the
-// blocks a factorisation leaves non-zero
-__global__ __launch_bounds__(256) void clear_segments_kernel(const int4 *__restrict__ seg, int nmax,
-                                                             double *__restrict__ W)
-{
-    const int4 sg = seg[blockIdx.x];
-    double *row = W + (size_t)blockIdx.y * nmax * nmax + (size_t)sg.x * nmax + sg.y;
-    for (int c = threadIdx.x; c < sg.z; c += 256) row[c] = 0.0;
-}
-
-void launch_clear_segments(const DevParts &P, const int4 *seg, int nseg, hipStream_t st)
-{
-    if (nseg > 0 && P.nParts > 0)
-        hipLaunchKernelGGL(clear_segments_kernel, dim3(nseg, P.nParts), dim3(256), 0, st, seg, P.nmax, P.W);
 }
 
 void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st)

@@ -40,26 +40,6 @@ def test_compact_factor_storage_is_close_to_the_structural_nonzeros():
     ts.close()
 
 
-@pytest.mark.parametrize("name,steps", [("bunny5K_LTSS", 3), ("bar17K_twist", 2)])
-def test_recursive_rocblas_factorisation_still_matches(name, steps):
-    """DOTMI_TILE_FACTOR=0 keeps the round-2 formulation (recursive inverse-Cholesky on rocBLAS batched GEMM, dense
-    nmax x nmax blocks): same iterations as the oracle, positions to 1e-9 -- and therefore as the tile tasks."""
-    os.environ["DOTMI_TILE_FACTOR"] = "0"
-    try:
-        sc, ep, n, ts, orc = _pair(name)
-    finally:
-        del os.environ["DOTMI_TILE_FACTOR"]
-    assert dl.load().dotmi_factor_storage_bytes(ts._h) == 8 * n * dl.load().dotmi_padded_size(ts._h) ** 2
-    for _ in range(steps):
-        idx, pos = sc.scripter.step(ts.getResult(), sc.cfg.dt)
-        ts.setDirichlet(idx, pos)
-        orc.move(idx, pos)
-        st, so = ts.step(), orc.step()
-        assert (st.status, st.iters, st.ls_halvings) == (so.status, so.iters, so.ls_halvings)
-    assert np.abs(ts.getResult() - orc.state()[0]).max() < 1e-9
-    ts.close(); orc.close()
-
-
 def test_synthetic_bar_of_4M_tets_steps_on_one_gpu():
     """a synthetic bar of more than 4 M tets (224 x 56 x 56 cubes, 1024 subdomains) on ONE MI355X.
     Size-independent properties: the step converges to the reference's tolerance, the energy of the iterates never
@@ -100,13 +80,13 @@ def test_bench_kernel_entry_covers_every_kernel_class():
     ts.close()
 
 
-@pytest.mark.parametrize("env", [{"DOTMI_PATCH_ELEMS": "512"}, {"DOTMI_TILE_THREADS": "256"},
+@pytest.mark.parametrize("env", [{"DOTMI_PATCH_ELEMS": "512"}, {"DOTMI_TILE_EAGER_MIN_RMUL": "-1"}, {"DOTMI_TILE_EAGER_MIN_RMUL": "0"},
                                  {"DOTMI_TILE_EAGER_MIN": "1000"}, {"DOTMI_TILE_EAGER_MIN": "1", "DOTMI_TILE_EAGER_CHUNK": "1"},
-                                 {"DOTMI_TILE_XCD_ORDER": "0", "DOTMI_TILE_ROWS_LONG": "16"}, {"DOTMI_EARLY_BACKSOLVE": "0"},
+                                 {"DOTMI_TILE_ROWS_LONG": "16"}, {"DOTMI_TILE_SPLIT": "1"}, {"DOTMI_EARLY_BACKSOLVE": "0"},
                                  {"DOTMI_EARLY_BACKSOLVE": "2"}, {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_FUSE_STEP": "0"},
                                  {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_FUSE_DIR": "0"},
                                  {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_EARLY_ABORT": "0"},
-                                 {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_EARLY_HOST_CTL": "0"}])
+                                 {"DOTMI_ND_LEVELS": "3"}])
 def test_tuning_switches_do_not_change_results(env):
     """Every tuning variable of DESIGN.md section 10 that selects another variant of a round-3 kernel / schedule: same
     iterations as the oracle, positions to 1e-9 (horse7K: FCR with SVD in the element pass, 8 subdomains, back-tracking)."""

@@ -274,20 +274,19 @@ def test_in_loop_kernel_forms_are_priced_on_the_live_state_without_disturbing_it
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("pack", ["1", "0"])
-def test_owner_exchange_survives_a_change_of_the_fixed_set_and_a_restart(pack):
+def test_owner_exchange_survives_a_change_of_the_fixed_set_and_a_restart():
     """DOTMI_FLAG_OWNER_EXCHANGE on the 1-rank communicator (FORCE_DIST; no vertex is shared, so the packets are their tails):
     dotmi_refix (rubberBandPull's release, DOTTimeStepper.cpp:185-270) and dotmi_set_state + refactor (the `restart` path,
     Optimizer.cpp:1096-1177) rebuild the preconditioner through the owner's partial operator as well -- same iterations and
-    positions as the plain single-GPU handle, with the dot products in the packets (pack = 1) and as collectives (0)."""
+    positions as the plain single-GPU handle (the dot products ride in the packets)."""
     V, T = scene.synthetic_bar(8, 3, 3)
     cfg = scene.Config(energy="FCR", script="stretch", dt=0.025, rho=1000.0, YM=1e5, PR=0.4, handle_ratio=0.01)
     runs = []
     for flags in (0, dl.FLAG_FORCE_DIST | dl.FLAG_OWNER_EXCHANGE):
         sc = scene.build_scene(cfg, V, T)
         ep = scene.partition_rcb(sc.V_rest, sc.T, 4)
-        old = {k: os.environ.get(k) for k in ("DOTMI_OWNER_PACK", "DOTMI_SHARD_ELEMS")}
-        os.environ.update({"DOTMI_OWNER_PACK": pack, "DOTMI_SHARD_ELEMS": "1"})
+        old = {k: os.environ.get(k) for k in ("DOTMI_SHARD_ELEMS",)}
+        os.environ.update({"DOTMI_SHARD_ELEMS": "1"})
         try:
             ts = DOTTimeStepper(sc, ep, 4, flags=flags)
         finally:

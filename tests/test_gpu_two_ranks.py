@@ -19,8 +19,6 @@ def _worker(rank, world, initfile, outdir, workload, shard_elems, steps):
     sys.path.insert(0, ROOT)
     owner = shard_elems.startswith("owner")   # DOTMI_FLAG_OWNER_EXCHANGE: interface-only exchange, owner-summed dot products
     if owner:
-        # "owner": the dot products ride in the vector packets (default); "owner5": as scalar collectives of their own
-        os.environ["DOTMI_OWNER_PACK"] = "0" if shard_elems == "owner5" else "1"
         shard_elems = "1"
     os.environ["DOTMI_SHARD_ELEMS"] = shard_elems
     os.environ["OMP_NUM_THREADS"] = "2"
@@ -66,12 +64,11 @@ def _worker(rank, world, initfile, outdir, workload, shard_elems, steps):
 # one device).
 # "owner" (round 4): DOTMI_FLAG_OWNER_EXCHANGE -- the loop's vector collectives carry only the entries of vertices held by
 # more than one rank, the dot products travel inside those packets (taken before the exchange where they are linear in the
-# exchanged vector; "owner5": as owner-summed scalar collectives of their own), the positions are made whole once per step.
+# exchanged vector), the positions are made whole once per step.
 CASES = [("bunny5K_LTSS", 4, "0", 2), ("bunny5K_LTSS", 4, "1", 2), ("horse7K_stretch", 4, "0", 2),
          ("horse7K_stretch", 4, "1", 2), ("monkey18K_stiff", 1, "0", 2), ("synbar:40x10x10:32", 2, "1", 4),
          ("bunny5K_LTSS", 4, "owner", 2), ("horse7K_stretch", 4, "owner", 2), ("bar17K_twist", 2, "owner", 4),
-         ("synbar:40x10x10:32", 2, "owner", 4), ("monkey18K_stiff", 1, "owner", 3), ("bunny5K_LTSS", 4, "owner5", 2),
-         ("monkey18K_stiff", 1, "owner5", 2)]
+         ("synbar:40x10x10:32", 2, "owner", 4), ("monkey18K_stiff", 1, "owner", 3)]
 
 
 @pytest.mark.parametrize("workload,steps,shard_elems,world", CASES)
@@ -102,8 +99,7 @@ def test_ranks_on_one_gpu_reproduce_the_single_gpu_run(workload, steps, shard_el
     # the loop runs on the device; replicated element pass: ONE collective per slot (+ the end-of-batch agreement);
     # sharded element pass: z + alpha_0 scalars + staged [g ; 0 ; E] per slot
     # owner exchange: packed [z ; y_i.z] + two scalars + packed [g ; E ; statistics] per slot, the positions once per step
-    # (owner5: packed z + five scalars + two scalars + packed [g ; E] + 21 scalars)
-    per_iter = {"0": 1, "1": 3, "owner": 3, "owner5": 5}[shard_elems]
+    per_iter = {"0": 1, "1": 3, "owner": 3}[shard_elems]
     assert all(int(R[r]["calls"]) == int(R[0]["calls"]) for r in range(world))
     assert int(R[0]["calls"]) >= per_iter * int(R[0]["its"].sum())
     if shard_elems.startswith("owner"):
