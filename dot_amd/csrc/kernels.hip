@@ -2579,7 +2579,7 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
 
 // ---- owner exchange (DOTMI_FLAG_OWNER_EXCHANGE): only the entries of vertices held by more than one rank travel ----------------
 // red0 / red1: up to two partial arrays whose rows workgroup 0 sums into the packet's tail on the way (the energy's two columns
-// combined, the statistics' columns) -- the same single-wave sums as dotmi.hip's reduce_rows_kernel, without launches of their own
+// combined, the statistics' columns) -- the same single-wave sums as dotmi_collectives.hip's reduce_rows_kernel, without launches of their own
 __device__ __forceinline__ void pack_reduce_rows(const PackRed &r, double *__restrict__ pack)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

@@ -4,7 +4,7 @@ Subdomains are the unit: rank r owns a contiguous group of parts, the elements o
 (energy / gradient contributions), the dense factors of those parts (back-solve), and a contiguous
 vertex slice (inertia terms, rows of the global SpMV).  Vectors are replicated; the only exchange
 steps are sum-all-reduces of p, of [g ; E] and of the two scalars of alpha_0.
-This module is the Python mirror of dotmi_plan_shards (dot_amd/csrc/dotmi.hip) plus the index sets
+This module is the Python mirror of dotmi_plan_shards (dot_amd/csrc/dotmi_create.hip) plus the index sets
 that follow from it; tests check the two agree."""
 from __future__ import annotations
 
