@@ -475,6 +475,25 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = dalloc(h, &P.tdots, (size_t)std::max(P.nltiles, 1) * P.maxChunks * 64)) return rc;
     HIPCHECK(h, hipMemset(P.tdots, 0, sizeof(double) * (size_t)std::max(P.nltiles, 1) * P.maxChunks * 64));
     if (int rc = upload(h, &P.trange, trange)) return rc;
+    {
+        // reduce_partial_p: the tiles of a part that hold a group of 16 columns, ascending (a tile's range starts on a multiple of 16)
+        const int ng = P.nmax / 16;
+        std::vector<int> rptr((size_t)std::max(P.nParts, 1) * (ng + 1) , 0), ridx;
+        for (int ls = 0; ls < P.nParts; ++ls) {
+            std::vector<std::vector<int>> lists(ng);
+            for (size_t b = 0; b < ranges[ls].size(); ++b)
+                for (int g = ranges[ls][b].x / 16; g <= (ranges[ls][b].y - 1) / 16 && g < ng; ++g)
+                    lists[g].push_back((int)b | (std::min(16, ranges[ls][b].y - 16 * g) << 24));   // tile | columns of the group it holds
+            for (int g = 0; g < ng; ++g) {
+                rptr[(size_t)ls * (ng + 1) + g] = (int)ridx.size();
+                ridx.insert(ridx.end(), lists[g].begin(), lists[g].end());
+            }
+            rptr[(size_t)ls * (ng + 1) + ng] = (int)ridx.size();
+        }
+        if (ridx.empty()) ridx.push_back(0);
+        if (int rc = upload(h, &P.rp_ptr, rptr)) return rc;
+        if (int rc = upload(h, &P.rp_idx, ridx)) return rc;
+    }
     if (int rc = upload(h, &P.vp_ptr, vp_ptr)) return rc;
     if (int rc = upload(h, &P.vp_off, vp_off)) return rc;
     {

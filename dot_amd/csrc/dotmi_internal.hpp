@@ -84,6 +84,7 @@ struct DevParts {
     int2 *lworkByPart;
     int nbmax;              // max row tiles per part
     int2 *trange;           // owned * nbmax: columns [first, end) each tile of a part contributes to
+    int *rp_ptr, *rp_idx;   // reduce_partial_p: per part and group of 16 columns (CSR, owned * (nmax / 16 + 1)) the tiles that hold it, ascending
     double *ppart;          // owned * nbmax * nmax partial results of the back-solve tiles
     double *psub;           // owned * nmax per-part results (padded positions)
     double *rpad;           // owned * nmax right-hand sides in padded order (zeros on the padding): what the back-solve

@@ -1237,8 +1237,12 @@ extern "C" int dotmi_debug_bs_prof(long long *out, int n)
 __device__ const double g_zero_slot = 0.0;
 
 // psub_s[k] = sum over the row tiles b of the part whose column range holds k of ppart[s][b][k]
-//   (fixed order, coalesced in k)
-__global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int2 *__restrict__ trange,
+//   (fixed order b = 0, 1, ..., coalesced in k)
+// Round 5: the tiles that can hold a column are LISTED per group of 16 columns (rp_ptr / rp_idx, ascending b; a tile's range
+// starts on a multiple of 16, so a listed tile holds the first entry >> 24 columns of the group) instead of testing all
+// nbmax tiles of the part for every column -- with three dissection levels a part has ~80 tiles of which ~17 hold a given
+// column (1 M tets: 44.4 -> 17.7 us per launch, bunny5K 8 -> 6.6; profiles/r05_factor.txt E).  Same additions, same order.
+__global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int *__restrict__ rp_ptr, const int *__restrict__ rp_idx,
                                                                const double *__restrict__ ppart, int nmax,
                                                                int nbmax, double *__restrict__ psub,
                                                                const DevLoop *__restrict__ ctl, int s0)
@@ -1247,37 +1251,41 @@ __global__ __launch_bounds__(256) void reduce_partial_p_kernel(const int2 *__res
     const int s = blockIdx.y + s0;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= nmax) return;
-    const int2 *tr = trange + (size_t)s * nbmax;
     const double *base = ppart + (size_t)s * nbmax * nmax + k;
-    // tiles that do not hold column k read a zero instead (select on the address, not a branch around the load),
-    // so the loads of a group of tiles are all in flight together; the order of the sum stays b = 0, 1, ...
+    const int ng = nmax >> 4;
+    const int *pp = rp_ptr + (size_t)s * (ng + 1) + (k >> 4);
+    const int e0 = pp[0], e1 = pp[1];
+    // a listed tile that ends in front of column k reads a zero instead (select on the address, not a branch around the
+    // load), so the loads of a batch are all in flight together
     double acc = 0.0;
-    int b = 0;
-    for (; b + 16 <= nbmax; b += 16) {
-        double v[16];
+    int e = e0;
+    for (; e + 8 <= e1; e += 8) {
+        int bb[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int2 cr = tr[b + u];
-            const double *src = (k >= cr.x && k < cr.y) ? base + (size_t)(b + u) * nmax : &g_zero_slot;
+        for (int u = 0; u < 8; ++u) bb[u] = rp_idx[e + u];
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            // entry = tile | (columns of the group the tile holds, 1 .. 16) << 24
+            const double *src = (k & 15) < (bb[u] >> 24) ? base + (size_t)(bb[u] & 0xffffff) * nmax : &g_zero_slot;
             v[u] = *src;
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc += v[u];
+        for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; b + 4 <= nbmax; b += 4) {
-        double v[4];
+    {
+        int bb[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int2 cr = tr[b + u];
-            const double *src = (k >= cr.x && k < cr.y) ? base + (size_t)(b + u) * nmax : &g_zero_slot;
+        for (int u = 0; u < 8; ++u) bb[u] = (e + u < e1) ? rp_idx[e + u] : 0;
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double *src = (k & 15) < (bb[u] >> 24) ? base + (size_t)(bb[u] & 0xffffff) * nmax : &g_zero_slot;
             v[u] = *src;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc += v[u];
-    }
-    for (; b < nbmax; ++b) {
-        const int2 cr = tr[b];
-        if (k >= cr.x && k < cr.y) acc += base[(size_t)b * nmax];
+        for (int u = 0; u < 8; ++u)
+            if (e + u < e1) acc += v[u];
     }
     psub[(size_t)s * nmax + k] = acc;
 }
@@ -1452,8 +1460,8 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
 void launch_reduce_partial(const DevParts &P, hipStream_t st, const DevLoop *ctl)
 {
     if (P.nParts > 0)
-        hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.trange, P.ppart,
-                           P.nmax, P.nbmax, P.psub, ctl, 0);
+        hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, P.nParts), dim3(256), 0, st, P.rp_ptr, P.rp_idx,
+                           P.ppart, P.nmax, P.nbmax, P.psub, ctl, 0);
 }
 
 // p[dofmap_s[k]] = psub_s[k] on the live positions of part s (p was cleared by the caller)
@@ -1487,8 +1495,8 @@ void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, con
         hipLaunchKernelGGL((backsolve_long_kernel<1>), dim3(nlwork), dim3(BSL_THREADS), 0, st, P.ltileByPart, lwork, P.dofmap,
                            P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, (const DevLoop *)nullptr, 0);
     }
-    hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, 1), dim3(256), 0, st, P.trange, P.ppart, P.nmax,
-                       P.nbmax, P.psub, (const DevLoop *)nullptr, ls);
+    hipLaunchKernelGGL(reduce_partial_p_kernel, dim3((P.nmax + 255) / 256, 1), dim3(256), 0, st, P.rp_ptr, P.rp_idx, P.ppart,
+                       P.nmax, P.nbmax, P.psub, (const DevLoop *)nullptr, ls);
     hipLaunchKernelGGL(fill_part_kernel, dim3((P.nmax + 255) / 256), dim3(256), 0, st, P.dofmap, P.psub, P.nmax, ls, p);
 }
 

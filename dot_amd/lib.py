@@ -96,8 +96,9 @@ def load() -> C.CDLL:
     L.dotmi_last_error.argtypes = [H]
     L.dotmi_last_error.restype = C.c_char_p
     L.dotmi_comm_unique_id.argtypes = [C.c_void_p]
-    L.dotmi_comm_ranks.argtypes = [H]
-    L.dotmi_comm_ranks.restype = C.c_int32
+    if hasattr(L, "dotmi_comm_ranks"):     # (a DOTMI_LIBRARY build from before round 5 lacks the two measurement entries)
+        L.dotmi_comm_ranks.argtypes = [H]
+        L.dotmi_comm_ranks.restype = C.c_int32
     L.dotmi_set_state.argtypes = [H, c_dp, c_dp, c_dp]
     L.dotmi_get_state.argtypes = [H, c_dp, c_dp, c_dp]
     L.dotmi_set_dirichlet.argtypes = [H, C.c_int32, c_ip, c_dp]
@@ -121,8 +122,9 @@ def load() -> C.CDLL:
     L.dotmi_probe_direction.argtypes = [H, c_dp, C.c_int32, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp]
     L.dotmi_factor_storage_bytes.argtypes = [H]
     L.dotmi_factor_storage_bytes.restype = C.c_int64
-    L.dotmi_factor_kind.argtypes = [H]
-    L.dotmi_factor_kind.restype = C.c_int32
+    if hasattr(L, "dotmi_factor_kind"):
+        L.dotmi_factor_kind.argtypes = [H]
+        L.dotmi_factor_kind.restype = C.c_int32
     L.dotmi_bench_precond.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]
     L.dotmi_bench_energy.argtypes = [H, C.c_int32, c_dp, C.POINTER(C.c_int64)]
     L.dotmi_bench_kernel.argtypes = [H, C.c_int32, C.c_int32, c_dp, C.POINTER(C.c_int64)]
@@ -133,7 +135,9 @@ def load() -> C.CDLL:
     L.dotmi_plan_layout.argtypes = [C.c_int32, C.c_int32, c_ip, c_dp, c_ip, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, c_ip, c_ip, c_ip, c_ip]
     for name in EXPORTS:
-        fn = getattr(L, name)
+        fn = getattr(L, name, None)
+        if fn is None:
+            continue
         if fn.restype is C.c_int or name in ("dotmi_create",):
             fn.restype = C.c_int
     _lib = L
