@@ -233,16 +233,18 @@ int build_device_mesh(dotmi_handle *h)
     P.nParts = h->p1 - h->p0;
     // ---- nested-dissection layout of the owned subdomains ---------------------------------------
     int ndLevels = h->tune.ndLevels;
-    const int ndMin = h->tune.ndMin;
+    int ndMin = h->tune.ndMin;
     std::vector<std::vector<std::vector<int>>> region;  // [node][owned part] -> vertices of the leaf / separator
     {
         std::vector<std::vector<int>> sets(P.nParts);
         for (int ls = 0; ls < P.nParts; ++ls) sets[ls] = h->partVerts[h->p0 + ls];
-        if (ndLevels < 0) {   // from the sizes of ALL subdomains of the mesh: the same tree on every rank
-            int nsAll = 0;
-            for (const auto &pv : h->partVerts) nsAll = std::max(nsAll, 3 * (int)pv.size());
-            ndLevels = nd_default_levels(nsAll, (int)h->partVerts.size());
+        if (ndLevels < 0 && !getenv("DOTMI_ND_MIN")) {
+            // depth and split threshold from ALL subdomains of the mesh: the same tree on every rank (nd_layout.hpp)
+            nd_choose_depth(h->partVerts, nV, adj_ptr, adj_idx, h->Xrest.data(), BS_NARROW, ndMin, ndLevels, ndMin);
+        } else if (ndLevels < 0) {
+            ndLevels = nd_default_levels(h->partVerts);
         }
+        if (h->tune.fuseLog) fprintf(stderr, "dotmi: dissection: %d levels, regions split down to %d scalars\n", ndLevels, ndMin);
         nd_plan(sets, nV, adj_ptr, adj_idx, h->Xrest.data(), ndLevels, ndMin, h->nd, region);
     }
     P.nmax = h->nd[0].size;
@@ -363,11 +365,11 @@ int build_device_mesh(dotmi_handle *h)
         }
         tiles.swap(shortTiles);
     }
-    // tiles whose rows need the 512-thread variant (more than 2560 columns) first: when both kinds exist they are
+    // tiles whose rows need the 512-thread variant (more than BS_NARROW columns) first: when both kinds exist they are
     // launched separately, so that the short ones run on the 256-thread kernel (two workgroups per CU instead of one)
-    std::stable_partition(tiles.begin(), tiles.end(), [](const int4 &t) { return t.y + (t.z >> 16) - t.w > 2560; });
+    std::stable_partition(tiles.begin(), tiles.end(), [](const int4 &t) { return t.y + (t.z >> 16) - t.w > BS_NARROW; });
     P.ntilesWide = 0;
-    for (const int4 &t : tiles) P.ntilesWide += (t.y + (t.z >> 16) - t.w > 2560);
+    for (const int4 &t : tiles) P.ntilesWide += (t.y + (t.z >> 16) - t.w > BS_NARROW);
     P.ntiles = (int)tiles.size();
     P.nltiles = (int)ltiles.size();
     P.nlwork = (int)lwork.size();
@@ -1010,21 +1012,20 @@ int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xr
     }
     std::vector<NdNode> tree;
     std::vector<std::vector<std::vector<int>>> region;
-    int levelsDefault = 2;
-    if (levels < 0) {   // dotmi_create's rule: from the sizes of ALL subdomains of the mesh
-        std::vector<int> cnt(nParts, 0), mark(nV, -1);
-        for (int pI = 0; pI < nParts; ++pI)
-            for (int e = 0; e < nT; ++e)
-                if (epart[e] == pI)
-                    for (int k = 0; k < 4; ++k)
-                        if (mark[T[4 * e + k]] != pI) {
-                            mark[T[4 * e + k]] = pI;
-                            cnt[pI] += 3;
-                        }
-        levelsDefault = nd_default_levels(*std::max_element(cnt.begin(), cnt.end()), nParts);
+    // dotmi_create's rule: depth (and, with it, the split threshold) from ALL subdomains of the mesh
+    int levelsUse = levels, minUse = min_split < 128 ? ND_MIN_SPLIT : min_split;
+    if (levels < 0) {
+        std::vector<std::vector<int>> allSets(nParts);
+        for (int e = 0; e < nT; ++e)
+            for (int k = 0; k < 4; ++k) allSets[epart[e]].push_back(T[4 * e + k]);
+        for (auto &v : allSets) {
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+        }
+        if (min_split < 128) nd_choose_depth(allSets, nV, adj_ptr, adj_idx, Xrest, BS_NARROW, ND_MIN_SPLIT, levelsUse, minUse);
+        else levelsUse = nd_default_levels(allSets);
     }
-    *nmax = nd_plan(sets, nV, adj_ptr, adj_idx, Xrest, levels < 0 ? levelsDefault : levels,
-                    min_split < 128 ? ND_MIN_SPLIT : min_split, tree, region);
+    *nmax = nd_plan(sets, nV, adj_ptr, adj_idx, Xrest, levelsUse, minUse, tree, region);
     *n_nodes = (int32_t)tree.size();
     if (nodes) {
         if ((int)tree.size() > node_cap) return DOTMI_E_INVALID;

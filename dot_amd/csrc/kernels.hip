@@ -990,13 +990,16 @@ typedef double nt_double2 __attribute__((ext_vector_type(2)));
 // (the leaves of the dissection) take many rows per pass, long rows few, so that every pass has about
 // the same number of bytes in flight: the pass count of a tile -- a chain of HBM latency, butterfly
 // and LDS exchange -- is what bounds a tile, not its byte count.
-template <int THREADS, int MAXCH, int SUB>
+// RLDS (round 5, rows of 2561 .. 3072 columns on the 256-thread kernel): the thread's right-hand side entries live in LDS
+// (rs: each thread reads back only what it wrote -- a manual spill of 24 registers) so that six chunks of rows fit the
+// register tile at two workgroups per CU; the dot products keep their order of additions (chunk after chunk).
+template <int THREADS, int MAXCH, int SUB, bool RLDS = false>
 __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restrict__ dofmap,
                                                const double *__restrict__ W, int nmax, const RowTile *__restrict__ rt,
                                                const double *__restrict__ q, double *__restrict__ ppart,
                                                int nbmax, double (*sm)[THREADS / 64][32],
                                                const int *__restrict__ abortp = nullptr, int epoch = 0,
-                                               int *s_abort = nullptr)
+                                               int *s_abort = nullptr, double2 *__restrict__ rs = nullptr)
 {
     constexpr int NW = THREADS / 64;
     const int s = jb.x, i0 = jb.y, tileIdx = jb.z & 0xffff, cb = jb.w;
@@ -1012,15 +1015,21 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
     const double *Ws = W + (rb.off - (long long)(i0 & ~63) * ldw - rb.c0);
     const int *dm = dofmap + (size_t)s * nmax;
     const double *rp = q + (size_t)s * nmax;   // right-hand side in padded order (zeros on the padding)
-    double2 r[MAXCH], pacc[MAXCH];
+    double2 r[RLDS ? 1 : MAXCH], pacc[RLDS ? 1 : MAXCH];   // (RLDS: both in LDS, rs[.] and rs[THREADS * MAXCH + .])
     int cend[MAXCH];  // first column this thread's pair of chunk m is NOT loaded for: 0 for identity-padding columns
 #pragma unroll
     for (int m = 0; m < MAXCH; ++m) {
         const int c = cb + 2 * tid + 2 * THREADS * m;
         const int2 dd = (c < ncol) ? *reinterpret_cast<const int2 *>(dm + c) : make_int2(-1, -1);
         const int d0 = dd.x, d1 = dd.y;
-        r[m] = (c < ncol) ? *reinterpret_cast<const double2 *>(rp + c) : make_double2(0.0, 0.0);
-        pacc[m] = make_double2(0.0, 0.0);
+        const double2 rv = (c < ncol) ? *reinterpret_cast<const double2 *>(rp + c) : make_double2(0.0, 0.0);
+        if constexpr (RLDS) {
+            rs[tid + THREADS * m] = rv;
+            rs[THREADS * MAXCH + tid + THREADS * m] = make_double2(0.0, 0.0);
+        } else {
+            r[m] = rv;
+            pacc[m] = make_double2(0.0, 0.0);
+        }
         // padding columns of live rows hold zeros (separator rows span the padding of every region): not read
         cend[m] = (d0 >= 0 || d1 >= 0) ? c : 0x7fffffff;
     }
@@ -1058,12 +1067,23 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
 #pragma unroll
         for (int g = 0; g < SUB / 8; ++g) {
             double d[8];
+            if constexpr (RLDS) {
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) d[rr] = 0.0;
+#pragma unroll
+                for (int m = 0; m < MAXCH; ++m) {
+                    const double2 rv = rs[tid + THREADS * m];
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) d[rr] += y[8 * g + rr][m].x * rv.x + y[8 * g + rr][m].y * rv.y;
+                }
+            } else {
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
                 double acc = 0.0;
 #pragma unroll
                 for (int m = 0; m < MAXCH; ++m) acc += y[8 * g + rr][m].x * r[m].x + y[8 * g + rr][m].y * r[m].y;
                 d[rr] = acc;
+            }
             }
             // transposed butterfly: 8 values over 64 lanes -> lane group lane>>3 holds one row's wave sum
             double e4[4], e2[2], e1;
@@ -1097,6 +1117,27 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
         if (abortp && tid == 0) s_abort[sb & 1] = abortSeen;
         __syncthreads();
         if (abortp && s_abort[sb & 1] == epoch) return;   // the result would not be used
+        if constexpr (RLDS) {
+            // the same additions in the same order (row after row into each accumulator), the accumulators through LDS
+            double t[SUB];
+#pragma unroll
+            for (int rr = 0; rr < SUB; ++rr) {
+                double a = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) a += sm[buf][w][rr];
+                t[rr] = a;
+            }
+#pragma unroll
+            for (int m = 0; m < MAXCH; ++m) {
+                double2 pa = rs[THREADS * MAXCH + tid + THREADS * m];
+#pragma unroll
+                for (int rr = 0; rr < SUB; ++rr) {
+                    pa.x += t[rr] * y[rr][m].x;
+                    pa.y += t[rr] * y[rr][m].y;
+                }
+                rs[THREADS * MAXCH + tid + THREADS * m] = pa;
+            }
+        } else {
 #pragma unroll
         for (int rr = 0; rr < SUB; ++rr) {
             double t = 0.0;
@@ -1108,12 +1149,16 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
                 pacc[m].y += t * y[rr][m].y;
             }
         }
+        }
     }
     double *out = ppart + ((size_t)s * nbmax + tileIdx) * nmax;
 #pragma unroll
     for (int m = 0; m < MAXCH; ++m) {
         const int c = cb + 2 * tid + 2 * THREADS * m;
-        if (c < ncol) *reinterpret_cast<double2 *>(out + c) = pacc[m];
+        if (c < ncol) {
+            if constexpr (RLDS) *reinterpret_cast<double2 *>(out + c) = rs[THREADS * MAXCH + tid + THREADS * m];
+            else *reinterpret_cast<double2 *>(out + c) = pacc[m];
+        }
     }
 }
 
@@ -1130,7 +1175,7 @@ __device__ __forceinline__ void backsolve_block(int jobIdx, const int4 *__restri
                                                 const double *__restrict__ W, int nmax, const RowTile *__restrict__ rt,
                                                 const double *__restrict__ q, double *__restrict__ ppart, int nbmax,
                                                 double (*sm)[THREADS / 64][32], const int *__restrict__ abortp = nullptr,
-                                                int epoch = 0, int *s_abort = nullptr)
+                                                int epoch = 0, int *s_abort = nullptr, double2 *__restrict__ rs = nullptr)
 {
     if (abortp) {   // workgroups that start after the verdict leave at once (one thread asks: a uniform answer)
         if (threadIdx.x == 0) s_abort[2] = __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1155,7 +1200,8 @@ __device__ __forceinline__ void backsolve_block(int jobIdx, const int4 *__restri
         if (len <= 512) backsolve_tile<256, 1, 32>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
         else if (len <= 1024) backsolve_tile<256, 2, 16>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
         else if (len <= 1536) backsolve_tile<256, 3, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
-        else backsolve_tile<256, 5, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
+        else if (len <= 2560) backsolve_tile<256, 5, 8>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
+        else backsolve_tile<256, 6, 8, true>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort, rs);   // <= BS_NARROW
     } else {
         if (len <= 1024) backsolve_tile<512, 1, 32>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
         else if (len <= 2048) backsolve_tile<512, 2, 16>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, epoch, s_abort);
@@ -1171,7 +1217,7 @@ __device__ __forceinline__ void backsolve_block(int jobIdx, const int4 *__restri
 // spec: the launch is speculative (early back-solve, enqueue_loop_slot): it runs on the trial gradient before the
 // controller has decided about the trial, so the retry phase does not gate it
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restrict__ job,
+__global__ __launch_bounds__(THREADS, 2) void backsolve_kernel(const int4 *__restrict__ job,
                                                             const int *__restrict__ dofmap,
                                                             const double *__restrict__ W, int nmax,
                                                             const RowTile *__restrict__ rt,
@@ -1181,11 +1227,12 @@ __global__ __launch_bounds__(THREADS) void backsolve_kernel(const int4 *__restri
 {
     __shared__ double sm[2][THREADS / 64][32];
     __shared__ int s_abort[3];
+    __shared__ double2 rs[THREADS == 256 ? 2 * 256 * 6 : 1];   // (256 threads: right-hand side + accumulators of rows beyond 2560 columns)
     if (ctl && (ctl->status != 0 || (ctl->phase != 0 && !spec))) return;
     // spec > 0: the slot's epoch (its 1-based index in the step); the controller, which runs meanwhile, publishes the epoch
     // of a slot whose trial it rejects or that ends the loop (DevLoop::abortEpoch)
     backsolve_block<THREADS>(blockIdx.x, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm,
-                             (ctl && spec > 0 && spec < (1 << 30)) ? &ctl->abortEpoch : nullptr, spec, s_abort);
+                             (ctl && spec > 0 && spec < (1 << 30)) ? &ctl->abortEpoch : nullptr, spec, s_abort, rs);
 }
 
 // The same tiles with the loop controller as workgroup 0 of the launch: the controller's ~7 us (partial sums, the
@@ -1200,6 +1247,7 @@ __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__res
 {
     __shared__ double sm[2][4][32];
     __shared__ int s_abort[3];
+    __shared__ double2 rs[2 * 256 * 6];
     // (which workgroup hosts the controller makes no difference: index 0 / 256 / 520 / last measured 47.0-47.5 us)
     if (blockIdx.x == 0) {
         loop_control_body(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init);
@@ -1225,7 +1273,7 @@ __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__res
         __syncthreads();
     }
     backsolve_block<256>(blockIdx.x - 1, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm,
-                         epoch < (1 << 30) ? &ca.ctl->abortEpoch : nullptr, epoch, s_abort);
+                         epoch < (1 << 30) ? &ca.ctl->abortEpoch : nullptr, epoch, s_abort, rs);
 }
 #ifdef BS_PROFILE
 extern "C" int dotmi_debug_bs_prof(long long *out, int n)
@@ -1482,7 +1530,7 @@ void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, con
     hipLaunchKernelGGL(gather_pad_kernel, dim3((P.nmax + 255) / 256), dim3(256), 0, st, P.nmax, P.dofmap + (size_t)ls * P.nmax,
                        q, P.rpad + (size_t)ls * P.nmax);
     if (njobs > 0) {
-        if (P.maxTileLen <= 2560)
+        if (P.maxTileLen <= BS_NARROW)
             hipLaunchKernelGGL((backsolve_kernel<256>), dim3(njobs), dim3(256), 0, st, job, P.dofmap, P.W, P.nmax, P.rt, P.rpad,
                                P.ppart, P.nbmax, (const DevLoop *)nullptr, 0);
         else

@@ -292,6 +292,15 @@ inline int nd_default_levels(const std::vector<std::vector<int>> &partVerts)
     for (auto &v : partVerts) nsmax = std::max(nsmax, 3 * (int)v.size());
     return nd_default_levels(nsmax, (int)partVerts.size());
 }
+// Depth and split threshold for a mesh (round 5).  When the size rule above leaves two levels, a THIRD level with regions split
+// down to 384 scalars is tried on the layout of ALL subdomains of the mesh (so that every rank of a sharded run decides alike)
+// and kept when its padded size still fits the 256-thread back-solve kernel (narrowLimit = BS_NARROW columns, two workgroups
+// per CU): bar17K / 32 subdomains 2368 -> 2944 columns, X 229 -> 197 MB, factorisation 1.08 -> 0.98 ms; bunny5K / 8
+// 2368 -> 2688, factorisation 0.35 -> 0.31 ms.  Beyond that limit the longer padded rows cost the back-solve more than the
+// bytes save (horse7K / 8: 4096 columns) and the two levels stay.
+inline void nd_choose_depth(const std::vector<std::vector<int>> &allParts, int nV, const std::vector<int> &adj_ptr,
+                            const std::vector<int> &adj_idx, const double *Xrest, int narrowLimit, int defaultMinSplit,
+                            int &levels, int &minSplit);
 constexpr int ND_MIN_SPLIT = 512;   // smallest region (scalars) that is still split (round 5: 768 -> 512: the 1200-dof subdomains
                                     // of the stiff monkey get their second level -- X 165 -> 124 MB, factor 0.78 -> 0.55 ms)
 
@@ -309,6 +318,23 @@ inline int nd_plan(const std::vector<std::vector<int>> &partVerts, int nV, const
     if (tree[root].size < 128) tree[root].size = 128;  // only a leaf root can be that small
     nb.layout(root, 0);
     return tree[root].size;
+}
+
+inline void nd_choose_depth(const std::vector<std::vector<int>> &allParts, int nV, const std::vector<int> &adj_ptr,
+                            const std::vector<int> &adj_idx, const double *Xrest, int narrowLimit, int defaultMinSplit,
+                            int &levels, int &minSplit)
+{
+    levels = nd_default_levels(allParts);
+    minSplit = defaultMinSplit;
+    if (levels != 2) return;
+    std::vector<NdNode> tree2, tree3;
+    std::vector<std::vector<std::vector<int>>> region;
+    const int n2 = nd_plan(allParts, nV, adj_ptr, adj_idx, Xrest, 2, defaultMinSplit, tree2, region);
+    const int n3 = nd_plan(allParts, nV, adj_ptr, adj_idx, Xrest, 3, 384, tree3, region);
+    if (tree3.size() > tree2.size() && n3 > n2 && n3 <= narrowLimit) {
+        levels = 3;
+        minSplit = 384;
+    }
 }
 
 }  // namespace dotmi

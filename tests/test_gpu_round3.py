@@ -25,13 +25,16 @@ def _pair(name):
 
 def test_compact_factor_storage_is_close_to_the_structural_nonzeros():
     """the factors were nParts x nmax^2 doubles (1.44 GB for 229 MB of non-zeros on bar17K).  With the
-    64-row blocks of the compact layout (dotmi_internal.hpp RowTile) the storage is < 1.5 x the bytes one back-solve
-    streams, and X^T X H_s = I still holds on the factors read back through dotmi_part_matrix."""
+    64-row blocks of the compact layout (dotmi_internal.hpp RowTile) the storage stays within 2 x the bytes one back-solve
+    streams (round 3: 1.39 x on two dissection levels; round 5's third level streams 14 % fewer bytes -- 229 -> 197 MB -- out
+    of a layout whose padded regions store 13 % more -- 318 -> 360 MB: 1.83 x), and X^T X H_s = I still holds on the factors
+    read back through dotmi_part_matrix."""
     sc, ep, n = load_workload("bar17K_twist")
     ts = DOTTimeStepper(sc, ep, n)
     st = ts.step()
     stored = dl.load().dotmi_factor_storage_bytes(ts._h)
-    assert 0.9 * st.precond_bytes < stored < 1.5 * st.precond_bytes, (stored, st.precond_bytes)
+    assert 0.9 * st.precond_bytes < stored < 2.0 * st.precond_bytes, (stored, st.precond_bytes)
+    assert stored < 0.3 * 8 * n * dl.load().dotmi_padded_size(ts._h) ** 2      # (dense blocks would be nParts x nmax^2)
     for p in (0, 17):
         Hs, _ = ts.partMatrix(p)
         X, _ = ts.partMatrix(p, inverse=True)
