@@ -257,6 +257,26 @@ int build_device_mesh(dotmi_handle *h)
     const bool fewTiles = (long long)P.nParts * P.nmax / 64 < 2 * 256;
     int tileRows = fewTiles ? 32 : 64;
     if (h->tune.tileRows > 0) tileRows = h->tune.tileRows;
+    // Round 5: is the back-solve launch SHALLOW -- its workgroups (one-tile jobs + packs of four small tiles, at 64 rows per tile)
+    // resident at once, or nearly (<= 1.5 x the 512 slots of two 256-thread workgroups per CU)?  Then the launch lasts as long as
+    // its longest tile, and the long rows' tiles are cut to DOTMI_TILE_PASSES passes (below); in a deep launch (horse7K@r1:64:
+    // 1646 workgroups, 1 M tets: 8640) the queue sets the length and more, smaller tiles cost (+8 % per iteration on the horse).
+    bool shallowLaunch = false;
+    if (h->tune.wavePacks && !fewTiles) {
+        long long big = 0, small = 0;
+        for (int ls = 0; ls < P.nParts; ++ls)
+            for (size_t nd = 0; nd < h->nd.size(); ++nd) {
+                const NdNode &N = h->nd[nd];
+                const int used = 3 * (int)region[nd][ls].size();
+                const int ro = nd_region_first_row(N, used);
+                const int cb = N.a < 0 ? (ro & ~15) : N.off;
+                for (int r0 = ro, rows = 0; r0 < ro + used; r0 += rows) {
+                    rows = std::min(std::min(tileRows, ro + used - r0), 64 - (r0 & 63));
+                    (r0 + rows - cb <= BS_WAVE ? small : big)++;
+                }
+            }
+        shallowLaunch = big + (small + 3) / 4 <= 768;
+    }
     std::vector<int4> tiles;
     std::vector<std::vector<int2>> ranges(P.nParts);
     h->precond_bytes = 0;
@@ -297,12 +317,19 @@ int build_device_mesh(dotmi_handle *h)
             // (profiles/r03_factor_tiles.txt section E); with few subdomains the launch lasts as long as its longest tile
             // (bunny5K / 8: a 32-row tile of the root separator is 512 KB at ~30 GB/s per workgroup), so those rows get
             // tiles of ~256 KB: 16 rows at 2000 columns, 8 at 3000 (round 4: bunny5K 23.0 -> 16.8 us, horse7K 46.5 -> 31.8)
+            // Round 5: a tile is a CHAIN of passes (rows in registers -> dot products -> butterfly -> exchange -> update), ~5.5 us
+            // each, and the launch lasts at least as long as its longest chain.  Rows of more than 1024 columns go 8 to a pass,
+            // so their 64-row tiles were 8 passes = 42-50 us -- the whole launch on bar17K (tools/prof_backsolve.sh: the 110
+            // root tiles start at t = 0 and end last, whatever the other slots do).  In a shallow launch (above) the rows beyond
+            // 1536 columns are cut to DOTMI_TILE_PASSES = 4 passes (32 rows).  That pays only together with the packs of small
+            // tiles: alone either change leaves the launch at 50 us (the shorter root tiles queue behind ~800 small workgroups
+            // for the slots), together 50.0 -> 42.1; cutting the rows beyond 1024 columns too puts the queue back (47.9)
+            // (profiles/r05_backsolve_tiles.txt).
             const int len = ro + used - cb;
             int trows = tileRows;
-            if (len > 1536) {
-                if (h->tune.tileRowsLong > 0) trows = std::min(tileRows, h->tune.tileRowsLong);
-                else if (fewTiles) trows = std::min(tileRows, std::max(8, (32768 / len) / 8 * 8));
-            }
+            if (len > 1536 && h->tune.tileRowsLong > 0) trows = std::min(tileRows, h->tune.tileRowsLong);
+            else if (len > 1536 && fewTiles) trows = std::min(tileRows, std::max(8, (32768 / len) / 8 * 8));
+            else if (len > 1536 && shallowLaunch) trows = std::min(tileRows, 8 * h->tune.tilePasses);
             for (int r0 = ro, rows = 0; r0 < ro + used; r0 += rows) {
                 rows = std::min(std::min(trows, ro + used - r0), 64 - (r0 & 63));
                 tiles.push_back(make_int4(ls, r0, b | (rows << 16), cb));
@@ -370,7 +397,23 @@ int build_device_mesh(dotmi_handle *h)
     std::stable_partition(tiles.begin(), tiles.end(), [](const int4 &t) { return t.y + (t.z >> 16) - t.w > BS_NARROW; });
     P.ntilesWide = 0;
     for (const int4 &t : tiles) P.ntilesWide += (t.y + (t.z >> 16) - t.w > BS_NARROW);
-    P.ntiles = (int)tiles.size();
+    // small tiles (rows of at most BS_WAVE columns) leave the one-tile jobs: four of them share a workgroup, one wavefront each
+    // (kernels.hip, backsolve_wave_tile); heavy first, so the four of a pack are about equally long
+    P.nquad = 0;
+    if (h->tune.wavePacks) {
+        std::vector<int4> big, small;
+        for (const int4 &t : tiles) (tile_len(t) <= BS_WAVE ? small : big).push_back(t);
+        if (small.size() >= 8) {
+            while (small.size() % 4) small.push_back(make_int4(0, 0, 0, 0));   // rows = 0: the wavefront leaves at once
+            P.nquad = (int)small.size() / 4;
+            tiles = big;
+            P.ntiles = (int)tiles.size();
+            tiles.insert(tiles.end(), small.begin(), small.end());
+        }
+    }
+    if (P.nquad == 0) P.ntiles = (int)tiles.size();
+    if (h->tune.fuseLog)
+        fprintf(stderr, "dotmi: back-solve: %d one-tile jobs (%d wide), %d packs of four small tiles\n", P.ntiles, P.ntilesWide, P.nquad);
     P.nltiles = (int)ltiles.size();
     P.nlwork = (int)lwork.size();
     // merge lists (owned parts only)

@@ -61,6 +61,8 @@ using namespace dotmi;
 struct Tuning {
     int ndLevels = -1;        // DOTMI_ND_LEVELS      depth of the nested dissection (-1: nd_default_levels)
     int ndMin = ND_MIN_SPLIT; // DOTMI_ND_MIN         smallest region (scalars) that is still split
+    bool wavePacks = true;    // DOTMI_WAVE_PACKS=0   small back-solve tiles as one-tile jobs like the others instead of four per workgroup
+    int tilePasses = 4;       // DOTMI_TILE_PASSES    most passes (of 8 rows) a back-solve tile of rows beyond 1024 columns takes (8: 64-row tiles)
     int tileRows = 0;         // DOTMI_TILE_ROWS      rows per back-solve tile (0: 64, or 32 for few subdomains)
     int tileRowsLong = 0;     // DOTMI_TILE_ROWS_LONG rows per back-solve tile when the rows have more than 1536 columns (0: as the
                               //                      other rows, or ~256 KB tiles where few subdomains leave the launch bound by
@@ -100,6 +102,8 @@ struct Tuning {
     static Tuning from_env()
     {
         Tuning t;
+        t.wavePacks = geti("DOTMI_WAVE_PACKS", 1) != 0;
+        t.tilePasses = std::min(8, std::max(1, geti("DOTMI_TILE_PASSES", 4)));
         t.ndLevels = geti("DOTMI_ND_LEVELS", -1);
         if (t.ndLevels < -1) t.ndLevels = 0;
         t.ndMin = std::max(128, geti("DOTMI_ND_MIN", ND_MIN_SPLIT));

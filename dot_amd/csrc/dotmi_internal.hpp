@@ -14,6 +14,7 @@ constexpr int HIST_MAX = 6;     // L-BFGS pairs kept (reference uses 5, DOTTimeS
 inline int elem_wg_cap(int mat) { return mat == 1 ? 768 : 512; }
 constexpr int NB_RED = 256;     // blocks of every reducing kernel (fixed => run-to-run bit-identical sums)
 constexpr int RED_K = 3 * HIST_MAX + 3;  // partial values per block
+constexpr int BS_WAVE = 256;    // rows of at most that many columns: four tiles per workgroup, one wavefront each
 constexpr int BS_NARROW = 3072; // longest row the 256-thread form of that kernel takes (two workgroups per CU; round 5: 2560 -> 3072 with the
                                 // right-hand side of the sixth chunk's rows in LDS); longer rows go to the 512-thread form in a launch of their own
 constexpr int BS_LONG = 5120;   // longest row (columns) the single-pass back-solve kernel holds in registers (512 threads x 5 x 2)
@@ -73,6 +74,8 @@ struct DevParts {
     RowTile *rt;            // owned * (nmax / 64) row blocks
     int ntiles;             // back-solve jobs, heavy first:
     int4 *tile;             //   (part, first row, tile index within the part | rows << 16, first column)
+    int nquad;              // behind the ntiles one-tile jobs: nquad packs of four SMALL tiles (rows of at most BS_WAVE columns; one
+                            //   wavefront each, backsolve_wave_tile), padded with empty entries (rows = 0): tile[ntiles + 4 k ..]
     int ntilesWide;         // the first ntilesWide tiles have rows of more than BS_NARROW columns (512-thread kernel)
     int maxTileLen;         // longest row of a tile in `tile` (<= BS_LONG: longer tiles are in `ltile`)
     // tiles whose rows exceed BS_LONG columns: two-phase back-solve over column chunks (kernels.hip)

@@ -1162,9 +1162,112 @@ __device__ __forceinline__ void backsolve_tile(const int4 jb, const int *__restr
     }
 }
 
+
 #ifdef BS_PROFILE
 __device__ long long g_bs_prof[8192][5];
 #endif
+
+// ---- small tiles, one WAVEFRONT each (round 5) -----------------------------------------------------------------------------
+// On a deep dissection most tiles are small: bar17K on three levels has 1163 tiles of which 796 have rows of at most 256
+// columns -- 68 % of the workgroups for 17 % of the bytes (512 of them average 24 KB), each holding a 252-register slot of the
+// launch for ~10 us of latency (descriptor -> right-hand side -> rows -> butterfly -> LDS exchange -> barrier; tools/
+// prof_backsolve.sh: every slot of the GPU busy for the whole launch, 3.9 TB/s).  Four such tiles share a workgroup now,
+// one wavefront each, with nothing in common: no LDS, no barrier -- lane l holds columns cb + 2 l (+ 128), 16 rows per pass
+// in registers, the rows' dot products through the transposed butterfly and v_readlane broadcasts, the rank-16 update from the
+// same registers.  The tile's partial result goes where the block form puts it (ppart[s][tile][.]).
+__device__ __forceinline__ double bs_readlane(double v, int srclane)
+{
+    union {
+        double d;
+        int i[2];
+    } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], srclane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], srclane);
+    return u.d;
+}
+__device__ __forceinline__ void backsolve_wave_tile(const int4 jb, const int *__restrict__ dofmap, const double *__restrict__ W,
+                                                    int nmax, const RowTile *__restrict__ rt, const double *__restrict__ q,
+                                                    double *__restrict__ ppart, int nbmax, const int *__restrict__ abortp,
+                                                    int epoch)
+{
+    constexpr int WCH = 2, WSUB = 16;   // 2 x 128 columns, 16 rows per pass
+    const int rows = jb.z >> 16;
+    if (rows == 0) return;              // padding of the last pack
+    if (abortp && __builtin_amdgcn_readfirstlane(__hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch)
+        return;
+    const int s = jb.x, i0 = jb.y, tileIdx = jb.z & 0xffff, cb = jb.w;
+    const int ns = i0 + rows;
+    const int ncol = min((ns + 15) & ~15, nmax);
+    const int lane = threadIdx.x & 63;
+    const RowTile rb = rt[(size_t)s * (nmax >> 6) + (i0 >> 6)];
+    const int ldw = rb.ld;
+    const double *Ws = W + (rb.off - (long long)(i0 & ~63) * ldw - rb.c0);
+    const int *dm = dofmap + (size_t)s * nmax;
+    const double *rp = q + (size_t)s * nmax;
+    double2 r[WCH], pacc[WCH];
+    int cend[WCH];
+#pragma unroll
+    for (int m = 0; m < WCH; ++m) {
+        const int c = cb + 2 * lane + 128 * m;
+        const int2 dd = (c < ncol) ? *reinterpret_cast<const int2 *>(dm + c) : make_int2(-1, -1);
+        r[m] = (c < ncol) ? *reinterpret_cast<const double2 *>(rp + c) : make_double2(0.0, 0.0);
+        pacc[m] = make_double2(0.0, 0.0);
+        cend[m] = (dd.x >= 0 || dd.y >= 0) ? c : 0x7fffffff;
+    }
+#pragma unroll 1
+    for (int ib = i0; ib < ns; ib += WSUB) {
+        int ab = 0;
+        if (abortp) ab = __hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (answer used behind the loads)
+        double2 y[WSUB][WCH];
+#pragma unroll
+        for (int rr = 0; rr < WSUB; ++rr) {
+            const double *row = Ws + (long long)min(ib + rr, ns - 1) * ldw;
+            const int rend = ((ib + rr) < ns) ? min(ncol, (ib + rr + 16) & ~15) : 0;
+#pragma unroll
+            for (int m = 0; m < WCH; ++m) {
+                const int c = cb + 2 * lane + 128 * m;
+                if (cend[m] < rend) {
+                    const nt_double2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_double2 *>(row + c));
+                    y[rr][m] = make_double2(v.x, v.y);
+                } else {
+                    y[rr][m] = make_double2(0.0, 0.0);
+                }
+            }
+        }
+        double t[WSUB];
+#pragma unroll
+        for (int g = 0; g < WSUB / 8; ++g) {
+            double d[8];
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < WCH; ++m) acc += y[8 * g + rr][m].x * r[m].x + y[8 * g + rr][m].y * r[m].y;
+                d[rr] = acc;
+            }
+            const double e1 = wave_sum8_transposed(d, lane);   // lane 8 k holds the wave sum of row k of the group
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) t[8 * g + rr] = bs_readlane(e1, 8 * rr);
+        }
+        if (abortp && __builtin_amdgcn_readfirstlane(ab) == epoch) return;   // the result would not be used
+#pragma unroll
+        for (int rr = 0; rr < WSUB; ++rr) {
+#pragma unroll
+            for (int m = 0; m < WCH; ++m) {
+                pacc[m].x += t[rr] * y[rr][m].x;
+                pacc[m].y += t[rr] * y[rr][m].y;
+            }
+        }
+    }
+    double *out = ppart + ((size_t)s * nbmax + tileIdx) * nmax;
+#pragma unroll
+    for (int m = 0; m < WCH; ++m) {
+        const int c = cb + 2 * lane + 128 * m;
+        if (c < ncol) *reinterpret_cast<double2 *>(out + c) = pacc[m];
+    }
+}
+
 __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, const double *__restrict__ partE, int nbE,
                                   const double *__restrict__ partR, const double *__restrict__ alpha_dev,
                                   int *__restrict__ flags_host, int init);
@@ -1223,7 +1326,7 @@ __global__ __launch_bounds__(THREADS, 2) void backsolve_kernel(const int4 *__res
                                                             const RowTile *__restrict__ rt,
                                                             const double *__restrict__ q,
                                                             double *__restrict__ ppart, int nbmax,
-                                                            const DevLoop *__restrict__ ctl, int spec)
+                                                            const DevLoop *__restrict__ ctl, int spec, int nBig)
 {
     __shared__ double sm[2][THREADS / 64][32];
     __shared__ int s_abort[3];
@@ -1231,8 +1334,26 @@ __global__ __launch_bounds__(THREADS, 2) void backsolve_kernel(const int4 *__res
     if (ctl && (ctl->status != 0 || (ctl->phase != 0 && !spec))) return;
     // spec > 0: the slot's epoch (its 1-based index in the step); the controller, which runs meanwhile, publishes the epoch
     // of a slot whose trial it rejects or that ends the loop (DevLoop::abortEpoch)
-    backsolve_block<THREADS>(blockIdx.x, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm,
-                             (ctl && spec > 0 && spec < (1 << 30)) ? &ctl->abortEpoch : nullptr, spec, s_abort, rs);
+    const int *abortp = (ctl && spec > 0 && spec < (1 << 30)) ? &ctl->abortEpoch : nullptr;
+    if constexpr (THREADS == 256) {
+        if ((int)blockIdx.x >= nBig) {   // a pack of four small tiles, one wavefront each (backsolve_wave_tile)
+            const int4 jq = job[nBig + 4 * ((int)blockIdx.x - nBig) + (threadIdx.x >> 6)];
+#ifdef BS_PROFILE
+            if (threadIdx.x == 0 && blockIdx.x < 8192) {
+                g_bs_prof[blockIdx.x][0] = wall_clock64();
+                g_bs_prof[blockIdx.x][2] = jq.y + (jq.z >> 16) - jq.w;
+                g_bs_prof[blockIdx.x][3] = -(jq.z >> 16);
+                g_bs_prof[blockIdx.x][4] = 0;
+            }
+#endif
+            backsolve_wave_tile(jq, dofmap, W, nmax, rt, q, ppart, nbmax, abortp, spec);
+#ifdef BS_PROFILE
+            if (threadIdx.x == 0 && blockIdx.x < 8192) g_bs_prof[blockIdx.x][1] = wall_clock64();
+#endif
+            return;
+        }
+    }
+    backsolve_block<THREADS>(blockIdx.x, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm, abortp, spec, s_abort, rs);
 }
 
 // The same tiles with the loop controller as workgroup 0 of the launch: the controller's ~7 us (partial sums, the
@@ -1243,7 +1364,7 @@ __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__res
                                                             const double *__restrict__ W, int nmax,
                                                             const RowTile *__restrict__ rt, const double *__restrict__ q,
                                                             double *__restrict__ ppart, int nbmax, CtlArgs ca,
-                                                            int epoch)
+                                                            int epoch, int nBig)
 {
     __shared__ double sm[2][4][32];
     __shared__ int s_abort[3];
@@ -1272,7 +1393,24 @@ __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__res
         if (s_abort[2]) return;
         __syncthreads();
     }
-    backsolve_block<256>(blockIdx.x - 1, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm,
+    const int jobIdx = (int)blockIdx.x - 1;
+    if (jobIdx >= nBig) {   // a pack of four small tiles, one wavefront each
+        const int4 jq = job[nBig + 4 * (jobIdx - nBig) + (threadIdx.x >> 6)];
+#ifdef BS_PROFILE
+        if (threadIdx.x == 0 && jobIdx < 8192) {
+            g_bs_prof[jobIdx][0] = wall_clock64();
+            g_bs_prof[jobIdx][2] = jq.y + (jq.z >> 16) - jq.w;
+            g_bs_prof[jobIdx][3] = -(jq.z >> 16);   // (negative: a pack; rows of its first tile)
+            g_bs_prof[jobIdx][4] = 0;
+        }
+#endif
+        backsolve_wave_tile(jq, dofmap, W, nmax, rt, q, ppart, nbmax, epoch < (1 << 30) ? &ca.ctl->abortEpoch : nullptr, epoch);
+#ifdef BS_PROFILE
+        if (threadIdx.x == 0 && jobIdx < 8192) g_bs_prof[jobIdx][1] = wall_clock64();   // (wavefront 0 of the four)
+#endif
+        return;
+    }
+    backsolve_block<256>(jobIdx, job, dofmap, W, nmax, rt, q, ppart, nbmax, sm,
                          epoch < (1 << 30) ? &ca.ctl->abortEpoch : nullptr, epoch, s_abort, rs);
 }
 #ifdef BS_PROFILE
@@ -1455,7 +1593,7 @@ __global__ __launch_bounds__(BSL_THREADS) void backsolve_long_kernel(const int4 
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,
                  const CtlArgs *ca, int spec)
 {
-    if (P.ntiles == 0 && P.nltiles == 0) return;
+    if (P.ntiles == 0 && P.nquad == 0 && P.nltiles == 0) return;
     if (q) {   // right-hand sides not in padded order yet
         const int total = P.nParts * P.nmax;
         int nb = (total + 255) / 256;
@@ -1467,34 +1605,36 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
     // reports as the kernel's duration) -- two hipEventRecord calls around the launch add ~5 us of barrier packets
     // wide tiles (rows of 2561..4096 columns) on the 512-thread kernel, the rest on the 256-thread one (two workgroups per
     // CU instead of one); the events (if any) span both launches: start of the first, stop of the last
-    const int nW = P.ntilesWide, nN = P.ntiles - P.ntilesWide;
+    // P.tile = [wide tiles | narrow tiles of more than 256 columns | packs of four small tiles]: job k < nN of the narrow launch
+    // is one tile, job nN + k the four tiles P.tile[ntiles + 4 k ..] (one wavefront each, backsolve_wave_tile)
+    const int nW = P.ntilesWide, nN = P.ntiles - P.ntilesWide, nG = nN + P.nquad;
     const bool timed = ev0 && ev1;
     if (ca && spec <= 0) spec = 1;   // (callers pass the slot's epoch: > 0)
-    if (ca && nN == 0)   // no launch of the 256-thread kernel to host it: the controller on its own, in front
+    if (ca && nG == 0)   // no launch of the 256-thread kernel to host it: the controller on its own, in front
         launch_loop_control(ca->ctl, ca->partE, ca->nbE, ca->partR, ca->alpha_dev, ca->flags_host, st, ca->init);
     if (nW > 0) {
         if (timed)
-            hipExtLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, ev0, nN > 0 ? (hipEvent_t) nullptr : ev1, 0,
-                                  P.tile, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, ctl, spec);
+            hipExtLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, ev0, nG > 0 ? (hipEvent_t) nullptr : ev1, 0,
+                                  P.tile, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, ctl, spec, nW);
         else
             hipLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax, P.rt, P.rpad,
-                               P.ppart, P.nbmax, ctl, spec);
+                               P.ppart, P.nbmax, ctl, spec, nW);
     }
-    if (nN > 0 && ca) {
+    if (nG > 0 && ca) {
         // one workgroup more: the controller (backsolve_ctl_kernel)
         if (timed)
-            hipExtLaunchKernelGGL(backsolve_ctl_kernel, dim3(nN + 1), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
-                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, *ca, spec);
+            hipExtLaunchKernelGGL(backsolve_ctl_kernel, dim3(nG + 1), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
+                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, *ca, spec, nN);
         else
-            hipLaunchKernelGGL(backsolve_ctl_kernel, dim3(nN + 1), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax, P.rt,
-                               (const double *)P.rpad, P.ppart, P.nbmax, *ca, spec);
-    } else if (nN > 0) {
+            hipLaunchKernelGGL(backsolve_ctl_kernel, dim3(nG + 1), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax, P.rt,
+                               (const double *)P.rpad, P.ppart, P.nbmax, *ca, spec, nN);
+    } else if (nG > 0) {
         if (timed)
-            hipExtLaunchKernelGGL((backsolve_kernel<256>), dim3(nN), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
-                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, ctl, spec);
+            hipExtLaunchKernelGGL((backsolve_kernel<256>), dim3(nG), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
+                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, ctl, spec, nN);
         else
-            hipLaunchKernelGGL((backsolve_kernel<256>), dim3(nN), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax, P.rt,
-                               P.rpad, P.ppart, P.nbmax, ctl, spec);
+            hipLaunchKernelGGL((backsolve_kernel<256>), dim3(nG), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax, P.rt,
+                               P.rpad, P.ppart, P.nbmax, ctl, spec, nN);
     }
     if (P.nltiles > 0) {
         hipLaunchKernelGGL((backsolve_long_kernel<0>), dim3(P.nlwork), dim3(BSL_THREADS), 0, st, P.ltile, P.lwork, P.dofmap,
@@ -1532,10 +1672,10 @@ void launch_gemv_part(const DevParts &P, int ls, const int4 *job, int njobs, con
     if (njobs > 0) {
         if (P.maxTileLen <= BS_NARROW)
             hipLaunchKernelGGL((backsolve_kernel<256>), dim3(njobs), dim3(256), 0, st, job, P.dofmap, P.W, P.nmax, P.rt, P.rpad,
-                               P.ppart, P.nbmax, (const DevLoop *)nullptr, 0);
+                               P.ppart, P.nbmax, (const DevLoop *)nullptr, 0, njobs);
         else
             hipLaunchKernelGGL((backsolve_kernel<512>), dim3(njobs), dim3(512), 0, st, job, P.dofmap, P.W, P.nmax, P.rt, P.rpad,
-                               P.ppart, P.nbmax, (const DevLoop *)nullptr, 0);
+                               P.ppart, P.nbmax, (const DevLoop *)nullptr, 0, njobs);
     }
     if (nlwork > 0) {   // rows beyond the register tile: the two-phase kernel on this part's work items
         hipLaunchKernelGGL((backsolve_long_kernel<0>), dim3(nlwork), dim3(BSL_THREADS), 0, st, P.ltileByPart, lwork, P.dofmap,

@@ -20,8 +20,8 @@ a = a[a[:, 0] > 0]
 t0 = a[:, 0].min()
 st, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0   # 100 MHz -> us
 print("workgroups", len(a), "span %.1f us" % en.max())
-for lo, hi in [(0, 512), (512, 1024), (1024, 1536), (1536, 4096)]:
-    m = (a[:, 2] > lo) & (a[:, 2] <= hi)
+for lo, hi in [(0, 256), (256, 512), (512, 1024), (1024, 1536), (1536, 2560), (2560, 5120)]:
+    m = (a[:, 2] > lo) & (a[:, 2] <= hi) & (a[:, 3] > 0)
     if m.any():
         print("len (%4d,%4d]: %4d tiles  start %.1f..%.1f  duration mean %.1f max %.1f  end max %.1f" % (
             lo, hi, m.sum(), st[m].min(), st[m].max(), (en - st)[m].mean(), (en - st)[m].max(), en[m].max()))
@@ -34,4 +34,7 @@ print("tiles per XCC:", np.bincount(xcc.astype(int), minlength=8).tolist())
 byx = [en[xcc == x].max() for x in range(8) if (xcc == x).any()]
 print("last end per XCC:", [round(float(v), 1) for v in byx])
 order = np.argsort(en)[-10:]
+pk = a[:, 3] < 0
+if pk.any():
+    print("packs of four small tiles: %d  start %.1f..%.1f  duration (wavefront 0) mean %.1f max %.1f  end max %.1f" % (pk.sum(), st[pk].min(), st[pk].max(), (en - st)[pk].mean(), (en - st)[pk].max(), en[pk].max()))
 print("last 10 to finish: (block, len, rows, start, end)", [(int(i), int(a[i, 2]), int(a[i, 3]), round(float(st[i]), 1), round(float(en[i]), 1)) for i in order])
