@@ -417,7 +417,7 @@ def main():
         fact_ms = float(np.mean([s.ms_factor for s in stats]))
         fact_tf = stats[0].factor_flops / (fact_ms * 1e-3) / 1e12 if fact_ms > 0 else 0.0
         rec["roofline_factor"] = {
-            "bound": "mfma", "kernel_name": {1: "tile_task_kernel", 2: "tile_flow_kernel"}.get(int(L.dotmi_factor_kind(ts._h)), "?"),
+            "bound": "mfma", "kernel_name": {1: "tile_task_kernel", 2: "tile_flow_kernel", 3: "tile_gemm_kernel + tile_task_kernel"}.get(int(L.dotmi_factor_kind(ts._h)), "?"),
             "kernel": "tile_task_kernel / tile_flow_kernel: block-sparse inverse-Cholesky of the subdomain blocks as 64x64 "
             "tile tasks (v_mfma_f64_16x16x4_f64 from LDS), once per step",
             "achieved": round(fact_tf, 2), "peak": FP64_MFMA_PEAK, "unit": "TFLOP/s", "frac": round(fact_tf / FP64_MFMA_PEAK, 4),

@@ -1153,7 +1153,7 @@ int dotmi_comm_unique_id(void *out128)
 int32_t dotmi_factor_kind(const dotmi_handle *h)
 {
     if (!h) return DOTMI_E_INVALID;
-    return h->tileFlow ? 2 : 1;
+    return h->tileFlow ? 2 : h->tileSplit ? 3 : 1;
 }
 
 int32_t dotmi_comm_ranks(const dotmi_handle *h)

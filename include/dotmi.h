@@ -296,7 +296,8 @@ int32_t dotmi_padded_size(const dotmi_handle *h);
  * non-zeros dotmi_step_stats.precond_bytes counts; DOTMI_TILE_FACTOR=0: nParts x padded_size^2 x 8) */
 int64_t dotmi_factor_storage_bytes(const dotmi_handle *h);
 /* which kernel family factorises this handle's subdomains (for measurement records): 1 = tile tasks, one launch per level
- * (tile_task_kernel), 2 = tile tasks as one dataflow launch (tile_flow_kernel) */
+ * (tile_task_kernel), 2 = tile tasks as one dataflow launch (tile_flow_kernel), 3 = one launch pair per level: the diagonal
+ * tasks in tile_task_kernel beside the product / row / inverse tasks on half tiles in tile_gemm_kernel (above 64 subdomains) */
 int32_t dotmi_factor_kind(const dotmi_handle *h);
 int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *M, int32_t *l2g);
 

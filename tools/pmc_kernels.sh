@@ -18,7 +18,8 @@ CLASSES = [("elem_patch_kernel", "elem_pass"), ("vertex_gather_kernel", "vertex_
            ("backsolve_kernel", "backsolve"), ("merge_tiles_kernel", "merge"), ("merge_tiles_early_kernel", "merge_early"), ("merge_kernel", "merge_split"), ("reduce_partial_p_kernel", "reduce_partial"),
            ("spmv_zp_kernel", "spmv_zp"), ("build_qpad_kernel", "build_qpad"),
            ("build_p_kernel", "build_p"), ("step_forward_kernel", "step_forward"), ("elem_hessian_kernel", "elem_hessian"),
-           ("assemble_kernel", "assemble"), ("tile_task_kernel", "tile_task"), ("dense_fill_kernel", "dense_fill")]
+           ("assemble_kernel", "assemble"), ("tile_task_kernel", "tile_task"), ("tile_flow_kernel", "tile_flow"), ("tile_gemm_kernel", "tile_gemm"),
+           ("dense_fill_kernel", "dense_fill"), ("clear_tiles_kernel", "clear_tiles")]
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"/tmp/pmc_{c}/**/*counter_collection.csv", recursive=True)
