@@ -1186,16 +1186,17 @@ __device__ __forceinline__ double bs_readlane(double v, int srclane)
     u.i[1] = __builtin_amdgcn_readlane(u.i[1], srclane);
     return u.d;
 }
-__device__ __forceinline__ void backsolve_wave_tile(const int4 jb, const int *__restrict__ dofmap, const double *__restrict__ W,
-                                                    int nmax, const RowTile *__restrict__ rt, const double *__restrict__ q,
-                                                    double *__restrict__ ppart, int nbmax, const int *__restrict__ abortp,
-                                                    int epoch)
+// WCH chunks of 128 columns, WSUB rows per pass: <2, 16> for rows of 129 .. 256 columns, <1, 32> for rows of at most 128 (most
+// small tiles: bar17K's 512 tiles of that kind average 24 KB) -- the same registers hold twice the rows, so a 64-row tile is
+// a chain of two passes instead of four (the packs were the last finishers of the launch: monkey18K 34.4 us, its last ten
+// workgroups packs of 48 .. 80-column tiles that started at 17 us and took 15; profiles/r05_backsolve_tiles.txt G)
+template <int WCH, int WSUB>
+__device__ __forceinline__ void backsolve_wave_tile_t(const int4 jb, const int *__restrict__ dofmap, const double *__restrict__ W,
+                                                      int nmax, const RowTile *__restrict__ rt, const double *__restrict__ q,
+                                                      double *__restrict__ ppart, int nbmax, const int *__restrict__ abortp,
+                                                      int epoch)
 {
-    constexpr int WCH = 2, WSUB = 16;   // 2 x 128 columns, 16 rows per pass
     const int rows = jb.z >> 16;
-    if (rows == 0) return;              // padding of the last pack
-    if (abortp && __builtin_amdgcn_readfirstlane(__hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch)
-        return;
     const int s = jb.x, i0 = jb.y, tileIdx = jb.z & 0xffff, cb = jb.w;
     const int ns = i0 + rows;
     const int ncol = min((ns + 15) & ~15, nmax);
@@ -1235,7 +1236,9 @@ __device__ __forceinline__ void backsolve_wave_tile(const int4 jb, const int *__
                 }
             }
         }
-        double t[WSUB];
+        if (abortp && __builtin_amdgcn_readfirstlane(ab) == epoch) return;   // the result would not be used
+        // eight rows at a time: their dot products, the wave sums, and at once their rank-8 update (rows ascending into every
+        // accumulator, as in the block form) -- only eight row sums are alive
 #pragma unroll
         for (int g = 0; g < WSUB / 8; ++g) {
             double d[8];
@@ -1248,15 +1251,13 @@ __device__ __forceinline__ void backsolve_wave_tile(const int4 jb, const int *__
             }
             const double e1 = wave_sum8_transposed(d, lane);   // lane 8 k holds the wave sum of row k of the group
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr) t[8 * g + rr] = bs_readlane(e1, 8 * rr);
-        }
-        if (abortp && __builtin_amdgcn_readfirstlane(ab) == epoch) return;   // the result would not be used
+            for (int rr = 0; rr < 8; ++rr) {
+                const double t = bs_readlane(e1, 8 * rr);
 #pragma unroll
-        for (int rr = 0; rr < WSUB; ++rr) {
-#pragma unroll
-            for (int m = 0; m < WCH; ++m) {
-                pacc[m].x += t[rr] * y[rr][m].x;
-                pacc[m].y += t[rr] * y[rr][m].y;
+                for (int m = 0; m < WCH; ++m) {
+                    pacc[m].x += t * y[8 * g + rr][m].x;
+                    pacc[m].y += t * y[8 * g + rr][m].y;
+                }
             }
         }
     }
@@ -1266,6 +1267,19 @@ __device__ __forceinline__ void backsolve_wave_tile(const int4 jb, const int *__
         const int c = cb + 2 * lane + 128 * m;
         if (c < ncol) *reinterpret_cast<double2 *>(out + c) = pacc[m];
     }
+}
+__device__ __forceinline__ void backsolve_wave_tile(const int4 jb, const int *__restrict__ dofmap, const double *__restrict__ W,
+                                                    int nmax, const RowTile *__restrict__ rt, const double *__restrict__ q,
+                                                    double *__restrict__ ppart, int nbmax, const int *__restrict__ abortp,
+                                                    int epoch)
+{
+    const int rows = jb.z >> 16;
+    if (rows == 0) return;              // padding of the last pack
+    if (abortp && __builtin_amdgcn_readfirstlane(__hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == epoch)
+        return;
+    // (wave-uniform: a tile is one wavefront's)
+    if (jb.y + rows - jb.w <= 128) backsolve_wave_tile_t<1, 32>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, abortp, epoch);
+    else backsolve_wave_tile_t<2, 16>(jb, dofmap, W, nmax, rt, q, ppart, nbmax, abortp, epoch);
 }
 
 __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, const double *__restrict__ partE, int nbE,
