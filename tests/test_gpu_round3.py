@@ -89,7 +89,8 @@ def test_bench_kernel_entry_covers_every_kernel_class():
                                  {"DOTMI_EARLY_BACKSOLVE": "2"}, {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_FUSE_STEP": "0"},
                                  {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_FUSE_DIR": "0"},
                                  {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_EARLY_ABORT": "0"},
-                                 {"DOTMI_ND_LEVELS": "3"}])
+                                 {"DOTMI_ND_LEVELS": "3"}, {"DOTMI_WAVE_PACKS": "0"}, {"DOTMI_TILE_PASSES": "8"},
+                                 {"DOTMI_WAVE_PACKS": "0", "DOTMI_TILE_PASSES": "8", "DOTMI_ND_LEVELS": "2"}])
 def test_tuning_switches_do_not_change_results(env):
     """Every tuning variable of DESIGN.md section 10 that selects another variant of a round-3 kernel / schedule: same
     iterations as the oracle, positions to 1e-9 (horse7K: FCR with SVD in the element pass, 8 subdomains, back-tracking)."""

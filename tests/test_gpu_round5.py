@@ -54,3 +54,38 @@ def test_synbar_1M_tets_full_size_matches_the_oracle_fixture():
             assert dx < 1e-9, (k, dx)
     finally:
         ts.close()
+
+
+@pytest.mark.parametrize("workload", ["bar17K_twist", "monkey18K_stiff", "synbar:40x10x10:256"])
+def test_tile_packs_and_short_long_row_tiles_apply_the_same_preconditioner(workload):
+    """Round 5's back-solve tiling -- tiles of at most 256 columns four to a workgroup, one wavefront each
+    (backsolve_wave_tile, <1, 32> up to 128 columns, <2, 16> above), long rows of a shallow launch in 4-pass tiles -- against
+    the one-tile-per-workgroup, 64-row tiling of round 4 on the same factors: p = M r agrees to rounding for random right-hand
+    sides (the two sum every row's dot product and every column's updates in another order, nothing else differs), X^T X H_s = I
+    still holds, and both agree with the CPU oracle's block solve.  synbar:40x10x10:256 has ONLY small tiles (165 dofs per
+    subdomain): its narrow launch consists of packs alone."""
+    from tests import oracle_py as O
+    sc, ep, n = load_workload(workload)
+    cfg = sc.cfg
+    rng = np.random.default_rng(5)
+    r = rng.standard_normal((sc.V_rest.shape[0], 3)) * (1 - sc.fixed[:, None])
+    out = {}
+    for name, env in (("packs", {}), ("plain", {"DOTMI_WAVE_PACKS": "0", "DOTMI_TILE_PASSES": "8"})):
+        os.environ.update(env)
+        try:
+            ts = DOTTimeStepper(sc, ep, n)
+        finally:
+            for k in env:
+                del os.environ[k]
+        out[name] = ts.applyPrecond(r)
+        if name == "packs":
+            Hs, _ = ts.partMatrix(0)
+            X, _ = ts.partMatrix(0, inverse=True)
+            assert np.abs(X.T @ X @ Hs - np.eye(Hs.shape[0])).max() < 1e-9
+        ts.close()
+    scale = np.abs(out["plain"]).max()
+    assert np.abs(out["packs"] - out["plain"]).max() <= 1e-12 * scale
+    orc = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, n, cfg.with_gravity)
+    po = orc.apply_precond(r)
+    orc.close()
+    assert np.abs(out["packs"] - po).max() <= 1e-9 * np.abs(po).max()
