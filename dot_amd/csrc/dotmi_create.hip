@@ -1,5 +1,6 @@
 // dotmi_create.hip -- dotmi_create and what it builds: mesh features, tolerance, partition maps, dissection layout, back-solve tiles, factor storage, tile schedule, patches; the host-only planning entry points; dotmi_destroy
 #include "dotmi_handle.hpp"
+#include "bs_tiles.hpp"
 
 namespace dotmi {
 std::string g_create_error;
@@ -252,33 +253,12 @@ int build_device_mesh(dotmi_handle *h)
     // per part: padded position of every local vertex, tiles of the back-solve, structural non-zeros
     h->partPos.assign(P.nParts, {});
     std::vector<int> dofmap((size_t)P.nParts * P.nmax, -1);
-    // rows per back-solve tile: 64, or 32 when 64-row tiles would not give every CU two workgroups (few subdomains:
-    // the launch is then bound by the pass chain of a workgroup, which halves)
-    const bool fewTiles = (long long)P.nParts * P.nmax / 64 < 2 * 256;
-    int tileRows = fewTiles ? 32 : 64;
-    if (h->tune.tileRows > 0) tileRows = h->tune.tileRows;
-    // Round 5: is the back-solve launch SHALLOW -- its workgroups (one-tile jobs + packs of four small tiles, at 64 rows per tile)
-    // resident at once, or nearly (<= 1.5 x the 512 slots of two 256-thread workgroups per CU)?  Then the launch lasts as long as
-    // its longest tile, and the long rows' tiles are cut to DOTMI_TILE_PASSES passes (below); in a deep launch (horse7K@r1:64:
-    // 1646 workgroups, 1 M tets: 8640) the queue sets the length and more, smaller tiles cost (+8 % per iteration on the horse).
-    bool shallowLaunch = false;
-    if (h->tune.wavePacks && !fewTiles) {
-        long long big = 0, small = 0;
-        for (int ls = 0; ls < P.nParts; ++ls)
-            for (size_t nd = 0; nd < h->nd.size(); ++nd) {
-                const NdNode &N = h->nd[nd];
-                const int used = 3 * (int)region[nd][ls].size();
-                const int ro = nd_region_first_row(N, used);
-                const int cb = N.a < 0 ? (ro & ~15) : N.off;
-                for (int r0 = ro, rows = 0; r0 < ro + used; r0 += rows) {
-                    rows = std::min(std::min(tileRows, ro + used - r0), 64 - (r0 & 63));
-                    (r0 + rows - cb <= BS_WAVE ? small : big)++;
-                }
-            }
-        shallowLaunch = big + (small + 3) / 4 <= 768;
-    }
-    std::vector<int4> tiles;
-    std::vector<std::vector<int2>> ranges(P.nParts);
+    // the job table of the back-solve launches (bs_tiles.hpp): tiles per region, wide / narrow / packs, heavy first
+    BsTilePlan TP;
+    plan_backsolve_tiles(h->nd, [&](int k, int ls) { return 3 * (int)region[k][ls].size(); }, P.nParts, P.nmax,
+                         BsTileRules{h->tune.tileRows, h->tune.tileRowsLong, h->tune.tilePasses, h->tune.wavePacks}, TP);
+    std::vector<int4> &tiles = TP.tiles;
+    std::vector<std::vector<int2>> &ranges = TP.ranges;
     h->precond_bytes = 0;
     int64_t nnzX = 0;
     for (int ls = 0; ls < P.nParts; ++ls) {
@@ -302,40 +282,12 @@ int build_device_mesh(dotmi_handle *h)
         for (int c = 0; c < P.nmax; ++c) usedBefore[c + 1] = usedBefore[c] + live[c];
         h->partPos[ls].resize(pv.size());
         for (size_t i = 0; i < pv.size(); ++i) h->partPos[ls][i] = posOf.at(pv[i]);
-        int b = 0;
+        // structural non-zeros: every row of a region from the region's first column to the diagonal, live columns only
         for (size_t nd = 0; nd < h->nd.size(); ++nd) {
             const NdNode &N = h->nd[nd];
             const int used = 3 * (int)region[nd][ls].size();
-            const int ro = nd_region_first_row(N, used);  // first live row of the region
-            // the rows of a region start at their node's first column (a leaf's padding sits in front of its
-            // live rows and is skipped; 16-column granularity keeps the 128-byte lines whole)
+            const int ro = nd_region_first_row(N, used);
             const int cb = N.a < 0 ? (ro & ~15) : N.off;
-            // a tile stays inside one 64-row block of the factor storage (RowTile): the first tile of a region ends
-            // at the next multiple of 64
-            // rows of more than 1536 columns (the separators of the upper tree levels) can take fewer rows per tile
-            // (DOTMI_TILE_ROWS_LONG).  Where every CU has its two workgroups anyway (bar17K: 1116 tiles) that buys nothing
-            // (profiles/r03_factor_tiles.txt section E); with few subdomains the launch lasts as long as its longest tile
-            // (bunny5K / 8: a 32-row tile of the root separator is 512 KB at ~30 GB/s per workgroup), so those rows get
-            // tiles of ~256 KB: 16 rows at 2000 columns, 8 at 3000 (round 4: bunny5K 23.0 -> 16.8 us, horse7K 46.5 -> 31.8)
-            // Round 5: a tile is a CHAIN of passes (rows in registers -> dot products -> butterfly -> exchange -> update), ~5.5 us
-            // each, and the launch lasts at least as long as its longest chain.  Rows of more than 1024 columns go 8 to a pass,
-            // so their 64-row tiles were 8 passes = 42-50 us -- the whole launch on bar17K (tools/prof_backsolve.sh: the 110
-            // root tiles start at t = 0 and end last, whatever the other slots do).  In a shallow launch (above) the rows beyond
-            // 1536 columns are cut to DOTMI_TILE_PASSES = 4 passes (32 rows).  That pays only together with the packs of small
-            // tiles: alone either change leaves the launch at 50 us (the shorter root tiles queue behind ~800 small workgroups
-            // for the slots), together 50.0 -> 42.1; cutting the rows beyond 1024 columns too puts the queue back (47.9)
-            // (profiles/r05_backsolve_tiles.txt).
-            const int len = ro + used - cb;
-            int trows = tileRows;
-            if (len > 1536 && h->tune.tileRowsLong > 0) trows = std::min(tileRows, h->tune.tileRowsLong);
-            else if (len > 1536 && fewTiles) trows = std::min(tileRows, std::max(8, (32768 / len) / 8 * 8));
-            else if (len > 1536 && shallowLaunch) trows = std::min(tileRows, 8 * h->tune.tilePasses);
-            for (int r0 = ro, rows = 0; r0 < ro + used; r0 += rows) {
-                rows = std::min(std::min(trows, ro + used - r0), 64 - (r0 & 63));
-                tiles.push_back(make_int4(ls, r0, b | (rows << 16), cb));
-                ranges[ls].push_back(make_int2(cb, r0 + rows));
-                ++b;
-            }
             for (int r = ro; r < ro + used; ++r) nnzX += usedBefore[r + 1] - usedBefore[cb];
         }
     }
@@ -345,75 +297,18 @@ int build_device_mesh(dotmi_handle *h)
     for (auto &r : ranges) P.nbmax = std::max(P.nbmax, (int)r.size());
     std::vector<int2> trange((size_t)std::max(P.nParts, 1) * P.nbmax, make_int2(0, 0));
     for (int ls = 0; ls < P.nParts; ++ls) std::copy(ranges[ls].begin(), ranges[ls].end(), trange.begin() + (size_t)ls * P.nbmax);
-    // the same tiles grouped by part (GSDD solves one subdomain at a time): register-kernel tiles, and the long-row tiles
-    // with their (tile, column chunk) work items
-    auto tile_len = [](const int4 &t) { return t.y + (t.z >> 16) - t.w; };
-    std::vector<int4> tilesByPart, ltilesByPart;
-    std::vector<int2> lworkByPart;
-    h->partTilePtr.assign(P.nParts + 1, 0);
-    h->partLworkPtr.assign(P.nParts + 1, 0);
-    for (const int4 &t : tiles) {   // generated part after part
-        if (tile_len(t) > BS_LONG) {
-            const int nch = (((tile_len(t) + 15) & ~15) + BS_LONG - 1) / BS_LONG;
-            for (int c = 0; c < nch; ++c) lworkByPart.push_back(make_int2((int)ltilesByPart.size(), c));
-            ltilesByPart.push_back(t);
-            h->partLworkPtr[t.x + 1] += nch;
-        } else {
-            tilesByPart.push_back(t);
-            h->partTilePtr[t.x + 1]++;
-        }
-    }
-    for (int ls = 0; ls < P.nParts; ++ls) {
-        h->partTilePtr[ls + 1] += h->partTilePtr[ls];
-        h->partLworkPtr[ls + 1] += h->partLworkPtr[ls];
-    }
-    // heavy tiles first: work ~ rows * row length
-    auto tile_work = [](const int4 &t) { return (long long)(t.z >> 16) * (t.y + 64 - t.w); };
-    std::stable_sort(tiles.begin(), tiles.end(), [&](const int4 &a, const int4 &b) { return tile_work(a) > tile_work(b); });
-    // rows longer than the register tile of the single-pass kernel go through the two-phase kernel, cut into
-    // column chunks of BS_LONG
-    std::vector<int4> ltiles;
-    std::vector<int2> lwork;
-    {
-        std::vector<int4> shortTiles;
-        P.maxTileLen = 0;
-        P.maxChunks = 1;
-        for (const int4 &t : tiles) {
-            const int len = t.y + (t.z >> 16) - t.w;
-            if (len > BS_LONG) {
-                const int nch = (((len + 15) & ~15) + BS_LONG - 1) / BS_LONG;
-                for (int c = 0; c < nch; ++c) lwork.push_back(make_int2((int)ltiles.size(), c));
-                P.maxChunks = std::max(P.maxChunks, nch);
-                ltiles.push_back(t);
-            } else {
-                P.maxTileLen = std::max(P.maxTileLen, len);
-                shortTiles.push_back(t);
-            }
-        }
-        tiles.swap(shortTiles);
-    }
-    // tiles whose rows need the 512-thread variant (more than BS_NARROW columns) first: when both kinds exist they are
-    // launched separately, so that the short ones run on the 256-thread kernel (two workgroups per CU instead of one)
-    std::stable_partition(tiles.begin(), tiles.end(), [](const int4 &t) { return t.y + (t.z >> 16) - t.w > BS_NARROW; });
-    P.ntilesWide = 0;
-    for (const int4 &t : tiles) P.ntilesWide += (t.y + (t.z >> 16) - t.w > BS_NARROW);
-    // small tiles (rows of at most BS_WAVE columns) leave the one-tile jobs: four of them share a workgroup, one wavefront each
-    // (kernels.hip, backsolve_wave_tile); heavy first, so the four of a pack are about equally long
-    P.nquad = 0;
-    if (h->tune.wavePacks) {
-        std::vector<int4> big, small;
-        for (const int4 &t : tiles) (tile_len(t) <= BS_WAVE ? small : big).push_back(t);
-        if (small.size() >= 8) {
-            while (small.size() % 4) small.push_back(make_int4(0, 0, 0, 0));   // rows = 0: the wavefront leaves at once
-            P.nquad = (int)small.size() / 4;
-            tiles = big;
-            P.ntiles = (int)tiles.size();
-            tiles.insert(tiles.end(), small.begin(), small.end());
-        }
-    }
-    if (P.nquad == 0) P.ntiles = (int)tiles.size();
+    std::vector<int4> &tilesByPart = TP.tilesByPart, &ltilesByPart = TP.ltilesByPart, &ltiles = TP.ltiles;
+    std::vector<int2> &lworkByPart = TP.lworkByPart, &lwork = TP.lwork;
+    h->partTilePtr = TP.partTilePtr;
+    h->partLworkPtr = TP.partLworkPtr;
+    P.maxTileLen = TP.maxTileLen;
+    P.maxChunks = TP.maxChunks;
+    P.ntiles = TP.ntiles;
+    P.ntilesWide = TP.ntilesWide;
+    P.nquad = TP.nquad;
     if (h->tune.fuseLog)
-        fprintf(stderr, "dotmi: back-solve: %d one-tile jobs (%d wide), %d packs of four small tiles\n", P.ntiles, P.ntilesWide, P.nquad);
+        fprintf(stderr, "dotmi: back-solve: %d one-tile jobs (%d wide), %d packs of four small tiles%s\n", P.ntiles, P.ntilesWide,
+                P.nquad, TP.shallow ? ", shallow launch: long rows in 4-pass tiles" : "");
     P.nltiles = (int)ltiles.size();
     P.nlwork = (int)lwork.size();
     // merge lists (owned parts only)
@@ -1092,6 +987,59 @@ int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xr
         }
     }
     return 0;
+}
+
+// host-only: the job table of the back-solve launches dotmi_create builds for parts [p0, p1) of this mesh (bs_tiles.hpp) -- the
+// product's own planners (nd_choose_depth / nd_plan, plan_backsolve_tiles) on the caller's mesh, no device touched.
+// tiles: up to `cap` rows of 6 int32 {part (local), first row, rows, first column, tile index in the part, job}: job = index of
+// the launch's workgroup that runs the tile -- 0 .. n_wide-1 in the 512-thread launch, then 0 .. n_narrow-1 one-tile jobs of the
+// 256-thread launch, then n_narrow + k for the four tiles of pack k; tiles of the two-phase kernel (rows beyond 5120 columns)
+// have job = -1.  counts: {tiles, n_wide, n_narrow, n_packs, n_long, nmax, shallow launch (0 / 1), few-subdomains rule (0 / 1)}.
+int dotmi_plan_backsolve_tiles(int32_t nV, int32_t nT, const int32_t *T, const double *Xrest, const int32_t *epart, int32_t nParts,
+                               int32_t p0, int32_t p1, int32_t cap, int32_t *tiles, int32_t *counts)
+{
+    if (nV < 1 || nT < 1 || !T || !Xrest || !epart || nParts < 1 || p0 < 0 || p1 > nParts || p0 > p1 || !counts) return DOTMI_E_INVALID;
+    for (int e = 0; e < nT; ++e) {
+        if (epart[e] < 0 || epart[e] >= nParts) return DOTMI_E_INVALID;
+        for (int k = 0; k < 4; ++k)
+            if (T[4 * e + k] < 0 || T[4 * e + k] >= nV) return DOTMI_E_INVALID;
+    }
+    std::vector<int> adj_ptr, adj_idx;
+    build_adjacency(nV, nT, T, adj_ptr, adj_idx);
+    std::vector<std::vector<int>> allSets(nParts);
+    for (int e = 0; e < nT; ++e)
+        for (int k = 0; k < 4; ++k) allSets[epart[e]].push_back(T[4 * e + k]);
+    for (auto &v : allSets) {
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+    }
+    const Tuning tune = Tuning::from_env();
+    int levels = tune.ndLevels, minSplit = tune.ndMin;
+    if (levels < 0 && !getenv("DOTMI_ND_MIN")) nd_choose_depth(allSets, nV, adj_ptr, adj_idx, Xrest, BS_NARROW, minSplit, levels, minSplit);
+    else if (levels < 0) levels = nd_default_levels(allSets);
+    std::vector<std::vector<int>> sets(allSets.begin() + p0, allSets.begin() + p1);
+    std::vector<NdNode> tree;
+    std::vector<std::vector<std::vector<int>>> region;
+    const int nmax = nd_plan(sets, nV, adj_ptr, adj_idx, Xrest, levels, minSplit, tree, region);
+    BsTilePlan TP;
+    plan_backsolve_tiles(tree, [&](int k, int ls) { return 3 * (int)region[k][ls].size(); }, p1 - p0, nmax,
+                         BsTileRules{tune.tileRows, tune.tileRowsLong, tune.tilePasses, tune.wavePacks}, TP);
+    const int nN = TP.ntiles - TP.ntilesWide;
+    int n = 0;
+    auto put = [&](const int4 &t, int job) {
+        if (tiles && n < cap) {
+            int32_t *o = tiles + 6 * (size_t)n;
+            o[0] = t.x; o[1] = t.y; o[2] = t.z >> 16; o[3] = t.w; o[4] = t.z & 0xffff; o[5] = job;
+        }
+        ++n;
+    };
+    for (int j = 0; j < TP.ntiles; ++j) put(TP.tiles[j], j < TP.ntilesWide ? j : j - TP.ntilesWide);
+    for (int k = 0; k < 4 * TP.nquad; ++k)
+        if ((TP.tiles[TP.ntiles + k].z >> 16) > 0) put(TP.tiles[TP.ntiles + k], nN + k / 4);
+    for (const int4 &t : TP.ltiles) put(t, -1);
+    counts[0] = n; counts[1] = TP.ntilesWide; counts[2] = nN; counts[3] = TP.nquad; counts[4] = (int)TP.ltiles.size();
+    counts[5] = nmax; counts[6] = TP.shallow ? 1 : 0; counts[7] = TP.fewTiles ? 1 : 0;
+    return (tiles && n > cap) ? DOTMI_E_INVALID : 0;
 }
 
 // host-only: what one rank owns under dotmi_create's plan

@@ -230,6 +230,15 @@ int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pat
  * order as dotmi_plan_tile_schedule; dep_idx == NULL returns the count only. */
 int dotmi_plan_tile_deps(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0, int32_t eager_min,
                          int32_t eager_chunk, int64_t *dep_ptr, int64_t *dep_idx, int64_t *n_deps);
+/* (host only) the job table of the back-solve launches dotmi_create builds for parts [p0, p1) of this mesh: how the rows of every
+ * tree region are cut into tiles, which launch / kernel form takes them and which workgroup runs them (dot_amd/csrc/bs_tiles.hpp;
+ * the reference has no counterpart: CHOLMODSolver::solve, CHOLMODSolver.cpp:149-163, walks CHOLMOD's supernodes).  tiles: up to cap
+ * rows of 6 int32 {local part, first row, rows, first column, tile index in the part, job}; job = workgroup of its launch (wide
+ * launch: 0 .. n_wide-1; narrow launch: one-tile jobs 0 .. n_narrow-1, then n_narrow + k for the four tiles of pack k; -1: the
+ * two-phase kernel of rows beyond 5120 columns).  counts[8] = {tiles, n_wide, n_narrow, n_packs, n_long, nmax, shallow, few}.
+ * tiles may be NULL (counts only).  tests/test_host_logic.py */
+int dotmi_plan_backsolve_tiles(int32_t nV, int32_t nT, const int32_t *T, const double *Xrest, const int32_t *epart, int32_t nParts,
+                               int32_t p0, int32_t p1, int32_t cap, int32_t *tiles, int32_t *counts);
 int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xrest, const int32_t *epart,
                       int32_t nParts, int32_t p0, int32_t p1, int32_t levels, int32_t min_split,
                       int32_t node_cap, int32_t *nodes, int32_t *n_nodes, int32_t *nmax, int32_t *pos);

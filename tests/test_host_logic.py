@@ -562,3 +562,90 @@ def test_bench_source_id_is_stable_and_pmc_files_carry_it():
     import bench
     a, b = bench.source_id(), bench.source_id()
     assert a == b and len(a) == 12 and int(a, 16) >= 0
+
+
+# ---- the job table of the back-solve launches (dot_amd/csrc/bs_tiles.hpp; round 5) ---------------------------------------
+def _plan_bs_tiles(name, env=None):
+    import ctypes as C
+    from dot_amd import lib as dl
+    from dot_amd.sharding import plan_layout
+    from dot_amd.workloads import load_workload
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        sc, ep, n = load_workload(name)
+        L = dl.load()
+        T = np.ascontiguousarray(sc.T, dtype=np.int32)
+        X = np.ascontiguousarray(sc.V_rest, dtype=np.float64)
+        epa = np.ascontiguousarray(ep, dtype=np.int32)
+        counts = np.zeros(8, dtype=np.int32)
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        dp = X.ctypes.data_as(C.POINTER(C.c_double))
+        assert L.dotmi_plan_backsolve_tiles(X.shape[0], T.shape[0], ip(T), dp, ip(epa), n, 0, n, 0, None, ip(counts)) == 0
+        tiles = np.zeros((int(counts[0]), 6), dtype=np.int32)
+        assert L.dotmi_plan_backsolve_tiles(X.shape[0], T.shape[0], ip(T), dp, ip(epa), n, 0, n, tiles.shape[0], ip(tiles), ip(counts)) == 0
+        nodes, nmax, pos, verts = plan_layout(sc.V_rest, sc.T, ep, n)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    return tiles, dict(zip("tiles n_wide n_narrow n_packs n_long nmax shallow few".split(), (int(c) for c in counts))), nodes, nmax, pos, n
+
+
+@pytest.mark.parametrize("name", ["bar17K_twist", "monkey18K_stiff", "horse7K_stretch", "synbar:40x10x10:256", "kingkong18K_SS_1K"])
+def test_backsolve_job_table_covers_every_live_row_once_and_sorts_tiles_into_their_kernels(name):
+    """The product's own planner (dotmi_plan_backsolve_tiles = nd_choose_depth + nd_plan + plan_backsolve_tiles, host only):
+    every live row of every subdomain lies in exactly one tile, a tile stays inside one 64-row block of the factor storage and
+    starts at or right of its region's first column, tile indices of a part are 0 .. k-1, and every tile sits in the launch /
+    kernel form its row length asks for: packs of four (one wavefront each) up to 256 columns, the 256-thread kernel up to 3072,
+    the 512-thread kernel up to 5120, the two-phase kernel beyond; one-tile jobs heavy first, pack members at most four per job."""
+    tiles, c, nodes, nmax, pos, n = _plan_bs_tiles(name)
+    assert c["nmax"] == nmax and c["tiles"] == len(tiles)
+    part, r0, rows, cb, idx, job = tiles.T
+    ln = r0 + rows - cb
+    assert (rows >= 1).all() and (rows <= 64).all() and ((r0 % 64) + rows <= 64).all() and (cb >= 0).all() and (cb <= r0).all()
+    for p in range(n):
+        m = part == p
+        live = np.zeros(nmax, dtype=np.int32)
+        for q in pos[p]:
+            live[q:q + 3] += 1
+        cover = np.zeros(nmax, dtype=np.int32)
+        for a, k in zip(r0[m], rows[m]):
+            cover[a:a + k] += 1
+        assert np.array_equal(cover, live), (name, p)                     # every live row once, no padding row at all
+        assert sorted(idx[m]) == list(range(int(m.sum())))
+    nW, nN, nP = c["n_wide"], c["n_narrow"], c["n_packs"]
+    long_ = job < 0
+    assert long_.sum() == c["n_long"] and (ln[long_] > 5120).all() and (ln[~long_] <= 5120).all()
+    wide = (~long_) & (ln > 3072)
+    assert wide.sum() == nW and sorted(job[wide]) == list(range(nW))
+    packed = (~long_) & (~wide) & (job >= nN)
+    single = (~long_) & (~wide) & (job < nN)
+    assert sorted(job[single]) == list(range(nN))
+    if nP:
+        assert (ln[packed] <= 256).all() and (ln[single] > 256).all()
+        assert np.bincount(job[packed] - nN, minlength=nP).max() <= 4 and len(np.unique(job[packed])) == nP
+    else:
+        assert packed.sum() == 0
+    work = (rows * (r0 + 64 - cb)).astype(np.int64)
+    order = np.argsort(job[single], kind="stable")
+    assert (np.diff(work[single][order]) <= 0).all()                      # heavy first: the hardware starts jobs in index order
+
+
+def test_backsolve_job_table_reproduces_the_launches_measured_on_the_gpu():
+    """Counts the -DBS_PROFILE build printed on the device (profiles/r05_backsolve_tiles.txt) from the host-only planner: bar17K on
+    its three-level layout = 469 one-tile jobs (212 root tiles of 32 rows: the 4-pass rule of a shallow launch) + 199 packs = 668
+    workgroups; without packs and with 64-row tiles 1163; the stiff monkey 394 + 231 = 625; horse7K / 8 keeps the few-subdomains
+    rule and two levels; the switches select what they say."""
+    _, c, _, nmax, _, _ = _plan_bs_tiles("bar17K_twist")
+    assert (nmax, c["n_wide"], c["n_narrow"], c["n_packs"], c["shallow"], c["few"]) == (2944, 0, 469, 199, 1, 0)
+    t, c, *_ = _plan_bs_tiles("bar17K_twist", {"DOTMI_WAVE_PACKS": "0", "DOTMI_TILE_PASSES": "8"})
+    assert (c["n_narrow"], c["n_packs"], c["shallow"]) == (1163, 0, 0)
+    assert int(((t[:, 1] + t[:, 2] - t[:, 3]) > 2560).sum()) == 110          # the root-separator tiles that ran the whole launch
+    _, c, *_ = _plan_bs_tiles("bar17K_twist", {"DOTMI_TILE_PASSES": "8"})
+    assert (c["n_narrow"], c["n_packs"]) == (367, 199)                         # 566 workgroups: packs alone
+    _, c, *_ = _plan_bs_tiles("bar17K_twist", {"DOTMI_ND_LEVELS": "2"})
+    assert c["nmax"] == 2368                                                    # round 4's two-level layout
+    _, c, _, nmax, _, _ = _plan_bs_tiles("monkey18K_stiff")
+    assert (nmax, c["n_narrow"] + c["n_packs"], c["n_packs"], c["shallow"]) == (1664, 625, 231, 1)
+    _, c, _, nmax, _, _ = _plan_bs_tiles("horse7K_stretch")
+    assert (nmax, c["few"], c["shallow"]) == (3456, 1, 0)
