@@ -68,7 +68,10 @@ def _worker(rank, world, initfile, outdir, workload, shard_elems, steps):
 CASES = [("bunny5K_LTSS", 4, "0", 2), ("bunny5K_LTSS", 4, "1", 2), ("horse7K_stretch", 4, "0", 2),
          ("horse7K_stretch", 4, "1", 2), ("monkey18K_stiff", 1, "0", 2), ("synbar:40x10x10:32", 2, "1", 4),
          ("bunny5K_LTSS", 4, "owner", 2), ("horse7K_stretch", 4, "owner", 2), ("bar17K_twist", 2, "owner", 4),
-         ("synbar:40x10x10:32", 2, "owner", 4), ("monkey18K_stiff", 1, "owner", 3)]
+         ("synbar:40x10x10:32", 2, "owner", 4), ("monkey18K_stiff", 1, "owner", 3),
+         # eight ranks, what `bench.py --gpus 8` hands a node: bunny5K / 8 leaves every rank ONE subdomain, bar17K / 32 four
+         ("bunny5K_LTSS", 3, "0", 8), ("bar17K_twist", 2, "0", 8), ("bar17K_twist", 2, "owner", 8),
+         ("synbar:40x10x10:32", 2, "1", 8), ("synbar:40x10x10:32", 2, "owner", 8)]
 
 
 @pytest.mark.parametrize("workload,steps,shard_elems,world", CASES)
