@@ -517,7 +517,7 @@ int build_device_mesh(dotmi_handle *h)
         // keeps 4 / 4)
         const bool tiny = (long long)P.nParts * nt <= 320;
         const int eagerMin = h->tune.tileEagerMin > 0 ? h->tune.tileEagerMin : (tiny ? 2 : P.nParts <= 64 ? 4 : 8);
-        const int eagerChunk = h->tune.tileEagerChunk > 0 ? h->tune.tileEagerChunk : (tiny ? 2 : P.nParts <= 64 ? 4 : 8);
+        const int eagerChunk = tiny ? 2 : P.nParts <= 64 ? 4 : 8;   // early products per eager task
         // the last task of a Q tile (sum, then the multiplication with -Q_jj): up to 64 subdomains it keeps ONE early product and
         // hands the others to a task that runs beside DIAG(j) -- the launch between two diagonal launches is then as short as
         // before round 5 (bar17K 1.125 -> 1.077 ms); above, where every launch is several rounds of workgroups, it keeps them
@@ -1286,12 +1286,13 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         HIPCHECK(h, hipMemsetAsync(h->HvalOwn, 0, sizeof(double) * 9 * h->M.nnzb, h->st));
     }
     if (int rc = dalloc(h, &h->partE, (size_t)2 * ELEM_NB_MAX)) return rc;
+    if (int rc = dalloc(h, &h->partE2, (size_t)2 * ELEM_NB_MAX)) return rc;
     double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG, &h->partGR, &h->partGC};
     for (double **pp : parts) {
         if (int rc = dalloc(h, pp, (size_t)NB_RED * RED_K)) return rc;
         HIPCHECK(h, hipMemsetAsync(*pp, 0, sizeof(double) * NB_RED * RED_K, h->st));
     }
-    if (int rc = dalloc(h, &h->alpha_dev, 8)) return rc;
+    if (int rc = dalloc(h, &h->alpha_dev, 8)) return rc;   // (dalloc counts doubles: [0] the trial's step, [1] a paired trial's full step)
     if (int rc = dalloc(h, &h->gstage, (size_t)n + 2)) return rc;
     HIPCHECK(h, hipMemsetAsync(h->gstage, 0, sizeof(double) * ((size_t)n + 2), h->st));
     HIPCHECK(h, hipHostMalloc((void **)&h->h_partE, sizeof(double) * 2 * ELEM_NB_MAX));

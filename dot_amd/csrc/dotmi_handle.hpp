@@ -85,10 +85,11 @@ struct Tuning {
                               //                         default: where a level holds fewer tasks than the GPU holds workgroups
     int tileFlowWaitMs = 2000;   // DOTMI_TILE_FLOW_WAIT_MS  a task that waits longer for one of its dependencies gives up (error)
     int tileEagerMinRmul = -1; // DOTMI_TILE_EAGER_MIN_RMUL early products the last task of a Q tile may keep (-1: as the others; 0: none)
-    int tileEagerChunk = 0;   // DOTMI_TILE_EAGER_CHUNK early products per eager tile task
     bool fuseDir = true;      // DOTMI_FUSE_DIR=0     (early order) build_p and spmv_dots as two launches instead of one on cached H s_j
     bool fuseStep = true;     // DOTMI_FUSE_STEP=0    (early order) step_forward as a launch of its own instead of inside the element pass
     bool earlyAbort = true;   // DOTMI_EARLY_ABORT=0  (ablation) speculative back-solves run to their end even when the trial is rejected
+    int pairTrials = -1;      // DOTMI_PAIR_TRIALS    -1 (default): paired line-search trials (StepArgs::pairBlocks) in a step whose predecessor
+                              //                      halved in at least a tenth of its iterations; 1: in every step; 0: never
     bool earlyHold = true;    // DOTMI_EARLY_HOLD=0   the back-solve of a trial that is expected to be rejected still starts speculatively
     int earlyBs = 2;          // DOTMI_EARLY_BACKSOLVE 0: the back-solve after the controller, on q; 1: speculatively on the trial
                               //                      gradient with the controller inside its launch, in the steps where
@@ -123,10 +124,10 @@ struct Tuning {
         t.fastDiag = geti("DOTMI_FAST_DIAG", 1);
         t.tileFlowWaitMs = std::max(1, geti("DOTMI_TILE_FLOW_WAIT_MS", 2000));
         t.tileEagerMinRmul = geti("DOTMI_TILE_EAGER_MIN_RMUL", -1);
-        t.tileEagerChunk = std::max(0, geti("DOTMI_TILE_EAGER_CHUNK", 0));
         t.earlyBs = geti("DOTMI_EARLY_BACKSOLVE", 2) != 0 ? 2 : 0;   // (1, round 3's per-step rule, now means "on")
         t.earlyAbort = geti("DOTMI_EARLY_ABORT", 1) != 0;
         t.earlyHold = geti("DOTMI_EARLY_HOLD", 1) != 0;
+        t.pairTrials = geti("DOTMI_PAIR_TRIALS", -1);
         t.fuseStep = geti("DOTMI_FUSE_STEP", 1) != 0;
         t.fuseDir = geti("DOTMI_FUSE_DIR", 1) != 0;
         return t;
@@ -216,6 +217,10 @@ struct dotmi_handle {
     double *u_old = nullptr, *MY[HIST_MAX + 1] = {nullptr};
     double *HS[HIST_MAX + 1] = {nullptr};   // H s_i of the stored pairs (fused direction kernel of the early order)
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
+    double *partE2 = nullptr;   // paired trials: the energy partials of the full step
+    bool pairNow = false;       // this step's slots launch the element pass twice as wide (enqueue_loop_slot_early)
+    int pairSlots = 0, pairRedo = 0;
+    int pairState[3] = {1, 1, 1};   // DevLoop::pairCtr, carried from step to step
     double *gstage = nullptr;   // sharded element pass, device loop: [g (n) ; 0 ; E] staging buffer of the gradient all-reduce
     double *zstage = nullptr;   // sharded subdomains, early order: this rank's undivided partial merge, all-reduced in place
     // owner exchange (DOTMI_FLAG_OWNER_EXCHANGE)

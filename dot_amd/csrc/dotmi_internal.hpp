@@ -136,6 +136,8 @@ __host__ __device__ inline double chunked_sum(int n, Get get)
     return tot;
 }
 
+__host__ __device__ inline int pair_band(double a0) { return a0 < 0.7 ? 0 : (a0 < 0.9 ? 1 : 2); }
+
 struct XiArgs {
     double xi[HIST_MAX];
 };
@@ -172,8 +174,18 @@ struct DevLoop {
     // the controller; they wait for its verdict (holdVerdict = 2 * slot + (rejected or last iterate)) and leave at once
     // when it is a rejection.  The expectation is what happened to the last trial of the same kind (first trial of an
     // iteration / retry after a halving), kept by the controller; holdNext is its forecast for the slot that follows.
-    int holdEnable, holdNext, holdVerdict, padHold;
+    int holdEnable, holdNext, holdVerdict;
+    // Paired trial: the slot evaluated alpha_0 / 2 in full and the energy at alpha_0.  alpha_0 rejected (as expected): the
+    // controller goes on with the half step as if a retry slot had run.  alpha_0 acceptable: redo = 1, the next slot evaluates
+    // alpha_0 in full as a plain trial (phase 1, alpha = alpha_0) and keeps the statistics of a first trial.
+    int redo;
     int heldSlots, heldRejected;   // slots whose tiles were told to wait / of those, rejected (statistics)
+    int pairSlots, pairRedo;       // paired slots / of those, the ones whose full step was acceptable (statistics)
+    // is "alpha_0 < 1" a sign of a rejection on THIS workload?  Learned from every first trial with alpha_0 < 1, paired or not:
+    // one saturating counter (0 .. 3) per band of alpha_0 (< 0.7, < 0.9, < 1); the element pass pairs when the band's counter
+    // is 3 (stiff monkey: nine in ten such trials are rejected; refined horse, early steps: one in three -- there a redone
+    // slot costs more than a saved retry, so the rule has to be sure)
+    int pairCtr[3], pairPad;
     // two-level forecast per kind of trial (0: first trial of an iteration, 1: retry): the last two outcomes of the kind
     // select one of four saturating counters (0 .. 3, >= 2 forecasts a rejection) -- a plain "same as last time" is wrong
     // every time on the alternating pattern stiff steps show (measured: profiles/r04_hold.txt)
@@ -195,6 +207,7 @@ struct CtlArgs {
     int *flags_host;
     int nbE;
     int init;   // the evaluation at the start of the step (nothing to decide yet)
+    const double *partE2 = nullptr;   // paired trial: the energy partials of the full step (StepArgs::partials2)
 };
 
 // ---- kernel launchers (kernels.hip) --------------------------------------------------------------
@@ -211,8 +224,13 @@ void launch_step_forward(int n, const double *x0, const double *p, double *x, co
 // (alpha from the SpMV partials as in launch_step_forward) instead of by a launch of its own
 struct StepArgs {
     const double *p, *spmv_partials;
-    double *alpha_out;
+    double *alpha_out;       // [0] the step of the trial the gather and the controller work on, [1] paired trial: the full step (else 0)
     double alpha_min;
+    // Paired trial (DOTMI_PAIR_TRIALS, elem_patch_kernel): pairBlocks > 0 = the launch has 2 x pairBlocks workgroups; when the
+    // step estimate alpha_0 is below 1 -- the first trial is then rejected nine times out of ten on back-tracking workloads --
+    // the first half evaluates alpha_0 / 2 in full and the second half the ENERGY at alpha_0 (partials2), in one slot
+    int pairBlocks = 0;
+    double *partials2 = nullptr;
 };
 void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, double dtSq, const double *x,
                              const double *xt, int v0, int v1, int grad, double *partials, int *nblocks_out,

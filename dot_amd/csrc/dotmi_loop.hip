@@ -160,7 +160,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     // (owner exchange: the inertia loop runs over every vertex with the owner's share of the mass, so the fused form writes the
     // whole trial point there too -- x + alpha 0 off the held vertices)
     if (h->tune.fuseStep && (!se || ow)) {   // the step x_trial = x_cur + alpha p inside the element pass
-        StepArgs sa{h->p, spart, h->alpha_dev, h->alphaMin};
+        StepArgs sa{h->p, spart, h->alpha_dev, h->alphaMin, h->pairNow ? 1 : 0, h->partE2};
         launch_elem_energy_grad(ow ? h->Mown : h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, ow ? 0 : h->v0,
                                 ow ? h->nV : h->v1, 1, h->partE, &nb, h->st, h->ctl, &sa);
     } else {
@@ -228,7 +228,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size() &&
                        (h->timeCount++ % h->timeStride) == 0;
     h->slotTimed.push_back(timed ? h->evUsed : -1);
-    CtlArgs ca{h->ctl, ctlE, ctlR, h->alpha_dev, h->h_flags, nb, 0};
+    CtlArgs ca{h->ctl, ctlE, ctlR, h->alpha_dev, h->h_flags, nb, 0, h->pairNow ? h->partE2 : nullptr};
     launch_gemv(h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr, &ca,
                 h->tune.earlyAbort ? (int)h->slotTimed.size() /* the slot's epoch, 1-based */ : (1 << 30) /* never stopped */);
     if (timed) h->evUsed += 2;
@@ -339,6 +339,10 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     // (Round 3's per-step rule from the previous step's counts, DOTMI_EARLY_BACKSOLVE=1, is gone: with the stop and the held
     // launches the early order is at least as fast on every workload, and the owner exchange has no other order -- ADVICE r04.)
     h->earlyNow = h->earlyBs;
+    // paired trials: one rank, the fused step inside the element pass, the early order with held launches (the tiles of a paired
+    // slot wait for the verdict); -1: only in steps that follow a step with halvings in at least a tenth of its iterations
+    h->pairNow = h->earlyNow && !h->dist && h->tune.fuseStep && h->tune.fuseDir && h->tune.earlyAbort && h->tune.earlyHold &&
+                 (h->tune.pairTrials > 0 || (h->tune.pairTrials < 0 && h->prevIters > 0 && 10 * h->prevHalv >= h->prevIters));
     C.iterCap = h->iterCap;
     C.hist = h->hist;
     C.tol = h->targetGRes;
@@ -358,6 +362,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     // the forecast carries over from the last step (a function of the handle's own history)
     memcpy(C.predHist, h->predState, sizeof(int) * 2);
     memcpy(&C.predCtr[0][0], h->predState + 2, sizeof(int) * 8);
+    memcpy(C.pairCtr, h->pairState, sizeof(int) * 3);
     C.log_alpha = h->dlog;
     C.log_E = h->dlog + h->logCap;
     C.log_g2 = h->dlog + 2 * (size_t)h->logCap;
@@ -537,8 +542,13 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     h->prevHalv = C.halvings;
     memcpy(h->predState, C.predHist, sizeof(int) * 2);
     memcpy(h->predState + 2, &C.predCtr[0][0], sizeof(int) * 8);
+    memcpy(h->pairState, C.pairCtr, sizeof(int) * 3);
     h->heldSlots = C.heldSlots;
     h->heldRejected = C.heldRejected;
+    h->pairSlots = C.pairSlots;
+    h->pairRedo = C.pairRedo;
+    if (h->tune.fuseLog && C.pairSlots)
+        fprintf(stderr, "dotmi: paired trials: %d slots, %d of them redone (the full step was acceptable)\n", C.pairSlots, C.pairRedo);
     *failed = C.status == 3;
     *lastE = C.E_cur;
     *g2 = C.g2_cur;
@@ -863,8 +873,12 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         st->factor_flops = h->factorFlops;
         st->backsolve_launches = it;
         st->backsolve_stopped = (h->devLoop && h->earlyNow) ? (h->numLineSearch - ls0) + 1 : 0;
+        // (a paired slot whose full step was rejected takes a halving without a stopped launch; one that is redone stops without one)
+        if (h->devLoop && h->pairNow) st->backsolve_stopped += 2 * h->pairRedo - h->pairSlots;
         st->backsolve_held = (h->devLoop && h->earlyNow) ? h->heldSlots : 0;
         st->backsolve_held_rejected = (h->devLoop && h->earlyNow) ? h->heldRejected : 0;
+        st->paired_slots = (h->devLoop && h->pairNow) ? h->pairSlots : 0;
+        st->paired_redone = (h->devLoop && h->pairNow) ? h->pairRedo : 0;
         for (int k = 0; k + 1 < h->evArUsed; k += 2) {
             float ms = 0;
             hipEventElapsedTime(&ms, h->evAr[k], h->evAr[k + 1]);

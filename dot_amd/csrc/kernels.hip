@@ -88,6 +88,10 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
         x = fuse ? ctl->x_cur : ctl->x_trial;
         x_out = ctl->x_trial;
     }
+    // paired trial (StepArgs::pairBlocks): the launch is twice as wide; workgroup nbP + b mirrors workgroup b on the FULL step
+    const int nbP = (fuse && sa.pairBlocks > 0) ? sa.pairBlocks : (int)gridDim.x;
+    const bool second = (int)blockIdx.x >= nbP;
+    const int bIdx = second ? (int)blockIdx.x - nbP : (int)blockIdx.x;
     double pgv[NB_RED / 64], pHpv[NB_RED / 64];
     const bool usePart = fuse && ctl->phase == 0;   // a retry steps with the halved alpha the controller left
     if (usePart && threadIdx.x < 64) {              // requested here, summed after this thread's other loads are out
@@ -114,8 +118,14 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
                 a = fmax(sa.alpha_min, fmin(1.0, -pg / pHp));  // Optimizer.cpp:1085
             }
             if (threadIdx.x == 0) {
-                sh_alpha = a;
-                if (blockIdx.x == 0) *sa.alpha_out = a;
+                // paired: alpha_0 < 1 (the quadratic model's minimum lies inside the unit step) -- the full step's energy
+                // from the second half of the launch, the half step in full from the first
+                const bool pair = sa.pairBlocks > 0 && usePart && a < 1.0 && a / 2.0 > 0.0 && ctl->pairCtr[pair_band(a)] >= 3;
+                sh_alpha = pair ? (second ? a : a / 2.0) : (second ? -1.0 : a);
+                if (blockIdx.x == 0) {
+                    sa.alpha_out[0] = pair ? a / 2.0 : a;
+                    if (sa.pairBlocks > 0) sa.alpha_out[1] = pair ? a : 0.0;
+                }
             }
         }
         __syncthreads();
@@ -132,8 +142,8 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
     const size_t strideA = (size_t)PT.nPatches * PE;
     double acc = 0.0;  // sum vol * Psi
     // inertia operands of this thread's first vertex: independent of the element work, requested ahead of it
-    const int gstride = gridDim.x * blockDim.x;
-    const int vfirst = v0 + blockIdx.x * blockDim.x + tid;
+    const int gstride = nbP * blockDim.x;
+    const int vfirst = v0 + bIdx * blockDim.x + tid;
     double ix[3] = {0, 0, 0}, ixt[3] = {0, 0, 0}, ip[3] = {0, 0, 0}, im = 0.0;
     if (vfirst < v1) {
 #pragma unroll
@@ -193,18 +203,18 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
     PatchOps cur, nxt;
     int nvN = 0, gidN = -1, slotN = 0;   // ids of the patch after next
     unsigned short cpN = 0;
-    if ((int)blockIdx.x < PT.nPatches) {
-        issue_ids(blockIdx.x, cur);
-        issue_ops(blockIdx.x, cur);
+    if (bIdx < PT.nPatches) {
+        issue_ids(bIdx, cur);
+        issue_ops(bIdx, cur);
         issue_pos(cur);
-        if (PIPE && (int)(blockIdx.x + gridDim.x) < PT.nPatches) issue_ids(blockIdx.x + gridDim.x, nxt);
+        if (PIPE && bIdx + nbP < PT.nPatches) issue_ids(bIdx + nbP, nxt);
     }
-    for (int p = blockIdx.x; p < PT.nPatches; p += gridDim.x) {
+    for (int p = bIdx; p < PT.nPatches; p += nbP) {
         // PIPE: the instantiation for meshes whose workgroups walk several patches (the prefetched set costs ~50 registers,
         // which the one-patch-per-workgroup meshes keep for occupancy)
-        const int pn = p + gridDim.x, pn2 = pn + gridDim.x;
+        const int pn = p + nbP, pn2 = pn + nbP;
         const bool more = PIPE && pn < PT.nPatches, more2 = PIPE && pn2 < PT.nPatches;
-        if (!PIPE && p != (int)blockIdx.x) {
+        if (!PIPE && p != bIdx) {
             issue_ids(p, cur);
             issue_ops(p, cur);
             issue_pos(cur);
@@ -224,7 +234,10 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
             for (int lv = tid + 256; lv <= nv; lv += 256) cptr[lv] = cp[lv];
             for (int lv = tid + 256; lv < nv; lv += 256) vslot[lv] = PT.pv_slot[vb + lv];
         }
-        if (fuse && !haveAlpha) finish_alpha();
+        if (fuse && !haveAlpha) {
+            finish_alpha();
+            if (second && alpha < 0.0) return;   // (the whole workgroup: not a paired slot)
+        }
         if (cur.gid0 >= 0) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) xs[3 * tid + d] = fuse ? cur.xv[d] + alpha * cur.pv[d] : cur.xv[d];
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
                                   F.m[2][0] * F.m[2][0] + F.m[2][1] * F.m[2][1] + F.m[2][2] * F.m[2][2];
                 const double JmA = J - (1.0 + m[u] / l[u]);
                 acc += (m[u] * (ic - 3.0) + l[u] * JmA * JmA) / 2.0 * vo[u];
-                if (GRAD) {
+                if (GRAD && !second) {
                     const double t = l[u] * JmA;
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
@@ -292,7 +305,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
                 double S[3];
                 svd3(F, U, S, V);
                 acc += psi<MAT>(S, m[u], l[u]) * vo[u];
-                if (GRAD) {
+                if (GRAD && !second) {
                     double d[3];
                     dpsi<MAT>(S, m[u], l[u], d);
 #pragma unroll
@@ -303,7 +316,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
                                            U.m[r][2] * d[2] * V.m[c][2]);
                 }
             }
-            if (GRAD) {
+            if (GRAD && !second) {
                 double g[12];
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
                 }
             }
         }
-        if (GRAD) {
+        if (GRAD && !second) {
             __syncthreads();
             EP_STAMP(2);
             // one lane per (vertex, component): a contiguous run of LDS, four entries in flight, added in run order
@@ -354,13 +367,16 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
     }
     // inertia: sum_v 1/2 m_v |x_v - x~_v|^2 over this rank's vertex slice
     double ine = 0.0;
-    if (fuse && !haveAlpha) finish_alpha();   // (a workgroup without a patch)
+    if (fuse && !haveAlpha) {   // (a workgroup without a patch)
+        finish_alpha();
+        if (second && alpha < 0.0) return;
+    }
     if (vfirst < v1) {
         if (fuse) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 ix[d] = ix[d] + alpha * ip[d];
-                x_out[3 * vfirst + d] = ix[d];
+                if (!second) x_out[3 * vfirst + d] = ix[d];
             }
         }
         const double dx = ix[0] - ixt[0], dy = ix[1] - ixt[1], dz = ix[2] - ixt[2];
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
             xv[d] = x[3 * v + d];
             if (fuse) {
                 xv[d] = xv[d] + alpha * sa.p[3 * v + d];
-                x_out[3 * v + d] = xv[d];
+                if (!second) x_out[3 * v + d] = xv[d];
             }
         }
         const double dx = xv[0] - xt[3 * v], dy = xv[1] - xt[3 * v + 1], dz = xv[2] - xt[3 * v + 2];
@@ -388,8 +404,9 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
     }
     __syncthreads();
     if (tid == 0) {
-        partials[2 * blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);      // to be scaled by dtSq by the consumer
-        partials[2 * blockIdx.x + 1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+        double *out = second ? sa.partials2 : partials;
+        out[2 * bIdx] = (sm[0] + sm[1]) + (sm[2] + sm[3]);      // to be scaled by dtSq by the consumer
+        out[2 * bIdx + 1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
     }
     EP_STAMP(4);
 }
@@ -400,6 +417,7 @@ void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, do
 {
     StepArgs sa{nullptr, nullptr, nullptr, 0.0};
     if (step && ctl) sa = *step;
+    const bool paired = sa.p && sa.pairBlocks != 0 && grad;
     // at most elem_wg_cap() workgroups take the patches (as many as are resident at once): beyond that a workgroup walks several
     // patches and prefetches the next one's operands (elem_patch_kernel)
     // (the instantiation with the step inside: two per CU; a handle whose loop uses it fixes 512 for all of them, PT.wgCap)
@@ -411,22 +429,24 @@ void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, do
     if (nb > ELEM_NB_MAX) nb = ELEM_NB_MAX;
     if (nb < 1) nb = 1;
     *nblocks_out = nb;
+    sa.pairBlocks = paired ? nb : 0;
+    const int nbLaunch = paired ? 2 * nb : nb;
     const int ept = PT.PE / 256;
     const size_t shm = sizeof(double) * ((size_t)3 * PT.PV + (grad ? (size_t)12 * PT.PE : 0)) +
                        (grad ? 2 * (size_t)((PT.PV + 1 + 3) & ~3) + 4 * (size_t)PT.PV : 0);
 #define DM_LAUNCH(MATV, GRADV, EPTV)                                                                            \
     do {                                                                                                            \
         if (sa.p && pipe)                                                                                           \
-            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, true, true>), dim3(nb), dim3(256), shm, st, PT, M.mass, \
+            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, true, true>), dim3(nbLaunch), dim3(256), shm, st, PT, M.mass, \
                                x, xt, v0, v1, dtSq, partials, ctl, sa);                                             \
         else if (sa.p)                                                                                              \
-            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, true, false>), dim3(nb), dim3(256), shm, st, PT, M.mass, \
+            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, true, false>), dim3(nbLaunch), dim3(256), shm, st, PT, M.mass, \
                                x, xt, v0, v1, dtSq, partials, ctl, sa);                                             \
         else if (pipe)                                                                                              \
-            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, false, true>), dim3(nb), dim3(256), shm, st, PT, M.mass, \
+            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, false, true>), dim3(nbLaunch), dim3(256), shm, st, PT, M.mass, \
                                x, xt, v0, v1, dtSq, partials, ctl, sa);                                             \
         else                                                                                                        \
-            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, false, false>), dim3(nb), dim3(256), shm, st, PT, M.mass, \
+            hipLaunchKernelGGL((elem_patch_kernel<MATV, GRADV, EPTV, false, false>), dim3(nbLaunch), dim3(256), shm, st, PT, M.mass, \
                                x, xt, v0, v1, dtSq, partials, ctl, sa);                                             \
     } while (0)
 #define DM_LAUNCH_E(MATV, GRADV)      \
@@ -1284,7 +1304,7 @@ __device__ __forceinline__ void backsolve_wave_tile(const int4 jb, const int *__
 
 __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, const double *__restrict__ partE, int nbE,
                                   const double *__restrict__ partR, const double *__restrict__ alpha_dev,
-                                  int *__restrict__ flags_host, int init);
+                                  int *__restrict__ flags_host, int init, const double *__restrict__ partE2 = nullptr);
 
 // the tile of job[jobIdx] by the calling workgroup
 template <int THREADS>
@@ -1385,11 +1405,13 @@ __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__res
     __shared__ double2 rs[2 * 256 * 6];
     // (which workgroup hosts the controller makes no difference: index 0 / 256 / 520 / last measured 47.0-47.5 us)
     if (blockIdx.x == 0) {
-        loop_control_body(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init);
+        loop_control_body(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init, ca.partE2);
         return;
     }
     if (ca.ctl->status != 0) return;
-    if (epoch < (1 << 30) && ca.ctl->holdNext) {
+    // (a paired slot -- alpha_dev[1] > 0, written by the element pass of this slot -- waits as well: its gather worked on the half
+    // step, which only counts if the controller finds the full step's energy too high)
+    if (epoch < (1 << 30) && (ca.ctl->holdNext || (ca.partE2 && ca.alpha_dev[1] > 0.0))) {
         // the trial is expected to be rejected (DevLoop::holdNext): wait for the controller's verdict instead of streaming
         // the factors beside it -- a rejection then costs the controller's ~7 us, not a stopped back-solve's ~20.  (A
         // workgroup that starts after the controller has stored its forecast for the NEXT slot reads that one: the verdict
@@ -3333,7 +3355,7 @@ void launch_step_forward(int n, const double *x0, const double *p, double *x, co
 // (a device function: the controller is a launch of its own, or workgroup 0 of the back-solve launch -- 256 threads)
 __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, const double *__restrict__ partE, int nbE,
                                   const double *__restrict__ partR, const double *__restrict__ alpha_dev,
-                                  int *__restrict__ flags_host, int init)
+                                  int *__restrict__ flags_host, int init, const double *__restrict__ partE2)
 {
     static_assert(sizeof(DevLoop) % 8 == 0, "DevLoop is copied as 8-byte words");
     static_assert(RED_K <= 32, "two passes of 16 columns");
@@ -3348,6 +3370,8 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
         for (int i = t; i < NW8; i += 256) dst[i] = src[i];
     }
     const double alpha_in = *alpha_dev;
+    const double alpha_full = (partE2 && !init) ? alpha_dev[1] : 0.0;   // > 0: a paired slot (elem_patch_kernel)
+    __shared__ double chunk2[2][SUM_CHUNKS];
     // chunked_sum() order (dotmi_internal.hpp), one thread per (column, chunk): every load of the kernel is in flight at
     // once and the dependent add chains are 16 long instead of NB_RED long.  The column index runs fastest over the
     // lanes, so a load instruction touches a few 168-byte partial rows instead of 64 different ones.
@@ -3384,6 +3408,19 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
             }
             for (; k < k1; ++k) e += partE[2 * k + c];
             chunk[RED_K + c][ch] = e;
+            if (alpha_full > 0.0) {   // the same chunks of the full step's partials (same order: the same bits as a plain slot)
+                double e2 = 0.0;
+                int k2 = k0;
+                for (; k2 + 8 <= k1; k2 += 8) {
+                    double ve[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) ve[u] = partE2[2 * (k2 + u) + c];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) e2 += ve[u];
+                }
+                for (; k2 < k1; ++k2) e2 += partE2[2 * k2 + c];
+                chunk2[c][ch] = e2;
+            }
         }
         if (hasA) {
             double a = 0.0;
@@ -3416,12 +3453,58 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
     } else if (t == 0) {
         double alpha = alpha_in;
         const double E = C.dtSq * R[RED_K] + R[RED_K + 1];
-        C.evals++;
         if (C.slots < C.kindCap) C.slot_kind[C.slots] = C.phase == 0 ? 1 : 2;
         C.slots++;
-        const int kind = C.phase == 0 ? 0 : 1;   // first trial of an iteration / retry after a halving
-        C.heldSlots += C.holdNext;
-        if (E > C.E_cur && alpha > 0.0) {
+        int kind = (C.phase == 0 || C.redo) ? 0 : 1;   // first trial of an iteration / retry after a halving
+        // what a first trial with alpha_0 < 1 teaches the pairing rule (a redone trial has taught it already)
+        const double a0 = alpha_full > 0.0 ? alpha_full : alpha_in;
+        const bool learns = C.phase == 0 && a0 < 1.0;
+        C.redo = 0;
+        bool decided = false;
+        if (alpha_full > 0.0) {
+            // Paired slot: the energy of the FULL step first, as the reference's line search would see it
+            double ea = 0.0, ei = 0.0;
+#pragma unroll
+            for (int c = 0; c < SUM_CHUNKS; ++c) {
+                ea += chunk2[0][c];
+                ei += chunk2[1][c];
+            }
+            const double EA = C.dtSq * ea + ei;
+            C.pairSlots++;
+            {
+                int &pc = C.pairCtr[pair_band(alpha_full)];
+                pc = (EA > C.E_cur) ? min(3, pc + 1) : max(0, pc - 1);
+            }
+            if (!(EA > C.E_cur)) {
+                // the full step is acceptable: the slot's gradient belongs to the half step and is of no use.  The next slot
+                // evaluates the full step as a plain trial (its energy is counted there); nothing else has happened
+                C.pairRedo++;
+                C.abortEpoch = C.slots;
+                __hip_atomic_store(&ctl->abortEpoch, C.slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                C.holdVerdict = 2 * C.slots + 1;
+                __hip_atomic_store(&ctl->holdVerdict, C.holdVerdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                C.phase = 1;
+                C.alpha = alpha_full;
+                C.redo = 1;
+                decided = true;
+            } else {
+                // rejected: one halving; the trial in front of the controller is the retry with the half step
+                C.evals++;
+                C.halvings++;
+                int &ctr = C.predCtr[kind][C.predHist[kind] & 3];
+                ctr = min(3, ctr + 1);
+                C.predHist[kind] = ((C.predHist[kind] << 1) | 1) & 3;
+                kind = 1;
+            }
+        }
+        if (!decided) C.evals++;
+        C.heldSlots += (C.holdNext || alpha_full > 0.0) ? 1 : 0;
+        if (learns && alpha_full == 0.0) {
+            int &pc = C.pairCtr[pair_band(a0)];
+            pc = (E > C.E_cur && alpha > 0.0) ? min(3, pc + 1) : max(0, pc - 1);
+        }
+        if (decided) {
+        } else if (E > C.E_cur && alpha > 0.0) {
             // back-tracking (c1 = 0, lower bound 0)
             // a speculative back-solve on this trial's gradient may be running beside this workgroup: tell it to stop
             C.abortEpoch = C.slots;
@@ -3433,7 +3516,7 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
                 ctr = min(3, ctr + 1);
                 C.predHist[kind] = ((C.predHist[kind] << 1) | 1) & 3;
             }
-            C.heldRejected += C.holdNext;
+            C.heldRejected += (C.holdNext || alpha_full > 0.0) ? 1 : 0;
             alpha /= 2.0;
             C.halvings++;
             if (alpha == 0.0) {
@@ -3595,7 +3678,7 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
     // forecast for the slot that follows: hold its back-solve if its kind's counter for the current pattern says "rejected"
     if (t == 0 && !init) {
         const int nk = C.phase == 0 ? 0 : 1;
-        C.holdNext = (C.holdEnable && C.status == 0 && C.predCtr[nk][C.predHist[nk] & 3] >= 2) ? 1 : 0;
+        C.holdNext = (C.holdEnable && C.status == 0 && !C.redo && C.predCtr[nk][C.predHist[nk] & 3] >= 2) ? 1 : 0;
     }
     __syncthreads();
     {

@@ -56,7 +56,8 @@ class StepStats(C.Structure):
                 ("collective_calls", C.c_int64), ("collective_bytes", C.c_int64), ("ms_collective", C.c_double),
                 ("collective_timed", C.c_int64), ("collective_timed_bytes", C.c_int64),
                 ("backsolve_launches", C.c_int64), ("backsolve_stopped", C.c_int64),
-                ("backsolve_held", C.c_int64), ("backsolve_held_rejected", C.c_int64)]
+                ("backsolve_held", C.c_int64), ("backsolve_held_rejected", C.c_int64),
+                ("paired_slots", C.c_int64), ("paired_redone", C.c_int64)]
 
 
 # enum dotmi_bench_kind (include/dotmi.h)

@@ -181,6 +181,9 @@ typedef struct {
                                        (the trial was expected to be rejected: a two-level forecast from the outcomes of the earlier trials of its kind) */
     int64_t backsolve_held_rejected; /* ... and were rejected: these left without reading a factor (they are part of
                                        backsolve_stopped) */
+    int64_t paired_slots;           /* DOTMI_PAIR_TRIALS: slots that evaluated the half step in full and the energy of the full step
+                                       (the line search of Optimizer.cpp:806-833 with its first two trials in one launch) */
+    int64_t paired_redone;          /* ... whose full step was acceptable after all: evaluated again, in full, by the next slot */
 } dotmi_step_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

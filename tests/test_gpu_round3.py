@@ -84,7 +84,7 @@ def test_bench_kernel_entry_covers_every_kernel_class():
 
 
 @pytest.mark.parametrize("env", [{"DOTMI_PATCH_ELEMS": "512"}, {"DOTMI_TILE_EAGER_MIN_RMUL": "-1"}, {"DOTMI_TILE_EAGER_MIN_RMUL": "0"},
-                                 {"DOTMI_TILE_EAGER_MIN": "1000"}, {"DOTMI_TILE_EAGER_MIN": "1", "DOTMI_TILE_EAGER_CHUNK": "1"},
+                                 {"DOTMI_TILE_EAGER_MIN": "1000"}, {"DOTMI_TILE_EAGER_MIN": "1"}, {"DOTMI_PAIR_TRIALS": "1"},
                                  {"DOTMI_TILE_ROWS_LONG": "16"}, {"DOTMI_TILE_SPLIT": "1"}, {"DOTMI_EARLY_BACKSOLVE": "0"},
                                  {"DOTMI_EARLY_BACKSOLVE": "2"}, {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_FUSE_STEP": "0"},
                                  {"DOTMI_EARLY_BACKSOLVE": "2", "DOTMI_FUSE_DIR": "0"},

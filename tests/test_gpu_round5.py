@@ -89,3 +89,45 @@ def test_tile_packs_and_short_long_row_tiles_apply_the_same_preconditioner(workl
     po = orc.apply_precond(r)
     orc.close()
     assert np.abs(out["packs"] - po).max() <= 1e-9 * np.abs(po).max()
+
+
+# ---- paired line-search trials (DOTMI_PAIR_TRIALS) ---------------------------------------------------------
+@pytest.mark.parametrize("workload,steps", [("monkey18K_stiff", 2), ("bunny5K_LTSS", 14), ("horse7K_stretch", 8)])
+def test_paired_trials_take_the_same_steps_bit_for_bit(workload, steps, monkeypatch):
+    """A paired slot evaluates the half step in full and the ENERGY of the full step in one launch when alpha_0 < 1; the controller
+    then decides as the reference's line search would have (Optimizer.cpp:806-833: the full step first).  Whatever the rule pairs
+    or redoes, the trajectory is the unpaired one bit for bit: iterations, halvings, energy evaluations, energies, positions."""
+    import numpy as np
+    from tests.workloads import load_workload
+    from dot_amd.timestepper import DOTTimeStepper
+
+    def run(mode):
+        monkeypatch.setenv("DOTMI_PAIR_TRIALS", mode)
+        sc, ep, n = load_workload(workload)
+        ts = DOTTimeStepper(sc, ep, n)
+        rec, paired, redone, stopped = [], 0, 0, []
+        for _ in range(steps):
+            x = ts.getResult()
+            idx, pos = sc.scripter.step(x, sc.cfg.dt)
+            ts.setDirichlet(idx, pos)
+            st = ts.step()
+            rec.append((st.iters, st.ls_halvings, st.energy_evals, st.E))
+            paired += st.paired_slots
+            redone += st.paired_redone
+            stopped.append((st.backsolve_stopped, st.backsolve_launches))
+        x = ts.getResult().copy()
+        ts.close()
+        return rec, x, paired, redone, stopped
+
+    rec0, x0, p0, r0, s0 = run("0")
+    rec1, x1, p1, r1, s1 = run("1")
+    assert p0 == 0 and r0 == 0
+    assert rec1 == rec0
+    assert np.array_equal(x1, x0)
+    halvings = sum(r[1] for r in rec0)
+    print(f"{workload}: {sum(r[0] for r in rec0)} iterations, {halvings} halvings; paired slots {p1}, redone {r1}")
+    if workload == "monkey18K_stiff":
+        assert p1 >= 20 and r1 <= p1 // 3       # the rule finds its trials there, and is right about most of them
+    # a stopped launch per rejected trial that had a slot of its own, one per redone slot, one at the end of the step
+    for (st1, ln1), (it, hv, _, _) in zip(s1, rec1):
+        assert ln1 == it and 1 <= st1 <= hv + 1 + r1
