@@ -390,6 +390,11 @@ def main():
             # held_rejected: those of them that were rejected and left without streaming (part of launches_stopped)
             "launches_held": int(sum(s.backsolve_held for s in stats)),
             "launches_held_rejected": int(sum(s.backsolve_held_rejected for s in stats)),
+            # paired line-search trials: slots that evaluated alpha_0 / 2 in full and the energy of
+            # alpha_0 in one launch; redone: the full step was acceptable after all and took the next slot (paired slots wait
+            # like held ones and are counted among them)
+            "slots_paired": int(sum(getattr(s, "paired_slots", 0) for s in stats)),
+            "slots_paired_redone": int(sum(getattr(s, "paired_redone", 0) for s in stats)),
             "share_of_step_time": round(avg_ms * sum(s.backsolve_launches for s in stats) / (1e3 * elapsed), 3),
         }
         w = np.array(walls) * 1e3
