@@ -27,9 +27,10 @@ for s in range(steps):
         pr = orc.probe_direction(x, S, Y)
         p = pr["p"]
         pg = float((p * g).sum())
+        pHp = float((p * orc.spmv(p)).sum())
         rc = orc.step_iterate()
         a, e, g2 = orc.iter_log()
-        rows.append((s, it, pr["alpha0"], pr["E"], lastE, a[-1], e[-1], g2[-1], pg, len(S)))
+        rows.append((s, it, pr["alpha0"], pr["E"], lastE, a[-1], e[-1], g2[-1], pg, len(S), pHp))
         it += 1
         if rc != 0:
             break
