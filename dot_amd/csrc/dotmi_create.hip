@@ -1285,8 +1285,8 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         if (int rc = dalloc(h, &h->HvalOwn, (size_t)9 * h->M.nnzb)) return rc;
         HIPCHECK(h, hipMemsetAsync(h->HvalOwn, 0, sizeof(double) * 9 * h->M.nnzb, h->st));
     }
-    if (int rc = dalloc(h, &h->partE, (size_t)2 * ELEM_NB_MAX)) return rc;
-    if (int rc = dalloc(h, &h->partE2, (size_t)2 * ELEM_NB_MAX)) return rc;
+    if (h->tune.pairTrials != 0 && h->world == 1) warm_pair_unit();   // (the second code object, before the first step needs it)
+    if (int rc = dalloc(h, &h->partE, (size_t)4 * ELEM_NB_MAX)) return rc;   // (second half: a paired trial's full-step partials)
     double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG, &h->partGR, &h->partGC};
     for (double **pp : parts) {
         if (int rc = dalloc(h, pp, (size_t)NB_RED * RED_K)) return rc;

@@ -89,7 +89,7 @@ struct Tuning {
     bool fuseStep = true;     // DOTMI_FUSE_STEP=0    (early order) step_forward as a launch of its own instead of inside the element pass
     bool earlyAbort = true;   // DOTMI_EARLY_ABORT=0  (ablation) speculative back-solves run to their end even when the trial is rejected
     int pairTrials = -1;      // DOTMI_PAIR_TRIALS    -1 (default): paired line-search trials (StepArgs::pairBlocks) in a step whose predecessor
-                              //                      halved in at least a tenth of its iterations; 1: in every step; 0: never
+                              //                      halved in at least a quarter of its iterations; 1: in every step; 0: never
     bool earlyHold = true;    // DOTMI_EARLY_HOLD=0   the back-solve of a trial that is expected to be rejected still starts speculatively
     int earlyBs = 2;          // DOTMI_EARLY_BACKSOLVE 0: the back-solve after the controller, on q; 1: speculatively on the trial
                               //                      gradient with the controller inside its launch, in the steps where
@@ -217,7 +217,6 @@ struct dotmi_handle {
     double *u_old = nullptr, *MY[HIST_MAX + 1] = {nullptr};
     double *HS[HIST_MAX + 1] = {nullptr};   // H s_i of the stored pairs (fused direction kernel of the early order)
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
-    double *partE2 = nullptr;   // paired trials: the energy partials of the full step
     bool pairNow = false;       // this step's slots launch the element pass twice as wide (enqueue_loop_slot_early)
     int pairSlots = 0, pairRedo = 0;
     int pairState[3] = {1, 1, 1};   // DevLoop::pairCtr, carried from step to step

@@ -206,8 +206,8 @@ struct CtlArgs {
     const double *partE, *partR, *alpha_dev;
     int *flags_host;
     int nbE;
-    int init;   // the evaluation at the start of the step (nothing to decide yet)
-    const double *partE2 = nullptr;   // paired trial: the energy partials of the full step (StepArgs::partials2)
+    int init;   // bit 0: the evaluation at the start of the step (nothing to decide yet); bit 1: a step with paired trials -- the
+                // full step's energy partials follow partE at + 2 ELEM_NB_MAX, alpha_dev[1] > 0 marks a paired slot
 };
 
 // ---- kernel launchers (kernels.hip) --------------------------------------------------------------
@@ -225,16 +225,20 @@ void launch_step_forward(int n, const double *x0, const double *p, double *x, co
 struct StepArgs {
     const double *p, *spmv_partials;
     double *alpha_out;       // [0] the step of the trial the gather and the controller work on, [1] paired trial: the full step (else 0)
+    // alpha_min < 0: PAIRED launch (DOTMI_PAIR_TRIALS, elem_patch_kernel) with the lower bound -alpha_min -- twice as many
+    // workgroups; when the step estimate alpha_0 is below 1 -- the first trial is then rejected nine times out of ten on
+    // back-tracking workloads -- the first half evaluates alpha_0 / 2 in full and the second half the ENERGY at alpha_0, into the
+    // second half of the partials array (+ 2 ELEM_NB_MAX).  (Packed into the sign: every byte added to the kernel arguments of the
+    // loop's kernels showed up as time -- profiles/r05_paired_trials.txt F.)
     double alpha_min;
-    // Paired trial (DOTMI_PAIR_TRIALS, elem_patch_kernel): pairBlocks > 0 = the launch has 2 x pairBlocks workgroups; when the
-    // step estimate alpha_0 is below 1 -- the first trial is then rejected nine times out of ten on back-tracking workloads --
-    // the first half evaluates alpha_0 / 2 in full and the second half the ENERGY at alpha_0 (partials2), in one slot
-    int pairBlocks = 0;
-    double *partials2 = nullptr;
 };
 void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, double dtSq, const double *x,
                              const double *xt, int v0, int v1, int grad, double *partials, int *nblocks_out,
                              hipStream_t st, const DevLoop *ctl = nullptr, const StepArgs *step = nullptr);
+// the same launch from the unit compiled with -DDOTMI_PAIR_TU (kernels_pair.o): StepArgs::alpha_min < 0 makes it a paired launch
+void launch_elem_energy_grad_pair(const DevMesh &M, const DevPatches &PT, int mat, double dtSq, const double *x,
+                                  const double *xt, int v0, int v1, int grad, double *partials, int *nblocks_out,
+                                  hipStream_t st, const DevLoop *ctl = nullptr, const StepArgs *step = nullptr);
 // vertex gather of element gradients + inertia; optional L-BFGS pair + stats partials
 struct GatherArgs {
     const double *x, *xt, *g_old, *p, *alpha_dev;
@@ -277,6 +281,10 @@ void launch_build_q(int n, const double *g, const LbfgsArgs &L, const double *xi
 // (the back-solve is speculative: issued on the trial gradient before the controller has accepted the trial)
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
                  hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr, int spec = 0);
+void warm_pair_unit();   // (kernels_pair.o: loads its code object)
+// ... from kernels_pair.o: the controller that understands paired slots (CtlArgs::init bit 1)
+void launch_gemv_pair(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
+                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr, int spec = 0);
 // rpad_s[k] = q[dofmap_s[k]] with q = -g - sum_j xi_j y_j formed on the fly (same operations as build_q), 0 on padding
 // spec (device loop, early back-solve): 1: rpad = -g_cur, 2: rpad = -g_trial whatever the phase; no history terms
 void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, const double *xi_host, hipStream_t st,

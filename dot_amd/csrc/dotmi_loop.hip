@@ -160,9 +160,11 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     // (owner exchange: the inertia loop runs over every vertex with the owner's share of the mass, so the fused form writes the
     // whole trial point there too -- x + alpha 0 off the held vertices)
     if (h->tune.fuseStep && (!se || ow)) {   // the step x_trial = x_cur + alpha p inside the element pass
-        StepArgs sa{h->p, spart, h->alpha_dev, h->alphaMin, h->pairNow ? 1 : 0, h->partE2};
-        launch_elem_energy_grad(ow ? h->Mown : h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, ow ? 0 : h->v0,
-                                ow ? h->nV : h->v1, 1, h->partE, &nb, h->st, h->ctl, &sa);
+        StepArgs sa{h->p, spart, h->alpha_dev, h->pairNow ? -h->alphaMin : h->alphaMin};   // (negative: a paired launch)
+        // (a step with paired trials takes these two launches from the unit compiled for them, kernels_pair.o)
+        (h->pairNow ? launch_elem_energy_grad_pair : launch_elem_energy_grad)(
+            ow ? h->Mown : h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, ow ? 0 : h->v0, ow ? h->nV : h->v1, 1, h->partE, &nb,
+            h->st, h->ctl, &sa);
     } else {
         launch_step_forward(n, h->x, h->p, h->x_trial, spart, 0.0, 1, h->alphaMin, h->alpha_dev, nullptr, h->st, h->ctl, h->held());
         launch_elem_energy_grad(ow ? h->Mown : h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, ow ? 0 : h->v0, ow ? h->nV : h->v1,
@@ -228,9 +230,10 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     const bool timed = (h->flags & DOTMI_FLAG_TIME_BACKSOLVE) && h->evUsed + 2 <= (int)h->evPre.size() &&
                        (h->timeCount++ % h->timeStride) == 0;
     h->slotTimed.push_back(timed ? h->evUsed : -1);
-    CtlArgs ca{h->ctl, ctlE, ctlR, h->alpha_dev, h->h_flags, nb, 0, h->pairNow ? h->partE2 : nullptr};
-    launch_gemv(h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr, &ca,
-                h->tune.earlyAbort ? (int)h->slotTimed.size() /* the slot's epoch, 1-based */ : (1 << 30) /* never stopped */);
+    CtlArgs ca{h->ctl, ctlE, ctlR, h->alpha_dev, h->h_flags, nb, h->pairNow ? 2 : 0};
+    (h->pairNow ? launch_gemv_pair : launch_gemv)(
+        h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr, &ca,
+        h->tune.earlyAbort ? (int)h->slotTimed.size() /* the slot's epoch, 1-based */ : (1 << 30) /* never stopped */);
     if (timed) h->evUsed += 2;
     if (!h->dist) {
         launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl);
@@ -340,9 +343,9 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     // launches the early order is at least as fast on every workload, and the owner exchange has no other order -- ADVICE r04.)
     h->earlyNow = h->earlyBs;
     // paired trials: one rank, the fused step inside the element pass, the early order with held launches (the tiles of a paired
-    // slot wait for the verdict); -1: only in steps that follow a step with halvings in at least a tenth of its iterations
+    // slot wait for the verdict); -1: only in steps that follow a step with halvings in at least a quarter of its iterations
     h->pairNow = h->earlyNow && !h->dist && h->tune.fuseStep && h->tune.fuseDir && h->tune.earlyAbort && h->tune.earlyHold &&
-                 (h->tune.pairTrials > 0 || (h->tune.pairTrials < 0 && h->prevIters > 0 && 10 * h->prevHalv >= h->prevIters));
+                 (h->tune.pairTrials > 0 || (h->tune.pairTrials < 0 && h->prevIters > 0 && 4 * h->prevHalv >= h->prevIters));
     C.iterCap = h->iterCap;
     C.hist = h->hist;
     C.tol = h->targetGRes;

@@ -30,6 +30,23 @@
 
 namespace dotmi {
 
+// This file is compiled TWICE (Makefile): as it stands into kernels.o, and with -DDOTMI_PAIR_TU into kernels_pair.o, whose only
+// exported functions are launch_elem_energy_grad_pair / launch_gemv_pair -- the element pass and the back-solve + controller
+// launch of a step with PAIRED line-search trials.  The plain unit compiles every paired branch away, so
+// its kernels are the ones it had before the pairing existed: the loop's kernels reacted to ANY change of their code or
+// argument layout by 1-2 % (profiles/r05_paired_trials.txt F), and the steps that never pair should not pay for those that do.
+#ifdef DOTMI_PAIR_TU
+#define launch_elem_energy_grad launch_elem_energy_grad_pair
+#define launch_gemv launch_gemv_pair
+#define PAIR_ARG_DECL0 , const double *__restrict__ partE2 = nullptr
+#define PAIR_ARG_DECL , const double *__restrict__ partE2
+#define PAIR_INIT_MASK &1
+#else
+#define PAIR_ARG_DECL0
+#define PAIR_ARG_DECL
+#define PAIR_INIT_MASK
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------------
@@ -88,10 +105,27 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
         x = fuse ? ctl->x_cur : ctl->x_trial;
         x_out = ctl->x_trial;
     }
-    // paired trial (StepArgs::pairBlocks): the launch is twice as wide; workgroup nbP + b mirrors workgroup b on the FULL step
-    const int nbP = (fuse && sa.pairBlocks > 0) ? sa.pairBlocks : (int)gridDim.x;
-    const bool second = (int)blockIdx.x >= nbP;
+#ifdef DOTMI_PAIR_TU
+    // paired trial (StepArgs::alpha_min < 0): the launch is twice as wide; workgroup nbP + b mirrors workgroup b on the FULL step
+    const bool pairedLaunch = fuse && sa.alpha_min < 0.0;
+    const double alphaMin = pairedLaunch ? -sa.alpha_min : sa.alpha_min;
+    const int nbP = pairedLaunch ? (int)gridDim.x / 2 : (int)gridDim.x;
+    const bool second = pairedLaunch && (int)blockIdx.x >= nbP;
     const int bIdx = second ? (int)blockIdx.x - nbP : (int)blockIdx.x;
+#define EP_BIDX bIdx
+#define EP_NBP nbP
+#define EP_AMIN alphaMin
+#define EP_GRAD (GRAD && !second)
+#define EP_LEAVE_IF_NOT_PAIRED() do { if (second && alpha < 0.0) return; } while (0)   /* (the whole workgroup: not a paired slot) */
+#define EP_FIRST_HALF(stmt) do { if (!second) { stmt; } } while (0)
+#else
+#define EP_BIDX blockIdx.x
+#define EP_NBP gridDim.x
+#define EP_AMIN sa.alpha_min
+#define EP_GRAD GRAD
+#define EP_LEAVE_IF_NOT_PAIRED() do { } while (0)
+#define EP_FIRST_HALF(stmt) stmt
+#endif
     double pgv[NB_RED / 64], pHpv[NB_RED / 64];
     const bool usePart = fuse && ctl->phase == 0;   // a retry steps with the halved alpha the controller left
     if (usePart && threadIdx.x < 64) {              // requested here, summed after this thread's other loads are out
@@ -115,17 +149,22 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
                 }
                 pg = __shfl(wave_sum(pg), 0, 64);
                 pHp = __shfl(wave_sum(pHp), 0, 64);
-                a = fmax(sa.alpha_min, fmin(1.0, -pg / pHp));  // Optimizer.cpp:1085
+                a = fmax(EP_AMIN, fmin(1.0, -pg / pHp));  // Optimizer.cpp:1085
             }
             if (threadIdx.x == 0) {
+#ifdef DOTMI_PAIR_TU
                 // paired: alpha_0 < 1 (the quadratic model's minimum lies inside the unit step) -- the full step's energy
                 // from the second half of the launch, the half step in full from the first
-                const bool pair = sa.pairBlocks > 0 && usePart && a < 1.0 && a / 2.0 > 0.0 && ctl->pairCtr[pair_band(a)] >= 3;
+                const bool pair = pairedLaunch && usePart && a < 1.0 && a / 2.0 > 0.0 && ctl->pairCtr[pair_band(a)] >= 3;
                 sh_alpha = pair ? (second ? a : a / 2.0) : (second ? -1.0 : a);
                 if (blockIdx.x == 0) {
                     sa.alpha_out[0] = pair ? a / 2.0 : a;
-                    if (sa.pairBlocks > 0) sa.alpha_out[1] = pair ? a : 0.0;
+                    if (pairedLaunch) sa.alpha_out[1] = pair ? a : 0.0;
                 }
+#else
+                sh_alpha = a;
+                if (blockIdx.x == 0) *sa.alpha_out = a;
+#endif
             }
         }
         __syncthreads();
@@ -142,8 +181,8 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
     const size_t strideA = (size_t)PT.nPatches * PE;
     double acc = 0.0;  // sum vol * Psi
     // inertia operands of this thread's first vertex: independent of the element work, requested ahead of it
-    const int gstride = nbP * blockDim.x;
-    const int vfirst = v0 + bIdx * blockDim.x + tid;
+    const int gstride = EP_NBP * blockDim.x;
+    const int vfirst = v0 + EP_BIDX * blockDim.x + tid;
     double ix[3] = {0, 0, 0}, ixt[3] = {0, 0, 0}, ip[3] = {0, 0, 0}, im = 0.0;
     if (vfirst < v1) {
 #pragma unroll
@@ -203,18 +242,18 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
     PatchOps cur, nxt;
     int nvN = 0, gidN = -1, slotN = 0;   // ids of the patch after next
     unsigned short cpN = 0;
-    if (bIdx < PT.nPatches) {
-        issue_ids(bIdx, cur);
-        issue_ops(bIdx, cur);
+    if ((int)EP_BIDX < PT.nPatches) {
+        issue_ids(EP_BIDX, cur);
+        issue_ops(EP_BIDX, cur);
         issue_pos(cur);
-        if (PIPE && bIdx + nbP < PT.nPatches) issue_ids(bIdx + nbP, nxt);
+        if (PIPE && (int)(EP_BIDX + EP_NBP) < PT.nPatches) issue_ids(EP_BIDX + EP_NBP, nxt);
     }
-    for (int p = bIdx; p < PT.nPatches; p += nbP) {
+    for (int p = EP_BIDX; p < PT.nPatches; p += EP_NBP) {
         // PIPE: the instantiation for meshes whose workgroups walk several patches (the prefetched set costs ~50 registers,
         // which the one-patch-per-workgroup meshes keep for occupancy)
-        const int pn = p + nbP, pn2 = pn + nbP;
+        const int pn = p + EP_NBP, pn2 = pn + EP_NBP;
         const bool more = PIPE && pn < PT.nPatches, more2 = PIPE && pn2 < PT.nPatches;
-        if (!PIPE && p != bIdx) {
+        if (!PIPE && p != (int)EP_BIDX) {
             issue_ids(p, cur);
             issue_ops(p, cur);
             issue_pos(cur);
@@ -236,7 +275,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
         }
         if (fuse && !haveAlpha) {
             finish_alpha();
-            if (second && alpha < 0.0) return;   // (the whole workgroup: not a paired slot)
+            EP_LEAVE_IF_NOT_PAIRED();
         }
         if (cur.gid0 >= 0) {
 #pragma unroll
@@ -287,7 +326,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
                                   F.m[2][0] * F.m[2][0] + F.m[2][1] * F.m[2][1] + F.m[2][2] * F.m[2][2];
                 const double JmA = J - (1.0 + m[u] / l[u]);
                 acc += (m[u] * (ic - 3.0) + l[u] * JmA * JmA) / 2.0 * vo[u];
-                if (GRAD && !second) {
+                if (EP_GRAD) {
                     const double t = l[u] * JmA;
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
@@ -305,7 +344,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
                 double S[3];
                 svd3(F, U, S, V);
                 acc += psi<MAT>(S, m[u], l[u]) * vo[u];
-                if (GRAD && !second) {
+                if (EP_GRAD) {
                     double d[3];
                     dpsi<MAT>(S, m[u], l[u], d);
 #pragma unroll
@@ -316,7 +355,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
                                            U.m[r][2] * d[2] * V.m[c][2]);
                 }
             }
-            if (GRAD && !second) {
+            if (EP_GRAD) {
                 double g[12];
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
@@ -334,7 +373,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
                 }
             }
         }
-        if (GRAD && !second) {
+        if (EP_GRAD) {
             __syncthreads();
             EP_STAMP(2);
             // one lane per (vertex, component): a contiguous run of LDS, four entries in flight, added in run order
@@ -369,14 +408,14 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
     double ine = 0.0;
     if (fuse && !haveAlpha) {   // (a workgroup without a patch)
         finish_alpha();
-        if (second && alpha < 0.0) return;
+        EP_LEAVE_IF_NOT_PAIRED();
     }
     if (vfirst < v1) {
         if (fuse) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 ix[d] = ix[d] + alpha * ip[d];
-                if (!second) x_out[3 * vfirst + d] = ix[d];
+                EP_FIRST_HALF(x_out[3 * vfirst + d] = ix[d]);
             }
         }
         const double dx = ix[0] - ixt[0], dy = ix[1] - ixt[1], dz = ix[2] - ixt[2];
@@ -389,7 +428,7 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
             xv[d] = x[3 * v + d];
             if (fuse) {
                 xv[d] = xv[d] + alpha * sa.p[3 * v + d];
-                if (!second) x_out[3 * v + d] = xv[d];
+                EP_FIRST_HALF(x_out[3 * v + d] = xv[d]);
             }
         }
         const double dx = xv[0] - xt[3 * v], dy = xv[1] - xt[3 * v + 1], dz = xv[2] - xt[3 * v + 2];
@@ -404,9 +443,11 @@ __global__ __launch_bounds__(256) void elem_patch_kernel(DevPatches PT, const do
     }
     __syncthreads();
     if (tid == 0) {
-        double *out = second ? sa.partials2 : partials;
-        out[2 * bIdx] = (sm[0] + sm[1]) + (sm[2] + sm[3]);      // to be scaled by dtSq by the consumer
-        out[2 * bIdx + 1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+#ifdef DOTMI_PAIR_TU
+        if (second) partials += 2 * ELEM_NB_MAX;
+#endif
+        partials[2 * EP_BIDX] = (sm[0] + sm[1]) + (sm[2] + sm[3]);      // to be scaled by dtSq by the consumer
+        partials[2 * EP_BIDX + 1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
     }
     EP_STAMP(4);
 }
@@ -417,7 +458,9 @@ void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, do
 {
     StepArgs sa{nullptr, nullptr, nullptr, 0.0};
     if (step && ctl) sa = *step;
-    const bool paired = sa.p && sa.pairBlocks != 0 && grad;
+#ifdef DOTMI_PAIR_TU
+    const bool paired = sa.p && sa.alpha_min < 0.0 && grad;
+#endif
     // at most elem_wg_cap() workgroups take the patches (as many as are resident at once): beyond that a workgroup walks several
     // patches and prefetches the next one's operands (elem_patch_kernel)
     // (the instantiation with the step inside: two per CU; a handle whose loop uses it fixes 512 for all of them, PT.wgCap)
@@ -429,8 +472,11 @@ void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, do
     if (nb > ELEM_NB_MAX) nb = ELEM_NB_MAX;
     if (nb < 1) nb = 1;
     *nblocks_out = nb;
-    sa.pairBlocks = paired ? nb : 0;
+#ifdef DOTMI_PAIR_TU
     const int nbLaunch = paired ? 2 * nb : nb;
+#else
+#define nbLaunch nb
+#endif
     const int ept = PT.PE / 256;
     const size_t shm = sizeof(double) * ((size_t)3 * PT.PV + (grad ? (size_t)12 * PT.PE : 0)) +
                        (grad ? 2 * (size_t)((PT.PV + 1 + 3) & ~3) + 4 * (size_t)PT.PV : 0);
@@ -463,6 +509,9 @@ void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, do
     }
 #undef DM_LAUNCH_E
 #undef DM_LAUNCH
+#ifndef DOTMI_PAIR_TU
+#undef nbLaunch
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1304,7 +1353,7 @@ __device__ __forceinline__ void backsolve_wave_tile(const int4 jb, const int *__
 
 __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, const double *__restrict__ partE, int nbE,
                                   const double *__restrict__ partR, const double *__restrict__ alpha_dev,
-                                  int *__restrict__ flags_host, int init, const double *__restrict__ partE2 = nullptr);
+                                  int *__restrict__ flags_host, int init PAIR_ARG_DECL0);
 
 // the tile of job[jobIdx] by the calling workgroup
 template <int THREADS>
@@ -1405,13 +1454,22 @@ __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__res
     __shared__ double2 rs[2 * 256 * 6];
     // (which workgroup hosts the controller makes no difference: index 0 / 256 / 520 / last measured 47.0-47.5 us)
     if (blockIdx.x == 0) {
-        loop_control_body(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init, ca.partE2);
+#ifdef DOTMI_PAIR_TU
+        loop_control_body(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init & 1,
+                          (ca.init & 2) ? ca.partE + 2 * ELEM_NB_MAX : nullptr);
+#else
+        loop_control_body(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init);
+#endif
         return;
     }
     if (ca.ctl->status != 0) return;
+#ifdef DOTMI_PAIR_TU
     // (a paired slot -- alpha_dev[1] > 0, written by the element pass of this slot -- waits as well: its gather worked on the half
     // step, which only counts if the controller finds the full step's energy too high)
-    if (epoch < (1 << 30) && (ca.ctl->holdNext || (ca.partE2 && ca.alpha_dev[1] > 0.0))) {
+    if (epoch < (1 << 30) && (ca.ctl->holdNext || ((ca.init & 2) && ca.alpha_dev[1] > 0.0))) {
+#else
+    if (epoch < (1 << 30) && ca.ctl->holdNext) {
+#endif
         // the trial is expected to be rejected (DevLoop::holdNext): wait for the controller's verdict instead of streaming
         // the factors beside it -- a rejection then costs the controller's ~7 us, not a stopped back-solve's ~20.  (A
         // workgroup that starts after the controller has stored its forecast for the NEXT slot reads that one: the verdict
@@ -1647,7 +1705,7 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
     const bool timed = ev0 && ev1;
     if (ca && spec <= 0) spec = 1;   // (callers pass the slot's epoch: > 0)
     if (ca && nG == 0)   // no launch of the 256-thread kernel to host it: the controller on its own, in front
-        launch_loop_control(ca->ctl, ca->partE, ca->nbE, ca->partR, ca->alpha_dev, ca->flags_host, st, ca->init);
+        launch_loop_control(ca->ctl, ca->partE, ca->nbE, ca->partR, ca->alpha_dev, ca->flags_host, st, ca->init PAIR_INIT_MASK);
     if (nW > 0) {
         if (timed)
             hipExtLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, ev0, nG > 0 ? (hipEvent_t) nullptr : ev1, 0,
@@ -3355,7 +3413,7 @@ void launch_step_forward(int n, const double *x0, const double *p, double *x, co
 // (a device function: the controller is a launch of its own, or workgroup 0 of the back-solve launch -- 256 threads)
 __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, const double *__restrict__ partE, int nbE,
                                   const double *__restrict__ partR, const double *__restrict__ alpha_dev,
-                                  int *__restrict__ flags_host, int init, const double *__restrict__ partE2)
+                                  int *__restrict__ flags_host, int init PAIR_ARG_DECL)
 {
     static_assert(sizeof(DevLoop) % 8 == 0, "DevLoop is copied as 8-byte words");
     static_assert(RED_K <= 32, "two passes of 16 columns");
@@ -3370,8 +3428,10 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
         for (int i = t; i < NW8; i += 256) dst[i] = src[i];
     }
     const double alpha_in = *alpha_dev;
+#ifdef DOTMI_PAIR_TU
     const double alpha_full = (partE2 && !init) ? alpha_dev[1] : 0.0;   // > 0: a paired slot (elem_patch_kernel)
     __shared__ double chunk2[2][SUM_CHUNKS];
+#endif
     // chunked_sum() order (dotmi_internal.hpp), one thread per (column, chunk): every load of the kernel is in flight at
     // once and the dependent add chains are 16 long instead of NB_RED long.  The column index runs fastest over the
     // lanes, so a load instruction touches a few 168-byte partial rows instead of 64 different ones.
@@ -3408,6 +3468,7 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
             }
             for (; k < k1; ++k) e += partE[2 * k + c];
             chunk[RED_K + c][ch] = e;
+#ifdef DOTMI_PAIR_TU
             if (alpha_full > 0.0) {   // the same chunks of the full step's partials (same order: the same bits as a plain slot)
                 double e2 = 0.0;
                 int k2 = k0;
@@ -3421,6 +3482,7 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
                 for (; k2 < k1; ++k2) e2 += partE2[2 * k2 + c];
                 chunk2[c][ch] = e2;
             }
+#endif
         }
         if (hasA) {
             double a = 0.0;
@@ -3453,6 +3515,7 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
     } else if (t == 0) {
         double alpha = alpha_in;
         const double E = C.dtSq * R[RED_K] + R[RED_K + 1];
+#ifdef DOTMI_PAIR_TU
         if (C.slots < C.kindCap) C.slot_kind[C.slots] = C.phase == 0 ? 1 : 2;
         C.slots++;
         int kind = (C.phase == 0 || C.redo) ? 0 : 1;   // first trial of an iteration / retry after a halving
@@ -3505,6 +3568,14 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
         }
         if (decided) {
         } else if (E > C.E_cur && alpha > 0.0) {
+#else
+        C.evals++;
+        if (C.slots < C.kindCap) C.slot_kind[C.slots] = C.phase == 0 ? 1 : 2;
+        C.slots++;
+        const int kind = C.phase == 0 ? 0 : 1;   // first trial of an iteration / retry after a halving
+        C.heldSlots += C.holdNext;
+        if (E > C.E_cur && alpha > 0.0) {
+#endif
             // back-tracking (c1 = 0, lower bound 0)
             // a speculative back-solve on this trial's gradient may be running beside this workgroup: tell it to stop
             C.abortEpoch = C.slots;
@@ -3516,7 +3587,11 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
                 ctr = min(3, ctr + 1);
                 C.predHist[kind] = ((C.predHist[kind] << 1) | 1) & 3;
             }
+#ifdef DOTMI_PAIR_TU
             C.heldRejected += (C.holdNext || alpha_full > 0.0) ? 1 : 0;
+#else
+            C.heldRejected += C.holdNext;
+#endif
             alpha /= 2.0;
             C.halvings++;
             if (alpha == 0.0) {
@@ -3678,7 +3753,11 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
     // forecast for the slot that follows: hold its back-solve if its kind's counter for the current pattern says "rejected"
     if (t == 0 && !init) {
         const int nk = C.phase == 0 ? 0 : 1;
+#ifdef DOTMI_PAIR_TU
         C.holdNext = (C.holdEnable && C.status == 0 && !C.redo && C.predCtr[nk][C.predHist[nk] & 3] >= 2) ? 1 : 0;
+#else
+        C.holdNext = (C.holdEnable && C.status == 0 && C.predCtr[nk][C.predHist[nk] & 3] >= 2) ? 1 : 0;
+#endif
     }
     __syncthreads();
     {
@@ -4006,6 +4085,17 @@ void launch_scatter_rows(int n, const int *idx, const double *pos, double *x, hi
     if (n > 0)
         hipLaunchKernelGGL(scatter_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, idx, pos, x);
 }
+
+#ifdef DOTMI_PAIR_TU
+// the code object of this unit is loaded at the first use of one of its kernels (a few milliseconds): dotmi_create asks for it
+// up front instead of leaving it to the first step that pairs
+void warm_pair_unit()
+{
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&backsolve_ctl_kernel));
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&elem_patch_kernel<1, true, 1, true, false>));
+}
+#endif
 
 void launch_copy(int n, const double *src, double *dst, hipStream_t st)
 {
