@@ -4,7 +4,7 @@
 // host-only entry dotmi_plan_backsolve_tiles returns it for tests (tests/test_host_logic.py) and tools.
 //
 // Role in the reference: none of its own -- CHOLMODSolver::solve (CHOLMODSolver.cpp:149-163) walks CHOLMOD's supernodes; here
-// the solve is p_s = X_s^T (X_s r_s) streamed once, and this table is its schedule (kernels.hip, backsolve_*).
+// the solve is p_s = X_s^T (X_s r_s) streamed once, and this table is its schedule (k_backsolve.hip, backsolve_*).
 #pragma once
 #include <algorithm>
 #include <vector>
@@ -159,7 +159,7 @@ inline void plan_backsolve_tiles(const std::vector<NdNode> &nd, UsedRows usedRow
     std::stable_partition(tiles.begin(), tiles.end(), [](const int4 &t) { return bs_tile_len(t) > BS_NARROW; });
     for (const int4 &t : tiles) out.ntilesWide += (bs_tile_len(t) > BS_NARROW);
     // small tiles (rows of at most BS_WAVE columns) leave the one-tile jobs: four of them share a workgroup, one wavefront each
-    // (kernels.hip, backsolve_wave_tile); heavy first, so the four of a pack are about equally long.  They go BEHIND the
+    // (k_backsolve.hip, backsolve_wave_tile); heavy first, so the four of a pack are about equally long.  They go BEHIND the
     // one-tile jobs (spread evenly among them: no gain, 1 M tets +3 %: profiles/r05_backsolve_tiles.txt H)
     if (R.wavePacks) {
         std::vector<int4> big, small;

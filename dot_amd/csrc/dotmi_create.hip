@@ -553,7 +553,7 @@ int build_device_mesh(dotmi_handle *h)
         const size_t nLevels = std::max<size_t>(S.levelStart.size() - 1, 1);
         h->tileFlow = !S.tasks.empty() &&
                       (h->tune.tileFlow > 0 || (h->tune.tileFlow < 0 && S.tasks.size() / nLevels <= 512));
-        // the diagonal tasks' per-lane bottom steps (kernels.hip, block_chol_inv<N, FAST>): every layout (DOTMI_FAST_DIAG=0: the
+        // the diagonal tasks' per-lane bottom steps (k_tilefactor.hip, block_chol_inv<N, FAST>): every layout (DOTMI_FAST_DIAG=0: the
         // one-row-per-lane base of round 3); the 256-thread level kernel keeps the old base, and then so does the dataflow launch
         h->fastDiag = h->tune.fastDiag != 0;
         if (h->tileFlow) {
@@ -1285,7 +1285,6 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         if (int rc = dalloc(h, &h->HvalOwn, (size_t)9 * h->M.nnzb)) return rc;
         HIPCHECK(h, hipMemsetAsync(h->HvalOwn, 0, sizeof(double) * 9 * h->M.nnzb, h->st));
     }
-    if (h->tune.pairTrials != 0 && h->world == 1) warm_pair_unit();   // (the second code object, before the first step needs it)
     if (int rc = dalloc(h, &h->partE, (size_t)4 * ELEM_NB_MAX)) return rc;   // (second half: a paired trial's full-step partials)
     double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG, &h->partGR, &h->partGC};
     for (double **pp : parts) {

@@ -78,7 +78,7 @@ struct DevParts {
                             //   wavefront each, backsolve_wave_tile), padded with empty entries (rows = 0): tile[ntiles + 4 k ..]
     int ntilesWide;         // the first ntilesWide tiles have rows of more than BS_NARROW columns (512-thread kernel)
     int maxTileLen;         // longest row of a tile in `tile` (<= BS_LONG: longer tiles are in `ltile`)
-    // tiles whose rows exceed BS_LONG columns: two-phase back-solve over column chunks (kernels.hip)
+    // tiles whose rows exceed BS_LONG columns: two-phase back-solve over column chunks (k_backsolve.hip)
     int nltiles, nlwork;    // long tiles; (long tile, chunk) work items
     int4 *ltile;            // same encoding as `tile`
     int2 *lwork;            // (index into ltile, chunk)
@@ -210,7 +210,7 @@ struct CtlArgs {
                 // full step's energy partials follow partE at + 2 ELEM_NB_MAX, alpha_dev[1] > 0 marks a paired slot
 };
 
-// ---- kernel launchers (kernels.hip) --------------------------------------------------------------
+// ---- kernel launchers (k_*.hip) ------------------------------------------------------------------
 // Launchers with a trailing `ctl` run in device-loop mode when it is non-null: operands that change from
 // iteration to iteration come from *ctl and the kernel returns at once when the loop has ended (or, for
 // the direction kernels, when the slot is a line-search retry).
@@ -235,7 +235,7 @@ struct StepArgs {
 void launch_elem_energy_grad(const DevMesh &M, const DevPatches &PT, int mat, double dtSq, const double *x,
                              const double *xt, int v0, int v1, int grad, double *partials, int *nblocks_out,
                              hipStream_t st, const DevLoop *ctl = nullptr, const StepArgs *step = nullptr);
-// the same launch from the unit compiled with -DDOTMI_PAIR_TU (kernels_pair.o): StepArgs::alpha_min < 0 makes it a paired launch
+// the PAIR instantiation of the same launch (k_element.hip): StepArgs::alpha_min < 0 makes it a paired launch
 void launch_elem_energy_grad_pair(const DevMesh &M, const DevPatches &PT, int mat, double dtSq, const double *x,
                                   const double *xt, int v0, int v1, int grad, double *partials, int *nblocks_out,
                                   hipStream_t st, const DevLoop *ctl = nullptr, const StepArgs *step = nullptr);
@@ -281,8 +281,7 @@ void launch_build_q(int n, const double *g, const LbfgsArgs &L, const double *xi
 // (the back-solve is speculative: issued on the trial gradient before the controller has accepted the trial)
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
                  hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr, int spec = 0);
-void warm_pair_unit();   // (kernels_pair.o: loads its code object)
-// ... from kernels_pair.o: the controller that understands paired slots (CtlArgs::init bit 1)
+// ... the PAIR instantiation: the controller that understands paired slots (CtlArgs::init bit 1)
 void launch_gemv_pair(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr, int spec = 0);
 // rpad_s[k] = q[dofmap_s[k]] with q = -g - sum_j xi_j y_j formed on the fly (same operations as build_q), 0 on padding
@@ -357,7 +356,7 @@ void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream
                      int nList = 0, const int *blk_ptr = nullptr, const int *blk_ent = nullptr, const double *mass = nullptr);
 void launch_dense_fill(const DevParts &P, const double *Hval, hipStream_t st);
 // one level of the tile schedule (tile_factor.hpp): one workgroup per task
-// fastDiag: the diagonal tasks' 16 x 16 bottom steps in the per-lane 8 x 8 form (kernels.hip, block_chol_inv<N, FAST>; 512 threads)
+// fastDiag: the diagonal tasks' 16 x 16 bottom steps in the per-lane 8 x 8 form (k_tilefactor.hip, block_chol_inv<N, FAST>; 512 threads)
 void launch_tile_level(const TileTask *tasks, int ntasks, const TileProd *prods, int *info, hipStream_t st, bool fastDiag = true);
 // the non-diagonal tasks of a level on half tiles, four workgroups per CU (tile_gemm_kernel)
 void launch_tile_gemm(const TileTask *tasks, int ntasks, const TileProd *prods, hipStream_t st);

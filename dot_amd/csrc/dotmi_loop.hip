@@ -161,7 +161,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     // whole trial point there too -- x + alpha 0 off the held vertices)
     if (h->tune.fuseStep && (!se || ow)) {   // the step x_trial = x_cur + alpha p inside the element pass
         StepArgs sa{h->p, spart, h->alpha_dev, h->pairNow ? -h->alphaMin : h->alphaMin};   // (negative: a paired launch)
-        // (a step with paired trials takes these two launches from the unit compiled for them, kernels_pair.o)
+        // (a step with paired trials takes the PAIR instantiations of these two launches)
         (h->pairNow ? launch_elem_energy_grad_pair : launch_elem_energy_grad)(
             ow ? h->Mown : h->M, h->PT, h->mat, h->dtSq, h->x_trial, h->xt, ow ? 0 : h->v0, ow ? h->nV : h->v1, 1, h->partE, &nb,
             h->st, h->ctl, &sa);

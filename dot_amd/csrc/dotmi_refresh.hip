@@ -125,23 +125,29 @@ int refactor_finish(dotmi_handle *h, double *ms_hess, double *ms_fact)
 #endif
     for (int i = 0; i < h->P.nParts && bad < 0; ++i)
         if (h->h_info[i] != 0) bad = i;
+    // a dataflow wait that timed out anywhere is a DEVICE failure, whatever pivot report stands in front of it (ADVICE r04)
+    int stuck = -1;
+    for (int i = 0; i < h->P.nParts && stuck < 0; ++i)
+        if (h->h_info[i] >= (1 << 30)) stuck = i;
     if (h->world > 1) {
-        // all ranks fail together: a rank that returned alone would leave the others blocked in the next collective
-        double f = bad >= 0 ? 1.0 : 0.0;
-        HIPCHECK(h, hipMemcpyAsync(h->ctrlDev, &f, sizeof(double), hipMemcpyHostToDevice, h->st));
-        if (int rc = allreduce_sum(h, h->ctrlDev, 1)) return rc;
-        HIPCHECK(h, hipMemcpyAsync(&f, h->ctrlDev, sizeof(double), hipMemcpyDeviceToHost, h->st));
+        // all ranks fail together -- a rank that returned alone would leave the others blocked in the next collective -- and with
+        // the SAME error class: both flags are reduced, every rank classifies from the sums
+        double f[2] = {bad >= 0 ? 1.0 : 0.0, stuck >= 0 ? 1.0 : 0.0};
+        HIPCHECK(h, hipMemcpyAsync(h->ctrlDev, f, sizeof(f), hipMemcpyHostToDevice, h->st));
+        if (int rc = allreduce_sum(h, h->ctrlDev, 2)) return rc;
+        HIPCHECK(h, hipMemcpyAsync(f, h->ctrlDev, sizeof(f), hipMemcpyDeviceToHost, h->st));
         HIPCHECK(h, hipStreamSynchronize(h->st));
-        if (f > 0.0 && bad < 0) {
+        if (f[1] > 0.0 && stuck < 0) {
+            h->err = "the tile factorisation's dataflow scheduler timed out on another rank";
+            h->poisoned = true;
+            return DOTMI_E_DEVICE;
+        }
+        if (f[0] > 0.0 && bad < 0) {
             h->err = "a subdomain Hessian on another rank is not positive definite";
             h->poisoned = true;
             return DOTMI_E_NOTSPD;
         }
     }
-    // a dataflow wait that timed out anywhere is a DEVICE failure, whatever pivot report stands in front of it (ADVICE r04)
-    int stuck = -1;
-    for (int i = 0; i < h->P.nParts && stuck < 0; ++i)
-        if (h->h_info[i] >= (1 << 30)) stuck = i;
     if (stuck >= 0) {
         h->err = "the tile factorisation's dataflow scheduler waited for a task that never finished (subdomain " +
                  std::to_string(h->p0 + stuck) + ")";

@@ -331,7 +331,9 @@ inline void nd_choose_depth(const std::vector<std::vector<int>> &allParts, int n
     std::vector<std::vector<std::vector<int>>> region;
     const int n2 = nd_plan(allParts, nV, adj_ptr, adj_idx, Xrest, 2, defaultMinSplit, tree2, region);
     const int n3 = nd_plan(allParts, nV, adj_ptr, adj_idx, Xrest, 3, 384, tree3, region);
-    if (tree3.size() > tree2.size() && n3 > n2 && n3 <= narrowLimit) {
+    // (a third level that really splits something -- a bigger tree -- and still fits the narrow kernel.  ADVICE r05: the earlier
+    // extra condition n3 > n2 rejected a three-level layout whose padded size came out equal or smaller, the better case)
+    if (tree3.size() > tree2.size() && n3 <= narrowLimit) {
         levels = 3;
         minSplit = 384;
     }

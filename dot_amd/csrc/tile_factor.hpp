@@ -360,7 +360,7 @@ inline void finish_tile_schedule(std::vector<TileTaskL> &all, TileSchedule &S, b
             v.swap(order);
         }
         }
-        // the diagonal-block tasks first: they go to a kernel of their own (tile_diag / tile_gemm, kernels.hip)
+        // the diagonal-block tasks first: they go to a kernel of their own (tile_diag / tile_gemm, k_tilefactor.hip)
         std::stable_partition(v.begin(), v.end(), [&](size_t k) { return all[k].t.post == TP_DIAG; });
         int nd = 0;
         for (size_t k : v) nd += all[k].t.post == TP_DIAG;
@@ -377,7 +377,7 @@ inline void finish_tile_schedule(std::vector<TileTaskL> &all, TileSchedule &S, b
     }
 }
 
-// ---- dependencies of the ordered task list, for the dataflow kernel (tile_flow_kernel, kernels.hip) ------------------------
+// ---- dependencies of the ordered task list, for the dataflow kernel (tile_flow_kernel, k_tilefactor.hip) ------------------------
 // The level schedule above synchronises with launch boundaries: every task of level l waits for ALL tasks of level l - 1.
 // The dataflow kernel hands the same tasks, in the same (topological) order, to persistent workgroups and lets each wait
 // only for the tasks whose tiles it touches: per tile, a reader comes after the last writer, a writer after the previous

@@ -135,8 +135,9 @@ def load() -> C.CDLL:
     L.dotmi_partition.argtypes = [C.c_int32, C.c_int32, c_ip, c_dp, C.c_int32, c_ip]
     L.dotmi_plan_layout.argtypes = [C.c_int32, C.c_int32, c_ip, c_dp, c_ip, C.c_int32, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, c_ip, c_ip, c_ip, c_ip]
-    L.dotmi_plan_backsolve_tiles.argtypes = [C.c_int32, C.c_int32, c_ip, c_dp, c_ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
-                                             c_ip, c_ip]
+    if hasattr(L, "dotmi_plan_backsolve_tiles"):   # (round 5 entry; guarded like the two above -- ADVICE r05)
+        L.dotmi_plan_backsolve_tiles.argtypes = [C.c_int32, C.c_int32, c_ip, c_dp, c_ip, C.c_int32, C.c_int32, C.c_int32,
+                                                 C.c_int32, c_ip, c_ip]
     for name in EXPORTS:
         fn = getattr(L, name, None)
         if fn is None:

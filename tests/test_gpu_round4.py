@@ -317,7 +317,7 @@ def test_owner_exchange_survives_a_change_of_the_fixed_set_and_a_restart():
 
 def test_per_lane_diagonal_base_gives_the_same_factors_to_rounding():
     """DOTMI_FAST_DIAG (round 4, default on): the diagonal tile tasks' 16 x 16 bottom steps on 4 x 4 blocks that every lane
-    factors for itself (kernels.hip, block_chol_inv<N, FAST>; hardware rsqrt + Goldschmidt instead of sqrt and a division)
+    factors for itself (k_tilefactor.hip, block_chol_inv<N, FAST>; hardware rsqrt + Goldschmidt instead of sqrt and a division)
     against the one-row-per-lane base of round 3: the inverse factors agree to rounding, the steps take the same iterations
     and end at the same positions -- on a dataflow layout (bunny5K) and on a level-scheduled one (bar17K)."""
     for workload, steps in (("bunny5K_LTSS", 3), ("bar17K_twist", 2)):

@@ -1,5 +1,5 @@
 // micro-benchmark harness for back-solve kernel variants (timing only; data is synthetic)
-#include "../dot_amd/csrc/kernels.hip"
+#include "../dot_amd/csrc/k_backsolve.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

@@ -1,8 +1,8 @@
-// Where the time of a diagonal tile task goes: the 64 x 64 inverse-Cholesky step (block_chol_inv<64>, kernels.hip) and its
+// Where the time of a diagonal tile task goes: the 64 x 64 inverse-Cholesky step (block_chol_inv<64>, k_tilefactor.hip) and its
 // parts -- the 16 x 16 register base case and the small matrix-core products -- timed with the 100 MHz wall clock inside one
 // 512-thread workgroup (and 32 of them side by side), results checked against a host Cholesky.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I dot_amd/csrc -o tools/bench_diag tools/bench_diag.hip
-#include "kernels.hip"
+#include "k_tilefactor.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>

@@ -3,6 +3,6 @@
 # usage (GPU box): bash tools/prof_backsolve.sh [workload]      (environment switches apply, e.g. DOTMI_ND_LEVELS=2)
 set -e
 cd "$(dirname "$0")/../dot_amd/csrc"
-touch kernels.hip && make -s EXTRA=-DBS_PROFILE kernels.o ../libdotmi.so
+touch k_backsolve.hip && make -s EXTRA=-DBS_PROFILE k_backsolve.o ../libdotmi.so
 python ../../tools/prof_backsolve.py "${1:-bar17K_twist}" || true
-touch kernels.hip && make -s
+touch k_backsolve.hip && make -s
