@@ -498,14 +498,18 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
     case DOTMI_BENCH_SPMV_ZP:            // 72 nnzb + z, g read, p, Hp written, m pairs of (s_j, H s_j) read
         bytes = 72 * (int64_t)h->M.nnzb + 8 * (int64_t)n * (4 + 2 * L.m);
         live = true;
-        run = [&] { launch_spmv_zp(h->M, h->Hval, h->z, h->partC, h->p, h->Hp, h->partS, h->st, h->ctl); };
+        run = [&] {
+            launch_spmv_zp(h->M, h->Hval, h->z, h->dist ? h->partC : h->partCT, h->p, h->Hp, h->partS, h->st, h->ctl, 0, -1, nullptr,
+                           nullptr, VList(), !h->dist);
+        };
         break;
     case DOTMI_BENCH_MERGE_EARLY:        // tile partials + u_old read / written, z written, M y_new written, m x (y_j, M y_j) read
         bytes = 8 * (int64_t)h->mergeEntries + 8 * (int64_t)n * (4 + 2 * L.m);
         live = true;
         run = [&] {
             if (!h->P.mt_ptr) launch_reduce_partial(h->P, h->st, h->ctl);
-            launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl);
+            launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, nullptr, nullptr, VList(), nullptr, 0, nullptr,
+                               h->dist ? nullptr : h->partCT);
         };
         break;
     case DOTMI_BENCH_ELEM_STEP: {        // the element pass with the line-search step inside: + p read, trial point written
@@ -533,6 +537,17 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
         a.vp_off = h->P.vp_off;
         a.rpad = h->P.rpad;
         run = [&] { launch_vertex_gather(h->M, h->PT, a, L, h->partR, h->st, h->ctl); };
+        break;
+    }
+    case DOTMI_BENCH_DIRSTEP: {         // what spmv_zp and the stepping element pass read and write together (p is not re-read)
+        if (h->dist || !dirstep_fits(h->PT)) return DOTMI_E_INVALID;
+        bytes = 72 * (int64_t)h->M.nnzb + 8 * (int64_t)n * (4 + 2 * L.m) + 112 * nTo + 56 * nVo + 24 * (int64_t)nV;
+        live = true;
+        run = [&] {
+            StepArgs sa{h->p, h->partS, h->alpha_dev, h->alphaMin};
+            launch_dirstep(h->M, h->PT, h->mat, h->dtSq, h->xt, h->partE, &nb, h->Hval, h->z, h->partCT, h->p, h->Hp, h->partS, h->st,
+                           h->ctl, sa);
+        };
         break;
     }
     default:

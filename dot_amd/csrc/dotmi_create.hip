@@ -443,6 +443,8 @@ int build_device_mesh(dotmi_handle *h)
         // reduce_partial_p + merge.
         P.mt_ptr = nullptr;
         P.mt_ent = nullptr;
+        P.mt_wave = nullptr;
+        P.mt_il = nullptr;
         const long long ppartN = (long long)P.nParts * P.nbmax * P.nmax;
         // Big meshes: the walk over a dof's ~20 tile partials is a walk over scattered 8-byte words and 4-byte list entries
         // (1 M tets: 75 us per iteration at 0.26 of the HBM peak); the two-launch form reads the partials coalesced in the
@@ -478,6 +480,24 @@ int build_device_mesh(dotmi_handle *h)
             } else if (lists) {
                 if (int rc = upload(h, &P.mt_ptr, mp)) return rc;
                 if (int rc = upload(h, &P.mt_ent, ment)) return rc;
+                // the lists once more, interleaved by wavefront (DevParts::mt_il): what the merge kernels walk when they visit
+                // every dof (the owner exchange's vertex lists keep the CSR walk)
+                const int n3 = 3 * nV, nw = (n3 + 63) / 64;
+                std::vector<int2> mw(nw);
+                std::vector<int> il;
+                for (int w = 0; w < nw; ++w) {
+                    int L = 0;
+                    for (int l = 0; l < 64 && 64 * w + l < n3; ++l) L = std::max(L, mp[64 * w + l + 1] - mp[64 * w + l]);
+                    mw[w] = make_int2((int)il.size(), L);
+                    il.resize(il.size() + (size_t)64 * L, MT_PAD);
+                    for (int l = 0; l < 64 && 64 * w + l < n3; ++l)
+                        for (int q = 0, e = mp[64 * w + l]; e < mp[64 * w + l + 1]; ++q, ++e) il[(size_t)mw[w].x + 64 * q + l] = ment[e];
+                }
+                if (il.empty()) il.push_back(MT_PAD);
+                if (il.size() < (size_t)1 << 31) {
+                    if (int rc = upload(h, &P.mt_wave, mw)) return rc;
+                    if (int rc = upload(h, &P.mt_il, il)) return rc;
+                }
             }
             if (h->tune.fuseLog)
                 fprintf(stderr, "dotmi: merge: %.1f tile partials per dof -> %s\n", (double)count / std::max(1, 3 * nV),
@@ -1280,13 +1300,13 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         if (int rc = dalloc(h, &h->Y[s], (size_t)n)) return rc;
     }
     if (int rc = dalloc(h, &h->He, (size_t)144 * std::max(h->nHessElems, 1))) return rc;
-    if (int rc = dalloc(h, &h->Hval, (size_t)9 * h->M.nnzb)) return rc;
+    if (int rc = dalloc(h, &h->Hval, hval_size(h->M.nnzb))) return rc;
     if (h->owner) {
-        if (int rc = dalloc(h, &h->HvalOwn, (size_t)9 * h->M.nnzb)) return rc;
-        HIPCHECK(h, hipMemsetAsync(h->HvalOwn, 0, sizeof(double) * 9 * h->M.nnzb, h->st));
+        if (int rc = dalloc(h, &h->HvalOwn, hval_size(h->M.nnzb))) return rc;
+        HIPCHECK(h, hipMemsetAsync(h->HvalOwn, 0, sizeof(double) * hval_size(h->M.nnzb), h->st));
     }
     if (int rc = dalloc(h, &h->partE, (size_t)4 * ELEM_NB_MAX)) return rc;   // (second half: a paired trial's full-step partials)
-    double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG, &h->partGR, &h->partGC};
+    double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG, &h->partGR, &h->partGC, &h->partCT};
     for (double **pp : parts) {
         if (int rc = dalloc(h, pp, (size_t)NB_RED * RED_K)) return rc;
         HIPCHECK(h, hipMemsetAsync(*pp, 0, sizeof(double) * NB_RED * RED_K, h->st));

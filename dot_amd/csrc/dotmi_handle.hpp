@@ -90,6 +90,9 @@ struct Tuning {
     bool earlyAbort = true;   // DOTMI_EARLY_ABORT=0  (ablation) speculative back-solves run to their end even when the trial is rejected
     int pairTrials = -1;      // DOTMI_PAIR_TRIALS    -1 (default): paired line-search trials (StepArgs::pairBlocks) in a step whose predecessor
                               //                      halved in at least a quarter of its iterations; 1: in every step; 0: never
+    int specStep = -1;        // DOTMI_SPEC_STEP      -1 (default): the unit step taken speculatively beside the direction kernel (k_dirstep.hip)
+                              //                      in a step whose predecessor's first trials took the unit estimate at least nine
+                              //                      times in ten; 1: in every step; 0: never
     bool earlyHold = true;    // DOTMI_EARLY_HOLD=0   the back-solve of a trial that is expected to be rejected still starts speculatively
     int earlyBs = 2;          // DOTMI_EARLY_BACKSOLVE 0: the back-solve after the controller, on q; 1: speculatively on the trial
                               //                      gradient with the controller inside its launch, in the steps where
@@ -128,6 +131,7 @@ struct Tuning {
         t.earlyAbort = geti("DOTMI_EARLY_ABORT", 1) != 0;
         t.earlyHold = geti("DOTMI_EARLY_HOLD", 1) != 0;
         t.pairTrials = geti("DOTMI_PAIR_TRIALS", -1);
+        t.specStep = geti("DOTMI_SPEC_STEP", -1);
         t.fuseStep = geti("DOTMI_FUSE_STEP", 1) != 0;
         t.fuseDir = geti("DOTMI_FUSE_DIR", 1) != 0;
         return t;
@@ -217,8 +221,12 @@ struct dotmi_handle {
     double *u_old = nullptr, *MY[HIST_MAX + 1] = {nullptr};
     double *HS[HIST_MAX + 1] = {nullptr};   // H s_i of the stored pairs (fused direction kernel of the early order)
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
+    double *partCT = nullptr;   // the y_i . z partials once more, column-major (write_partials' partialsT): what the one-rank loop's direction kernels read
     bool pairNow = false;       // this step's slots launch the element pass twice as wide (enqueue_loop_slot_early)
     int pairSlots = 0, pairRedo = 0;
+    bool specNow = false;       // this step's new-direction slots take the unit step speculatively (launch_dirstep)
+    int specSlots = 0, specRedo = 0;
+    int prevFirst = 0, prevUnit = 0;   // last step's first trials / of those, the ones whose estimate alpha_0 was the unit step
     int pairState[3] = {1, 1, 1};   // DevLoop::pairCtr, carried from step to step
     double *gstage = nullptr;   // sharded element pass, device loop: [g (n) ; 0 ; E] staging buffer of the gradient all-reduce
     double *zstage = nullptr;   // sharded subdomains, early order: this rank's undivided partial merge, all-reduced in place

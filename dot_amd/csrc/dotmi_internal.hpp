@@ -22,6 +22,14 @@ constexpr int ELEM_NB_MAX = 8192; // most workgroups (= partial energy rows) of 
 constexpr int CHOL_NB = 64;     // tile of the inverse-Cholesky factorisation (LDS resident)
 
 // ---- mesh + topology resident in HBM ------------------------------------------------------------
+// Layout of the global Hessian's 3 x 3 blocks (round 6): blocks in groups of eight, a group's 72 doubles entry-major --
+// entry e of block b at (b >> 3) * 72 + 8 e + (b & 7).  The eight lanes of a row's group in the SpMV kernels read the same entry
+// of eight consecutive blocks with one instruction: 64 contiguous bytes instead of eight words 72 bytes apart.  With block-major
+// storage (9 b + e, until round 5) every one of the 27 block loads of a trip touched ~80 lines per wave and the direction kernel
+// spent ~7 of its ~12 us in the address path of the vector memory unit (tools/prof_dirstep.sh), not in waiting.
+__host__ __device__ inline size_t hval_idx(int blk, int e) { return (size_t)(blk >> 3) * 72 + (size_t)(8 * e + (blk & 7)); }
+inline size_t hval_size(int nnzb) { return (size_t)72 * (((size_t)nnzb + 7) / 8); }
+
 struct DevMesh {
     int nV, nT, nTp;        // nTp = nT padded to 64 (SoA stride)
     int4 *T;                // nT   vertex ids
@@ -99,6 +107,12 @@ struct DevParts {
     // the same merge straight from the tile partials: per global scalar dof (CSR mt_ptr over 3 nV) the offsets into ppart
     // that make up its value, subdomain after subdomain; the first entry of a subdomain is stored complemented (~off)
     int *mt_ptr, *mt_ent;
+    // round 6: the same lists INTERLEAVED by wavefront -- entry q of the 64 consecutive dofs [64 w, 64 w + 64) is contiguous at
+    // mt_il[mt_wave[w].x + 64 q + lane], q < mt_wave[w].y (the longest list of the 64; shorter ones end in MT_PAD) -- so that a
+    // list load of a wave touches two 128-byte lines instead of ~34 (a lane's own list is ~17 x 4 contiguous bytes, the lanes'
+    // lists lie one behind the other: every load instruction of the CSR walk strides through 64 x 68 bytes)
+    int2 *mt_wave;
+    int *mt_il;
     int splitMerge;         // big meshes: no such lists -- reduce_partial_p (coalesced, in the subdomains' own order) leaves psub
                             // and the merge kernels gather from it through vp_ptr / vp_off (round 4: 1 M tets, loop -2 ms)
     int *dup;               // nV (global multiplicity, DOTTimeStepper.cpp:47-56)
@@ -109,6 +123,8 @@ struct DevParts {
     int npad;               // identity padding entries
     long long *pad_dst;
 };
+
+constexpr int MT_PAD = -2147483647 - 1;   // end of a dof's interleaved list (no offset, plain or complemented, has this value)
 
 struct LbfgsArgs {
     int m;
@@ -190,10 +206,38 @@ struct DevLoop {
     // select one of four saturating counters (0 .. 3, >= 2 forecasts a rejection) -- a plain "same as last time" is wrong
     // every time on the alternating pattern stiff steps show (measured: profiles/r04_hold.txt)
     int predHist[2], predCtr[2][4];
+    // Speculative unit step (round 6, k_dirstep.hip): the SpMV partial rows the controller of such a step sums for alpha_0, the
+    // lower bound of the clamp; statistics: new-direction slots that speculated / of those, redone with alpha_0 < 1; first trials
+    // of the step / of those, the ones whose estimate was the unit step (every controller counts these two: the next step's gate)
+    const double *specPartials;
+    double alphaMin;
+    int specSlots, specRedo, firstTrials, unitFirst;
     double *u_old, *MY[HIST_MAX + 1];
     // H s_i of the stored pairs (same slots as S): H p = H z + sum_j delta_j (H s_j), H s_new = alpha H p (spmv_zp_kernel)
     double *HS[HIST_MAX + 1];
+    // Round 6: what the loop's kernels used to find by index -- S[slot], HS[order[j]], MY[order[i]] -- RESOLVED by whoever changes
+    // slot / order (devloop_resolve: the host at the start of a step, the controller after an accepted trial).  Every kernel of
+    // the loop starts with a read of this struct from memory another XCD wrote (~1 us per dependent scalar load): with the
+    // pointers resolved and all of a kernel's loop-state loads issued in front of its first branch that is ONE round trip
+    // instead of three (tools/prof_loopkern.sh: 2.9 us of the gather's 6.2 and of merge_early's 9.6 were this prologue).
+    double *s_new, *y_new, *hs_new;          // S[slot], Y[slot], HS[slot]: the pair of the running trial
+    double *my_new;                          // MY[order[m - 1]]: where M y of the newest stored pair goes (merge_early)
+    const double *Lmy[HIST_MAX], *Lhs[HIST_MAX];   // chronological views like L.s / L.y: M y_i, H s_i of the stored pairs
 };
+// the resolved views from slot / order / L.m (host: before the state is uploaded; controller: after it has changed them)
+template <class DL>
+__host__ __device__ inline void devloop_resolve(DL &C)
+{
+    C.s_new = C.S[C.slot];
+    C.y_new = C.Y[C.slot];
+    C.hs_new = C.HS[C.slot];
+    const int m = C.L.m;
+    for (int i = 0; i < HIST_MAX; ++i) {
+        C.Lmy[i] = i < m ? C.MY[C.order[i]] : nullptr;
+        C.Lhs[i] = i < m ? C.HS[C.order[i]] : nullptr;
+    }
+    C.my_new = m > 0 ? C.MY[C.order[m - 1]] : nullptr;
+}
 // owner exchange: the vertices a rank holds -- the vector kernels of the loop then visit only these (everything else is zero
 // and stays zero); v == nullptr: every vertex
 struct VList {
@@ -284,6 +328,15 @@ void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLo
 // ... the PAIR instantiation: the controller that understands paired slots (CtlArgs::init bit 1)
 void launch_gemv_pair(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr, int spec = 0);
+// ... the controller of a step that takes the unit step speculatively (checks alpha_0 afterwards; DevLoop::specPartials)
+void launch_gemv_spec(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
+                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr, int spec = 0);
+// the direction kernel and the first trial's element pass at the unit step in one launch of two workgroup populations
+// (k_dirstep.hip): replaces launch_spmv_zp + launch_elem_energy_grad in the slots of a speculating step
+bool dirstep_fits(const DevPatches &PT);   // (meshes of at most 512 patches: every patch a workgroup)
+void launch_dirstep(const DevMesh &M, const DevPatches &PT, int mat, double dtSq, const double *xt, double *partE, int *nblocks_out,
+                    const double *Hval, const double *z, const double *c_partials, double *p, double *Hp, double *partS,
+                    hipStream_t st, const DevLoop *ctl, const StepArgs &sa);
 // rpad_s[k] = q[dofmap_s[k]] with q = -g - sum_j xi_j y_j formed on the fly (same operations as build_q), 0 on padding
 // spec (device loop, early back-solve): 1: rpad = -g_cur, 2: rpad = -g_trial whatever the phase; no history terms
 void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, const double *xi_host, hipStream_t st,
@@ -299,7 +352,7 @@ void launch_reduce_partial(const DevParts &P, hipStream_t st, const DevLoop *ctl
 // sums, partials = nullptr)
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
                         const DevLoop *ctl, const double *zsum = nullptr, const uint8_t *ownMask = nullptr, VList vl = VList(),
-                        const uint8_t *kind = nullptr, int pre = 0, double *zshare = nullptr);
+                        const uint8_t *kind = nullptr, int pre = 0, double *zshare = nullptr, double *partialsT = nullptr);
 // owner exchange: the entries of the vertices held by more than one rank, packed / unpacked (idx: their vertex ids);
 // tail: `ntail` further scalars copied from / to tailp behind the packed entries
 // red0 / red1: partial arrays whose rows workgroup 0 of the pack sums into the packet's tail (pack[dst ...]): `cols` columns of
@@ -337,7 +390,7 @@ void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_
 // p.Hp over them, p.g over the vertices it owns
 void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const double *c_partials, double *p, double *Hp,
                     double *partials, hipStream_t st, const DevLoop *ctl, int v0 = 0, int v1 = -1,
-                    const uint8_t *rowMask = nullptr, const uint8_t *ownMask = nullptr, VList vl = VList());
+                    const uint8_t *rowMask = nullptr, const uint8_t *ownMask = nullptr, VList vl = VList(), bool ctrans = false);
 // Hp = H p on rows [v0,v1), partial sums of p.g and p.Hp
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
                       int v0, int v1, double *partials, hipStream_t st, const DevLoop *ctl = nullptr);

@@ -136,11 +136,20 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     const bool fuseDir = h->tune.fuseDir;
     const bool se = h->shardElems;   // sharded element pass: this rank's rows of H, its elements; three collectives per slot
     const bool ow = h->owner;        // owner exchange: only the entries of shared vertices travel, dots are owner-summed scalars
-    if (ow) {
+    int nb = 0;
+    if (h->specNow) {
+        // the direction kernel and the first trial's element pass at the unit step in ONE launch (k_dirstep.hip); a retry slot:
+        // the element pass alone, on the stored p with the controller's alpha
+        StepArgs sa{h->p, h->partS, h->alpha_dev, h->alphaMin};
+        launch_dirstep(h->M, h->PT, h->mat, h->dtSq, h->xt, h->partE, &nb, h->Hval, h->z, h->partCT, h->p, h->Hp, h->partS, h->st,
+                       h->ctl, sa);
+    } else if (ow) {
         launch_spmv_zp(h->M, h->HvalOwn, h->z, h->partGC, h->p, h->Hp, h->partS, h->st, h->ctl, 0, -1, h->heldMask, h->ownMask,
                        h->held());
     } else if (fuseDir) {   // build_p + spmv_dots in one launch, H p from the cached H s_j
-        launch_spmv_zp(h->M, h->Hval, h->z, h->partC, h->p, h->Hp, h->partS, h->st, h->ctl, se ? h->v0 : 0, se ? h->v1 : -1);
+        // (one rank: the y_i . z partials from their column-major twin, which merge_early writes beside the rows)
+        launch_spmv_zp(h->M, h->Hval, h->z, h->dist ? h->partC : h->partCT, h->p, h->Hp, h->partS, h->st, h->ctl, se ? h->v0 : 0,
+                       se ? h->v1 : -1, nullptr, nullptr, VList(), !h->dist);
     } else {
         launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
         launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st, h->ctl);
@@ -153,13 +162,13 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         if (int rc = allreduce_sum(h, h->partG, 2)) return rc;
         spart = h->partG;
     }
-    int nb = 0;
     // (not on meshes whose workgroups walk several patches: the prefetched operands leave no registers for it)
     // (sharded element pass: the fused form writes the trial point only on this rank's vertex slice -- its inertia loop --,
     // so the step stays a launch of its own there)
     // (owner exchange: the inertia loop runs over every vertex with the owner's share of the mass, so the fused form writes the
     // whole trial point there too -- x + alpha 0 off the held vertices)
-    if (h->tune.fuseStep && (!se || ow)) {   // the step x_trial = x_cur + alpha p inside the element pass
+    if (h->specNow) {
+    } else if (h->tune.fuseStep && (!se || ow)) {   // the step x_trial = x_cur + alpha p inside the element pass
         StepArgs sa{h->p, spart, h->alpha_dev, h->pairNow ? -h->alphaMin : h->alphaMin};   // (negative: a paired launch)
         // (a step with paired trials takes the PAIR instantiations of these two launches)
         (h->pairNow ? launch_elem_energy_grad_pair : launch_elem_energy_grad)(
@@ -231,12 +240,12 @@ int enqueue_loop_slot_early(dotmi_handle *h)
                        (h->timeCount++ % h->timeStride) == 0;
     h->slotTimed.push_back(timed ? h->evUsed : -1);
     CtlArgs ca{h->ctl, ctlE, ctlR, h->alpha_dev, h->h_flags, nb, h->pairNow ? 2 : 0};
-    (h->pairNow ? launch_gemv_pair : launch_gemv)(
+    (h->pairNow ? launch_gemv_pair : h->specNow ? launch_gemv_spec : launch_gemv)(
         h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr, &ca,
         h->tune.earlyAbort ? (int)h->slotTimed.size() /* the slot's epoch, 1-based */ : (1 << 30) /* never stopped */);
     if (timed) h->evUsed += 2;
     if (!h->dist) {
-        launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl);
+        launch_merge_early(h->M, h->P, h->z, h->partC, 0, h->st, h->ctl, nullptr, nullptr, VList(), nullptr, 0, nullptr, h->partCT);
     } else {
         // sharded subdomains: this rank's part of the sum, the one collective of the iteration (issued in every slot,
         // whatever the controller decided: every rank enqueues the same sequence), then the division and the history terms
@@ -346,6 +355,14 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     // slot wait for the verdict); -1: only in steps that follow a step with halvings in at least a quarter of its iterations
     h->pairNow = h->earlyNow && !h->dist && h->tune.fuseStep && h->tune.fuseDir && h->tune.earlyAbort && h->tune.earlyHold &&
                  (h->tune.pairTrials > 0 || (h->tune.pairTrials < 0 && h->prevIters > 0 && 4 * h->prevHalv >= h->prevIters));
+    // the unit step speculatively beside the direction kernel: one rank, the fused kernels, every patch a workgroup, no pairing
+    // in this step (a step whose predecessor halved often); -1: only after a step whose first trials took the unit estimate at
+    // least nine times in ten (a slot whose estimate is below 1 is redone: ~45 us lost against ~10 saved)
+    h->specNow = h->earlyNow && !h->dist && !h->pairNow && h->tune.fuseStep && h->tune.fuseDir && h->tune.earlyAbort &&
+                 dirstep_fits(h->PT) &&
+                 (h->tune.specStep > 0 || (h->tune.specStep < 0 && h->prevFirst > 0 && 10 * h->prevUnit >= 9 * h->prevFirst));
+    C.specPartials = h->partS;
+    C.alphaMin = h->alphaMin;
     C.iterCap = h->iterCap;
     C.hist = h->hist;
     C.tol = h->targetGRes;
@@ -361,6 +378,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
         C.HS[s] = h->HS[s];
     }
     C.u_old = h->u_old;
+    devloop_resolve(C);   // (slot 0, no pair yet)
     C.holdEnable = h->tune.earlyHold && h->tune.earlyAbort ? 1 : 0;
     // the forecast carries over from the last step (a function of the handle's own history)
     memcpy(C.predHist, h->predState, sizeof(int) * 2);
@@ -414,7 +432,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
             CtlArgs ca{h->ctl, h->partE, h->partR, h->alpha_dev, h->h_flags, nb, 1};
             launch_gemv(h->P, nullptr, h->st, h->ctl, nullptr, nullptr, &ca, 1 << 30);
             if (!h->dist) {
-                launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl);
+                launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, nullptr, nullptr, VList(), nullptr, 0, nullptr, h->partCT);
             } else {
                 launch_merge(h->M, h->P, L0, h->zstage, h->partC, 0, h->st, h->ctl);
                 if (int rc = allreduce_sum(h, h->zstage, n_)) return rc;
@@ -550,6 +568,10 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     h->heldRejected = C.heldRejected;
     h->pairSlots = C.pairSlots;
     h->pairRedo = C.pairRedo;
+    h->specSlots = C.specSlots;
+    h->specRedo = C.specRedo;
+    h->prevFirst = C.firstTrials;
+    h->prevUnit = C.unitFirst;
     if (h->tune.fuseLog && C.pairSlots)
         fprintf(stderr, "dotmi: paired trials: %d slots, %d of them redone (the full step was acceptable)\n", C.pairSlots, C.pairRedo);
     *failed = C.status == 3;
@@ -878,6 +900,9 @@ int dotmi_step(dotmi_handle *h, dotmi_step_stats *st)
         st->backsolve_stopped = (h->devLoop && h->earlyNow) ? (h->numLineSearch - ls0) + 1 : 0;
         // (a paired slot whose full step was rejected takes a halving without a stopped launch; one that is redone stops without one)
         if (h->devLoop && h->pairNow) st->backsolve_stopped += 2 * h->pairRedo - h->pairSlots;
+        if (h->devLoop && h->specNow) st->backsolve_stopped += h->specRedo;   // (a redone slot's back-solve stops without a halving)
+        st->spec_slots = (h->devLoop && h->specNow) ? h->specSlots : 0;
+        st->spec_redone = (h->devLoop && h->specNow) ? h->specRedo : 0;
         st->backsolve_held = (h->devLoop && h->earlyNow) ? h->heldSlots : 0;
         st->backsolve_held_rejected = (h->devLoop && h->earlyNow) ? h->heldRejected : 0;
         st->paired_slots = (h->devLoop && h->pairNow) ? h->pairSlots : 0;

@@ -12,14 +12,20 @@ namespace dotmi {
 // the same order the host path uses, so both paths produce the same bits.
 // ------------------------------------------------------------------------------------------------
 // (a device function: the controller is a launch of its own, or workgroup 0 of the back-solve launch -- 256 threads)
-// PAIR: the controller of a step with paired line-search trials (it understands paired slots: the full step's energy partials
-// in partE2, alpha_dev[1] > 0 marks a paired slot).  A template parameter: the plain instantiation compiles those branches away
-// (until round 5 through a second compilation of the file under -DDOTMI_PAIR_TU).
-template <bool PAIR>
+// CTL_PAIR: the controller of a step with paired line-search trials (it understands paired slots: the full step's energy partials
+// in partE2, alpha_dev[1] > 0 marks a paired slot).  CTL_SPEC: the controller of a step whose new-direction slots take the unit
+// step speculatively (k_dirstep.hip): it sums the SpMV partials itself -- the element pass's prologue, the same additions -- and
+// when alpha_0 = clamp(-p.g / p.Hp, alphaMin, 1) is not 1 the slot did not evaluate the reference's first trial: its back-solve is
+// stopped and the next slot evaluates x + alpha_0 p as the first trial it is (phase 1, redo: nothing counted twice).  Template
+// parameters: the plain instantiation compiles those branches away (the pairing until round 5 through a second compilation of the
+// file under -DDOTMI_PAIR_TU).
+constexpr int CTL_PLAIN = 0, CTL_PAIR = 1, CTL_SPEC = 2;
+template <int CTL>
 __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, const double *__restrict__ partE, int nbE,
                                   const double *__restrict__ partR, const double *__restrict__ alpha_dev,
                                   int *__restrict__ flags_host, int init, const double *__restrict__ partE2 = nullptr)
 {
+    constexpr bool PAIR = CTL == CTL_PAIR, SPEC = CTL == CTL_SPEC;
     static_assert(sizeof(DevLoop) % 8 == 0, "DevLoop is copied as 8-byte words");
     static_assert(RED_K <= 32, "two passes of 16 columns");
     __shared__ double chunk[RED_K + 2][SUM_CHUNKS];
@@ -33,6 +39,18 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
         for (int i = t; i < NW8; i += 256) dst[i] = src[i];
     }
     const double alpha_in = *alpha_dev;
+    // SPEC: the partials of p.g and p.Hp, requested with everything else (wave 0; summed below as elem_patch_body's prologue does)
+    double pgv[NB_RED / 64], pHpv[NB_RED / 64];
+    if constexpr (SPEC) {
+        if (t < 64 && !init) {
+            const double *__restrict__ sp = ctl->specPartials;
+#pragma unroll
+            for (int u = 0; u < NB_RED / 64; ++u) {
+                pgv[u] = sp[(size_t)(t + 64 * u) * RED_K];
+                pHpv[u] = sp[(size_t)(t + 64 * u) * RED_K + 1];
+            }
+        }
+    }
     const double alpha_full = (PAIR && partE2 && !init) ? alpha_dev[1] : 0.0;   // > 0: a paired slot (elem_patch_kernel)
     __shared__ double chunk2[PAIR ? 2 : 1][SUM_CHUNKS];
     // chunked_sum() order (dotmi_internal.hpp), one thread per (column, chunk): every load of the kernel is in flight at
@@ -98,6 +116,20 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
             chunk[colB][chB] = b;
         }
     }
+    double a0spec = 1.0;   // SPEC: alpha_0 of the direction the slot computed (valid in thread 0)
+    if constexpr (SPEC) {
+        if (t < 64 && !init) {
+            double pg = 0.0, pHp = 0.0;
+#pragma unroll
+            for (int u = 0; u < NB_RED / 64; ++u) {
+                pg += pgv[u];
+                pHp += pHpv[u];
+            }
+            pg = wave_sum(pg);
+            pHp = wave_sum(pHp);
+            a0spec = fmax(ctl->alphaMin, fmin(1.0, -pg / pHp));  // Optimizer.cpp:1085
+        }
+    }
     __syncthreads();
     if (C.status != 0) return;
     if (t < RED_K + 2) {
@@ -125,6 +157,10 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
             // what a first trial with alpha_0 < 1 teaches the pairing rule (a redone trial has taught it already)
             const double a0 = alpha_full > 0.0 ? alpha_full : alpha_in;
             const bool learns = C.phase == 0 && a0 < 1.0;
+            if (C.phase == 0) {
+                C.firstTrials++;
+                C.unitFirst += a0 == 1.0 ? 1 : 0;
+            }
             C.redo = 0;
             if (alpha_full > 0.0) {
                 // Paired slot: the energy of the FULL step first, as the reference's line search would see it
@@ -168,11 +204,41 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
                 int &pc = C.pairCtr[pair_band(a0)];
                 pc = (E > C.E_cur && alpha > 0.0) ? min(3, pc + 1) : max(0, pc - 1);
             }
+        } else if constexpr (SPEC) {
+            if (C.slots < C.kindCap) C.slot_kind[C.slots] = C.phase == 0 ? 1 : 2;
+            C.slots++;
+            kind = (C.phase == 0 || C.redo) ? 0 : 1;   // first trial of an iteration (a redone slot is one) / retry after a halving
+            C.redo = 0;
+            if (C.phase == 0) {
+                // the slot computed a new direction and evaluated x + 1 p beside it
+                C.firstTrials++;
+                C.unitFirst += a0spec == 1.0 ? 1 : 0;
+                C.specSlots++;
+                if (a0spec != 1.0) {
+                    // the estimate lies inside (alphaMin, 1): the unit step is not the line search's first trial.  Nothing has
+                    // happened yet: the slot's back-solve stops, the next slot evaluates x + alpha_0 p (its energy is counted there)
+                    C.specRedo++;
+                    C.abortEpoch = C.slots;
+                    __hip_atomic_store(&ctl->abortEpoch, C.slots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    C.holdVerdict = 2 * C.slots + 1;
+                    __hip_atomic_store(&ctl->holdVerdict, C.holdVerdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    C.phase = 1;
+                    C.alpha = a0spec;
+                    C.redo = 1;
+                    decided = true;
+                }
+            }
+            if (!decided) C.evals++;
+            C.heldSlots += C.holdNext;
         } else {
             C.evals++;
             if (C.slots < C.kindCap) C.slot_kind[C.slots] = C.phase == 0 ? 1 : 2;
             C.slots++;
             kind = C.phase == 0 ? 0 : 1;   // first trial of an iteration / retry after a halving
+            if (C.phase == 0) {   // (the gate of the next step's speculation: how often the estimate is the unit step)
+                C.firstTrials++;
+                C.unitFirst += alpha_in == 1.0 ? 1 : 0;
+            }
             C.heldSlots += C.holdNext;
         }
         if (decided) {
@@ -345,12 +411,13 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
                     C.L.y[i] = C.Y[order[i]];
                 }
             }
+            devloop_resolve(C);   // (S[slot], MY[order[i]], HS[order[i]]: the kernels of the next slot read them resolved)
         }
     }
     // forecast for the slot that follows: hold its back-solve if its kind's counter for the current pattern says "rejected"
     if (t == 0 && !init) {
         const int nk = C.phase == 0 ? 0 : 1;
-        C.holdNext = (C.holdEnable && C.status == 0 && !(PAIR && C.redo) && C.predCtr[nk][C.predHist[nk] & 3] >= 2) ? 1 : 0;
+        C.holdNext = (C.holdEnable && C.status == 0 && !((PAIR || SPEC) && C.redo) && C.predCtr[nk][C.predHist[nk] & 3] >= 2) ? 1 : 0;
     }
     __syncthreads();
     {
@@ -373,7 +440,7 @@ __global__ __launch_bounds__(256) void loop_control_kernel(DevLoop *__restrict__
                                                            const double *__restrict__ alpha_dev,
                                                            int *__restrict__ flags_host, int init)
 {
-    loop_control_body<false>(ctl, partE, nbE, partR, alpha_dev, flags_host, init);
+    loop_control_body<CTL_PLAIN>(ctl, partE, nbE, partR, alpha_dev, flags_host, init);
 }
 
 void launch_loop_control(DevLoop *ctl, const double *partE, int nbE, const double *partR,
@@ -798,7 +865,7 @@ __global__ __launch_bounds__(THREADS, 2) void backsolve_kernel(const int4 *__res
 // decision about the trial, the history update) run beside the ~45 us of streaming instead of in front of them.  The
 // tiles read the loop state while workgroup 0 may be rewriting it: whichever value of `status` they see, the result is
 // only used (merge_early, after the launch) if the final state says so.
-template <bool PAIR>
+template <int CTL>
 __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__restrict__ job, const int *__restrict__ dofmap,
                                                             const double *__restrict__ W, int nmax,
                                                             const RowTile *__restrict__ rt, const double *__restrict__ q,
@@ -810,17 +877,17 @@ __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__res
     __shared__ double2 rs[2 * 256 * 6];
     // (which workgroup hosts the controller makes no difference: index 0 / 256 / 520 / last measured 47.0-47.5 us)
     if (blockIdx.x == 0) {
-        if constexpr (PAIR)
-            loop_control_body<true>(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init & 1,
-                                    (ca.init & 2) ? ca.partE + 2 * ELEM_NB_MAX : nullptr);
+        if constexpr (CTL == CTL_PAIR)
+            loop_control_body<CTL_PAIR>(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init & 1,
+                                        (ca.init & 2) ? ca.partE + 2 * ELEM_NB_MAX : nullptr);
         else
-            loop_control_body<false>(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init);
+            loop_control_body<CTL>(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init);
         return;
     }
     if (ca.ctl->status != 0) return;
     // (PAIR: a paired slot -- alpha_dev[1] > 0, written by the element pass of this slot -- waits as well: its gather worked on the
     // half step, which only counts if the controller finds the full step's energy too high)
-    if (epoch < (1 << 30) && (ca.ctl->holdNext || (PAIR && (ca.init & 2) && ca.alpha_dev[1] > 0.0))) {
+    if (epoch < (1 << 30) && (ca.ctl->holdNext || (CTL == CTL_PAIR && (ca.init & 2) && ca.alpha_dev[1] > 0.0))) {
         // the trial is expected to be rejected (DevLoop::holdNext): wait for the controller's verdict instead of streaming
         // the factors beside it -- a rejection then costs the controller's ~7 us, not a stopped back-solve's ~20.  (A
         // workgroup that starts after the controller has stored its forecast for the NEXT slot reads that one: the verdict
@@ -1034,7 +1101,7 @@ __global__ __launch_bounds__(BSL_THREADS) void backsolve_long_kernel(const int4 
     }
 }
 
-template <bool PAIR>
+template <int CTL>
 static void launch_gemv_impl(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,
                              const CtlArgs *ca, int spec)
 {
@@ -1068,10 +1135,10 @@ static void launch_gemv_impl(const DevParts &P, const double *q, hipStream_t st,
     if (nG > 0 && ca) {
         // one workgroup more: the controller (backsolve_ctl_kernel)
         if (timed)
-            hipExtLaunchKernelGGL(backsolve_ctl_kernel<PAIR>, dim3(nG + 1), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
+            hipExtLaunchKernelGGL(backsolve_ctl_kernel<CTL>, dim3(nG + 1), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
                                   P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, *ca, spec, nN);
         else
-            hipLaunchKernelGGL(backsolve_ctl_kernel<PAIR>, dim3(nG + 1), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax, P.rt,
+            hipLaunchKernelGGL(backsolve_ctl_kernel<CTL>, dim3(nG + 1), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax, P.rt,
                                (const double *)P.rpad, P.ppart, P.nbmax, *ca, spec, nN);
     } else if (nG > 0) {
         if (timed)
@@ -1092,13 +1159,19 @@ static void launch_gemv_impl(const DevParts &P, const double *q, hipStream_t st,
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,
                  const CtlArgs *ca, int spec)
 {
-    launch_gemv_impl<false>(P, q, st, ctl, ev0, ev1, ca, spec);
+    launch_gemv_impl<CTL_PLAIN>(P, q, st, ctl, ev0, ev1, ca, spec);
 }
 // ... with the controller that understands paired slots (CtlArgs::init bit 1)
 void launch_gemv_pair(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,
                       const CtlArgs *ca, int spec)
 {
-    launch_gemv_impl<true>(P, q, st, ctl, ev0, ev1, ca, spec);
+    launch_gemv_impl<CTL_PAIR>(P, q, st, ctl, ev0, ev1, ca, spec);
+}
+// ... with the controller of a step that takes the unit step speculatively (k_dirstep.hip)
+void launch_gemv_spec(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,
+                      const CtlArgs *ca, int spec)
+{
+    launch_gemv_impl<CTL_SPEC>(P, q, st, ctl, ev0, ev1, ca, spec);
 }
 // the tile partials of every owned subdomain summed in the subdomains' own order (coalesced) -> psub
 void launch_reduce_partial(const DevParts &P, hipStream_t st, const DevLoop *ctl)

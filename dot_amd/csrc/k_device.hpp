@@ -88,7 +88,13 @@ __device__ __forceinline__ double wave_sum8_transposed(const double (&d)[8], int
 
 // block-sum the first nvals accumulators (nvals uniform over the block) and store them as this block's partial row.
 // sm: 4*RED_K doubles.
-__device__ __forceinline__ void write_partials(double (&acc)[RED_K], int nvals, double *partials, double *sm)
+// partialsT (round 6): the same values once more in COLUMN-major form, partialsT[t * NB_RED + block] -- the layout for partial
+// arrays that EVERY workgroup of the next kernel reads (the y_i . z columns in front of the direction kernels): a wave's load of
+// one column of 64 consecutive rows is then 4 lines of 128 bytes instead of 64 (rows are 168 bytes apart), which with ~600
+// workgroups reading the same 43 KB was ~1 M line requests on a few L2 channels -- microseconds in front of every workgroup's
+// first real load (tools/prof_dirstep.sh)
+__device__ __forceinline__ void write_partials(double (&acc)[RED_K], int nvals, double *partials, double *sm,
+                                               double *partialsT = nullptr)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
@@ -105,8 +111,11 @@ __device__ __forceinline__ void write_partials(double (&acc)[RED_K], int nvals, 
     }
     __syncthreads();
     const int t = threadIdx.x;
-    if (t < nvals)
-        partials[(size_t)blockIdx.x * RED_K + t] = (sm[t] + sm[RED_K + t]) + (sm[2 * RED_K + t] + sm[3 * RED_K + t]);
+    if (t < nvals) {
+        const double v = (sm[t] + sm[RED_K + t]) + (sm[2 * RED_K + t] + sm[3 * RED_K + t]);
+        partials[(size_t)blockIdx.x * RED_K + t] = v;
+        if (partialsT) partialsT[(size_t)t * NB_RED + blockIdx.x] = v;
+    }
 }
 
 // sum over the 8 lanes of an aligned lane group (fixed butterfly => deterministic); all 8 get the total
@@ -117,6 +126,79 @@ __device__ __forceinline__ double group8_sum(double v)
     v += __shfl_xor(v, 1, 64);
     return v;
 }
+
+// the y_i . z partial columns of the NB_RED rows, summed per lane of wave 0 (lane l: rows l, l + 64, ...): every load of the lane
+// requested before the first addition (a loop over the rows with a running sum was four dependent round trips -- ~6 us on the
+// critical path of every kernel that starts with the two-loop's coefficients), the additions in row order as before
+// transposed: c_partials is the column-major twin (write_partials' partialsT)
+__device__ __forceinline__ void load_yz_partials(const double *__restrict__ c_partials, double (&c)[8], bool transposed = false)
+{
+    static_assert(NB_RED % 64 == 0 && HIST_MAX <= 8, "rows per lane, one transposed butterfly");
+    constexpr int U = NB_RED / 64;
+    double v[U][HIST_MAX];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < HIST_MAX; ++i)
+            v[u][i] = transposed ? c_partials[(size_t)i * NB_RED + threadIdx.x + 64 * u] : c_partials[(size_t)(threadIdx.x + 64 * u) * RED_K + i];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int i = 0; i < HIST_MAX; ++i) c[i] += v[u][i];
+}
+
+__device__ __forceinline__ double lane_bcast(double v, int srclane)   // (srclane: a constant)
+{
+    union {
+        double d;
+        int i[2];
+    } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], srclane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], srclane);
+    return u.d;
+}
+// The coefficients of the second half of the two-loop -- ys_i, s_j . y_i, xi_i: 48 doubles that lie one behind the other in the
+// loop state (DevLoop::L.ys, L.sy, X.xi) -- requested by wave 0 as ONE vector load, a coefficient per lane, together with the
+// y_i . z partial columns at the kernel's start; until round 6 they were scalar loads inside the recurrence, a round trip to the
+// memory the controller's XCD wrote on the critical path of every direction kernel.  delta: the recurrence of build_p_kernel
+// (DOTTimeStepper.cpp:455-467), the same operations in the same order.
+struct TwoLoopCoef {
+    double v;
+    static constexpr int NCOEF = HIST_MAX + HIST_MAX * HIST_MAX + HIST_MAX;
+    __device__ __forceinline__ void request(const DevLoop *__restrict__ ctl)   // (wave 0)
+    {
+        static_assert(offsetof(DevLoop, X) == offsetof(DevLoop, L) + offsetof(LbfgsArgs, ys) + sizeof(double) * (HIST_MAX + HIST_MAX * HIST_MAX),
+                      "ys, sy, xi contiguous");
+        static_assert(NCOEF <= 64, "a coefficient per lane");
+        const double *__restrict__ base = ctl->L.ys;
+        v = (int)threadIdx.x < NCOEF ? base[threadIdx.x] : 0.0;
+    }
+    // wave 0, all lanes: c = this lane's sums of the partial columns (load_yz_partials); lane 0 stores delta[0 .. HIST_MAX)
+    __device__ __forceinline__ void delta(const double (&c)[8], int m, double *__restrict__ out) const
+    {
+        const double tot = wave_sum8_transposed(c, threadIdx.x);
+        double ct[HIST_MAX], rys[HIST_MAX];
+#pragma unroll
+        for (int i = 0; i < HIST_MAX; ++i) {
+            ct[i] = __shfl(tot, 8 * i, 64);
+            rys[i] = (i < m) ? 1.0 / lane_bcast(v, i) : 0.0;   // independent divisions, off the recurrence's dependent chain
+        }
+        double d[HIST_MAX];
+#pragma unroll
+        for (int i = 0; i < HIST_MAX; ++i) {
+            d[i] = 0.0;
+            if (i < m) {
+                double yp = ct[i];
+#pragma unroll
+                for (int j = 0; j < HIST_MAX; ++j)
+                    if (j < i) yp += d[j] * lane_bcast(v, HIST_MAX + HIST_MAX * j + i);   // s_j . y_i
+                d[i] = lane_bcast(v, HIST_MAX + HIST_MAX * HIST_MAX + i) - yp * rys[i];
+            }
+            if (threadIdx.x == 0) out[i] = d[i];
+        }
+    }
+};
 
 // a zero to select instead of branching around a load (one copy per unit)
 static __device__ const double g_zero_slot = 0.0;

@@ -7,6 +7,12 @@
 namespace dotmi {
 
 constexpr int SPMV_R = 3;   // block rows a lane group works on at a time
+#ifdef DS_PROFILE
+static __device__ long long g_sv_prof[256][6];   // (tools/prof_dirstep.sh: stamps inside the direction rows' workgroups)
+#define SV_STAMP(i) do { if (threadIdx.x == 0 && bidx < 256) g_sv_prof[bidx][i] = wall_clock64(); } while (0)
+#else
+#define SV_STAMP(i) do { } while (0)
+#endif
 
 // Early order: build_p and spmv_dots in one launch.  The sparse product runs on z (ready when the launch starts); the
 // history terms of the direction and of H p are local to a row: p_v = z_v + sum_j delta_j s_j[v] (summed over the row's
@@ -16,6 +22,10 @@ constexpr int SPMV_R = 3;   // block rows a lane group works on at a time
 // (a device function: the kernel of its own -- spmv_zp_kernel, k_loopvec.hip -- or one of the two workgroup populations of the
 // speculative unit-step launch -- dirstep_kernel, k_dirstep.hip; bidx / nblocks: this workgroup's index and the number of
 // workgroups of the population; sm: 8 doubles, delta: HIST_MAX doubles of LDS)
+// NT threads per workgroup, R block rows per lane group and trip (256 x 3: one wave per SIMD with three rows' loads interleaved;
+// 1024 x 1: four waves per SIMD, a row each -- the same rows per workgroup and trip, the latencies overlapped by the hardware's
+// wave scheduling instead of by interleaving inside one wave; sm: 2 NT / 64 doubles)
+template <int NT = 256, int R = SPMV_R>
 __device__ __forceinline__ void spmv_zp_body(int nV, int v0, int v1, const uint8_t *__restrict__ rowMask,
                                              const uint8_t *__restrict__ ownMask, const int *__restrict__ adj_ptr,
                                              const int *__restrict__ adj_idx, const double *__restrict__ Hval,
@@ -24,64 +34,48 @@ __device__ __forceinline__ void spmv_zp_body(int nV, int v0, int v1, const uint8
                                              const DevLoop *__restrict__ ctl, VList vl, double *sm, double *delta, int bidx,
                                              int nblocks)
 {
-    if (ctl->status != 0 || ctl->phase != 0) return;
+    // the loop state this body needs, every load of it in front of the first branch (one round trip, not one per index)
+    const int status = ctl->status, phase = ctl->phase, m = ctl->L.m;
     const double *__restrict__ g = ctl->g_cur;
-    const LbfgsArgs &Lr = ctl->L;
-    const int m = Lr.m;
-    // wave 0: the y_i . z partial columns are requested now ...
+    const double *hs_[HIST_MAX], *hhs_[HIST_MAX];
+#pragma unroll
+    for (int j = 0; j < HIST_MAX; ++j) {
+        hs_[j] = ctl->L.s[j];
+        hhs_[j] = ctl->Lhs[j];
+    }
+    // wave 0: the y_i . z partial columns and the recurrence's coefficients are requested now ...
     double c[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) c[i] = 0.0;
+    TwoLoopCoef coef;
     if (threadIdx.x < 64) {
-        for (int b = threadIdx.x; b < c_blocks; b += 64) {
-#pragma unroll
-            for (int i = 0; i < HIST_MAX; ++i) c[i] += c_partials[(size_t)b * RED_K + i];
-        }
+        coef.request(ctl);
+        load_yz_partials(c_partials, c, c_blocks < 0);   // (|c_blocks| == NB_RED: every caller's; negative: the column-major twin)
     }
+    if (status != 0 || phase != 0) return;
     bool haveDelta = false;
     const int sub = threadIdx.x & 7;
     double mydelta = 0.0;   // delta of the pair this lane carries (lane j of a row's group: pair j)
     auto finish_delta = [&]() {   // ... and reduced here (build_p_kernel's prologue); one barrier, all threads
-        if (threadIdx.x < 64) {
-            const double tot = wave_sum8_transposed(c, threadIdx.x);
-            double ct[HIST_MAX], rys[HIST_MAX];
-#pragma unroll
-            for (int i = 0; i < HIST_MAX; ++i) {
-                ct[i] = __shfl(tot, 8 * i, 64);
-                rys[i] = (i < m) ? 1.0 / Lr.ys[i] : 0.0;
-            }
-            double d[HIST_MAX];
-#pragma unroll
-            for (int i = 0; i < HIST_MAX; ++i) {
-                d[i] = 0.0;
-                if (i < m) {
-                    double yp = ct[i];
-#pragma unroll
-                    for (int j = 0; j < HIST_MAX; ++j)
-                        if (j < i) yp += d[j] * Lr.sy[j][i];
-                    d[i] = ctl->X.xi[i] - yp * rys[i];
-                }
-                if (threadIdx.x == 0) delta[i] = d[i];
-            }
-        }
+        if (threadIdx.x < 64) coef.delta(c, m, delta);
         __syncthreads();
         mydelta = (sub < m) ? delta[sub < HIST_MAX ? sub : 0] : 0.0;
         haveDelta = true;
     };
+    SV_STAMP(0);
     double pg = 0, pHp = 0;
-    const int ngroups = nblocks * 32;
-    constexpr int R = SPMV_R;
+    const int ngroups = nblocks * (NT / 8);
     static_assert(HIST_MAX <= 8, "one lane of a row's group per stored pair");
     const double *__restrict__ hist_s = nullptr, *__restrict__ hist_hs = nullptr;
 #pragma unroll
     for (int j = 0; j < HIST_MAX; ++j)
         if (j == sub && j < m) {
-            hist_s = Lr.s[j];
-            hist_hs = ctl->HS[ctl->order[j]];
+            hist_s = hs_[j];
+            hist_hs = hhs_[j];
         }
     // (the trip count is the same for every thread of a workgroup: finish_delta's barrier sits inside the first trip)
     const int nrows = vl.v ? vl.n : nV;   // owner exchange: the rows of the held vertices only (p is zero elsewhere)
-    for (int base = bidx * 32; base < nrows; base += R * ngroups) {
+    for (int base = bidx * (NT / 8); base < nrows; base += R * ngroups) {
         const int vbase = base + (threadIdx.x >> 3);
         double a[R][3], zv[R][3], gg[R][3], sv[R][3], hv[R][3];   // sv / hv: pair number `sub` of the history (lanes 0 .. m-1)
         int kb[R], nk[R], vv[R], nkmax = 0;
@@ -120,6 +114,7 @@ __device__ __forceinline__ void spmv_zp_body(int nV, int v0, int v1, const uint8
         }
 #pragma unroll
         for (int u = 0; u < R; ++u) nkmax = max(nkmax, nk[u]);
+        SV_STAMP(1);
         for (int t = sub; t < nkmax; t += 8) {
             int col[R];
             double h[R][9], pc[R][3];
@@ -128,9 +123,8 @@ __device__ __forceinline__ void spmv_zp_body(int nV, int v0, int v1, const uint8
 #pragma unroll
             for (int u = 0; u < R; ++u)
                 if (t < nk[u]) {
-                    const double *b = Hval + (size_t)9 * (kb[u] + t);
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) h[u][i] = b[i];
+                    for (int i = 0; i < 9; ++i) h[u][i] = Hval[hval_idx(kb[u] + t, i)];
                 }
 #pragma unroll
             for (int u = 0; u < R; ++u)
@@ -146,7 +140,9 @@ __device__ __forceinline__ void spmv_zp_body(int nV, int v0, int v1, const uint8
                     a[u][2] += h[u][6] * pc[u][0] + h[u][7] * pc[u][1] + h[u][8] * pc[u][2];
                 }
         }
+        SV_STAMP(2);
         if (!haveDelta) finish_delta();
+        SV_STAMP(3);
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             const int v = vv[u];
@@ -170,16 +166,32 @@ __device__ __forceinline__ void spmv_zp_body(int nV, int v0, int v1, const uint8
         }
     }
     if (!haveDelta) finish_delta();
+    SV_STAMP(4);
     const double w0 = wave_sum(pg), w1 = wave_sum(pHp);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int NW = NT / 64;
     if (lane == 0) {
         sm[w] = w0;
-        sm[4 + w] = w1;
+        sm[NW + w] = w1;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        partials[(size_t)bidx * RED_K] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
-        partials[(size_t)bidx * RED_K + 1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+        // (a fixed pairwise tree over the waves' sums: (s0 + s1) + (s2 + s3) for four waves, as ever)
+        double t0[NW], t1[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            t0[i] = sm[i];
+            t1[i] = sm[NW + i];
+        }
+#pragma unroll
+        for (int span = 1; span < NW; span *= 2)
+#pragma unroll
+            for (int i = 0; i + span < NW; i += 2 * span) {
+                t0[i] = t0[i] + t0[i + span];
+                t1[i] = t1[i] + t1[i + span];
+            }
+        partials[(size_t)bidx * RED_K] = t0[0];
+        partials[(size_t)bidx * RED_K + 1] = t1[0];
     }
 }
 

@@ -25,6 +25,12 @@ static __device__ long long g_ep_prof[8192][6];   // (read back by dotmi_debug_e
 #else
 #define EP_STAMP(i) do { } while (0)
 #endif
+#ifdef DS_PROFILE
+static __device__ long long g_sp_prof[4096][4];   // (tools/prof_dirstep.sh: stamps inside the speculative prologue)
+#define SP_STAMP(i) do { if (SPEC && threadIdx.x == 0 && bIdx0 < 4096) g_sp_prof[bIdx0][i] = wall_clock64(); } while (0)
+#else
+#define SP_STAMP(i) do { } while (0)
+#endif
 // PAIR: the instantiation of a step with paired line-search trials -- a template parameter, so the plain
 // instantiation compiles every paired branch away (until round 5 the file was compiled twice, with and without -DDOTMI_PAIR_TU)
 // SPEC (k_dirstep.hip, round 6): the unit step is taken SPECULATIVELY beside the direction kernel instead of behind it.  The
@@ -34,8 +40,62 @@ static __device__ long long g_ep_prof[8192][6];   // (read back by dotmi_debug_e
 // the positions are the bits the plain slot forms from the stored p with alpha = 1).  alpha_0 clamps to 1 in most iterations
 // (bar17K: all of them); the controller checks it afterwards and has the slot redone with the true alpha_0 otherwise
 // (loop_control_body).  A retry slot (phase != 0) of such a step runs this body in its plain form on the stored p.
+// The inertia term and the trial point (one vertex per thread, element workgroup b those of vertices 256 b ...) are the work of a
+// third population of that launch (inertia_step_body below: nbIne = ceil(nV / 256) small workgroups that write the inertia
+// column of the energy partials -- the same vertices, the same sums as the element workgroup b makes in the plain form), so the
+// patches' workgroups do not carry the operands of p for a second vertex (42 registers).
 struct SpecArgs {
-    const double *z, *c_partials;   // the preconditioned vector of the two-loop, the y_i . z partial rows (NB_RED x RED_K)
+    const double *z, *c_partials;   // the preconditioned vector of the two-loop, the y_i . z partials in COLUMN-major form (HIST_MAX x NB_RED)
+    int nbIne;                      // workgroups of the inertia population (element workgroups beyond them store a zero inertia partial)
+};
+// the operands of p at scalar dof k: z and the stored s_j, requested together, combined once delta is known
+struct DirOps {
+    double w[1 + HIST_MAX];
+};
+// delta (second half of the two-loop) and p = z + sum_j delta_j s_j formed outside spmv_zp_body, with ITS statements: the y_i . z
+// partial columns requested by wave 0 (request), reduced and run through the recurrence (finish: delta -> LDS; the caller's
+// barrier follows), p_k combined in the order the row's lane group of spmv_zp_body adds its eight terms (form)
+struct SpecDir {
+    double cyz[8];
+    TwoLoopCoef coef;
+    int hm;
+    const double *__restrict__ hs[HIST_MAX];
+    const double *__restrict__ z;
+    __device__ __forceinline__ void request(const DevLoop *__restrict__ ctl, const SpecArgs &sx, bool spec)
+    {
+        hm = ctl->L.m;
+        z = sx.z;
+#pragma unroll
+        for (int j = 0; j < HIST_MAX; ++j) hs[j] = ctl->L.s[j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cyz[i] = 0.0;
+        if (spec && threadIdx.x < 64) {
+            coef.request(ctl);
+            load_yz_partials(sx.c_partials, cyz, true);   // (the column-major twin: SpecArgs)
+        }
+    }
+    // wave 0 (threadIdx.x < 64): delta[0 .. HIST_MAX) -> LDS
+    __device__ __forceinline__ void finish(const DevLoop *__restrict__, double *delta) { coef.delta(cyz, hm, delta); }
+    __device__ __forceinline__ void load(int k, DirOps &o) const
+    {
+        o.w[0] = z[k];
+#pragma unroll
+        for (int j = 0; j < HIST_MAX; ++j) o.w[1 + j] = (j < hm) ? hs[j][k] : 0.0;
+    }
+    // lane j of the row's group of eight holds t_j = (j == 0 ? z_k : 0) + s_j[k] delta_j (zero beyond the stored pairs) and the
+    // group's butterfly adds them as ((t0 + t4) + (t2 + t6)) + ((t1 + t5) + (t3 + t7))
+    __device__ __forceinline__ double form(const DirOps &o, const double *delta) const
+    {
+        double t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double zz = j == 0 ? o.w[0] : 0.0;
+            const double sj = j < HIST_MAX ? o.w[1 + (j < HIST_MAX ? j : 0)] : 0.0;
+            const double dj = j < HIST_MAX ? delta[j < HIST_MAX ? j : 0] : 0.0;
+            t[j] = zz + sj * dj;
+        }
+        return ((t[0] + t[4]) + (t[2] + t[6])) + ((t[1] + t[5]) + (t[3] + t[7]));
+    }
 };
 // bIdx0 / nbAll: this workgroup's index in the population of element workgroups and their number (the whole grid unless SPEC);
 // lds: the dynamic LDS of the launch; sm: 8 doubles; sh: 1 + HIST_MAX doubles (alpha, delta)
@@ -55,10 +115,18 @@ __device__ __forceinline__ void elem_patch_body(const DevPatches &PT, const doub
     // and one pass over x, p less per line-search trial
     constexpr bool fuse = FUSE;   // (a template parameter: the plain instantiation keeps its register count)
     double *__restrict__ x_out = nullptr;
+    // (device loop: the loop state this body needs, every load of it in front of the first branch -- one round trip)
+    int lphase = 0;
+    double lalpha = 0.0;
     if (ctl) {
-        if (ctl->status != 0) return;
-        x = fuse ? ctl->x_cur : ctl->x_trial;
-        x_out = ctl->x_trial;
+        const int status = ctl->status;
+        lphase = ctl->phase;
+        lalpha = ctl->alpha;
+        const double *xc = ctl->x_cur;
+        double *xtr = ctl->x_trial;
+        if (status != 0) return;
+        x = fuse ? xc : xtr;
+        x_out = xtr;
     }
     // paired trial (PAIR, StepArgs::alpha_min < 0): the launch is twice as wide; workgroup nbP + b mirrors workgroup b on the FULL step
     const bool pairedLaunch = PAIR && fuse && sa.alpha_min < 0.0;
@@ -69,48 +137,13 @@ __device__ __forceinline__ void elem_patch_body(const DevPatches &PT, const doub
     const bool withGrad = GRAD && !second;
     double pgv[NB_RED / 64], pHpv[NB_RED / 64];
     // SPEC: the slot computes a new direction (phase 0) -> the unit step on a direction formed here; a retry: the plain form
-    const bool spec = SPEC && ctl->phase == 0;
-    const bool usePart = fuse && !spec && ctl->phase == 0;   // a retry steps with the halved alpha the controller left
+    const bool spec = SPEC && lphase == 0;
+    const bool usePart = fuse && !spec && lphase == 0;   // a retry steps with the halved alpha the controller left
     // SPEC: wave 0 requests the y_i . z partial columns now (spmv_zp_body's prologue, the same statements: the same delta)
-    double cyz[8];
-    const LbfgsArgs *Lp = nullptr;
-    if constexpr (SPEC) Lp = &ctl->L;
-    const int hm = SPEC ? Lp->m : 0;
-    const double *__restrict__ hs[HIST_MAX];
-    if constexpr (SPEC) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) cyz[i] = 0.0;
-        if (spec && threadIdx.x < 64) {
-            for (int b = threadIdx.x; b < NB_RED; b += 64) {
-#pragma unroll
-                for (int i = 0; i < HIST_MAX; ++i) cyz[i] += sx.c_partials[(size_t)b * RED_K + i];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < HIST_MAX; ++j) hs[j] = (j < hm) ? Lp->s[j] : nullptr;
-    }
-    // the operands of p at scalar dof k (SPEC): z and the stored s_j, requested together, combined once delta is known
-    struct DirOps {
-        double w[1 + HIST_MAX];
-    };
-    auto dir_load = [&](int k, DirOps &o) {
-        o.w[0] = sx.z[k];
-#pragma unroll
-        for (int j = 0; j < HIST_MAX; ++j) o.w[1 + j] = (j < hm) ? hs[j][k] : 0.0;
-    };
-    // p_k as spmv_zp_body forms it: lane j of the row's group of eight holds t_j = (j == 0 ? z_k : 0) + s_j[k] delta_j (zero
-    // beyond the stored pairs) and the group's butterfly adds them as ((t0 + t4) + (t2 + t6)) + ((t1 + t5) + (t3 + t7))
-    auto dir_form = [&](const DirOps &o) -> double {
-        double t[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const double zz = j == 0 ? o.w[0] : 0.0;
-            const double sj = j < HIST_MAX ? o.w[1 + (j < HIST_MAX ? j : 0)] : 0.0;
-            const double dj = j < HIST_MAX ? sh[1 + (j < HIST_MAX ? j : 0)] : 0.0;
-            t[j] = zz + sj * dj;
-        }
-        return ((t[0] + t[4]) + (t[2] + t[6])) + ((t[1] + t[5]) + (t[3] + t[7]));
-    };
+    SpecDir sd;
+    if constexpr (SPEC) sd.request(ctl, sx, spec);
+    auto dir_load = [&](int k, DirOps &o) { sd.load(k, o); };
+    auto dir_form = [&](const DirOps &o) -> double { return sd.form(o, sh + 1); };
     if (usePart && threadIdx.x < 64) {              // requested here, summed after this thread's other loads are out
 #pragma unroll
         for (int u = 0; u < NB_RED / 64; ++u) {
@@ -124,26 +157,7 @@ __device__ __forceinline__ void elem_patch_body(const DevPatches &PT, const doub
         if (spec) {
             // delta (second half of the two-loop, build_p_kernel's prologue) by wave 0 -> LDS; the step is 1
             if (threadIdx.x < 64) {
-                const double tot = wave_sum8_transposed(cyz, threadIdx.x);
-                double ct[HIST_MAX], rys[HIST_MAX];
-#pragma unroll
-                for (int i = 0; i < HIST_MAX; ++i) {
-                    ct[i] = __shfl(tot, 8 * i, 64);
-                    rys[i] = (i < hm) ? 1.0 / Lp->ys[i] : 0.0;
-                }
-                double dl[HIST_MAX];
-#pragma unroll
-                for (int i = 0; i < HIST_MAX; ++i) {
-                    dl[i] = 0.0;
-                    if (i < hm) {
-                        double yp = ct[i];
-#pragma unroll
-                        for (int j = 0; j < HIST_MAX; ++j)
-                            if (j < i) yp += dl[j] * Lp->sy[j][i];
-                        dl[i] = ctl->X.xi[i] - yp * rys[i];
-                    }
-                    if (threadIdx.x == 0) sh[1 + i] = dl[i];
-                }
+                sd.finish(ctl, sh + 1);
                 if (threadIdx.x == 0) {
                     sh_alpha = 1.0;
                     if (bIdx0 == 0) *sa.alpha_out = 1.0;   // what the gather scales the pair with; the controller checks alpha_0
@@ -155,7 +169,7 @@ __device__ __forceinline__ void elem_patch_body(const DevPatches &PT, const doub
             return;
         }
         if (threadIdx.x < 64) {
-            double a = ctl->alpha;
+            double a = lalpha;
             if (usePart) {
                 double pg = 0.0, pHp = 0.0;
 #pragma unroll
@@ -199,17 +213,14 @@ __device__ __forceinline__ void elem_patch_body(const DevPatches &PT, const doub
     // inertia operands of this thread's first vertex: independent of the element work, requested ahead of it
     const int gstride = nbP * blockDim.x;
     const int vfirst = v0 + bIdx * blockDim.x + tid;
+    // (SPEC: the inertia term and the trial point are another population's work, inertia_step_body)
     double ix[3] = {0, 0, 0}, ixt[3] = {0, 0, 0}, ip[3] = {0, 0, 0}, im = 0.0;
-    DirOps ipo[SPEC ? 3 : 1];
-    if (vfirst < v1) {
+    if (!SPEC && vfirst < v1) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             ix[d] = x[3 * vfirst + d];
             ixt[d] = xt[3 * vfirst + d];
-            if constexpr (SPEC) {
-                if (spec) dir_load(3 * vfirst + d, ipo[d]);
-                else ip[d] = sa.p[3 * vfirst + d];
-            } else if (fuse) ip[d] = sa.p[3 * vfirst + d];
+            if (fuse) ip[d] = sa.p[3 * vfirst + d];
         }
         im = mass[vfirst];
     }
@@ -266,6 +277,7 @@ __device__ __forceinline__ void elem_patch_body(const DevPatches &PT, const doub
     PatchOps cur, nxt;
     int nvN = 0, gidN = -1, slotN = 0;   // ids of the patch after next
     unsigned short cpN = 0;
+    SP_STAMP(0);
     if ((int)bIdx < PT.nPatches) {
         issue_ids(bIdx, cur);
         issue_ops(bIdx, cur);
@@ -297,10 +309,12 @@ __device__ __forceinline__ void elem_patch_body(const DevPatches &PT, const doub
             for (int lv = tid + 256; lv <= nv; lv += 256) cptr[lv] = cp[lv];
             for (int lv = tid + 256; lv < nv; lv += 256) vslot[lv] = PT.pv_slot[vb + lv];
         }
+        SP_STAMP(1);
         if (fuse && !haveAlpha) {
             finish_alpha();
             if (second && alpha < 0.0) return;   // (the whole workgroup: not a paired slot)
         }
+        SP_STAMP(2);
         if (cur.gid0 >= 0) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -449,13 +463,10 @@ __device__ __forceinline__ void elem_patch_body(const DevPatches &PT, const doub
         finish_alpha();
         if (second && alpha < 0.0) return;   // (the whole workgroup: not a paired slot)
     }
-    if (vfirst < v1) {
+    if (!SPEC && vfirst < v1) {
         if (fuse) {
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                if constexpr (SPEC) {
-                    if (spec) ip[d] = dir_form(ipo[d]);
-                }
                 ix[d] = ix[d] + alpha * ip[d];
                 if (!second) x_out[3 * vfirst + d] = ix[d];
             }
@@ -463,21 +474,13 @@ __device__ __forceinline__ void elem_patch_body(const DevPatches &PT, const doub
         const double dx = ix[0] - ixt[0], dy = ix[1] - ixt[1], dz = ix[2] - ixt[2];
         ine += (dx * dx + dy * dy + dz * dz) * im / 2.0;
     }
-    for (int v = vfirst + gstride; v < v1; v += gstride) {
+    for (int v = vfirst + gstride; !SPEC && v < v1; v += gstride) {
         double xv[3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             xv[d] = x[3 * v + d];
             if (fuse) {
-                double pd;
-                if (SPEC && spec) {
-                    DirOps o;
-                    dir_load(3 * v + d, o);
-                    pd = dir_form(o);
-                } else {
-                    pd = sa.p[3 * v + d];
-                }
-                xv[d] = xv[d] + alpha * pd;
+                xv[d] = xv[d] + alpha * sa.p[3 * v + d];
                 if (!second) x_out[3 * v + d] = xv[d];
             }
         }
@@ -495,9 +498,87 @@ __device__ __forceinline__ void elem_patch_body(const DevPatches &PT, const doub
     if (tid == 0) {
         if (second) partials += 2 * ELEM_NB_MAX;
         partials[2 * bIdx] = (sm[0] + sm[1]) + (sm[2] + sm[3]);      // to be scaled by dtSq by the consumer
-        partials[2 * bIdx + 1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+        if constexpr (SPEC) {
+            if (bIdx >= sx.nbIne) partials[2 * bIdx + 1] = 0.0;   // (below: inertia_step_body's)
+        } else {
+            partials[2 * bIdx + 1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
+        }
     }
     EP_STAMP(4);
+}
+
+// SPEC: the inertia slice of the element pass -- trial point x_trial = x_cur + alpha p and sum_v 1/2 m_v |x_v - x~_v|^2
+// (Optimizer.cpp:1023-1042, :1202-1215) -- for the vertices element workgroup j takes in the plain form (256 j + thread, then a
+// grid stride of 256 nbElem), as a workgroup of its own in the speculative launch; alpha and p as there: phase 0 the unit step on
+// p formed here (SpecDir), a retry slot the controller's alpha on the stored p.  sm: 8 doubles, sh: 1 + HIST_MAX doubles.
+__device__ __forceinline__ void inertia_step_body(const double *__restrict__ mass, const double *__restrict__ xt, int nV,
+                                                  double *__restrict__ partials, const DevLoop *__restrict__ ctl,
+                                                  const StepArgs &sa, const SpecArgs &sx, int j, int nbElem, double *sm, double *sh)
+{
+    const int status = ctl->status, lphase = ctl->phase;
+    const double lalpha = ctl->alpha;
+    const double *__restrict__ x = ctl->x_cur;
+    double *__restrict__ x_out = ctl->x_trial;
+    if (status != 0) return;
+    const bool spec = lphase == 0;
+    SpecDir sd;
+    sd.request(ctl, sx, spec);
+    const int tid = threadIdx.x;
+    const int gstride = nbElem * 256;
+    const int vfirst = j * 256 + tid;
+    double ix[3] = {0, 0, 0}, ixt[3] = {0, 0, 0}, ip[3] = {0, 0, 0}, im = 0.0;
+    DirOps ipo[3];
+    if (vfirst < nV) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            ix[d] = x[3 * vfirst + d];
+            ixt[d] = xt[3 * vfirst + d];
+            if (spec) sd.load(3 * vfirst + d, ipo[d]);
+            else ip[d] = sa.p[3 * vfirst + d];
+        }
+        im = mass[vfirst];
+    }
+    double alpha = 1.0;
+    if (spec) {
+        if (tid < 64) sd.finish(ctl, sh + 1);
+        __syncthreads();
+    } else {
+        alpha = lalpha;
+    }
+    double ine = 0.0;
+    if (vfirst < nV) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (spec) ip[d] = sd.form(ipo[d], sh + 1);
+            ix[d] = ix[d] + alpha * ip[d];
+            x_out[3 * vfirst + d] = ix[d];
+        }
+        const double dx = ix[0] - ixt[0], dy = ix[1] - ixt[1], dz = ix[2] - ixt[2];
+        ine += (dx * dx + dy * dy + dz * dz) * im / 2.0;
+    }
+    for (int v = vfirst + gstride; v < nV; v += gstride) {   // (no trip while nbElem >= ceil(nV / 256): the meshes this form is used on)
+        double xv[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            double pd;
+            if (spec) {
+                DirOps o;
+                sd.load(3 * v + d, o);
+                pd = sd.form(o, sh + 1);
+            } else {
+                pd = sa.p[3 * v + d];
+            }
+            xv[d] = x[3 * v + d] + alpha * pd;
+            x_out[3 * v + d] = xv[d];
+        }
+        const double dx = xv[0] - xt[3 * v], dy = xv[1] - xt[3 * v + 1], dz = xv[2] - xt[3 * v + 2];
+        ine += (dx * dx + dy * dy + dz * dz) * mass[v] / 2.0;
+    }
+    const double wi = wave_sum(ine);
+    const int lane = tid & 63, w = tid >> 6;
+    if (lane == 0) sm[4 + w] = wi;
+    __syncthreads();
+    if (tid == 0) partials[2 * j + 1] = (sm[4] + sm[5]) + (sm[6] + sm[7]);
 }
 
 

@@ -6,13 +6,40 @@
 
 namespace dotmi {
 
+#ifdef K_PROFILE
+// stage stamps of the loop's vector kernels (tools/prof_loopkern.sh): [kernel][workgroup][stage], thread 0 of the workgroup
+__device__ long long g_kprof[4][256][8];
+extern "C" int dotmi_debug_kprof(long long *out)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_kprof), sizeof(long long) * 4 * 256 * 8);
+}
+#define KSTAMP(kern, i) do { if (threadIdx.x == 0 && blockIdx.x < 256) g_kprof[kern][blockIdx.x][i] = wall_clock64(); } while (0)
+#else
+#define KSTAMP(kern, i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // vertex gather of element gradients (+ inertia), new L-BFGS pair and its statistics
 // partial layout per block (m = L.m):
 //   [0] |g_new|^2   [1] y_new.s_new   [2] s_new.g_new
 //   [3+i] s_i.y_new   [3+HIST_MAX+j] s_new.y_j   [3+2*HIST_MAX+i] s_i.g_new
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void pair_stats_accum(int k, double gn, double sn, double yn, const LbfgsArgs &L,
+// the stored pairs' vectors as a kernel holds them in registers (copied from the loop state in ONE batch of scalar loads)
+struct HistView {
+    int m;
+    const double *s[HIST_MAX], *y[HIST_MAX];
+    __device__ __forceinline__ void load(const LbfgsArgs &L)
+    {
+        m = L.m;
+#pragma unroll
+        for (int i = 0; i < HIST_MAX; ++i) {
+            s[i] = L.s[i];
+            y[i] = L.y[i];
+        }
+    }
+};
+template <class LV>
+__device__ __forceinline__ void pair_stats_accum(int k, double gn, double sn, double yn, const LV &L,
                                                  double (&acc)[RED_K])
 {
     acc[0] += gn * gn;
@@ -43,26 +70,28 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
     double *__restrict__ partials, const DevLoop *__restrict__ ctl)
 {
     __shared__ double sm[4 * RED_K];
+    KSTAMP(0, 0);
+    // the loop state this kernel needs, every load of it in front of the first branch (one round trip to the memory the
+    // controller's XCD wrote, not one per dependent index: DevLoop, "resolved")
+    double *__restrict__ hs_new = nullptr;
+    HistView Lr;
+    const double alpha = a.make_pair ? *a.alpha_dev : 0.0;
     if constexpr (DEV) {
-        if (ctl->status != 0) return;
+        const int status = ctl->status;
         a.x = ctl->x_trial;
         a.g_old = ctl->g_cur;
         if (!a.stage) a.g_new = ctl->g_trial;   // stage: this rank's partial gradient goes to the buffer the host named
-        a.s_new = ctl->S[ctl->slot];
-        a.y_new = ctl->Y[ctl->slot];
+        a.s_new = ctl->s_new;
+        a.y_new = ctl->y_new;
+        if (a.hp) hs_new = ctl->hs_new;
+        Lr.load(ctl->L);
+        if (status != 0) return;
+    } else {
+        Lr.load(L);
     }
-    double *__restrict__ hs_new = nullptr;
-    if constexpr (DEV) {
-        if (a.hp) hs_new = ctl->HS[ctl->slot];
-    }
-    const LbfgsArgs &Lr = [&]() -> const LbfgsArgs & {
-        if constexpr (DEV) return ctl->L;
-        else return L;
-    }();
     double acc[RED_K];
 #pragma unroll
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
-    const double alpha = a.make_pair ? *a.alpha_dev : 0.0;
     const VList vl{a.vlist, a.nlist};   // owner exchange: only the held vertices are visited
     const int n = vl_count3(vl, 3 * nV), G = gridDim.x * blockDim.x;
     constexpr int R = GATHER_R;
@@ -103,6 +132,7 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
                 }
             }
         }
+        KSTAMP(0, 1);
         // the first copies' padded positions are requested before the partial sums (off the stores' dependent chain)
         constexpr int VC = 4;
         int vo[R][VC];
@@ -113,6 +143,7 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
         int nkmax = 0;
 #pragma unroll
         for (int u = 0; u < R; ++u) nkmax = max(nkmax, ke[u] - kb[u]);
+        KSTAMP(0, 2);
         for (int t = 0; t < nkmax; t += GATHER_P) {
             double w[R][GATHER_P];
 #pragma unroll
@@ -126,6 +157,7 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
                 for (int j = 0; j < GATHER_P; ++j)
                     if (kb[u] + t + j < ke[u]) gn[u] += w[u][j];
         }
+        KSTAMP(0, 3);
 #pragma unroll
         for (int u = 0; u < R; ++u) {
             if (!live[u]) continue;
@@ -178,7 +210,9 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
             }
         }
     }
+    KSTAMP(0, 4);
     write_partials(acc, a.make_pair ? RED_K : 1, partials, sm);
+    KSTAMP(0, 5);
 }
 
 void launch_vertex_gather(const DevMesh &M, const DevPatches &PT, const GatherArgs &a, const LbfgsArgs &L,
@@ -379,10 +413,7 @@ __global__ __launch_bounds__(256) void build_p_kernel(int n, const double *__res
 #pragma unroll
         for (int i = 0; i < 8; ++i) c[i] = 0.0;
         static_assert(HIST_MAX <= 8, "one transposed butterfly");
-        for (int b = threadIdx.x; b < c_blocks; b += 64) {
-#pragma unroll
-            for (int i = 0; i < HIST_MAX; ++i) c[i] += c_partials[(size_t)b * RED_K + i];  // columns >= m: unused
-        }
+        load_yz_partials(c_partials, c);   // (c_blocks == NB_RED; columns >= m: unused)
         // wave totals of the (up to 8) columns in 10 cross-lane steps; lane 8 i holds column i
         const double tot = wave_sum8_transposed(c, threadIdx.x);
         double ct[HIST_MAX], rys[HIST_MAX];
@@ -539,17 +570,49 @@ __global__ __launch_bounds__(256) void merge_kernel(int nV, const int *__restric
 // the additions of reduce_partial_p_kernel followed by merge_kernel, in their order, without the psub round trip and
 // without a launch in between.
 constexpr int MT_CH = 24;   // list entries in flight per thread (a dof has ~15: two subdomains x ~8 tiles)
+// the walk over dof k's list in its wave-interleaved form (DevParts::mt_il): u = sum over the subdomains of (sum over the
+// subdomain's tiles of their partial) -- the additions of the CSR walk in its order; k >> 6 is uniform over the wave
+__device__ __forceinline__ double merge_walk_interleaved(int k, const int2 *__restrict__ mt_wave, const int *__restrict__ mt_il,
+                                                         const double *__restrict__ ppart, double u)
+{
+    const int2 wb = mt_wave[k >> 6];
+    const int *__restrict__ lst = mt_il + wb.x + (k & 63);
+    double ps = 0.0;
+    for (int q0 = 0; q0 < wb.y; q0 += MT_CH) {
+        int off[MT_CH];
+#pragma unroll
+        for (int q = 0; q < MT_CH; ++q) off[q] = (q0 + q < wb.y) ? lst[64 * (q0 + q)] : MT_PAD;
+        double w[MT_CH];
+#pragma unroll
+        for (int q = 0; q < MT_CH; ++q) {
+            const int o = off[q] < 0 ? ~off[q] : off[q];
+            w[q] = (off[q] != MT_PAD) ? ppart[o] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < MT_CH; ++q)
+            if (off[q] != MT_PAD) {
+                if (off[q] < 0 && q0 + q > 0) {   // a new subdomain starts: close the previous one
+                    u += ps;
+                    ps = 0.0;
+                }
+                ps += w[q];
+            }
+    }
+    return u + ps;
+}
 template <bool DEV>
 __global__ __launch_bounds__(256) void merge_tiles_kernel(int n3, const int *__restrict__ mt_ptr,
                                                           const int *__restrict__ mt_ent, const int *__restrict__ dup,
                                                           const double *__restrict__ ppart, LbfgsArgs L, int with_dots,
                                                           int divide, double *__restrict__ z,
-                                                          double *__restrict__ partials, const DevLoop *__restrict__ ctl, VList vl)
+                                                          double *__restrict__ partials, const DevLoop *__restrict__ ctl, VList vl,
+                                                          const int2 *__restrict__ mt_wave, const int *__restrict__ mt_il)
 {
     __shared__ double sm[4 * RED_K];
     if constexpr (DEV) {
         if (ctl->status != 0 || ctl->phase != 0) return;
     }
+    const bool il = mt_il != nullptr && vl.v == nullptr;
     const LbfgsArgs &Lr = [&]() -> const LbfgsArgs & {
         if constexpr (DEV) return ctl->L;
         else return L;
@@ -561,7 +624,7 @@ __global__ __launch_bounds__(256) void merge_tiles_kernel(int n3, const int *__r
     const int cnt = vl_count3(vl, n3);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
         const int k = vl_dof(vl, i);
-        const int e0 = mt_ptr[k], e1 = mt_ptr[k + 1];
+        const int e0 = il ? 0 : mt_ptr[k], e1 = il ? 0 : mt_ptr[k + 1];
         const int d = divide ? dup[k / 3] : 1;
         double yk[HIST_MAX];
         if (with_dots) {
@@ -570,6 +633,7 @@ __global__ __launch_bounds__(256) void merge_tiles_kernel(int n3, const int *__r
                 if (i < Lr.m) yk[i] = Lr.y[i][k];
         }
         double zk = 0.0, ps = 0.0;
+        if (il) zk = merge_walk_interleaved(k, mt_wave, mt_il, ppart, 0.0);
         // MT_CH entries at a time: offsets first, then the values, then the adds in list order
         for (int e = e0; e < e1; e += MT_CH) {
             int off[MT_CH];
@@ -619,22 +683,35 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
                                                                 const uint8_t *__restrict__ kind, int pre,
                                                                 double *__restrict__ zshare,
                                                                 double *__restrict__ z, double *__restrict__ partials,
-                                                                const DevLoop *__restrict__ ctl)
+                                                                const DevLoop *__restrict__ ctl, const int2 *__restrict__ mt_wave,
+                                                                const int *__restrict__ mt_il, double *__restrict__ partialsT)
 {
     __shared__ double sm[4 * RED_K];
-    if (ctl->status != 0 || ctl->phase != 0) return;
-    const LbfgsArgs &Lr = ctl->L;
-    const int m = first ? 0 : Lr.m;
-    const bool pairNew = !first && ctl->pairNew != 0 && m > 0;
+    KSTAMP(1, 0);
+    // (every load of the loop state in front of the first branch, the pointers resolved by the controller: one round trip)
+    const int status = ctl->status, phase = ctl->phase, lm = ctl->L.m, pnew = ctl->pairNew;
     double *__restrict__ u_old = ctl->u_old;
+    double *my_new_r = ctl->my_new;
+    HistView Lr;
+    Lr.load(ctl->L);
     const double *my[HIST_MAX];
     double xi[HIST_MAX];
-    double *my_new = nullptr;
 #pragma unroll
     for (int i = 0; i < HIST_MAX; ++i) {
-        my[i] = (i < m) ? ctl->MY[ctl->order[i]] : nullptr;
-        xi[i] = (i < m) ? ctl->X.xi[i] : 0.0;
-        if (pairNew && i == m - 1) my_new = ctl->MY[ctl->order[i]];
+        my[i] = ctl->Lmy[i];
+        xi[i] = ctl->X.xi[i];
+    }
+    if (status != 0 || phase != 0) return;
+    const bool il = mt_il != nullptr && vl.v == nullptr && !psub && !zsum;
+    const int m = first ? 0 : lm;
+    const bool pairNew = !first && pnew != 0 && m > 0;
+    double *my_new = pairNew ? my_new_r : nullptr;
+#pragma unroll
+    for (int i = 0; i < HIST_MAX; ++i) {
+        if (!(i < m)) {
+            my[i] = nullptr;
+            xi[i] = 0.0;
+        }
     }
     double acc[RED_K];
 #pragma unroll
@@ -648,7 +725,7 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
         if (psub) {
             c0 = vp_ptr[vtx];
             c1 = vp_ptr[vtx + 1];
-        } else if (!zsum) {
+        } else if (!zsum && !il) {
             e0 = mt_ptr[k];
             e1 = mt_ptr[k + 1];
         }
@@ -660,10 +737,12 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
             mk[i] = (i < m && !(pairNew && i == m - 1)) ? my[i][k] : 0.0;
         }
         const double uo = first ? 0.0 : u_old[k];
+        KSTAMP(1, 1);
         // zsum (sharded subdomains): the all-reduced sum over every rank's subdomains (merge_tiles_kernel without the division
         // into a staging buffer, then the collective -- on the staging buffer, so that a slot whose merge is gated off leaves z
         // alone); only the division and the history terms are left
         double u = zsum ? zsum[k] : 0.0, ps = 0.0;
+        if (il) u = merge_walk_interleaved(k, mt_wave, mt_il, ppart, 0.0);
         if (psub && !zsum) {
             // split form (big meshes): the subdomains' own sums are in psub (reduce_partial_p_kernel); same additions in the
             // same order as the list walk below -- tiles of a subdomain first, then the subdomains
@@ -698,6 +777,7 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
                 }
         }
         u += ps;
+        KSTAMP(1, 2);
         if (pre && (kind[vtx] & 2)) {
             // Owner exchange with the y_i . z in the packet, BEFORE it travels, at a vertex other ranks hold too: u is this
             // rank's subdomains' PART of the sum -- it goes to the buffer the packet is filled from.  With U = (sum over the
@@ -735,7 +815,9 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
                 if (i < m) acc[i] += yk[i] * zk;
         }
     }
-    if (partials) write_partials(acc, HIST_MAX, partials, sm);   // (nullptr: the y_i . z came with the packet, yz_pre_kernel)
+    KSTAMP(1, 3);
+    if (partials) write_partials(acc, HIST_MAX, partials, sm, partialsT);   // (nullptr: the y_i . z came with the packet, yz_pre_kernel)
+    KSTAMP(1, 4);
 }
 
 // ---- owner exchange (DOTMI_FLAG_OWNER_EXCHANGE): only the entries of vertices held by more than one rank travel ----------------
@@ -850,12 +932,12 @@ void launch_mask_owned(int n, double *v, const uint8_t *ownMask, hipStream_t st)
 
 void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *partials, int first, hipStream_t st,
                         const DevLoop *ctl, const double *zsum, const uint8_t *ownMask, VList vl, const uint8_t *kind, int pre,
-                        double *zshare)
+                        double *zshare, double *partialsT)
 {
     const bool split = !P.mt_ptr;
     hipLaunchKernelGGL(merge_tiles_early_kernel, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup, P.ppart,
                        first, zsum, split ? P.vp_ptr : nullptr, split ? P.vp_off : nullptr,
-                       split ? (const double *)P.psub : nullptr, ownMask, vl, kind, pre, zshare, z, partials, ctl);
+                       split ? (const double *)P.psub : nullptr, ownMask, vl, kind, pre, zshare, z, partials, ctl, P.mt_wave, P.mt_il, partialsT);
 }
 
 void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, double *z, double *partials,
@@ -864,10 +946,10 @@ void launch_merge(const DevMesh &M, const DevParts &P, const LbfgsArgs &L, doubl
     if (P.mt_ptr) {   // (launch_gemv left the tile partials in ppart and skipped the reduce)
         if (ctl)
             hipLaunchKernelGGL(merge_tiles_kernel<true>, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup,
-                               P.ppart, L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl, vl);
+                               P.ppart, L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl, vl, P.mt_wave, P.mt_il);
         else
             hipLaunchKernelGGL(merge_tiles_kernel<false>, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup,
-                               P.ppart, L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl, vl);
+                               P.ppart, L, with_dots & 1, (with_dots >> 1) & 1, z, partials, ctl, vl, P.mt_wave, P.mt_il);
         return;
     }
     // with_dots: bit0 = accumulate y_i.z partials, bit1 = divide by dup
@@ -979,9 +1061,8 @@ __global__ __launch_bounds__(256) void spmv_dots_kernel(int v0, int v1, const in
 #pragma unroll
             for (int u = 0; u < R; ++u)
                 if (t < nk[u]) {
-                    const double *b = Hval + (size_t)9 * (kb[u] + t);
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) h[u][i] = b[i];
+                    for (int i = 0; i < 9; ++i) h[u][i] = Hval[hval_idx(kb[u] + t, i)];
                 }
 #pragma unroll
             for (int u = 0; u < R; ++u)
@@ -1040,14 +1121,32 @@ __global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, int v0, int v1, co
     spmv_zp_body(nV, v0, v1, rowMask, ownMask, adj_ptr, adj_idx, Hval, z, c_partials, c_blocks, p, Hp, partials, ctl, vl, sm, delta,
                  (int)blockIdx.x, (int)gridDim.x);
 }
+// the same rows by workgroups of 1024 threads, one row per lane group (four waves per SIMD)
+__global__ __launch_bounds__(1024) void spmv_zp_wide_kernel(int nV, int v0, int v1, const uint8_t *__restrict__ rowMask,
+                                                            const uint8_t *__restrict__ ownMask, const int *__restrict__ adj_ptr,
+                                                            const int *__restrict__ adj_idx, const double *__restrict__ Hval,
+                                                            const double *__restrict__ z, const double *__restrict__ c_partials,
+                                                            int c_blocks, double *__restrict__ p, double *__restrict__ Hp,
+                                                            double *__restrict__ partials, const DevLoop *__restrict__ ctl, VList vl)
+{
+    __shared__ double sm[32];
+    __shared__ double delta[HIST_MAX];
+    spmv_zp_body<1024, 1>(nV, v0, v1, rowMask, ownMask, adj_ptr, adj_idx, Hval, z, c_partials, c_blocks, p, Hp, partials, ctl, vl, sm,
+                          delta, (int)blockIdx.x, (int)gridDim.x);
+}
 
 void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const double *c_partials, double *p, double *Hp,
                     double *partials, hipStream_t st, const DevLoop *ctl, int v0, int v1, const uint8_t *rowMask,
-                    const uint8_t *ownMask, VList vl)
+                    const uint8_t *ownMask, VList vl, bool ctrans)
 {
     if (v1 < 0) v1 = M.nV;
+    static const bool wide = getenv("DOTMI_SPMV_WIDE") && atoi(getenv("DOTMI_SPMV_WIDE")) != 0;   // (experiment)
+    if (wide)
+        hipLaunchKernelGGL(spmv_zp_wide_kernel, dim3(NB_RED), dim3(1024), 0, st, M.nV, v0, v1, rowMask, ownMask, M.adj_ptr, M.adj_idx,
+                           Hval, z, c_partials, ctrans ? -NB_RED : NB_RED, p, Hp, partials, ctl, vl);
+    else
     hipLaunchKernelGGL(spmv_zp_kernel, dim3(NB_RED), dim3(256), 0, st, M.nV, v0, v1, rowMask, ownMask, M.adj_ptr, M.adj_idx, Hval,
-                       z, c_partials, NB_RED, p, Hp, partials, ctl, vl);
+                       z, c_partials, ctrans ? -NB_RED : NB_RED, p, Hp, partials, ctl, vl);
 }
 
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(int nnzb, const int *__re
         }
         if (vr == vc && r == c) acc += mass[vr];  // DOTTimeStepper.cpp:598-607
     }
-    Hval[(size_t)9 * k + rc] = acc;
+    Hval[hval_idx(k, rc)] = acc;
 }
 
 void launch_assemble(const DevMesh &M, const double *He, double *Hval, hipStream_t st, const int *blist, int nList,
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void dense_fill_kernel(long long nfill9, const
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nfill9) return;
     const long long d = dst[t];
-    if (d >= 0) W[d] = Hval[(size_t)9 * src[t / 9] + t % 9];
+    if (d >= 0) W[d] = Hval[hval_idx(src[t / 9], (int)(t % 9))];
 }
 __global__ void pad_identity_kernel(int npad, const long long *__restrict__ dst, double *__restrict__ W)
 {

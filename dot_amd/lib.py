@@ -57,14 +57,15 @@ class StepStats(C.Structure):
                 ("collective_timed", C.c_int64), ("collective_timed_bytes", C.c_int64),
                 ("backsolve_launches", C.c_int64), ("backsolve_stopped", C.c_int64),
                 ("backsolve_held", C.c_int64), ("backsolve_held_rejected", C.c_int64),
-                ("paired_slots", C.c_int64), ("paired_redone", C.c_int64)]
+                ("paired_slots", C.c_int64), ("paired_redone", C.c_int64),
+                ("spec_slots", C.c_int64), ("spec_redone", C.c_int64)]
 
 
 # enum dotmi_bench_kind (include/dotmi.h)
 BENCH_KERNELS = ["elem_energy_grad", "elem_energy", "vertex_gather", "spmv_dots", "backsolve", "merge", "build_qpad",
                  "build_p", "step_forward", "elem_hessian", "assemble",
                  # the forms the device loop's early order launches (after at least one step)
-                 "spmv_zp", "merge_early", "elem_step", "gather_early"]
+                 "spmv_zp", "merge_early", "elem_step", "gather_early", "dirstep"]
 
 EXPORTS = [
     "dotmi_create", "dotmi_destroy", "dotmi_last_error", "dotmi_comm_unique_id", "dotmi_comm_ranks", "dotmi_set_state",

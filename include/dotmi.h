@@ -184,6 +184,8 @@ typedef struct {
     int64_t paired_slots;           /* DOTMI_PAIR_TRIALS: slots that evaluated the half step in full and the energy of the full step
                                        (the line search of Optimizer.cpp:806-833 with its first two trials in one launch) */
     int64_t paired_redone;          /* ... whose full step was acceptable after all: evaluated again, in full, by the next slot */
+    int64_t spec_slots;             /* DOTMI_SPEC_STEP: new-direction slots that evaluated the unit step beside the direction kernel ... */
+    int64_t spec_redone;            /* ... whose step estimate alpha_0 turned out below 1: evaluated again, at alpha_0, by the next slot */
 } dotmi_step_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -339,7 +341,8 @@ enum dotmi_bench_kind {
     DOTMI_BENCH_MERGE_EARLY = 12,     /* tile partials -> u, M y_new, z, y_i . z */
     DOTMI_BENCH_ELEM_STEP = 13,       /* element pass that takes the line-search step itself */
     DOTMI_BENCH_GATHER_EARLY = 14,    /* vertex pass that also writes -g into the padded right-hand sides and H s_new */
-    DOTMI_BENCH_COUNT = 15
+    DOTMI_BENCH_DIRSTEP = 15,         /* (round 6) the speculative unit-step launch: direction kernel + element pass + trial point in one launch */
+    DOTMI_BENCH_COUNT = 16
 };
 int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_per_launch, int64_t *bytes_per_launch);
 

@@ -197,7 +197,8 @@ def test_early_order_on_the_sharded_path_matches_the_single_rank_run(workload, s
             ts.setDirichlet(idx, pos)
         sa, sb = a.step(), b.step()
         assert (sa.status, sa.iters, sa.ls_halvings) == (sb.status, sb.iters, sb.ls_halvings), k
-        assert sa.backsolve_stopped == sb.backsolve_stopped == sa.ls_halvings + 1      # both ran the early order
+        # both ran the early order (the single-rank run may take the unit step speculatively: a redone slot stops one more launch)
+        assert sa.backsolve_stopped == sb.backsolve_stopped - sb.spec_redone == sa.ls_halvings + 1
         assert np.abs(a.getResult() - b.getResult()).max() < 1e-9
     a.close(); b.close()
 

@@ -1,0 +1,107 @@
+"""Round 6: the speculative unit-step launch (k_dirstep.hip) against the unspeculated loop -- through the C ABI on the GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from dot_amd import lib as dl
+from dot_amd.timestepper import DOTTimeStepper
+from tests.workloads import load_workload
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _run(workload, steps, env, monkeypatch, log=False):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sc, ep, n = load_workload(workload)
+    ts = DOTTimeStepper(sc, ep, n)
+    rec, spec, redone, stopped, logs = [], 0, 0, [], []
+    for _ in range(steps):
+        x = ts.getResult()
+        idx, pos = sc.scripter.step(x, sc.cfg.dt)
+        ts.setDirichlet(idx, pos)
+        st = ts.step()
+        rec.append((st.status, st.iters, st.ls_halvings, st.energy_evals, st.E, st.g2, st.E0, st.g2_0))
+        spec += st.spec_slots
+        redone += st.spec_redone
+        stopped.append((st.backsolve_stopped, st.backsolve_launches, st.spec_redone))
+        if log:
+            logs.append(tuple(np.array(v).copy() for v in ts.iterLog()))
+    x = ts.getResult().copy()
+    v = ts.getState()[1].copy()
+    ts.close()
+    for k in env:
+        monkeypatch.delenv(k)
+    return rec, x, v, spec, redone, stopped, logs
+
+
+# bar17K: the estimate alpha_0 = clamp(-p.g / p.Hp, 0.1, 1) is the unit step in every iteration (tools/linesearch_stats.py: 192 of
+# 192) -- every speculation holds; bunny5K: most; the stiff monkey: alpha_0 < 1 in three iterations of ten and more than a
+# halving per iteration -- redone slots, retries of redone slots, held back-solves; horse7K back-tracks from step 4 on
+@pytest.mark.parametrize("workload,steps", [("bar17K_twist", 4), ("bunny5K_LTSS", 14), ("monkey18K_stiff", 2), ("horse7K_stretch", 8)])
+def test_speculative_unit_step_takes_the_same_steps_bit_for_bit(workload, steps, monkeypatch):
+    """A speculating slot (DOTMI_SPEC_STEP, k_dirstep.hip) evaluates x + 1 p in the launch that computes p -- the element
+    workgroups form p_v = z_v + sum_j delta_j s_j[v] themselves -- and the controller checks alpha_0 afterwards: when it is not 1
+    the slot is redone at alpha_0 as the first trial it is (Optimizer.cpp:1076-1093, :806-833).  Whatever is speculated or redone,
+    the trajectory is the unspeculated loop's bit for bit: status, iterations, halvings, energy evaluations, energies, residuals,
+    the per-iteration log and the positions."""
+    rec0, x0, v0, s0, r0, st0, log0 = _run(workload, steps, {"DOTMI_SPEC_STEP": "0", "DOTMI_PAIR_TRIALS": "0"}, monkeypatch, log=True)
+    rec1, x1, v1, s1, r1, st1, log1 = _run(workload, steps, {"DOTMI_SPEC_STEP": "1", "DOTMI_PAIR_TRIALS": "0"}, monkeypatch, log=True)
+    assert s0 == 0 and r0 == 0
+    iters = sum(r[1] for r in rec0)
+    print(f"{workload}: {iters} iterations, {sum(r[2] for r in rec0)} halvings; speculating slots {s1}, redone {r1}")
+    assert rec1 == rec0
+    assert np.array_equal(x1, x0) and np.array_equal(v1, v0)
+    for (a0, e0, g0), (a1, e1, g1) in zip(log0, log1):
+        assert np.array_equal(a0, a1) and np.array_equal(e0, e1) and np.array_equal(g0, g1)
+    # every new direction was speculated on: one slot per iteration (+ the rejected last trials of steps that end in a failure)
+    assert s1 >= iters
+    if workload == "bar17K_twist":
+        assert r1 == 0                       # the unit estimate in every iteration
+    if workload == "monkey18K_stiff":
+        assert r1 >= iters // 10             # ... and far from it there: the redo path is what this case exercises
+    # a stopped launch per rejected trial, one per redone slot, one at the end of the step
+    for (stp, ln, rd), r in zip(st1, rec1):
+        assert ln == r[1]
+        if r[0] == 0:
+            assert stp == r[2] + 1 + rd, (stp, r, rd)
+
+
+def test_speculation_is_gated_by_the_previous_steps_unit_estimates(monkeypatch):
+    """Default rule (DOTMI_SPEC_STEP unset): a step speculates when at least nine in ten first trials of the step before took the
+    unit estimate.  bar17K: every step after the first; the stiff monkey: none (its steps pair their trials instead)."""
+    rec, x, v, spec, redone, stopped, _ = _run("bar17K_twist", 3, {}, monkeypatch)
+    iters = [r[1] for r in rec]
+    assert spec == sum(iters[1:]) and redone == 0, (spec, redone, iters)
+    rec, x, v, spec, redone, stopped, _ = _run("monkey18K_stiff", 2, {}, monkeypatch)
+    assert spec == 0 and redone == 0
+
+
+def test_speculative_steps_match_the_oracle(monkeypatch):
+    """The speculating loop against the CPU oracle: bunny5K, 6 steps, identical iterations and halvings, positions to 1e-9
+    (the bar of tests/test_gpu_parity.py::test_time_steps_match_oracle, with every step speculating)."""
+    from tests import oracle_py as O
+    monkeypatch.setenv("DOTMI_SPEC_STEP", "1")
+    sc, ep, n = load_workload("bunny5K_LTSS")
+    cfg = sc.cfg
+    ts = DOTTimeStepper(sc, ep, n)
+    orc = O.OracleSim(sc.V_rest, sc.T, cfg.YM, cfg.PR, cfg.rho, cfg.energy_id, cfg.dt, sc.fixed, sc.x0, ep, n, cfg.with_gravity)
+    try:
+        spec = 0
+        for k in range(6):
+            x = ts.getResult()
+            idx, pos = sc.scripter.step(x, cfg.dt)
+            ts.setDirichlet(idx, pos)
+            orc.move(idx, pos)
+            st, so = ts.step(), orc.step()
+            spec += st.spec_slots
+            assert st.status == 0 and (st.iters, st.ls_halvings) == (so.iters, so.ls_halvings), k
+            dx = np.abs(ts.getResult() - orc.state()[0]).max()
+            assert dx < 1e-9, (k, dx)
+        assert spec > 0
+    finally:
+        ts.close()
+        orc.close()
