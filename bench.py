@@ -45,6 +45,7 @@ REFERENCE_ANCHOR = {
     "bunny5K_LTSS": {"ms_per_step": [160, 360], "iters": [11, 10, 9, 9, 9, 10, 11, 11, 12, 12]},
     "monkey18K_stiff": {"ms_per_step": [4024, 10152], "iters": [108, 85, 98, 88, 145, 135, 145, 162, 131, 126]},
 }
+FP64_VECTOR_PEAK = 78.6  # TFLOP/s, FP64 vector (the same figure as the FP64 matrix peak on this part)
 FP64_MFMA_PEAK = 78.6   # TFLOP/s, MI355X FP64 matrix = vector peak (256 CUs x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
@@ -92,7 +93,7 @@ def compact_line(full):
     """The driver-facing JSON line: the contract's keys plus numbers-only `roofline`, `roofline_factor`, `cpu_baseline` and a
     one-row-per-workload summary.  Everything else (roofline_by_kernel, PMC sources, notes) is in bench_detail.json."""
     keep = ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-            "dtype", "data", "config", "ms_per_step_p50", "ms_per_step_p95", "iters_per_frame", "step_breakdown_ms")
+            "dtype", "data", "config", "ms_per_step_p50", "ms_per_step_p95", "iters_per_frame", "step_breakdown_ms", "us_per_iter")
     out = {k: full[k] for k in keep if k in full}
     out["data"] = "reference input mesh (fixture), scripted handles"
     r = full["roofline"]
@@ -106,6 +107,17 @@ def compact_line(full):
     f = full["roofline_factor"]
     out["roofline_factor"] = {"bound": "mfma", "kernel": f.get("kernel_name", "tile_task_kernel"), "achieved": f["achieved"], "peak": f["peak"],
                               "unit": "TFLOP/s", "frac": f["frac"], "flop": f["flop_per_factorisation"], "avg_ms": f["avg_ms"]}
+    if full.get("roofline_loop"):
+        lr = full["roofline_loop"]
+        out["roofline_loop"] = {k: lr[k] for k in ("algorithmic_bytes_per_iteration", "us_per_iter", "achieved", "frac")}
+    # the ALU side for the element kernels where a PMC flop count of this build is committed (FP64 vector peak)
+    alu = [{"kernel": r["kernel"], "workload": w.get("workload"), "fp64_flop": r["fp64_flop"], "us": r["us"],
+            "frac_of_fp64_vector_peak": r["frac_of_fp64_vector_peak"], "frac_of_hbm_peak": r["frac_of_hbm_peak"]}
+           for w in (full.get("workloads") or [{"workload": full["config"]["workload"], "roofline_by_kernel": full.get("roofline_by_kernel")}])
+           if "error" not in w
+           for r in (w.get("roofline_by_kernel") or []) if r.get("fp64_flop") and r["kernel"] in ("elem_step", "elem_energy_grad")]
+    if alu:
+        out["roofline_alu"] = alu
     if "collectives" in full:
         c = full["collectives"]
         out["collectives"] = {k: c[k] for k in ("allreduce_calls_per_step", "payload_MB_per_step", "est_ms_per_step") if k in c}
@@ -126,6 +138,7 @@ def compact_line(full):
         out["cpu_baseline"] = cb
     if full.get("workloads"):
         out["workloads"] = [{"name": w["workload"], "ms_per_step": w["ms_per_step"], "iters": w["iters_per_frame"],
+                             "us_per_iter": w.get("us_per_iter"), "loop_frac": (w.get("roofline_loop") or {}).get("frac"),
                              "backsolve_frac": w["roofline"]["frac"],
                              "factor_ms": w["step_breakdown_ms"]["subdomain_factor"],
                              "factor_frac": (w.get("roofline_factor") or {}).get("frac"),
@@ -195,6 +208,8 @@ def main():
     SRC_ID = source_id()
     stale = {}
 
+    flops_by_kernel = {}
+
     def pmc_by_kernel(workload):
         """HBM bytes per launch of every kernel class from the PMC counters (FETCH_SIZE / WRITE_SIZE need their own
         rocprofv3 passes, so they are collected separately on the same kernels + workload by tools/pmc_kernels.sh and
@@ -211,17 +226,25 @@ def main():
                 continue
             K = rec["kernels"]
 
-            def pick(cls, must=None, total=False):
+            def pick(cls, must=None, total=False, key="hbm_bytes_per_launch"):
                 import re
                 inst = {k: v for k, v in K.get(cls, {}).items()
-                        if "hbm_bytes_per_launch" in v and (must is None or re.search(must, k))}
+                        if key in v and (must is None or re.search(must, k))}
                 if not inst:
                     return None
-                vals = [v["hbm_bytes_per_launch"] for v in inst.values()]
+                vals = [v[key] for v in inst.values()]
                 return int(sum(vals)) if total else int(vals[0])
+            # (round 6) FP64 vector operations per launch from the same file's third pass: the ALU side of the roofline
+            flop = {"elem_energy_grad": pick("elem_pass", r"<\d, true, \d, false,", key="fp64_flop_per_launch"),
+                    "elem_energy": pick("elem_pass", r"<\d, false,", key="fp64_flop_per_launch"),
+                    "elem_step": pick("elem_pass", r"<\d, true, \d, true,", key="fp64_flop_per_launch"),
+                    "elem_hessian": pick("elem_hessian", key="fp64_flop_per_launch"),
+                    "dirstep": pick("dirstep", key="fp64_flop_per_launch"), "spmv_zp": pick("spmv_zp", key="fp64_flop_per_launch")}
+            flops_by_kernel[workload] = {k: v for k, v in flop.items() if v}
             # elem_patch_kernel<MAT, GRAD, EPT, FUSE (step inside), PIPE>
             out = {"elem_energy_grad": pick("elem_pass", r"<\d, true, \d, false,"), "elem_energy": pick("elem_pass", r"<\d, false,"),
                    "elem_step": pick("elem_pass", r"<\d, true, \d, true,"), "gather_early": pick("vertex_gather", "<true>"),
+                   "dirstep": pick("dirstep"),
                    "spmv_zp": pick("spmv_zp"), "merge_early": pick("merge_early"),
                    "vertex_gather": pick("vertex_gather", "<false>"), "spmv_dots": pick("spmv_dots"),
                    "backsolve": pick("backsolve", total=True), "merge": pick("merge", "<false>"),
@@ -260,9 +283,16 @@ def main():
             if rc != 0 or ms.value <= 0:
                 continue
             gbs = nbytes.value / (ms.value * 1e-3) / 1e9
-            out.append({"kernel": name, "us": round(1e3 * ms.value, 2), "algorithmic_bytes": int(nbytes.value),
-                        "GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
-                        "traffic": traffic.get(name), "traffic_source": tsrc if name in traffic else None})
+            row = {"kernel": name, "us": round(1e3 * ms.value, 2), "algorithmic_bytes": int(nbytes.value),
+                   "GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
+                   "traffic": traffic.get(name), "traffic_source": tsrc if name in traffic else None}
+            fl = flops_by_kernel.get(rec["workload"], {}).get(name)
+            if fl:
+                # the ALU side: FP64 vector operations as executed (PMC: ADD + MUL + 2 FMA + TRANS wave
+                # instructions x 64) against the FP64 vector peak -- what bounds the fixed-corotational element pass (SVD inside)
+                tf = fl / (ms.value * 1e-3) / 1e12
+                row.update({"fp64_flop": int(fl), "fp64_TFLOPs": round(tf, 2), "frac_of_fp64_vector_peak": round(tf / FP64_VECTOR_PEAK, 4)})
+            out.append(row)
         return out
 
     def reference_cholmod_leg(sc2, ep2, nparts, orc):
@@ -435,6 +465,24 @@ def main():
         }
         target = ts.targetGRes
         rec["roofline_by_kernel"] = kernel_rooflines(ts, rec) if rank == 0 or world == 1 else None
+        # ---- the loop as a whole: device time of the L-BFGS loop per iteration (comparable across rounds where
+        # a chaotic workload's iteration count moves) and the algorithmic bytes one iteration's launches read and write -- the
+        # back-solve's structural non-zeros + the four vector kernels' section 8(d) bytes in the forms the loop launches -- over it
+        it_mean = float(np.mean(iters))
+        us_iter = 1e3 * float(np.mean([s.ms_loop for s in stats])) / max(it_mean, 1.0)
+        rec["us_per_iter"] = round(us_iter, 2)
+        byk = {r["kernel"]: r for r in (rec["roofline_by_kernel"] or [])}
+        loop_k = ("spmv_zp", "elem_step", "gather_early", "merge_early")
+        if all(k in byk for k in loop_k):
+            lb = int(bytes_per_launch + sum(byk[k]["algorithmic_bytes"] for k in loop_k))
+            rec["roofline_loop"] = {"bound": "hbm", "algorithmic_bytes_per_iteration": lb, "us_per_iter": round(us_iter, 2),
+                                    "achieved": round(lb / (us_iter * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(lb / (us_iter * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                    "what": "back-solve + spmv_zp + element pass with the step + gather + merge_early, "
+                                            "algorithmic bytes of one iteration over the loop's device time per iteration (incl. "
+                                            "rejected trials, the start-of-step evaluation and the launch gaps)"}
+        rec["spec"] = {"slots": int(sum(getattr(s, "spec_slots", 0) for s in stats)),
+                       "redone": int(sum(getattr(s, "spec_redone", 0) for s in stats))}
         if rec["collectives"] is None:
             del rec["collectives"]
         ts.close()
@@ -491,8 +539,11 @@ def main():
             "ms_per_step_p50": rec["ms_per_step_p50"], "ms_per_step_p95": rec["ms_per_step_p95"],
             "iters_per_frame": rec["iters_per_frame"], "iters": iters,
             "step_breakdown_ms": rec["step_breakdown_ms"],
+            "us_per_iter": rec.get("us_per_iter"),
             "roofline": roofline,
             "roofline_factor": roofline_factor,
+            "roofline_loop": rec.get("roofline_loop"),
+            "spec": rec.get("spec"),
         }
         if "collectives" in rec:
             out["collectives"] = rec["collectives"]
