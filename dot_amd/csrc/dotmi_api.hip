@@ -540,12 +540,12 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
         break;
     }
     case DOTMI_BENCH_DIRSTEP: {         // what spmv_zp and the stepping element pass read and write together (p is not re-read)
-        if (h->dist || !dirstep_fits(h->PT)) return DOTMI_E_INVALID;
+        if (h->dist || !h->specFits) return DOTMI_E_INVALID;
         bytes = 72 * (int64_t)h->M.nnzb + 8 * (int64_t)n * (4 + 2 * L.m) + 112 * nTo + 56 * nVo + 24 * (int64_t)nV;
         live = true;
         run = [&] {
             StepArgs sa{h->p, h->partS, h->alpha_dev, h->alphaMin};
-            launch_dirstep(h->M, h->PT, h->mat, h->dtSq, h->xt, h->partE, &nb, h->Hval, h->z, h->partCT, h->p, h->Hp, h->partS, h->st,
+            launch_dirstep(h->M, h->PTspec, h->mat, h->dtSq, h->xt, h->partE, &nb, h->Hval, h->z, h->partCT, h->p, h->Hp, h->partS, h->st,
                            h->ctl, sa);
         };
         break;

@@ -689,6 +689,22 @@ int build_device_mesh(dotmi_handle *h)
         } else {
             h->PT = h->PTall;
         }
+        // the patches of a speculating step (one rank): the set that keeps direction rows + patches + trial-point workgroups
+        // resident at once -- the default set where it does, 512-element patches where only those do, none otherwise
+        h->specFits = false;
+        if (!h->dist && h->world == 1 && h->tune.specStep != 0) {
+            const int nbv = (nV + 255) / 256, room = 512 - NB_RED - nbv;
+            if (std::max(h->PT.nPatches, nbv) <= room) {
+                h->PTspec = h->PT;
+                h->specFits = true;
+            } else if (h->tune.patchElems == 0 && PE == 256) {
+                const HostPatches H2 = build_patches(nV, h->T.data(), h->Xrest.data(), all, 512);
+                if (std::max(H2.nPatches, nbv) <= room) {
+                    if (int rc = upload_patches(h, H2, h->PTspec)) return rc;
+                    h->specFits = true;
+                }
+            }
+        }
     }
     if (h->owner) {
         // who holds / owns a vertex: a rank HOLDS the vertices of its subdomains (= of its elements); the lowest rank that
@@ -1342,7 +1358,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         // the trials' grouping of the energy partials, everywhere: the start-of-step evaluation and the fused-step trials must
         // sum E in the same grouping or an `E > E_cur` verdict can flip at rounding level (the owner exchange runs the fused
         // step on its sharded element pass too)
-        if (h->earlyBs && h->tune.fuseStep && (!h->shardElems || h->owner)) h->PT.wgCap = 512;
+        if (h->earlyBs && h->tune.fuseStep && (!h->shardElems || h->owner)) h->PT.wgCap = h->PTspec.wgCap = 512;
         if (h->dist) {
             if (int rc = dalloc(h, &h->zstage, (size_t)h->n)) return rc;
             HIPCHECK(h, hipMemsetAsync(h->zstage, 0, sizeof(double) * h->n, h->st));   // (owner exchange: stays zero off the held set)

@@ -90,9 +90,10 @@ struct Tuning {
     bool earlyAbort = true;   // DOTMI_EARLY_ABORT=0  (ablation) speculative back-solves run to their end even when the trial is rejected
     int pairTrials = -1;      // DOTMI_PAIR_TRIALS    -1 (default): paired line-search trials (StepArgs::pairBlocks) in a step whose predecessor
                               //                      halved in at least a quarter of its iterations; 1: in every step; 0: never
-    int specStep = -1;        // DOTMI_SPEC_STEP      -1 (default): the unit step taken speculatively beside the direction kernel (k_dirstep.hip)
-                              //                      in a step whose predecessor's first trials took the unit estimate at least nine
-                              //                      times in ten; 1: in every step; 0: never
+    int specStep = 0;         // DOTMI_SPEC_STEP      the unit step taken speculatively beside the direction kernel (k_dirstep.hip): 0 (default)
+                              //                      never -- measured: the fused launch is as long as its two parts, profiles/r06_spec_step.txt;
+                              //                      -1: in a step whose predecessor's first trials took the unit estimate at least nine times
+                              //                      in ten; 1: in every step
     bool earlyHold = true;    // DOTMI_EARLY_HOLD=0   the back-solve of a trial that is expected to be rejected still starts speculatively
     int earlyBs = 2;          // DOTMI_EARLY_BACKSOLVE 0: the back-solve after the controller, on q; 1: speculatively on the trial
                               //                      gradient with the controller inside its launch, in the steps where
@@ -131,7 +132,7 @@ struct Tuning {
         t.earlyAbort = geti("DOTMI_EARLY_ABORT", 1) != 0;
         t.earlyHold = geti("DOTMI_EARLY_HOLD", 1) != 0;
         t.pairTrials = geti("DOTMI_PAIR_TRIALS", -1);
-        t.specStep = geti("DOTMI_SPEC_STEP", -1);
+        t.specStep = geti("DOTMI_SPEC_STEP", 0);
         t.fuseStep = geti("DOTMI_FUSE_STEP", 1) != 0;
         t.fuseDir = geti("DOTMI_FUSE_DIR", 1) != 0;
         return t;
@@ -207,6 +208,12 @@ struct dotmi_handle {
     std::vector<hipEvent_t> tFork, tJoin;      // per level
     double tileFlops = 0;
     DevPatches PT, PTall;   // element patches: this rank's own elements / all elements (same unless shardElems)
+    // the patches a SPECULATING step works on (k_dirstep.hip): the launch pays when its three workgroup populations are resident
+    // together (512 workgroups at the direction rows' register count), so where the 256-element patches are too many for that
+    // (bar17K: 256 + 337 + 68) such a step takes patches of 512 elements (256 + 169 + 68).  One patch set per step -- the
+    // start-of-step evaluation, the trials and the gathers of a step agree on the grouping of the energy partials.
+    DevPatches PTspec;
+    bool specFits = false;
     int nOwnElem = 0, v0 = 0, v1 = 0;
     double *x = nullptr, *x_trial = nullptr, *xn = nullptr, *v = nullptr, *xt = nullptr;
     double *g = nullptr, *g_trial = nullptr, *p = nullptr, *q = nullptr, *z = nullptr, *Hp = nullptr;
@@ -225,6 +232,7 @@ struct dotmi_handle {
     bool pairNow = false;       // this step's slots launch the element pass twice as wide (enqueue_loop_slot_early)
     int pairSlots = 0, pairRedo = 0;
     bool specNow = false;       // this step's new-direction slots take the unit step speculatively (launch_dirstep)
+    const DevPatches &stepPT() const { return specNow ? PTspec : PT; }   // the element patches of the running step
     int specSlots = 0, specRedo = 0;
     int prevFirst = 0, prevUnit = 0;   // last step's first trials / of those, the ones whose estimate alpha_0 was the unit step
     int pairState[3] = {1, 1, 1};   // DevLoop::pairCtr, carried from step to step

@@ -141,7 +141,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
         // the direction kernel and the first trial's element pass at the unit step in ONE launch (k_dirstep.hip); a retry slot:
         // the element pass alone, on the stored p with the controller's alpha
         StepArgs sa{h->p, h->partS, h->alpha_dev, h->alphaMin};
-        launch_dirstep(h->M, h->PT, h->mat, h->dtSq, h->xt, h->partE, &nb, h->Hval, h->z, h->partCT, h->p, h->Hp, h->partS, h->st,
+        launch_dirstep(h->M, h->PTspec, h->mat, h->dtSq, h->xt, h->partE, &nb, h->Hval, h->z, h->partCT, h->p, h->Hp, h->partS, h->st,
                        h->ctl, sa);
     } else if (ow) {
         launch_spmv_zp(h->M, h->HvalOwn, h->z, h->partGC, h->p, h->Hp, h->partS, h->st, h->ctl, 0, -1, h->heldMask, h->ownMask,
@@ -195,7 +195,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     const double *ctlE = h->partE;
     const bool packed = ow;   // owner exchange: the statistics ride in the gradient's packet
     if (!se) {
-        launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st, h->ctl);
+        launch_vertex_gather(h->M, h->stepPT(), a, L0, h->partR, h->st, h->ctl);
     } else if (packed) {
         // Owner exchange, the statistics in the gradient's packet.  The gradient is complete on the vertices only this rank
         // holds: the gather forms the pair, the right-hand sides and the statistics there as on one GPU; on the shared vertices
@@ -359,7 +359,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     // in this step (a step whose predecessor halved often); -1: only after a step whose first trials took the unit estimate at
     // least nine times in ten (a slot whose estimate is below 1 is redone: ~45 us lost against ~10 saved)
     h->specNow = h->earlyNow && !h->dist && !h->pairNow && h->tune.fuseStep && h->tune.fuseDir && h->tune.earlyAbort &&
-                 dirstep_fits(h->PT) &&
+                 h->specFits &&
                  (h->tune.specStep > 0 || (h->tune.specStep < 0 && h->prevFirst > 0 && 10 * h->prevUnit >= 9 * h->prevFirst));
     C.specPartials = h->partS;
     C.alphaMin = h->alphaMin;
@@ -403,7 +403,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     {
         // energy and gradient at the start of the step, reduced by the controller (no host round trip)
         int nb = 0;
-        launch_elem_energy_grad(h->owner ? h->Mown : h->M, h->PT, h->mat, h->dtSq, h->x, h->xt, h->owner ? 0 : h->v0,
+        launch_elem_energy_grad(h->owner ? h->Mown : h->M, h->stepPT(), h->mat, h->dtSq, h->x, h->xt, h->owner ? 0 : h->v0,
                                 h->owner ? h->nV : h->v1, 1, h->partE, &nb, h->st);
         GatherArgs a;
         memset(&a, 0, sizeof(a));
@@ -426,7 +426,7 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
             a.vp_off = h->P.vp_off;
             a.rpad = h->P.rpad;
         }
-        launch_vertex_gather(h->M, h->PT, a, L0, h->partR, h->st);
+        launch_vertex_gather(h->M, h->stepPT(), a, L0, h->partR, h->st);
         if (!h->shardElems && h->earlyNow) {
             // the first direction's solve, u = -M g_0 and z = u, with the start-of-step controller inside its launch
             CtlArgs ca{h->ctl, h->partE, h->partR, h->alpha_dev, h->h_flags, nb, 1};

@@ -1140,7 +1140,13 @@ void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const
                     const uint8_t *ownMask, VList vl, bool ctrans)
 {
     if (v1 < 0) v1 = M.nV;
-    static const bool wide = getenv("DOTMI_SPMV_WIDE") && atoi(getenv("DOTMI_SPMV_WIDE")) != 0;   // (experiment)
+    // Rows beyond one trip of the 256-thread form (256 workgroups x 32 lane groups x 3 rows): workgroups of 1024 threads, a
+    // row per lane group -- four waves per SIMD hide what the interleaving of three rows inside one wave cannot once the kernel
+    // is bound by throughput (1 M tets: 76.9 -> 56.9 us; bar17K, one trip: 11.8 -> 12.9, stays on 256 threads).
+    // DOTMI_SPMV_WIDE=0 / 1 forces the form.
+    static const int wideEnv = getenv("DOTMI_SPMV_WIDE") ? atoi(getenv("DOTMI_SPMV_WIDE")) : -1;
+    const int nrows = vl.v ? vl.n : M.nV;
+    const bool wide = wideEnv >= 0 ? wideEnv != 0 : nrows > NB_RED * 32 * SPMV_R;
     if (wide)
         hipLaunchKernelGGL(spmv_zp_wide_kernel, dim3(NB_RED), dim3(1024), 0, st, M.nV, v0, v1, rowMask, ownMask, M.adj_ptr, M.adj_idx,
                            Hval, z, c_partials, ctrans ? -NB_RED : NB_RED, p, Hp, partials, ctl, vl);

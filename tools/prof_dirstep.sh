@@ -3,5 +3,5 @@
 set -e
 cd "$(dirname "$0")/../dot_amd/csrc"
 touch k_dirstep.hip && make -s EXTRA="-DDS_PROFILE -DEP_PROFILE" k_dirstep.o ../libdotmi.so
-python ../../tools/prof_dirstep.py "${1:-bar17K_twist}" || true
+DOTMI_SPEC_STEP=1 python ../../tools/prof_dirstep.py "${1:-bar17K_twist}" || true
 touch k_dirstep.hip && make -s

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 for e in "$@"; do
   [ "$e" = "-" ] && e=""
   rm -rf /tmp/prof_pk
-  env $e rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pk -- python /root/repo/bench.py --no-cpu-baseline --extra-workloads none --steps 8 --warmup 2 > /tmp/prof_pk.log 2>&1
+  env $e rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_pk -- python /root/repo/bench.py --no-cpu-baseline --extra-workloads none --steps ${PK_STEPS:-8} --warmup 2 ${PK_ARGS} > /tmp/prof_pk.log 2>&1
   f=$(find /tmp/prof_pk -name "*kernel_stats.csv" | head -1)
   echo "== [$e]"
   python - "$f" <<'PY'
