@@ -85,6 +85,52 @@ double host_target_gres(const dotmi_handle *h)
     return cn * h->dtSq * h->dtSq;
 }
 
+// vertex patches (vpatches.hpp) -> device
+int upload_vpatches(dotmi_handle *h, const HostVPatches &H, DevVPatches &D)
+{
+    D.nPatches = H.nPatches;
+    D.PE = H.PE;
+    D.PV = H.PV;
+    D.PO = H.PO;
+    D.RUN = H.RUN;
+    const size_t ns = (size_t)H.nPatches * H.PE;
+    std::vector<ushort4> tl(ns), ep(ns);
+    std::vector<double> A(9 * ns, 0.0), mu(ns, 1.0), lam(ns, 1.0), vol(ns, 0.0), volE(ns, 0.0);
+    D.nSlotsUsed = 0;
+    for (size_t s = 0; s < ns; ++s) {
+        tl[s] = make_ushort4(H.tl[4 * s], H.tl[4 * s + 1], H.tl[4 * s + 2], H.tl[4 * s + 3]);
+        ep[s] = make_ushort4(H.epos[4 * s], H.epos[4 * s + 1], H.epos[4 * s + 2], H.epos[4 * s + 3]);
+        const int e = H.elem[s];
+        if (e < 0) continue;
+        D.nSlotsUsed++;
+        for (int k = 0; k < 9; ++k) A[(size_t)k * ns + s] = h->A[(size_t)9 * e + k];
+        mu[s] = h->mu[e];
+        lam[s] = h->lam[e];
+        vol[s] = h->vol[e];
+        volE[s] = H.eown[s] ? h->vol[e] : 0.0;
+    }
+    if (int rc = upload(h, &D.tl, tl)) return rc;
+    if (int rc = upload(h, &D.epos, ep)) return rc;
+    if (int rc = upload(h, &D.A, A)) return rc;
+    bool uniform = !h->mu.empty();
+    for (size_t e = 1; e < h->mu.size() && uniform; ++e) uniform = h->mu[e] == h->mu[0] && h->lam[e] == h->lam[0];
+    D.mu = D.lam = nullptr;
+    if (uniform) {
+        D.mu0 = h->mu[0];
+        D.lam0 = h->lam[0];
+    } else {
+        if (int rc = upload(h, &D.mu, mu)) return rc;
+        if (int rc = upload(h, &D.lam, lam)) return rc;
+    }
+    if (int rc = upload(h, &D.vol, vol)) return rc;
+    if (int rc = upload(h, &D.volE, volE)) return rc;
+    if (int rc = upload(h, &D.pv_gid, H.pv_gid)) return rc;
+    if (int rc = upload(h, &D.pv_cnt, H.pv_cnt)) return rc;
+    if (int rc = upload(h, &D.po_cnt, H.po_cnt)) return rc;
+    if (int rc = upload(h, &D.c_ptr, H.c_ptr)) return rc;
+    return 0;
+}
+
 // patch lists + the element operands in patch order -> device
 int upload_patches(dotmi_handle *h, const HostPatches &H, DevPatches &D)
 {
@@ -839,6 +885,32 @@ int dotmi_plan_patches(int32_t nV, int32_t nT, const int32_t *T, const double *X
     return 0;
 }
 
+// host-only: the vertex patches of vpatches.hpp (see include/dotmi.h)
+int dotmi_plan_vpatches(int32_t nV, int32_t nT, const int32_t *T, const double *X, int32_t PE, int32_t max_own, int32_t *hdr,
+                        int32_t *owner, int32_t *elem, int32_t *eown, int32_t *runlen)
+{
+    if (nV < 1 || nT < 1 || !T || !X || PE < 1 || max_own < 1 || !hdr) return DOTMI_E_INVALID;
+    const HostVPatches H = build_vpatches(nV, nT, T, X, PE, max_own);
+    hdr[0] = H.nPatches;
+    hdr[1] = H.PE;
+    hdr[2] = H.PV;
+    hdr[3] = H.PO;
+    hdr[4] = H.RUN;
+    if (!owner || H.nPatches == 0) return 0;
+    for (int p = 0; p < H.nPatches; ++p) {
+        const uint16_t *cp = &H.c_ptr[(size_t)p * (H.PO + 1)];
+        for (int lv = 0; lv < H.po_cnt[p]; ++lv) {
+            const int v = H.pv_gid[(size_t)p * H.PV + lv];
+            owner[v] = p;
+            if (runlen) runlen[v] = cp[lv + 1] - cp[lv];
+        }
+    }
+    if (elem) std::copy(H.elem.begin(), H.elem.end(), elem);
+    if (eown)
+        for (size_t s = 0; s < H.eown.size(); ++s) eown[s] = H.eown[s];
+    return 0;
+}
+
 // host-only: the level schedule of tile_factor.hpp for ONE block of nt x nt tiles with the given upper tile pattern, in the
 // compact row-block layout (c0[j] = first tile column stored for tile row j, c0[j] <= every pattern entry of column j).
 // Offsets are in doubles into one array: the factor storage first, the scratch tiles after it (*scratch_base).
@@ -1324,8 +1396,10 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
     if (int rc = dalloc(h, &h->partE, (size_t)4 * ELEM_NB_MAX)) return rc;   // (second half: a paired trial's full-step partials)
     double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG, &h->partGR, &h->partGC, &h->partCT};
     for (double **pp : parts) {
-        if (int rc = dalloc(h, pp, (size_t)NB_RED * RED_K)) return rc;
-        HIPCHECK(h, hipMemsetAsync(*pp, 0, sizeof(double) * NB_RED * RED_K, h->st));
+        // (partR: a step on vertex patches leaves one row of statistics per PATCH, up to 512 of them -- k_elemvert.hip)
+        const size_t rows = pp == &h->partR ? 512 : NB_RED;
+        if (int rc = dalloc(h, pp, rows * RED_K)) return rc;
+        HIPCHECK(h, hipMemsetAsync(*pp, 0, sizeof(double) * rows * RED_K, h->st));
     }
     if (int rc = dalloc(h, &h->alpha_dev, 8)) return rc;   // (dalloc counts doubles: [0] the trial's step, [1] a paired trial's full step)
     if (int rc = dalloc(h, &h->gstage, (size_t)n + 2)) return rc;
@@ -1359,6 +1433,21 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         // sum E in the same grouping or an `E > E_cur` verdict can flip at rounding level (the owner exchange runs the fused
         // step on its sharded element pass too)
         if (h->earlyBs && h->tune.fuseStep && (!h->shardElems || h->owner)) h->PT.wgCap = h->PTspec.wgCap = 512;
+        // vertex patches: one rank, the early order with both fused kernels (their statements are what k_elemvert.hip keeps), a
+        // 256-thread back-solve launch to host the controller, every patch a workgroup of its own, its LDS within 64 KB
+        h->vpFits = false;
+        if (h->earlyBs && !h->dist && h->world == 1 && h->tune.fuseStep && h->tune.fuseDir && h->tune.vertexPatches != 0 &&
+            h->P.ntiles - h->P.ntilesWide + h->P.nquad > 0 && !(h->flags & (DOTMI_FLAG_GSDD | DOTMI_FLAG_NEWTON | DOTMI_FLAG_HOST_LOOP))) {
+            const HostVPatches HV = build_vpatches(h->nV, h->nT, h->T.data(), h->Xrest.data(), 512, 85);
+            const size_t shm = sizeof(double) * ((size_t)3 * HV.PV + (size_t)3 * HV.RUN) + 2 * (size_t)((HV.PO + 1 + 3) & ~3);
+            if (HV.nPatches > 0 && HV.nPatches <= 512 && HV.nPatches <= ELEM_NB_MAX && shm <= 64 * 1024 && HV.PO + 1 <= 256) {
+                if (int rc = upload_vpatches(h, HV, h->VP)) return rc;
+                h->vpFits = true;
+                if (h->tune.fuseLog)
+                    fprintf(stderr, "dotmi: vertex patches: %d patches, %.2f x the elements, up to %d owned / %d touched vertices, runs %d, %zu B LDS\n",
+                            HV.nPatches, (double)h->VP.nSlotsUsed / std::max(1, h->nT), HV.PO, HV.PV, HV.RUN, shm);
+            }
+        }
         if (h->dist) {
             if (int rc = dalloc(h, &h->zstage, (size_t)h->n)) return rc;
             HIPCHECK(h, hipMemsetAsync(h->zstage, 0, sizeof(double) * h->n, h->st));   // (owner exchange: stays zero off the held set)

@@ -35,6 +35,7 @@
 #include "elem_math.hpp"
 #include "partition.hpp"
 #include "patches.hpp"
+#include "vpatches.hpp"
 
 
 namespace dotmi {
@@ -90,6 +91,9 @@ struct Tuning {
     bool earlyAbort = true;   // DOTMI_EARLY_ABORT=0  (ablation) speculative back-solves run to their end even when the trial is rejected
     int pairTrials = -1;      // DOTMI_PAIR_TRIALS    -1 (default): paired line-search trials (StepArgs::pairBlocks) in a step whose predecessor
                               //                      halved in at least a quarter of its iterations; 1: in every step; 0: never
+    int vertexPatches = -1;   // DOTMI_VERTEX_PATCHES 0: the element pass and the vertex gather of a trial as two launches on element patches
+                              //                      (until round 5); -1 (default): as ONE launch on vertex patches (k_elemvert.hip) where every
+                              //                      patch is a workgroup of its own (<= 512 patches, one rank); 1: the same rule (reserved)
     int specStep = 0;         // DOTMI_SPEC_STEP      the unit step taken speculatively beside the direction kernel (k_dirstep.hip): 0 (default)
                               //                      never -- measured: the fused launch is as long as its two parts, profiles/r06_spec_step.txt;
                               //                      -1: in a step whose predecessor's first trials took the unit estimate at least nine times
@@ -133,6 +137,7 @@ struct Tuning {
         t.earlyHold = geti("DOTMI_EARLY_HOLD", 1) != 0;
         t.pairTrials = geti("DOTMI_PAIR_TRIALS", -1);
         t.specStep = geti("DOTMI_SPEC_STEP", 0);
+        t.vertexPatches = geti("DOTMI_VERTEX_PATCHES", -1);
         t.fuseStep = geti("DOTMI_FUSE_STEP", 1) != 0;
         t.fuseDir = geti("DOTMI_FUSE_DIR", 1) != 0;
         return t;
@@ -214,6 +219,11 @@ struct dotmi_handle {
     // start-of-step evaluation, the trials and the gathers of a step agree on the grouping of the energy partials.
     DevPatches PTspec;
     bool specFits = false;
+    // vertex patches (vpatches.hpp): the trial's element pass + gather in one launch (k_elemvert.hip); vpFits: this handle's loop may
+    // use them (one rank, early order with the fused kernels, every patch a workgroup); vpNow: the running step does (a step that
+    // pairs or speculates keeps the element patches -- one patch set per step, so its energies are grouped alike)
+    DevVPatches VP;
+    bool vpFits = false, vpNow = false;
     int nOwnElem = 0, v0 = 0, v1 = 0;
     double *x = nullptr, *x_trial = nullptr, *xn = nullptr, *v = nullptr, *xt = nullptr;
     double *g = nullptr, *g_trial = nullptr, *p = nullptr, *q = nullptr, *z = nullptr, *Hp = nullptr;

@@ -61,6 +61,28 @@ struct DevPatches {
     double *gpart = nullptr;      // 3*nSlots per-(patch, vertex) partial gradients, vertex-major
 };
 
+// ---- vertex patches (vpatches.hpp): element pass + vertex gather in one launch (k_elemvert.hip) -------------------------------------
+struct DevVPatches {
+    int nPatches = 0, PE = 0, PV = 0, PO = 0, RUN = 0, nSlotsUsed = 0;
+    ushort4 *tl = nullptr, *epos = nullptr;   // nPatches*PE: corners' patch-local vertex indices / positions in their vertices' runs (0xFFFF: not owned)
+    double *A = nullptr;                      // [9][nPatches*PE] rest-shape inverse in patch order, SoA
+    double *vol = nullptr, *volE = nullptr;   // nPatches*PE: volume (0 on padding) / the same where this patch counts the element's energy, else 0
+    double *mu = nullptr, *lam = nullptr;     // nPatches*PE, or nullptr: every element has mu0 / lam0
+    double mu0 = 0.0, lam0 = 0.0;
+    int *pv_gid = nullptr, *pv_cnt = nullptr, *po_cnt = nullptr;   // touched vertices (owned first) / their number / the owned ones
+    unsigned short *c_ptr = nullptr;          // per patch (PO+1): offsets of the owned vertices' runs
+};
+struct ElemVertArgs {
+    const double *mass, *xt, *p, *hp, *spmv_partials;
+    const uint8_t *fixed;
+    const int *vp_ptr, *vp_off;   // the copies of a vertex in the padded right-hand sides (DevParts)
+    double *rpad;
+    double *partE, *partR, *alpha_out;
+    double dtSq, alpha_min;
+    const double *x0;             // ctl == nullptr (start of a step): evaluate here, no step, no pair ...
+    double *g0;                   // ... the gradient goes here
+};
+
 // ---- factor storage -------------------------------------------------------------------------------
 // A subdomain's X_s is kept by 64-row blocks (and H_s, then R, in a work buffer of the same layout: tile_factor.hpp).  Memory
 // row i of block J = i / 64, column c (c0 <= c < 64 (J + 1)) is at W[off + (i - 64 J) * ld + (c - c0)].  A block only holds
@@ -331,6 +353,10 @@ void launch_gemv_pair(const DevParts &P, const double *q, hipStream_t st, const 
 // ... the controller of a step that takes the unit step speculatively (checks alpha_0 afterwards; DevLoop::specPartials)
 void launch_gemv_spec(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr, int spec = 0);
+void launch_elem_vertex(const DevVPatches &VP, int mat, const ElemVertArgs &a, hipStream_t st, const DevLoop *ctl);
+// ... the controller of a step on vertex patches (k_elemvert.hip): it sums as many statistic rows as there are patches (CtlArgs::nbE)
+void launch_gemv_vp(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
+                    hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr, int spec = 0);
 // the direction kernel and the first trial's element pass at the unit step in one launch of two workgroup populations
 // (k_dirstep.hip): replaces launch_spmv_zp + launch_elem_energy_grad in the slots of a speculating step
 bool dirstep_fits(const DevPatches &PT);   // (meshes of at most 512 patches: every patch a workgroup)

@@ -119,6 +119,28 @@ void sum_stats(const dotmi_handle *h, int nvals, double *R)
     for (int j = 0; j < nvals; ++j) R[j] = chunked_sum(NB_RED, [&](int b) { return h->h_partR[(size_t)b * RED_K + j]; });
 }
 
+// the operands of the one-launch element pass + gather on vertex patches (k_elemvert.hip)
+static ElemVertArgs elem_vertex_args(const dotmi_handle *h)
+{
+    ElemVertArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mass = h->M.mass;
+    a.xt = h->xt;
+    a.p = h->p;
+    a.hp = h->Hp;
+    a.spmv_partials = h->partS;
+    a.fixed = h->M.fixed;
+    a.vp_ptr = h->P.vp_ptr;
+    a.vp_off = h->P.vp_off;
+    a.rpad = h->P.rpad;
+    a.partE = h->partE;
+    a.partR = h->partR;
+    a.alpha_out = h->alpha_dev;
+    a.dtSq = h->dtSq;
+    a.alpha_min = h->alphaMin;
+    return a;
+}
+
 // One slot of the device-resident loop: the nine kernels of an L-BFGS iteration (or, when the controller
 // asked for a retry, only the three of a line-search trial -- the others return at once) and the controller.
 // Early back-solve (one rank, h->earlyBs): the preconditioner M is fixed during a step and linear, so the solve for the
@@ -168,6 +190,10 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     // (owner exchange: the inertia loop runs over every vertex with the owner's share of the mass, so the fused form writes the
     // whole trial point there too -- x + alpha 0 off the held vertices)
     if (h->specNow) {
+    } else if (h->vpNow) {
+        // vertex patches: the element pass, the step, the gather, the pair and its statistics, -g into the right-hand sides: one launch
+        launch_elem_vertex(h->VP, h->mat, elem_vertex_args(h), h->st, h->ctl);
+        nb = h->VP.nPatches;
     } else if (h->tune.fuseStep && (!se || ow)) {   // the step x_trial = x_cur + alpha p inside the element pass
         StepArgs sa{h->p, spart, h->alpha_dev, h->pairNow ? -h->alphaMin : h->alphaMin};   // (negative: a paired launch)
         // (a step with paired trials takes the PAIR instantiations of these two launches)
@@ -194,7 +220,8 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     a.rpad = h->P.rpad;
     const double *ctlE = h->partE;
     const bool packed = ow;   // owner exchange: the statistics ride in the gradient's packet
-    if (!se) {
+    if (h->vpNow) {
+    } else if (!se) {
         launch_vertex_gather(h->M, h->stepPT(), a, L0, h->partR, h->st, h->ctl);
     } else if (packed) {
         // Owner exchange, the statistics in the gradient's packet.  The gradient is complete on the vertices only this rank
@@ -240,7 +267,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
                        (h->timeCount++ % h->timeStride) == 0;
     h->slotTimed.push_back(timed ? h->evUsed : -1);
     CtlArgs ca{h->ctl, ctlE, ctlR, h->alpha_dev, h->h_flags, nb, h->pairNow ? 2 : 0};
-    (h->pairNow ? launch_gemv_pair : h->specNow ? launch_gemv_spec : launch_gemv)(
+    (h->pairNow ? launch_gemv_pair : h->specNow ? launch_gemv_spec : h->vpNow ? launch_gemv_vp : launch_gemv)(
         h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr, &ca,
         h->tune.earlyAbort ? (int)h->slotTimed.size() /* the slot's epoch, 1-based */ : (1 << 30) /* never stopped */);
     if (timed) h->evUsed += 2;
@@ -361,6 +388,9 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     h->specNow = h->earlyNow && !h->dist && !h->pairNow && h->tune.fuseStep && h->tune.fuseDir && h->tune.earlyAbort &&
                  h->specFits &&
                  (h->tune.specStep > 0 || (h->tune.specStep < 0 && h->prevFirst > 0 && 10 * h->prevUnit >= 9 * h->prevFirst));
+    // the trial's element pass + gather as one launch on vertex patches: in the steps that neither pair nor speculate (one patch
+    // set per step: the start-of-step evaluation and the trials group their energy partials alike)
+    h->vpNow = h->vpFits && h->earlyNow && !h->dist && !h->pairNow && !h->specNow;
     C.specPartials = h->partS;
     C.alphaMin = h->alphaMin;
     C.iterCap = h->iterCap;
@@ -403,6 +433,14 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     {
         // energy and gradient at the start of the step, reduced by the controller (no host round trip)
         int nb = 0;
+        if (h->vpNow) {
+            // energy, gradient, |g|^2 and -g_0 in the padded right-hand sides from the one launch (no step, no pair: ctl == nullptr)
+            ElemVertArgs ea = elem_vertex_args(h);
+            ea.x0 = h->x;
+            ea.g0 = h->g;
+            launch_elem_vertex(h->VP, h->mat, ea, h->st, nullptr);
+            nb = h->VP.nPatches;
+        } else
         launch_elem_energy_grad(h->owner ? h->Mown : h->M, h->stepPT(), h->mat, h->dtSq, h->x, h->xt, h->owner ? 0 : h->v0,
                                 h->owner ? h->nV : h->v1, 1, h->partE, &nb, h->st);
         GatherArgs a;
@@ -426,11 +464,11 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
             a.vp_off = h->P.vp_off;
             a.rpad = h->P.rpad;
         }
-        launch_vertex_gather(h->M, h->stepPT(), a, L0, h->partR, h->st);
+        if (!h->vpNow) launch_vertex_gather(h->M, h->stepPT(), a, L0, h->partR, h->st);
         if (!h->shardElems && h->earlyNow) {
             // the first direction's solve, u = -M g_0 and z = u, with the start-of-step controller inside its launch
             CtlArgs ca{h->ctl, h->partE, h->partR, h->alpha_dev, h->h_flags, nb, 1};
-            launch_gemv(h->P, nullptr, h->st, h->ctl, nullptr, nullptr, &ca, 1 << 30);
+            (h->vpNow ? launch_gemv_vp : launch_gemv)(h->P, nullptr, h->st, h->ctl, nullptr, nullptr, &ca, 1 << 30);
             if (!h->dist) {
                 launch_merge_early(h->M, h->P, h->z, h->partC, 1, h->st, h->ctl, nullptr, nullptr, VList(), nullptr, 0, nullptr, h->partCT);
             } else {

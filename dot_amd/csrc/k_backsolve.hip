@@ -19,7 +19,9 @@ namespace dotmi {
 // stopped and the next slot evaluates x + alpha_0 p as the first trial it is (phase 1, redo: nothing counted twice).  Template
 // parameters: the plain instantiation compiles those branches away (the pairing until round 5 through a second compilation of the
 // file under -DDOTMI_PAIR_TU).
-constexpr int CTL_PLAIN = 0, CTL_PAIR = 1, CTL_SPEC = 2;
+// CTL_VP: the controller of a step on vertex patches (k_elemvert.hip): the statistics come in one row per PATCH (nbE rows, like the
+// energy partials) instead of NB_RED rows; summed in chunked_sum's order over that many rows.
+constexpr int CTL_PLAIN = 0, CTL_PAIR = 1, CTL_SPEC = 2, CTL_VP = 3;
 template <int CTL>
 __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, const double *__restrict__ partE, int nbE,
                                   const double *__restrict__ partR, const double *__restrict__ alpha_dev,
@@ -66,13 +68,15 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
         const int colB = qb % RED_K, chB = qb / RED_K;
         const bool hasA = qa < NPAIR, hasB = qb < NPAIR;
         double va[LR], vb[LR];
-        if (hasA) {
+        if constexpr (CTL != CTL_VP) {
+            if (hasA) {
 #pragma unroll
-            for (int k = 0; k < LR; ++k) va[k] = partR[(size_t)(chA * LR + k) * RED_K + colA];
-        }
-        if (hasB) {
+                for (int k = 0; k < LR; ++k) va[k] = partR[(size_t)(chA * LR + k) * RED_K + colA];
+            }
+            if (hasB) {
 #pragma unroll
-            for (int k = 0; k < LR; ++k) vb[k] = partR[(size_t)(chB * LR + k) * RED_K + colB];
+                for (int k = 0; k < LR; ++k) vb[k] = partR[(size_t)(chB * LR + k) * RED_K + colB];
+            }
         }
         const int te = qb - NPAIR;  // the next 2 * SUM_CHUNKS slots: the two energy columns
         if (te >= 0 && te < 2 * SUM_CHUNKS) {
@@ -103,6 +107,26 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
                 chunk2[PAIR ? c : 0][ch] = e2;
             }
         }
+        if constexpr (CTL == CTL_VP) {
+            // nbE rows of statistics: chunk ch of column col = rows [ch LE, (ch + 1) LE), eight loads in flight
+            auto chunk_rows = [&](int col, int ch) {
+                const int LE = (nbE + SUM_CHUNKS - 1) / SUM_CHUNKS;
+                const int k0 = ch * LE, k1 = min(nbE, (ch + 1) * LE);
+                double s = 0.0;
+                int k = k0;
+                for (; k + 8 <= k1; k += 8) {
+                    double v8[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v8[u] = partR[(size_t)(k + u) * RED_K + col];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += v8[u];
+                }
+                for (; k < k1; ++k) s += partR[(size_t)k * RED_K + col];
+                return s;
+            };
+            if (hasA) chunk[colA][chA] = chunk_rows(colA, chA);
+            if (hasB) chunk[colB][chB] = chunk_rows(colB, chB);
+        } else {
         if (hasA) {
             double a = 0.0;
 #pragma unroll
@@ -114,6 +138,7 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
 #pragma unroll
             for (int k = 0; k < LR; ++k) b += vb[k];
             chunk[colB][chB] = b;
+        }
         }
     }
     double a0spec = 1.0;   // SPEC: alpha_0 of the direction the slot computed (valid in thread 0)
@@ -1166,6 +1191,12 @@ void launch_gemv_pair(const DevParts &P, const double *q, hipStream_t st, const 
                       const CtlArgs *ca, int spec)
 {
     launch_gemv_impl<CTL_PAIR>(P, q, st, ctl, ev0, ev1, ca, spec);
+}
+// ... with the controller of a step on vertex patches (k_elemvert.hip)
+void launch_gemv_vp(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,
+                    const CtlArgs *ca, int spec)
+{
+    launch_gemv_impl<CTL_VP>(P, q, st, ctl, ev0, ev1, ca, spec);
 }
 // ... with the controller of a step that takes the unit step speculatively (k_dirstep.hip)
 void launch_gemv_spec(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,

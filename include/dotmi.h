@@ -225,6 +225,13 @@ int dotmi_plan_rank(int32_t nV, int32_t nT, const int32_t *T, const int32_t *epa
 int dotmi_plan_patches(int32_t nV, int32_t nT, const int32_t *T, const double *X, int32_t PE, int32_t *n_patches, int32_t *pv,
                        int32_t *n_slots, int32_t *elem, uint16_t *tl, uint16_t *epos, int32_t *pv_gid, int32_t *pv_slot,
                        int32_t *pv_cnt, uint16_t *c_ptr, int32_t *pp_rng);
+/* (host only, round 6) the VERTEX patches of the one-launch element pass + gather (dot_amd/csrc/vpatches.hpp, k_elemvert.hip): a
+ * patch owns up to max_own vertices and carries every element incident to them.  hdr[5] = {patches, PE, most touched vertices, most
+ * owned vertices, longest sum of runs}; with owner != NULL also: owner[nV] (the patch that owns a vertex), elem[patches * PE] (global
+ * element of every slot, -1 padding), eown[patches * PE] (1: this patch counts the element's energy), runlen[nV] (entries of the
+ * vertex' gradient run in its patch).  tests/test_gpu_round6.py / test_host_logic.py */
+int dotmi_plan_vpatches(int32_t nV, int32_t nT, const int32_t *T, const double *X, int32_t PE, int32_t max_own, int32_t *hdr,
+                        int32_t *owner, int32_t *elem, int32_t *eown, int32_t *runlen);
 /* (host only) the level schedule of the tile factorisation for one nt x nt tile block with the given upper tile pattern in
  * the compact row-block layout; see dot_amd/csrc/tile_factor.hpp and tests/test_tile_schedule.py */
 int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0, int32_t eager_min,

@@ -52,6 +52,7 @@ def test_speculative_unit_step_takes_the_same_steps_bit_for_bit(workload, steps,
     # monkey, where the default 256-element ones are too many: the comparison fixes that size for both runs, so that the energy
     # partials are grouped alike)
     pe = {"DOTMI_PATCH_ELEMS": "512"} if workload in ("bar17K_twist", "monkey18K_stiff") else {}
+    pe["DOTMI_VERTEX_PATCHES"] = "0"   # (the unspeculated run on the element patches as well, not on vertex patches)
     rec0, x0, v0, s0, r0, st0, log0 = _run(workload, steps, {"DOTMI_SPEC_STEP": "0", "DOTMI_PAIR_TRIALS": "0", **pe}, monkeypatch, log=True)
     rec1, x1, v1, s1, r1, st1, log1 = _run(workload, steps, {"DOTMI_SPEC_STEP": "1", "DOTMI_PAIR_TRIALS": "0", **pe}, monkeypatch, log=True)
     assert s0 == 0 and r0 == 0
@@ -191,3 +192,32 @@ def test_bar17K_stays_within_the_stated_band_of_the_oracle_on_the_references_svd
         assert dx < 2.5e-4, (k, dx)
     print(f"bar17K vs the oracle on the reference's SVD + CHOLMOD: iterations {[o[0].iters for o in out]} against "
           f"{[int(G[f'iters{k}']) for k in range(len(out))]}, max|dx| over ten steps {worst:.2e}")
+
+
+# ---- vertex patches: the trial's element pass + vertex gather in one launch (k_elemvert.hip) ------------------------------------
+@pytest.mark.parametrize("workload,steps", [("bar17K_twist", 4), ("bunny5K_LTSS", 8), ("monkey18K_stiff", 1), ("horse7K_stretch", 4)])
+def test_vertex_patches_take_the_element_patches_steps(workload, steps, monkeypatch):
+    """Default since round 6 on one rank where every patch is a workgroup of its own: a vertex patch owns its vertices and carries
+    every element incident to them, so ONE launch does what elem_patch_kernel + vertex_gather_kernel did (energy, gradient summed in
+    ascending element order over all incident elements, inertia, trial point, pair, statistics, -g into the right-hand sides).
+    Against the two-launch path (DOTMI_VERTEX_PATCHES=0): the sums are grouped differently (no per-patch partials any more), nothing
+    else -- identical iterations, halvings and energy evaluations, energies to 1e-9, positions to 1e-9 on the steps that do not
+    back-track (the stiff monkey, chaotic: its identical prefix of decisions)."""
+    base = {"DOTMI_PAIR_TRIALS": "0", "DOTMI_SPEC_STEP": "0"}
+    rec0, x0, v0, _, _, _, log0 = _run(workload, steps, {**base, "DOTMI_VERTEX_PATCHES": "0"}, monkeypatch, log=True)
+    rec1, x1, v1, _, _, _, log1 = _run(workload, steps, base, monkeypatch, log=True)
+    if workload == "monkey18K_stiff":
+        (a0, e0, _), (a1, e1, _) = log0[0], log1[0]
+        m = min(len(a0), len(a1))
+        same = np.isclose(a0[:m], a1[:m], rtol=1e-6, atol=0) & np.isclose(e0[:m], e1[:m], rtol=1e-9, atol=0)
+        prefix = m if same.all() else int(np.argmin(same))
+        print("monkey: identical prefix", prefix, "of", m, "iterations;", rec0, rec1)
+        assert prefix >= 25 and rec0[0][0] == rec1[0][0] == 0
+        return
+    for k, (r0, r1) in enumerate(zip(rec0, rec1)):
+        assert r0[:4] == r1[:4], (k, r0, r1)                       # status, iterations, halvings, energy evaluations
+        assert abs(r0[4] - r1[4]) <= 1e-9 * abs(r0[4]), (k, r0[4], r1[4])
+    quiet = all(r[2] == 0 for r in rec0)
+    dx = np.abs(x1 - x0).max()
+    print(f"{workload}: vertex patches vs element patches, max|dx| after {steps} steps {dx:.2e}")
+    assert dx < (1e-9 if quiet else 1e-6), dx

@@ -97,3 +97,39 @@ def test_patch_lists_and_two_stage_sum(mesh, PE):
             gpart[slot[p, v]] = s
     out = np.array([gpart[rng_[v, 0]:rng_[v, 1]].sum(0) for v in range(nV)])
     assert np.abs(out - ref).max() < 1e-12
+
+
+def test_vertex_patch_plan_owns_every_vertex_once_and_counts_every_element_once():
+    """dotmi_plan_vpatches (host only): every vertex is owned by exactly one patch, a patch carries every element incident to its
+    vertices (so its runs are complete: as many entries as incident corners), every element's energy is counted exactly once,
+    element slots ascend in element id inside a patch."""
+    import ctypes as C
+    sc, ep, n = load_workload("bunny5K_LTSS")
+    L = dl.load()
+    T = np.ascontiguousarray(sc.T, dtype=np.int32)
+    X = np.ascontiguousarray(sc.V_rest, dtype=np.float64)
+    nV, nT = X.shape[0], T.shape[0]
+    hdr = np.zeros(5, dtype=np.int32)
+    L.dotmi_plan_vpatches.argtypes = [C.c_int32, C.c_int32, dl.c_ip, dl.c_dp, C.c_int32, C.c_int32, dl.c_ip, dl.c_ip, dl.c_ip, dl.c_ip,
+                                      dl.c_ip]
+    assert L.dotmi_plan_vpatches(nV, nT, dl.ip(T), dl.dp(X), 512, 85, dl.ip(hdr), None, None, None, None) == 0
+    nP, PE, PV, PO, RUN = (int(v) for v in hdr)
+    assert 0 < nP <= 512 and PE == 512 and PO <= 85
+    owner = np.zeros(nV, dtype=np.int32)
+    elem = np.zeros(nP * PE, dtype=np.int32)
+    eown = np.zeros(nP * PE, dtype=np.int32)
+    runlen = np.zeros(nV, dtype=np.int32)
+    assert L.dotmi_plan_vpatches(nV, nT, dl.ip(T), dl.dp(X), 512, 85, dl.ip(hdr), dl.ip(owner), dl.ip(elem), dl.ip(eown),
+                                 dl.ip(runlen)) == 0
+    assert owner.min() >= 0 and owner.max() == nP - 1
+    inc = np.bincount(T.ravel(), minlength=nV)
+    assert np.array_equal(runlen, inc)                                   # complete runs
+    counted = np.zeros(nT, dtype=np.int64)
+    for p in range(nP):
+        el = elem[p * PE:(p + 1) * PE]
+        live = el[el >= 0]
+        assert np.all(np.diff(live) > 0)
+        need = np.unique(np.nonzero(np.isin(T, np.nonzero(owner == p)[0]).any(axis=1))[0])
+        assert np.array_equal(np.sort(live), need)                       # exactly the elements incident to the owned vertices
+        counted[live[eown[p * PE:(p + 1) * PE][el >= 0] != 0]] += 1
+    assert np.all(counted == 1)
