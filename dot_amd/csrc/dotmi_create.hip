@@ -1394,7 +1394,7 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         HIPCHECK(h, hipMemsetAsync(h->HvalOwn, 0, sizeof(double) * hval_size(h->M.nnzb), h->st));
     }
     if (int rc = dalloc(h, &h->partE, (size_t)4 * ELEM_NB_MAX)) return rc;   // (second half: a paired trial's full-step partials)
-    double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG, &h->partGR, &h->partGC, &h->partCT};
+    double **parts[] = {&h->partR, &h->partC, &h->partS, &h->partG, &h->partGR, &h->partGC, &h->partCT, &h->partST};
     for (double **pp : parts) {
         // (partR: a step on vertex patches leaves one row of statistics per PATCH, up to 512 of them -- k_elemvert.hip)
         const size_t rows = pp == &h->partR ? 512 : NB_RED;

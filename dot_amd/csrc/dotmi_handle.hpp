@@ -238,6 +238,7 @@ struct dotmi_handle {
     double *u_old = nullptr, *MY[HIST_MAX + 1] = {nullptr};
     double *HS[HIST_MAX + 1] = {nullptr};   // H s_i of the stored pairs (fused direction kernel of the early order)
     double *partE = nullptr, *partR = nullptr, *partC = nullptr, *partS = nullptr, *partG = nullptr;
+    double *partST = nullptr;   // p.g / p.Hp partials, column-major [2][NB_RED] (spmv_zp_body's partialsT): what elem_vertex_kernel reads
     double *partCT = nullptr;   // the y_i . z partials once more, column-major (write_partials' partialsT): what the one-rank loop's direction kernels read
     bool pairNow = false;       // this step's slots launch the element pass twice as wide (enqueue_loop_slot_early)
     int pairSlots = 0, pairRedo = 0;

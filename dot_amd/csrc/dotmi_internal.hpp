@@ -73,7 +73,8 @@ struct DevVPatches {
     unsigned short *c_ptr = nullptr;          // per patch (PO+1): offsets of the owned vertices' runs
 };
 struct ElemVertArgs {
-    const double *mass, *xt, *p, *hp, *spmv_partials;
+    const double *mass, *xt, *p, *hp;
+    const double *spmv_partials;   // p.g / p.Hp partials, COLUMN-major [2][NB_RED] (launch_spmv_zp's partialsT)
     const uint8_t *fixed;
     const int *vp_ptr, *vp_off;   // the copies of a vertex in the padded right-hand sides (DevParts)
     double *rpad;
@@ -416,7 +417,8 @@ void launch_build_p(int n, const double *z, const LbfgsArgs &L, const double *c_
 // p.Hp over them, p.g over the vertices it owns
 void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const double *c_partials, double *p, double *Hp,
                     double *partials, hipStream_t st, const DevLoop *ctl, int v0 = 0, int v1 = -1,
-                    const uint8_t *rowMask = nullptr, const uint8_t *ownMask = nullptr, VList vl = VList(), bool ctrans = false);
+                    const uint8_t *rowMask = nullptr, const uint8_t *ownMask = nullptr, VList vl = VList(), bool ctrans = false,
+                    double *partialsT = nullptr);   // (partialsT: p.g / p.Hp once more, column-major [2][NB_RED])
 // Hp = H p on rows [v0,v1), partial sums of p.g and p.Hp
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,
                       int v0, int v1, double *partials, hipStream_t st, const DevLoop *ctl = nullptr);

@@ -128,7 +128,7 @@ static ElemVertArgs elem_vertex_args(const dotmi_handle *h)
     a.xt = h->xt;
     a.p = h->p;
     a.hp = h->Hp;
-    a.spmv_partials = h->partS;
+    a.spmv_partials = h->partST;
     a.fixed = h->M.fixed;
     a.vp_ptr = h->P.vp_ptr;
     a.vp_off = h->P.vp_off;
@@ -171,7 +171,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     } else if (fuseDir) {   // build_p + spmv_dots in one launch, H p from the cached H s_j
         // (one rank: the y_i . z partials from their column-major twin, which merge_early writes beside the rows)
         launch_spmv_zp(h->M, h->Hval, h->z, h->dist ? h->partC : h->partCT, h->p, h->Hp, h->partS, h->st, h->ctl, se ? h->v0 : 0,
-                       se ? h->v1 : -1, nullptr, nullptr, VList(), !h->dist);
+                       se ? h->v1 : -1, nullptr, nullptr, VList(), !h->dist, h->partST);
     } else {
         launch_build_p(n, h->z, L0, h->partC, nullptr, h->p, h->st, h->ctl);
         launch_spmv_dots(h->M, h->Hval, h->p, h->g, nullptr, h->v0, h->v1, h->partS, h->st, h->ctl);

@@ -32,7 +32,7 @@ __device__ __forceinline__ void spmv_zp_body(int nV, int v0, int v1, const uint8
                                              const double *__restrict__ z, const double *__restrict__ c_partials, int c_blocks,
                                              double *__restrict__ p, double *__restrict__ Hp, double *__restrict__ partials,
                                              const DevLoop *__restrict__ ctl, VList vl, double *sm, double *delta, int bidx,
-                                             int nblocks)
+                                             int nblocks, double *__restrict__ partialsT = nullptr)
 {
     // the loop state this body needs, every load of it in front of the first branch (one round trip, not one per index)
     const int status = ctl->status, phase = ctl->phase, m = ctl->L.m;
@@ -192,6 +192,10 @@ __device__ __forceinline__ void spmv_zp_body(int nV, int v0, int v1, const uint8
             }
         partials[(size_t)bidx * RED_K] = t0[0];
         partials[(size_t)bidx * RED_K + 1] = t1[0];
+        if (partialsT) {   // the two columns once more, column-major: what EVERY workgroup of the element pass reads (k_device.hpp, write_partials)
+            partialsT[bidx] = t0[0];
+            partialsT[NB_RED + bidx] = t1[0];
+        }
     }
 }
 

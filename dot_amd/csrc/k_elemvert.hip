@@ -47,7 +47,10 @@ __global__ __launch_bounds__(256) void elem_vertex_kernel(DevVPatches VP, ElemVe
     __shared__ double sme[8];
     __shared__ double sh_alpha;
     const int tid = threadIdx.x, p = blockIdx.x;
-    EVSTAMP(0);
+    long long t_start = 0;
+#ifdef K_PROFILE
+    t_start = wall_clock64();
+#endif
     // ---- loop state (one batch of scalar loads in front of the first branch) ---------------------------------------------------
     const double *__restrict__ x = a.x0;
     double *__restrict__ x_out = nullptr, *__restrict__ g_out = a.g0;
@@ -76,28 +79,37 @@ __global__ __launch_bounds__(256) void elem_vertex_kernel(DevVPatches VP, ElemVe
         }
         if (status != 0) return;
     }
+#ifdef K_PROFILE
+    if (threadIdx.x == 0 && blockIdx.x < 512) g_evprof[blockIdx.x][7] = t_start;   // (only launches that do work leave stamps)
+#endif
+    EVSTAMP(0);
     // alpha_0 = clamp(-p.g / p.Hp, alphaMin, 1) from the SpMV partials (a new direction), else the controller's halved step
     double pgv[NB_RED / 64], pHpv[NB_RED / 64];
     const bool usePart = loop && lphase == 0;
     if (usePart && tid < 64) {
 #pragma unroll
         for (int u = 0; u < NB_RED / 64; ++u) {
-            pgv[u] = a.spmv_partials[(size_t)(tid + 64 * u) * RED_K];
-            pHpv[u] = a.spmv_partials[(size_t)(tid + 64 * u) * RED_K + 1];
+            pgv[u] = a.spmv_partials[tid + 64 * u];             // (column-major: 512 contiguous bytes per load and wave)
+            pHpv[u] = a.spmv_partials[NB_RED + tid + 64 * u];
         }
     }
     // ---- LDS: xs[3 PV] | gs[3][RUN] | cptr[PO + 1 .. padded to 4] (u16) ---------------------------------------------------------
     constexpr int PE = 256 * EV_EPT;
     double *xs = lds, *gs = lds + 3 * VP.PV;
     unsigned short *cptr = reinterpret_cast<unsigned short *>(gs + 3 * VP.RUN);
+    // (the vertex ids do not wait for the patch's counts: the touched list is padded with -1, and a lane of phase 3 beyond the owned
+    // vertices reads a touched vertex it then ignores -- one dependent round trip less in front of the positions)
     const int nv = VP.pv_cnt[p], no = VP.po_cnt[p];
     const size_t vb = (size_t)p * VP.PV;
-    const int gid = tid < nv ? VP.pv_gid[vb + tid] : -1;
-    if (tid <= VP.PO) cptr[tid] = VP.c_ptr[(size_t)p * (VP.PO + 1) + tid];
+    const int gid = tid < VP.PV ? VP.pv_gid[vb + tid] : -1;
+    // (the run offsets go to LDS further down: a store here would wait for its load -- and, the loads returning in order, hold
+    // back the request for phase 3's vertex ids behind a whole round trip)
+    const unsigned short cp_reg = tid <= VP.PO ? VP.c_ptr[(size_t)p * (VP.PO + 1) + tid] : (unsigned short)0;
     // phase 3's vertex: lane (v, d) of the first 3 no lanes
     const int ov = tid / 3, od = tid - 3 * ov;
+    const int ogid_raw = ov < VP.PV ? VP.pv_gid[vb + ov] : -1;
     const bool vlane = tid < 3 * no;
-    const int ogid = vlane ? VP.pv_gid[vb + ov] : -1;
+    const int ogid = vlane ? ogid_raw : -1;
     // ---- element operands (patch order: every load of a wave is one contiguous run) ---------------------------------------------
     ushort4 tl[EV_EPT], ep[EV_EPT];
     double Ai[EV_EPT][9], mu_[EV_EPT], la_[EV_EPT], vo[EV_EPT], voE[EV_EPT];
@@ -151,10 +163,7 @@ __global__ __launch_bounds__(256) void elem_vertex_kernel(DevVPatches VP, ElemVe
             }
         }
     }
-    constexpr int VC = 4;   // copies of a vertex (subdomains that hold it) whose padded positions are requested ahead of the stores
-    int vof[VC];
-#pragma unroll
-    for (int c = 0; c < VC; ++c) vof[c] = (cb + c < ce) ? a.vp_off[cb + c] : 0;
+    if (tid <= VP.PO) cptr[tid] = cp_reg;
     EVSTAMP(1);
     // ---- alpha ------------------------------------------------------------------------------------------------------------------
     if (tid < 64) {
@@ -190,6 +199,12 @@ __global__ __launch_bounds__(256) void elem_vertex_kernel(DevVPatches VP, ElemVe
     }
     __syncthreads();
     EVSTAMP(3);
+    // the padded positions of the vertex' copies (a second dependent load behind the vertex id: requested here, where the first has
+    // long arrived, not in front of the barriers above; used at the end)
+    constexpr int VC = 4;   // copies of a vertex (subdomains that hold it) whose positions are requested ahead of the stores
+    int vof[VC];
+#pragma unroll
+    for (int c = 0; c < VC; ++c) vof[c] = (cb + c < ce) ? a.vp_off[cb + c] : 0;
     // ---- phase 2: elements ------------------------------------------------------------------------------------------------------
     double acc = 0.0;   // sum vol * Psi over the elements whose energy this patch counts
 #pragma unroll

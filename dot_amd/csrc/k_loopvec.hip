@@ -1114,12 +1114,13 @@ __global__ __launch_bounds__(256) void spmv_zp_kernel(int nV, int v0, int v1, co
                                                       const double *__restrict__ Hval, const double *__restrict__ z,
                                                       const double *__restrict__ c_partials, int c_blocks,
                                                       double *__restrict__ p, double *__restrict__ Hp,
-                                                      double *__restrict__ partials, const DevLoop *__restrict__ ctl, VList vl)
+                                                      double *__restrict__ partials, const DevLoop *__restrict__ ctl, VList vl,
+                                                      double *__restrict__ partialsT)
 {
     __shared__ double sm[8];
     __shared__ double delta[HIST_MAX];
     spmv_zp_body(nV, v0, v1, rowMask, ownMask, adj_ptr, adj_idx, Hval, z, c_partials, c_blocks, p, Hp, partials, ctl, vl, sm, delta,
-                 (int)blockIdx.x, (int)gridDim.x);
+                 (int)blockIdx.x, (int)gridDim.x, partialsT);
 }
 // the same rows by workgroups of 1024 threads, one row per lane group (four waves per SIMD)
 __global__ __launch_bounds__(1024) void spmv_zp_wide_kernel(int nV, int v0, int v1, const uint8_t *__restrict__ rowMask,
@@ -1127,17 +1128,18 @@ __global__ __launch_bounds__(1024) void spmv_zp_wide_kernel(int nV, int v0, int 
                                                             const int *__restrict__ adj_idx, const double *__restrict__ Hval,
                                                             const double *__restrict__ z, const double *__restrict__ c_partials,
                                                             int c_blocks, double *__restrict__ p, double *__restrict__ Hp,
-                                                            double *__restrict__ partials, const DevLoop *__restrict__ ctl, VList vl)
+                                                            double *__restrict__ partials, const DevLoop *__restrict__ ctl, VList vl,
+                                                            double *__restrict__ partialsT)
 {
     __shared__ double sm[32];
     __shared__ double delta[HIST_MAX];
     spmv_zp_body<1024, 1>(nV, v0, v1, rowMask, ownMask, adj_ptr, adj_idx, Hval, z, c_partials, c_blocks, p, Hp, partials, ctl, vl, sm,
-                          delta, (int)blockIdx.x, (int)gridDim.x);
+                          delta, (int)blockIdx.x, (int)gridDim.x, partialsT);
 }
 
 void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const double *c_partials, double *p, double *Hp,
                     double *partials, hipStream_t st, const DevLoop *ctl, int v0, int v1, const uint8_t *rowMask,
-                    const uint8_t *ownMask, VList vl, bool ctrans)
+                    const uint8_t *ownMask, VList vl, bool ctrans, double *partialsT)
 {
     if (v1 < 0) v1 = M.nV;
     // Rows beyond one trip of the 256-thread form (256 workgroups x 32 lane groups x 3 rows): workgroups of 1024 threads, a
@@ -1149,10 +1151,10 @@ void launch_spmv_zp(const DevMesh &M, const double *Hval, const double *z, const
     const bool wide = wideEnv >= 0 ? wideEnv != 0 : nrows > NB_RED * 32 * SPMV_R;
     if (wide)
         hipLaunchKernelGGL(spmv_zp_wide_kernel, dim3(NB_RED), dim3(1024), 0, st, M.nV, v0, v1, rowMask, ownMask, M.adj_ptr, M.adj_idx,
-                           Hval, z, c_partials, ctrans ? -NB_RED : NB_RED, p, Hp, partials, ctl, vl);
+                           Hval, z, c_partials, ctrans ? -NB_RED : NB_RED, p, Hp, partials, ctl, vl, partialsT);
     else
     hipLaunchKernelGGL(spmv_zp_kernel, dim3(NB_RED), dim3(256), 0, st, M.nV, v0, v1, rowMask, ownMask, M.adj_ptr, M.adj_idx, Hval,
-                       z, c_partials, ctrans ? -NB_RED : NB_RED, p, Hp, partials, ctl, vl);
+                       z, c_partials, ctrans ? -NB_RED : NB_RED, p, Hp, partials, ctl, vl, partialsT);
 }
 
 void launch_spmv_dots(const DevMesh &M, const double *Hval, const double *p, const double *g, double *Hp,

@@ -16,10 +16,11 @@ L.dotmi_debug_evprof.argtypes = [ctypes.POINTER(ctypes.c_longlong)]
 assert L.dotmi_debug_evprof(buf) == 0
 a = np.frombuffer(buf, dtype=np.int64).reshape(512, 8)
 a = a[a[:, 0] > 0]
-t0 = a[:, 0].min()
+t0 = a[:, 7].min()
 T = (a[:, :7] - t0) / 100.0
+print("   %-70s p50 %.2f  p95 %.2f us" % ("kernel start -> loop state there", np.median((a[:, 0] - a[:, 7]) / 100.0), np.percentile((a[:, 0] - a[:, 7]) / 100.0, 95)))
 print("%d workgroups, first start -> last end %.2f us; start p50 %.2f max %.2f" % (len(a), T[:, 6].max(), np.median(T[:, 0]), T[:, 0].max()))
-for k, nm in enumerate(["start -> loop state read, every load requested", "alpha (SpMV partials) + barrier", "positions there, trial points in LDS + barrier",
+for k, nm in enumerate(["loop state there -> every load requested", "alpha (SpMV partials) + barrier", "positions there, trial points in LDS + barrier",
                         "2 x 256 elements, owned corners' entries in LDS + barrier", "run sums, gradient / pair / right-hand side stores, statistics",
                         "block sums -> end"]):
     d = T[:, k + 1] - T[:, k]
