@@ -115,7 +115,7 @@ def compact_line(full):
             "frac_of_fp64_vector_peak": r["frac_of_fp64_vector_peak"], "frac_of_hbm_peak": r["frac_of_hbm_peak"]}
            for w in (full.get("workloads") or [{"workload": full["config"]["workload"], "roofline_by_kernel": full.get("roofline_by_kernel")}])
            if "error" not in w
-           for r in (w.get("roofline_by_kernel") or []) if r.get("fp64_flop") and r["kernel"] in ("elem_step", "elem_energy_grad")]
+           for r in (w.get("roofline_by_kernel") or []) if r.get("fp64_flop") and r["kernel"] in ("elem_step", "elem_energy_grad", "elem_vertex")]
     if alu:
         out["roofline_alu"] = alu
     if "collectives" in full:
@@ -239,12 +239,13 @@ def main():
                     "elem_energy": pick("elem_pass", r"<\d, false,", key="fp64_flop_per_launch"),
                     "elem_step": pick("elem_pass", r"<\d, true, \d, true,", key="fp64_flop_per_launch"),
                     "elem_hessian": pick("elem_hessian", key="fp64_flop_per_launch"),
-                    "dirstep": pick("dirstep", key="fp64_flop_per_launch"), "spmv_zp": pick("spmv_zp", key="fp64_flop_per_launch")}
+                    "dirstep": pick("dirstep", key="fp64_flop_per_launch"), "spmv_zp": pick("spmv_zp", key="fp64_flop_per_launch"),
+                    "elem_vertex": pick("elem_vertex", key="fp64_flop_per_launch")}
             flops_by_kernel[workload] = {k: v for k, v in flop.items() if v}
             # elem_patch_kernel<MAT, GRAD, EPT, FUSE (step inside), PIPE>
             out = {"elem_energy_grad": pick("elem_pass", r"<\d, true, \d, false,"), "elem_energy": pick("elem_pass", r"<\d, false,"),
                    "elem_step": pick("elem_pass", r"<\d, true, \d, true,"), "gather_early": pick("vertex_gather", "<true>"),
-                   "dirstep": pick("dirstep"),
+                   "dirstep": pick("dirstep"), "elem_vertex": pick("elem_vertex"),
                    "spmv_zp": pick("spmv_zp"), "merge_early": pick("merge_early"),
                    "vertex_gather": pick("vertex_gather", "<false>"), "spmv_dots": pick("spmv_dots"),
                    "backsolve": pick("backsolve", total=True), "merge": pick("merge", "<false>"),

@@ -539,6 +539,34 @@ int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_p
         run = [&] { launch_vertex_gather(h->M, h->PT, a, L, h->partR, h->st, h->ctl); };
         break;
     }
+    case DOTMI_BENCH_ELEM_VERTEX: {     // what the stepping element pass and the early gather read and write together (the halo's
+                                        // re-reads are traffic, not algorithmic bytes)
+        if (!h->vpFits) return DOTMI_E_INVALID;
+        long long held = 0;
+        for (int v = 0; v < nV; ++v) held += h->dup[v];
+        bytes = 112 * nTo + 56 * nVo + 48 * (int64_t)nV + 80 * (int64_t)nV + (int64_t)(6 + 2 * L.m) * 8 * n + 24 * held;
+        live = true;
+        run = [&] {
+            ElemVertArgs ea;
+            memset(&ea, 0, sizeof(ea));
+            ea.mass = h->M.mass;
+            ea.xt = h->xt;
+            ea.p = h->p;
+            ea.hp = h->Hp;
+            ea.spmv_partials = h->partST;
+            ea.fixed = h->M.fixed;
+            ea.vp_ptr = h->P.vp_ptr;
+            ea.vp_off = h->P.vp_off;
+            ea.rpad = h->P.rpad;
+            ea.partE = h->partE;
+            ea.partR = h->partR;
+            ea.alpha_out = h->alpha_dev;
+            ea.dtSq = h->dtSq;
+            ea.alpha_min = h->alphaMin;
+            launch_elem_vertex(h->VP, h->mat, ea, h->st, h->ctl);
+        };
+        break;
+    }
     case DOTMI_BENCH_DIRSTEP: {         // what spmv_zp and the stepping element pass read and write together (p is not re-read)
         if (h->dist || !h->specFits) return DOTMI_E_INVALID;
         bytes = 72 * (int64_t)h->M.nnzb + 8 * (int64_t)n * (4 + 2 * L.m) + 112 * nTo + 56 * nVo + 24 * (int64_t)nV;

@@ -65,7 +65,7 @@ class StepStats(C.Structure):
 BENCH_KERNELS = ["elem_energy_grad", "elem_energy", "vertex_gather", "spmv_dots", "backsolve", "merge", "build_qpad",
                  "build_p", "step_forward", "elem_hessian", "assemble",
                  # the forms the device loop's early order launches (after at least one step)
-                 "spmv_zp", "merge_early", "elem_step", "gather_early", "dirstep"]
+                 "spmv_zp", "merge_early", "elem_step", "gather_early", "dirstep", "elem_vertex"]
 
 EXPORTS = [
     "dotmi_create", "dotmi_destroy", "dotmi_last_error", "dotmi_comm_unique_id", "dotmi_comm_ranks", "dotmi_set_state",

@@ -349,7 +349,8 @@ enum dotmi_bench_kind {
     DOTMI_BENCH_ELEM_STEP = 13,       /* element pass that takes the line-search step itself */
     DOTMI_BENCH_GATHER_EARLY = 14,    /* vertex pass that also writes -g into the padded right-hand sides and H s_new */
     DOTMI_BENCH_DIRSTEP = 15,         /* (round 6) the speculative unit-step launch: direction kernel + element pass + trial point in one launch */
-    DOTMI_BENCH_COUNT = 16
+    DOTMI_BENCH_ELEM_VERTEX = 16,     /* (round 6) element pass + step + vertex gather of a trial in one launch on vertex patches */
+    DOTMI_BENCH_COUNT = 17
 };
 int dotmi_bench_kernel(dotmi_handle *h, int32_t kind, int32_t reps, double *ms_per_launch, int64_t *bytes_per_launch);
 

@@ -272,7 +272,7 @@ def test_in_loop_kernel_forms_are_priced_on_the_live_state_without_disturbing_it
         for kind, name in enumerate(dl.BENCH_KERNELS):
             ms, nb = C.c_double(), C.c_int64()
             rc = L.dotmi_bench_kernel(a._h, kind, 3, C.byref(ms), C.byref(nb))
-            if name == "dirstep" and rc < 0:
+            if name in ("dirstep", "elem_vertex") and rc < 0:
                 continue    # (a handle created without DOTMI_SPEC_STEP has no speculative launch: tests/test_gpu_round6.py)
             assert rc == 0, name
             assert ms.value > 0 and nb.value > 0, name

@@ -18,7 +18,7 @@ python - "$wl" /root/repo/gpurun_out/${tag}_pmc_${slug}.json <<'PY'
 import csv, glob, json, sys, collections
 sys.path.insert(0, "/root/repo")
 from bench import source_id   # sha256 over dot_amd/csrc/*.hip, *.hpp: bench.py reports a traffic figure only for the build it runs
-CLASSES = [("dirstep_kernel", "dirstep"), ("elem_patch_kernel", "elem_pass"), ("vertex_gather_kernel", "vertex_gather"), ("spmv_dots_kernel", "spmv_dots"),
+CLASSES = [("dirstep_kernel", "dirstep"), ("elem_vertex_kernel", "elem_vertex"), ("spmv_zp_wide_kernel", "spmv_zp"), ("elem_patch_kernel", "elem_pass"), ("vertex_gather_kernel", "vertex_gather"), ("spmv_dots_kernel", "spmv_dots"),
            ("backsolve_kernel", "backsolve"), ("merge_tiles_kernel", "merge"), ("merge_tiles_early_kernel", "merge_early"), ("merge_kernel", "merge_split"), ("reduce_partial_p_kernel", "reduce_partial"),
            ("spmv_zp_kernel", "spmv_zp"), ("build_qpad_kernel", "build_qpad"),
            ("build_p_kernel", "build_p"), ("step_forward_kernel", "step_forward"), ("elem_hessian_kernel", "elem_hessian"),
