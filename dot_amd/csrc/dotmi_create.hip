@@ -545,9 +545,17 @@ int build_device_mesh(dotmi_handle *h)
                     if (int rc = upload(h, &P.mt_il, il)) return rc;
                 }
             }
-            if (h->tune.fuseLog)
-                fprintf(stderr, "dotmi: merge: %.1f tile partials per dof -> %s\n", (double)count / std::max(1, 3 * nV),
+            if (h->tune.fuseLog) {
+                int lmax = 0;
+                long long over24 = 0;
+                for (size_t k = 0; k + 1 < mp.size(); ++k) {
+                    lmax = std::max(lmax, mp[k + 1] - mp[k]);
+                    over24 += mp[k + 1] - mp[k] > 24;
+                }
+                fprintf(stderr, "dotmi: merge: %.1f tile partials per dof (longest list %d, %lld lists beyond 24) -> %s\n",
+                        (double)count / std::max(1, 3 * nV), lmax, over24,
                         P.splitMerge ? "sum per subdomain, then gather (split)" : "one walk over the list");
+            }
             h->mergeEntries = count;   // tile partials one merge reads (either form)
         } else {
             P.splitMerge = 0;

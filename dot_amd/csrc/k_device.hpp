@@ -93,6 +93,9 @@ __device__ __forceinline__ double wave_sum8_transposed(const double (&d)[8], int
 // one column of 64 consecutive rows is then 4 lines of 128 bytes instead of 64 (rows are 168 bytes apart), which with ~600
 // workgroups reading the same 43 KB was ~1 M line requests on a few L2 channels -- microseconds in front of every workgroup's
 // first real load (tools/prof_dirstep.sh)
+// NW: waves of the workgroup (4; 16 for the 1024-thread forms big meshes launch -- sm then holds NW * RED_K doubles and the
+// waves' sums are added in a fixed pairwise tree, which for four waves is (s0 + s1) + (s2 + s3) as ever)
+template <int NW = 4>
 __device__ __forceinline__ void write_partials(double (&acc)[RED_K], int nvals, double *partials, double *sm,
                                                double *partialsT = nullptr)
 {
@@ -112,7 +115,14 @@ __device__ __forceinline__ void write_partials(double (&acc)[RED_K], int nvals, 
     __syncthreads();
     const int t = threadIdx.x;
     if (t < nvals) {
-        const double v = (sm[t] + sm[RED_K + t]) + (sm[2 * RED_K + t] + sm[3 * RED_K + t]);
+        double tw[NW];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) tw[i] = sm[i * RED_K + t];
+#pragma unroll
+        for (int span = 1; span < NW; span *= 2)
+#pragma unroll
+            for (int i = 0; i + span < NW; i += 2 * span) tw[i] = tw[i] + tw[i + span];
+        const double v = tw[0];
         partials[(size_t)blockIdx.x * RED_K + t] = v;
         if (partialsT) partialsT[(size_t)t * NB_RED + blockIdx.x] = v;
     }

@@ -63,13 +63,15 @@ __device__ __forceinline__ void pair_stats_accum(int k, double gn, double sn, do
 // dependent round trips of a trip (partial range -> partials) are paid once for all of them.
 constexpr int GATHER_R = 4;
 constexpr int GATHER_P = 4;   // partials requested together; a vertex with more takes further rounds
-template <bool DEV>
-__global__ __launch_bounds__(256) void vertex_gather_kernel(
+// NT: threads per workgroup (256; 1024 for meshes whose dofs take the 256-thread form more than two trips: the same dofs per
+// workgroup with a quarter of them per lane -- four waves per SIMD instead of four dofs interleaved in one)
+template <bool DEV, int NT = 256, int GR = GATHER_R>
+__global__ __launch_bounds__(NT) void vertex_gather_kernel(
     int nV, const int2 *__restrict__ pp_rng, const double *__restrict__ gpart,
     const uint8_t *__restrict__ fixed, const double *__restrict__ mass, GatherArgs a, LbfgsArgs L,
     double *__restrict__ partials, const DevLoop *__restrict__ ctl)
 {
-    __shared__ double sm[4 * RED_K];
+    __shared__ double sm[(NT / 64) * RED_K];
     KSTAMP(0, 0);
     // the loop state this kernel needs, every load of it in front of the first branch (one round trip to the memory the
     // controller's XCD wrote, not one per dependent index: DevLoop, "resolved")
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
     for (int j = 0; j < RED_K; ++j) acc[j] = 0.0;
     const VList vl{a.vlist, a.nlist};   // owner exchange: only the held vertices are visited
     const int n = vl_count3(vl, 3 * nV), G = gridDim.x * blockDim.x;
-    constexpr int R = GATHER_R;
+    constexpr int R = GR;
     for (int kbase = blockIdx.x * blockDim.x + threadIdx.x; kbase < n; kbase += R * G) {
         double gn[R], ine[R], gold[R], pk[R], si[R][HIST_MAX], yi[R][HIST_MAX];
         int kb[R], ke[R], dd[R], cb[R], ce[R], kk[R], kd[R];
@@ -211,14 +213,18 @@ __global__ __launch_bounds__(256) void vertex_gather_kernel(
         }
     }
     KSTAMP(0, 4);
-    write_partials(acc, a.make_pair ? RED_K : 1, partials, sm);
+    write_partials<NT / 64>(acc, a.make_pair ? RED_K : 1, partials, sm);
     KSTAMP(0, 5);
 }
 
 void launch_vertex_gather(const DevMesh &M, const DevPatches &PT, const GatherArgs &a, const LbfgsArgs &L,
                           double *partials, hipStream_t st, const DevLoop *ctl)
 {
-    if (ctl)
+    const long long ndof = a.vlist ? 3ll * a.nlist : 3ll * M.nV;
+    if (ctl && ndof > 2ll * GATHER_R * NB_RED * 256)   // (more than two trips of the 256-thread form: 1 M tets)
+        hipLaunchKernelGGL((vertex_gather_kernel<true, 512, 2>), dim3(NB_RED), dim3(512), 0, st, M.nV, PT.pp_rng, PT.gpart,
+                           M.fixed, M.mass, a, L, partials, ctl);
+    else if (ctl)
         hipLaunchKernelGGL(vertex_gather_kernel<true>, dim3(NB_RED), dim3(256), 0, st, M.nV, PT.pp_rng, PT.gpart,
                            M.fixed, M.mass, a, L, partials, ctl);
     else
@@ -673,7 +679,8 @@ __global__ __launch_bounds__(256) void merge_tiles_kernel(int n3, const int *__r
 // newest pair's M y = M (g - g_old) = u_old - u costs no solve of its own.  Same sums per dof as merge_tiles_kernel
 // (tiles of a subdomain, then subdomains, then the division by the multiplicity), then the history terms newest first
 // like build_qpad's.  first: start of the step (no pair yet; u_old is only set).
-__global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const int *__restrict__ mt_ptr,
+template <int NT = 256>
+__global__ __launch_bounds__(NT) void merge_tiles_early_kernel(int n3, const int *__restrict__ mt_ptr,
                                                                 const int *__restrict__ mt_ent, const int *__restrict__ dup,
                                                                 const double *__restrict__ ppart, int first,
                                                                 const double *__restrict__ zsum,
@@ -686,7 +693,7 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
                                                                 const DevLoop *__restrict__ ctl, const int2 *__restrict__ mt_wave,
                                                                 const int *__restrict__ mt_il, double *__restrict__ partialsT)
 {
-    __shared__ double sm[4 * RED_K];
+    __shared__ double sm[(NT / 64) * RED_K];
     KSTAMP(1, 0);
     // (every load of the loop state in front of the first branch, the pointers resolved by the controller: one round trip)
     const int status = ctl->status, phase = ctl->phase, lm = ctl->L.m, pnew = ctl->pairNew;
@@ -816,7 +823,7 @@ __global__ __launch_bounds__(256) void merge_tiles_early_kernel(int n3, const in
         }
     }
     KSTAMP(1, 3);
-    if (partials) write_partials(acc, HIST_MAX, partials, sm, partialsT);   // (nullptr: the y_i . z came with the packet, yz_pre_kernel)
+    if (partials) write_partials<NT / 64>(acc, HIST_MAX, partials, sm, partialsT);   // (nullptr: the y_i . z came with the packet, yz_pre_kernel)
     KSTAMP(1, 4);
 }
 
@@ -935,7 +942,15 @@ void launch_merge_early(const DevMesh &M, const DevParts &P, double *z, double *
                         double *zshare, double *partialsT)
 {
     const bool split = !P.mt_ptr;
-    hipLaunchKernelGGL(merge_tiles_early_kernel, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup, P.ppart,
+    // (a thread of the 256-thread form takes a dof per trip: beyond two trips -- 1 M tets: eight -- workgroups of 1024 threads)
+    const long long ndof = vl.v ? 3ll * vl.n : 3ll * M.nV;
+    if (ndof > 2ll * NB_RED * 256)
+        hipLaunchKernelGGL(merge_tiles_early_kernel<512>, dim3(NB_RED), dim3(512), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup, P.ppart,
+                           first, zsum, split ? P.vp_ptr : nullptr, split ? P.vp_off : nullptr,
+                           split ? (const double *)P.psub : nullptr, ownMask, vl, kind, pre, zshare, z, partials, ctl, P.mt_wave, P.mt_il,
+                           partialsT);
+    else
+    hipLaunchKernelGGL(merge_tiles_early_kernel<256>, dim3(NB_RED), dim3(256), 0, st, 3 * M.nV, P.mt_ptr, P.mt_ent, P.dup, P.ppart,
                        first, zsum, split ? P.vp_ptr : nullptr, split ? P.vp_off : nullptr,
                        split ? (const double *)P.psub : nullptr, ownMask, vl, kind, pre, zshare, z, partials, ctl, P.mt_wave, P.mt_il, partialsT);
 }
