@@ -1444,7 +1444,10 @@ static int create_impl(dotmi_handle *h, const dotmi_mesh *mesh, const dotmi_para
         // vertex patches: one rank, the early order with both fused kernels (their statements are what k_elemvert.hip keeps), a
         // 256-thread back-solve launch to host the controller, every patch a workgroup of its own, its LDS within 64 KB
         h->vpFits = false;
+        // (Stable Neo-Hookean only: its element work is ~1 us of a workgroup's ~12, so carrying every element 1.9 times is free; with
+        // the fixed-corotational SVD the doubled element work costs what the saved launch gives -- bunny5K 1.656 -> 1.696 ms, measured)
         if (h->earlyBs && !h->dist && h->world == 1 && h->tune.fuseStep && h->tune.fuseDir && h->tune.vertexPatches != 0 &&
+            (h->mat == DOTMI_ENERGY_SNH || h->tune.vertexPatches > 0) &&
             h->P.ntiles - h->P.ntilesWide + h->P.nquad > 0 && !(h->flags & (DOTMI_FLAG_GSDD | DOTMI_FLAG_NEWTON | DOTMI_FLAG_HOST_LOOP))) {
             const HostVPatches HV = build_vpatches(h->nV, h->nT, h->T.data(), h->Xrest.data(), 512, 85);
             const size_t shm = sizeof(double) * ((size_t)3 * HV.PV + (size_t)3 * HV.RUN) + 2 * (size_t)((HV.PO + 1 + 3) & ~3);

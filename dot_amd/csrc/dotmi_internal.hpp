@@ -354,7 +354,10 @@ void launch_gemv_pair(const DevParts &P, const double *q, hipStream_t st, const 
 // ... the controller of a step that takes the unit step speculatively (checks alpha_0 afterwards; DevLoop::specPartials)
 void launch_gemv_spec(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr, int spec = 0);
+// (a.alpha_min < 0: a PAIRED launch -- twice as many workgroups, the second half the energy of the full step: StepArgs::alpha_min)
 void launch_elem_vertex(const DevVPatches &VP, int mat, const ElemVertArgs &a, hipStream_t st, const DevLoop *ctl);
+void launch_gemv_pair_vp(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
+                         hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr, int spec = 0);
 // ... the controller of a step on vertex patches (k_elemvert.hip): it sums as many statistic rows as there are patches (CtlArgs::nbE)
 void launch_gemv_vp(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl = nullptr,
                     hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, const CtlArgs *ca = nullptr, int spec = 0);

@@ -192,7 +192,9 @@ int enqueue_loop_slot_early(dotmi_handle *h)
     if (h->specNow) {
     } else if (h->vpNow) {
         // vertex patches: the element pass, the step, the gather, the pair and its statistics, -g into the right-hand sides: one launch
-        launch_elem_vertex(h->VP, h->mat, elem_vertex_args(h), h->st, h->ctl);
+        ElemVertArgs ea = elem_vertex_args(h);
+        if (h->pairNow) ea.alpha_min = -h->alphaMin;   // (negative: a paired launch, as StepArgs::alpha_min)
+        launch_elem_vertex(h->VP, h->mat, ea, h->st, h->ctl);
         nb = h->VP.nPatches;
     } else if (h->tune.fuseStep && (!se || ow)) {   // the step x_trial = x_cur + alpha p inside the element pass
         StepArgs sa{h->p, spart, h->alpha_dev, h->pairNow ? -h->alphaMin : h->alphaMin};   // (negative: a paired launch)
@@ -267,7 +269,7 @@ int enqueue_loop_slot_early(dotmi_handle *h)
                        (h->timeCount++ % h->timeStride) == 0;
     h->slotTimed.push_back(timed ? h->evUsed : -1);
     CtlArgs ca{h->ctl, ctlE, ctlR, h->alpha_dev, h->h_flags, nb, h->pairNow ? 2 : 0};
-    (h->pairNow ? launch_gemv_pair : h->specNow ? launch_gemv_spec : h->vpNow ? launch_gemv_vp : launch_gemv)(
+    (h->pairNow ? (h->vpNow ? launch_gemv_pair_vp : launch_gemv_pair) : h->specNow ? launch_gemv_spec : h->vpNow ? launch_gemv_vp : launch_gemv)(
         h->P, nullptr, h->st, h->ctl, timed ? h->evPre[h->evUsed] : nullptr, timed ? h->evPre[h->evUsed + 1] : nullptr, &ca,
         h->tune.earlyAbort ? (int)h->slotTimed.size() /* the slot's epoch, 1-based */ : (1 << 30) /* never stopped */);
     if (timed) h->evUsed += 2;
@@ -388,9 +390,10 @@ int run_device_loop(dotmi_handle *h, double *lastE, double *g2, int *it, bool *f
     h->specNow = h->earlyNow && !h->dist && !h->pairNow && h->tune.fuseStep && h->tune.fuseDir && h->tune.earlyAbort &&
                  h->specFits &&
                  (h->tune.specStep > 0 || (h->tune.specStep < 0 && h->prevFirst > 0 && 10 * h->prevUnit >= 9 * h->prevFirst));
-    // the trial's element pass + gather as one launch on vertex patches: in the steps that neither pair nor speculate (one patch
-    // set per step: the start-of-step evaluation and the trials group their energy partials alike)
-    h->vpNow = h->vpFits && h->earlyNow && !h->dist && !h->pairNow && !h->specNow;
+    // the trial's element pass + gather as one launch on vertex patches (paired steps too: elem_vertex_kernel<MAT, true>); a step that
+    // speculates keeps the element patches (one patch set per step: the start-of-step evaluation and the trials group their
+    // energy partials alike)
+    h->vpNow = h->vpFits && h->earlyNow && !h->dist && !h->specNow;
     C.specPartials = h->partS;
     C.alphaMin = h->alphaMin;
     C.iterCap = h->iterCap;

@@ -21,13 +21,15 @@ namespace dotmi {
 // file under -DDOTMI_PAIR_TU).
 // CTL_VP: the controller of a step on vertex patches (k_elemvert.hip): the statistics come in one row per PATCH (nbE rows, like the
 // energy partials) instead of NB_RED rows; summed in chunked_sum's order over that many rows.
-constexpr int CTL_PLAIN = 0, CTL_PAIR = 1, CTL_SPEC = 2, CTL_VP = 3;
+// CTL_PAIR_VP: both -- a step with paired trials on vertex patches.
+constexpr int CTL_PLAIN = 0, CTL_PAIR = 1, CTL_SPEC = 2, CTL_VP = 3, CTL_PAIR_VP = 4;
 template <int CTL>
 __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, const double *__restrict__ partE, int nbE,
                                   const double *__restrict__ partR, const double *__restrict__ alpha_dev,
                                   int *__restrict__ flags_host, int init, const double *__restrict__ partE2 = nullptr)
 {
-    constexpr bool PAIR = CTL == CTL_PAIR, SPEC = CTL == CTL_SPEC;
+    constexpr bool PAIR = CTL == CTL_PAIR || CTL == CTL_PAIR_VP, SPEC = CTL == CTL_SPEC;
+    constexpr bool VPROWS = CTL == CTL_VP || CTL == CTL_PAIR_VP;   // one row of statistics per patch (nbE rows)
     static_assert(sizeof(DevLoop) % 8 == 0, "DevLoop is copied as 8-byte words");
     static_assert(RED_K <= 32, "two passes of 16 columns");
     __shared__ double chunk[RED_K + 2][SUM_CHUNKS];
@@ -68,7 +70,7 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
         const int colB = qb % RED_K, chB = qb / RED_K;
         const bool hasA = qa < NPAIR, hasB = qb < NPAIR;
         double va[LR], vb[LR];
-        if constexpr (CTL != CTL_VP) {
+        if constexpr (!VPROWS) {
             if (hasA) {
 #pragma unroll
                 for (int k = 0; k < LR; ++k) va[k] = partR[(size_t)(chA * LR + k) * RED_K + colA];
@@ -107,7 +109,7 @@ __device__ __forceinline__ void loop_control_body(DevLoop *__restrict__ ctl, con
                 chunk2[PAIR ? c : 0][ch] = e2;
             }
         }
-        if constexpr (CTL == CTL_VP) {
+        if constexpr (VPROWS) {
             // nbE rows of statistics: chunk ch of column col = rows [ch LE, (ch + 1) LE), eight loads in flight
             auto chunk_rows = [&](int col, int ch) {
                 const int LE = (nbE + SUM_CHUNKS - 1) / SUM_CHUNKS;
@@ -902,9 +904,9 @@ __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__res
     __shared__ double2 rs[2 * 256 * 6];
     // (which workgroup hosts the controller makes no difference: index 0 / 256 / 520 / last measured 47.0-47.5 us)
     if (blockIdx.x == 0) {
-        if constexpr (CTL == CTL_PAIR)
-            loop_control_body<CTL_PAIR>(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init & 1,
-                                        (ca.init & 2) ? ca.partE + 2 * ELEM_NB_MAX : nullptr);
+        if constexpr (CTL == CTL_PAIR || CTL == CTL_PAIR_VP)
+            loop_control_body<CTL>(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init & 1,
+                                   (ca.init & 2) ? ca.partE + 2 * ELEM_NB_MAX : nullptr);
         else
             loop_control_body<CTL>(ca.ctl, ca.partE, ca.nbE, ca.partR, ca.alpha_dev, ca.flags_host, ca.init);
         return;
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(256, 2) void backsolve_ctl_kernel(const int4 *__res
     if (ca.ctl->status != 0) return;
     // (PAIR: a paired slot -- alpha_dev[1] > 0, written by the element pass of this slot -- waits as well: its gather worked on the
     // half step, which only counts if the controller finds the full step's energy too high)
-    if (epoch < (1 << 30) && (ca.ctl->holdNext || (CTL == CTL_PAIR && (ca.init & 2) && ca.alpha_dev[1] > 0.0))) {
+    if (epoch < (1 << 30) && (ca.ctl->holdNext || ((CTL == CTL_PAIR || CTL == CTL_PAIR_VP) && (ca.init & 2) && ca.alpha_dev[1] > 0.0))) {
         // the trial is expected to be rejected (DevLoop::holdNext): wait for the controller's verdict instead of streaming
         // the factors beside it -- a rejection then costs the controller's ~7 us, not a stopped back-solve's ~20.  (A
         // workgroup that starts after the controller has stored its forecast for the NEXT slot reads that one: the verdict
@@ -1191,6 +1193,12 @@ void launch_gemv_pair(const DevParts &P, const double *q, hipStream_t st, const 
                       const CtlArgs *ca, int spec)
 {
     launch_gemv_impl<CTL_PAIR>(P, q, st, ctl, ev0, ev1, ca, spec);
+}
+// ... paired trials on vertex patches
+void launch_gemv_pair_vp(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,
+                         const CtlArgs *ca, int spec)
+{
+    launch_gemv_impl<CTL_PAIR_VP>(P, q, st, ctl, ev0, ev1, ca, spec);
 }
 // ... with the controller of a step on vertex patches (k_elemvert.hip)
 void launch_gemv_vp(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,

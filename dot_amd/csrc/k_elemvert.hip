@@ -39,14 +39,20 @@ extern "C" int dotmi_debug_evprof(long long *out)
 #define EVSTAMP(i) do { } while (0)
 #endif
 
-template <int MAT>
+// PAIR: the instantiation of a step with paired line-search trials (elem_patch_body's: when alpha_0 < 1 the first half of a launch
+// twice as wide evaluates alpha_0 / 2 in full and the second half -- workgroup nP + b mirrors patch b -- the ENERGY at alpha_0,
+// into the second half of the energy partials; otherwise the second half leaves at once)
+template <int MAT, bool PAIR>
 __global__ __launch_bounds__(256) void elem_vertex_kernel(DevVPatches VP, ElemVertArgs a, const DevLoop *__restrict__ ctl)
 {
     extern __shared__ double lds[];
     __shared__ double sm[4 * RED_K];
     __shared__ double sme[8];
     __shared__ double sh_alpha;
-    const int tid = threadIdx.x, p = blockIdx.x;
+    const bool pairedLaunch = PAIR && a.alpha_min < 0.0;
+    const double alphaMin = pairedLaunch ? -a.alpha_min : a.alpha_min;
+    const bool second = pairedLaunch && (int)blockIdx.x >= VP.nPatches;
+    const int tid = threadIdx.x, p = second ? (int)blockIdx.x - VP.nPatches : (int)blockIdx.x;
     long long t_start = 0;
 #ifdef K_PROFILE
     t_start = wall_clock64();
@@ -177,15 +183,25 @@ __global__ __launch_bounds__(256) void elem_vertex_kernel(DevVPatches VP, ElemVe
             }
             pg = __shfl(wave_sum(pg), 0, 64);
             pHp = __shfl(wave_sum(pHp), 0, 64);
-            al = fmax(a.alpha_min, fmin(1.0, -pg / pHp));  // Optimizer.cpp:1085
+            al = fmax(alphaMin, fmin(1.0, -pg / pHp));  // Optimizer.cpp:1085
         }
         if (tid == 0) {
-            sh_alpha = al;
-            if (p == 0 && loop) *a.alpha_out = al;
+            if constexpr (PAIR) {
+                const bool pair = pairedLaunch && usePart && al < 1.0 && al / 2.0 > 0.0 && ctl->pairCtr[pair_band(al)] >= 3;
+                sh_alpha = pair ? (second ? al : al / 2.0) : (second ? -1.0 : al);
+                if (blockIdx.x == 0) {
+                    a.alpha_out[0] = pair ? al / 2.0 : al;
+                    if (pairedLaunch) a.alpha_out[1] = pair ? al : 0.0;
+                }
+            } else {
+                sh_alpha = al;
+                if (p == 0 && loop) *a.alpha_out = al;
+            }
         }
     }
     __syncthreads();
     const double alpha = sh_alpha;
+    if (second && alpha < 0.0) return;   // (the whole workgroup: not a paired slot)
     EVSTAMP(2);
     // ---- phase 1: trial positions of the touched vertices -> LDS ----------------------------------------------------------------
     if (gid >= 0) {
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(256) void elem_vertex_kernel(DevVPatches VP, ElemVe
         const int pkk[4] = {ep[u].x, ep[u].y, ep[u].z, ep[u].w};
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (pkk[k] != 0xFFFF) {   // the corner's vertex is this patch's
+            if (pkk[k] != 0xFFFF && !second) {   // the corner's vertex is this patch's
                 gs[pkk[k]] = g[3 * k];
                 gs[VP.RUN + pkk[k]] = g[3 * k + 1];
                 gs[2 * VP.RUN + pkk[k]] = g[3 * k + 2];
@@ -276,7 +292,12 @@ __global__ __launch_bounds__(256) void elem_vertex_kernel(DevVPatches VP, ElemVe
 #pragma unroll
     for (int j = 0; j < RED_K; ++j) st[j] = 0.0;
     double ine = 0.0;
-    if (vlane) {
+    if (vlane && second) {
+        if (od == 0) {   // (the energy of the full step: the inertia term of the owned vertices)
+            const double dx = xs[3 * ov] - xtv[0], dy = xs[3 * ov + 1] - xtv[1], dz = xs[3 * ov + 2] - xtv[2];
+            ine = (dx * dx + dy * dy + dz * dz) * ms / 2.0;
+        }
+    } else if (vlane) {
         const int kb = cptr[ov], ke = cptr[ov + 1];
         const double *run = gs + od * VP.RUN;
         double sum = 0.0;
@@ -327,10 +348,12 @@ __global__ __launch_bounds__(256) void elem_vertex_kernel(DevVPatches VP, ElemVe
         sme[wv] = we;
         sme[4 + wv] = wi;
     }
-    write_partials(st, loop ? RED_K : 1, a.partR, sm);   // (its first barrier also publishes sme)
+    if (!second) write_partials(st, loop ? RED_K : 1, a.partR, sm);   // (its first barrier also publishes sme)
+    else __syncthreads();
     if (tid == 0) {
-        a.partE[2 * p] = (sme[0] + sme[1]) + (sme[2] + sme[3]);      // to be scaled by dtSq by the consumer
-        a.partE[2 * p + 1] = (sme[4] + sme[5]) + (sme[6] + sme[7]);
+        double *pe = second ? a.partE + 2 * ELEM_NB_MAX : a.partE;   // (second half: the full step's partials)
+        pe[2 * p] = (sme[0] + sme[1]) + (sme[2] + sme[3]);      // to be scaled by dtSq by the consumer
+        pe[2 * p + 1] = (sme[4] + sme[5]) + (sme[6] + sme[7]);
     }
     EVSTAMP(6);
 }
@@ -338,8 +361,14 @@ __global__ __launch_bounds__(256) void elem_vertex_kernel(DevVPatches VP, ElemVe
 void launch_elem_vertex(const DevVPatches &VP, int mat, const ElemVertArgs &a, hipStream_t st, const DevLoop *ctl)
 {
     const size_t shm = sizeof(double) * ((size_t)3 * VP.PV + (size_t)3 * VP.RUN) + 2 * (size_t)((VP.PO + 1 + 3) & ~3);
-    if (mat == 0) hipLaunchKernelGGL((elem_vertex_kernel<0>), dim3(VP.nPatches), dim3(256), shm, st, VP, a, ctl);
-    else hipLaunchKernelGGL((elem_vertex_kernel<1>), dim3(VP.nPatches), dim3(256), shm, st, VP, a, ctl);
+    const bool paired = ctl && a.alpha_min < 0.0;
+    if (paired) {
+        if (mat == 0) hipLaunchKernelGGL((elem_vertex_kernel<0, true>), dim3(2 * VP.nPatches), dim3(256), shm, st, VP, a, ctl);
+        else hipLaunchKernelGGL((elem_vertex_kernel<1, true>), dim3(2 * VP.nPatches), dim3(256), shm, st, VP, a, ctl);
+    } else {
+        if (mat == 0) hipLaunchKernelGGL((elem_vertex_kernel<0, false>), dim3(VP.nPatches), dim3(256), shm, st, VP, a, ctl);
+        else hipLaunchKernelGGL((elem_vertex_kernel<1, false>), dim3(VP.nPatches), dim3(256), shm, st, VP, a, ctl);
+    }
 }
 
 }  // namespace dotmi

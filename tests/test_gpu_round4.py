@@ -231,10 +231,8 @@ def test_held_back_solves_change_no_decision_and_no_digit():
     verdict instead of streaming the factors beside it.  Only WHEN the back-solve runs changes, not what it computes:
     stiff monkey (about one halving per iteration), same iterations / halvings / energy evaluations and bit-identical
     positions with the forecast on and off -- and the forecast does hold launches on this workload."""
-    # (paired trials need the holds, and a step that pairs works on the element patches where an unpaired one works on vertex
-    # patches since round 6 -- other roundings: the pairing is off in both runs, so both take the same kernels)
-    a = _steps_with_env("monkey18K_stiff", 2, {"DOTMI_EARLY_HOLD": "0", "DOTMI_PAIR_TRIALS": "0"})
-    b = _steps_with_env("monkey18K_stiff", 2, {"DOTMI_EARLY_HOLD": "1", "DOTMI_PAIR_TRIALS": "0"})
+    a = _steps_with_env("monkey18K_stiff", 2, {"DOTMI_EARLY_HOLD": "0"})
+    b = _steps_with_env("monkey18K_stiff", 2, {"DOTMI_EARLY_HOLD": "1"})
     assert a[0] == b[0]
     assert np.array_equal(a[1], b[1])
     assert a[3] == 0 and b[3] > 20

@@ -103,9 +103,8 @@ def test_paired_trials_take_the_same_steps_bit_for_bit(workload, steps, monkeypa
 
     def run(mode):
         monkeypatch.setenv("DOTMI_PAIR_TRIALS", mode)
-        # (a paired step works on the element patches; the unpaired reference run is pinned to them too -- since round 6 it
-        # would otherwise take the one-launch element pass + gather on vertex patches, whose sums are grouped differently)
-        monkeypatch.setenv("DOTMI_VERTEX_PATCHES", "0")
+        # (the stiff monkey -- Stable Neo-Hookean -- runs both on vertex patches since round 6: elem_vertex_kernel<MAT, PAIR>; the
+        # two fixed-corotational workloads on the element patches)
         sc, ep, n = load_workload(workload)
         ts = DOTTimeStepper(sc, ep, n)
         rec, paired, redone, stopped = [], 0, 0, []

@@ -197,7 +197,8 @@ def test_bar17K_stays_within_the_stated_band_of_the_oracle_on_the_references_svd
 # ---- vertex patches: the trial's element pass + vertex gather in one launch (k_elemvert.hip) ------------------------------------
 @pytest.mark.parametrize("workload,steps", [("bar17K_twist", 4), ("bunny5K_LTSS", 8), ("monkey18K_stiff", 1), ("horse7K_stretch", 4)])
 def test_vertex_patches_take_the_element_patches_steps(workload, steps, monkeypatch):
-    """Default since round 6 on one rank where every patch is a workgroup of its own: a vertex patch owns its vertices and carries
+    """Default since round 6 on one rank for Stable Neo-Hookean meshes where every patch is a workgroup of its own (with the
+    fixed-corotational SVD the doubled element work costs what the saved launch gives: DOTMI_VERTEX_PATCHES=1 forces it there): a vertex patch owns its vertices and carries
     every element incident to them, so ONE launch does what elem_patch_kernel + vertex_gather_kernel did (energy, gradient summed in
     ascending element order over all incident elements, inertia, trial point, pair, statistics, -g into the right-hand sides).
     Against the two-launch path (DOTMI_VERTEX_PATCHES=0): the sums are grouped differently (no per-patch partials any more), nothing
@@ -205,7 +206,7 @@ def test_vertex_patches_take_the_element_patches_steps(workload, steps, monkeypa
     back-track (the stiff monkey, chaotic: its identical prefix of decisions)."""
     base = {"DOTMI_PAIR_TRIALS": "0", "DOTMI_SPEC_STEP": "0"}
     rec0, x0, v0, _, _, _, log0 = _run(workload, steps, {**base, "DOTMI_VERTEX_PATCHES": "0"}, monkeypatch, log=True)
-    rec1, x1, v1, _, _, _, log1 = _run(workload, steps, base, monkeypatch, log=True)
+    rec1, x1, v1, _, _, _, log1 = _run(workload, steps, {**base, "DOTMI_VERTEX_PATCHES": "1"}, monkeypatch, log=True)   # (1: FCR too)
     if workload == "monkey18K_stiff":
         (a0, e0, _), (a1, e1, _) = log0[0], log1[0]
         m = min(len(a0), len(a1))
@@ -221,3 +222,31 @@ def test_vertex_patches_take_the_element_patches_steps(workload, steps, monkeypa
     dx = np.abs(x1 - x0).max()
     print(f"{workload}: vertex patches vs element patches, max|dx| after {steps} steps {dx:.2e}")
     assert dx < (1e-9 if quiet else 1e-6), dx
+
+
+def test_paired_trials_on_vertex_patches_take_the_same_steps_bit_for_bit(monkeypatch):
+    """elem_vertex_kernel<MAT, PAIR> + loop_control_body<CTL_PAIR_VP>: the stiff monkey's steps pair their trials on vertex patches
+    (the second half of a launch twice as wide leaves the energy of the full step).  Paired in every step against never paired:
+    status, iterations, halvings, energy evaluations, energies and positions bit for bit (as on the element patches,
+    tests/test_gpu_round5.py), and the rule does pair there."""
+    def run(mode):
+        monkeypatch.setenv("DOTMI_PAIR_TRIALS", mode)
+        sc, ep, n = load_workload("monkey18K_stiff")
+        ts = DOTTimeStepper(sc, ep, n)
+        rec, paired, redone = [], 0, 0
+        for _ in range(2):
+            x = ts.getResult()
+            idx, pos = sc.scripter.step(x, sc.cfg.dt)
+            ts.setDirichlet(idx, pos)
+            st = ts.step()
+            rec.append((st.status, st.iters, st.ls_halvings, st.energy_evals, st.E, st.g2))
+            paired += st.paired_slots
+            redone += st.paired_redone
+        x = ts.getResult().copy()
+        ts.close()
+        return rec, x, paired, redone
+    rec0, x0, p0, r0 = run("0")
+    rec1, x1, p1, r1 = run("1")
+    assert p0 == 0 and p1 >= 20 and r1 <= p1 // 3
+    assert rec1 == rec0
+    assert np.array_equal(x1, x0)
