@@ -111,11 +111,16 @@ def compact_line(full):
         lr = full["roofline_loop"]
         out["roofline_loop"] = {k: lr[k] for k in ("algorithmic_bytes_per_iteration", "us_per_iter", "achieved", "frac")}
     # the ALU side for the element kernels where a PMC flop count of this build is committed (FP64 vector peak)
-    alu = [{"kernel": r["kernel"], "workload": w.get("workload"), "fp64_flop": r["fp64_flop"], "us": r["us"],
-            "frac_of_fp64_vector_peak": r["frac_of_fp64_vector_peak"], "frac_of_hbm_peak": r["frac_of_hbm_peak"]}
-           for w in (full.get("workloads") or [{"workload": full["config"]["workload"], "roofline_by_kernel": full.get("roofline_by_kernel")}])
+    # (the fixed-corotational workloads' element pass -- the SVD inside -- and the headline's one-launch element pass + gather; every
+    # other row is in bench_detail.json)
+    alu = [{"kernel": r["kernel"], "workload": w.get("workload"), "flop": r["fp64_flop"], "us": r["us"],
+            "frac_alu": r["frac_of_fp64_vector_peak"], "frac_hbm": r["frac_of_hbm_peak"]}
+           for w in (full.get("workloads") or [{"workload": full["config"]["workload"], "energy": full["config"].get("energy"),
+                                               "roofline_by_kernel": full.get("roofline_by_kernel")}])
            if "error" not in w
-           for r in (w.get("roofline_by_kernel") or []) if r.get("fp64_flop") and r["kernel"] in ("elem_step", "elem_energy_grad", "elem_vertex")]
+           for r in (w.get("roofline_by_kernel") or [])
+           if r.get("fp64_flop") and ((w.get("energy") == "FCR" and r["kernel"] == "elem_step") or
+                                      (w.get("workload") == full["config"]["workload"] and r["kernel"] == "elem_vertex"))]
     if alu:
         out["roofline_alu"] = alu
     if "collectives" in full:
