@@ -10,7 +10,12 @@ subdomain matrices (host only, no GPU):
       off-diagonal blocks counted (b1) exactly (sparse storage, the lower bound) and (b2) as dense panels over the rows of
       the ancestor node that are non-zero anywhere in the block (what a tile kernel would stream);
   (c) the factor itself, forward + backward substitution: 16 x nnz(L) -- with the library's ordering, and CHOLMOD's own
-      nnz_L (bench.py's cpu_baseline.reference_cholmod) quoted beside it when given.
+      nnz_L (bench.py's cpu_baseline.reference_cholmod) quoted beside it when given;
+  (h_k) the HYBRID: only the separators of the top k tree levels kept as L blocks (dense panels as in b2
+      + their inverted diagonal triangles), every subtree below them as an explicit inverse in the layout (rows from the
+      region's first column).  2 k joins instead of 2 x depth -- but the subtrees' inverses are then read TWICE as well
+      (y_R = X_R r_R before the top levels, p_R = X_R^T (y_R - sum_S L_SR^T p_S) after them):
+      16 x (nnz(X) of the rows below level k + panels and triangles of the top k levels).
 
 L is the symbolic Cholesky factor of the subdomain's vertex graph (3 x 3 blocks: x 9 scalars per vertex pair, the
 diagonal blocks' triangles x 6) in the order the layout gives (leaves, then separators, children before parents).
@@ -67,7 +72,7 @@ def count(name, levels_list, min_split=-1):
     fixed = sc.fixed.astype(bool)
     print(f"{name}: {nV} vertices, {sc.T.shape[0]} tets, {nparts} subdomains")
     print(f"{'levels':>6} {'nmax':>6} | {'(a) X one pass':>15} | {'(b1) part. inv, sparse L blocks':>32} | "
-          f"{'(b2) dense panels':>18} | {'(c) 2 x nnz(L)':>15}   [MB per back-solve]")
+          f"{'(b2) dense panels':>18} | {'(c) 2 x nnz(L)':>15} | (h_k) hybrid, top k = 1, 2, 3 levels as L panels   [MB per back-solve]")
     for levels in levels_list:
         nodes, nmax, pos, verts = plan_layout(sc.V_rest, sc.T, ep, nparts, levels=levels, min_split=min_split)
         # node of every padded row: leaves own [off, off+size), separators [offS, offS+sizeS); depth-first ids, children > parent
@@ -81,7 +86,13 @@ def count(name, levels_list, min_split=-1):
             else:
                 node_of[offS:offS + sizeS] = idx
                 first[offS:offS + sizeS] = off
-        a_bytes = b1 = b2 = c_bytes = 0
+        a_bytes = b1 = b2 = c_bytes = b3 = b4 = 0
+        depth = np.zeros(nn, dtype=np.int32)      # children follow their parent in the node list
+        for idx, (off, size, a, c, offS, sizeS) in enumerate(nodes):
+            if a >= 0:
+                depth[a] = depth[c] = depth[idx] + 1
+        KS = (1, 2, 3)
+        hyb = {k: 0 for k in KS}
         for p in range(nparts):
             v, ps = verts[p], pos[p]
             free = ~fixed[v]
@@ -97,6 +108,10 @@ def count(name, levels_list, min_split=-1):
                 for d in range(3):
                     r = q + d
                     a_bytes += 8 * (cum[r + 1] - cum[first[r]])
+                    for k in KS:     # rows of a separator in the top k levels are L panels (below); every other row as in (a), twice
+                        nr = node_of[r]
+                        if not (nodes[nr][2] >= 0 and depth[nr] < k):
+                            hyb[k] += 16 * (cum[r + 1] - cum[first[r]])
             inpart = set(int(x) for x in v)
             adj = {int(x): [int(w) for w in A.indices[A.indptr[x]:A.indptr[x + 1]] if int(w) in inpart and not fixed[w] and not fixed[x]]
                    for x in v}
@@ -105,6 +120,7 @@ def count(name, levels_list, min_split=-1):
             nnzL = 0
             blk = {}                   # (row node, col node) -> [nnz (vertex pairs), set of rows]
             nsize = np.bincount(nd_v, minlength=nn)
+            tpairs = set()             # (64-row tile, 64-column tile) pairs of the padded layout that hold an off-diagonal-block entry
             for i, row in enumerate(rows):
                 nnzL += 9 * len(row) + 6
                 for k in row:
@@ -113,11 +129,28 @@ def count(name, levels_list, min_split=-1):
                         e = blk.setdefault(key, [0, set()])
                         e[0] += 1
                         e[1].add(i)
+                        for ti in {int(psort[i]) // 64, (int(psort[i]) + 2) // 64}:
+                            for tk in {int(psort[k]) // 64, (int(psort[k]) + 2) // 64}:
+                                tpairs.add((ti, tk))
             diag = sum(int(3 * s) * (int(3 * s) + 1) // 2 for s in nsize)
             b1 += 16 * (diag + sum(9 * e[0] for e in blk.values()))
             b2 += 16 * (diag + sum(9 * len(e[1]) * int(nsize[key[1]]) for key, e in blk.items()))
             c_bytes += 16 * nnzL
-        print(f"{levels:>6} {nmax:>6} | {a_bytes / 1e6:>15.1f} | {b1 / 1e6:>32.1f} | {b2 / 1e6:>18.1f} | {c_bytes / 1e6:>15.1f}")
+            # (b3) the column form M_SN = L_SN X_NN: panels read twice (up and down the tree), the nodes' triangles ONCE (y_N = X_NN r'_N
+            # and X_NN^T y_N in the same pass, as today); (b4) the same with the panels at the 64 x 64 tiles of the padded layout
+            pan = sum(9 * len(e[1]) * int(nsize[key[1]]) for key, e in blk.items())
+            b3 += 8 * (diag + 2 * pan)
+            b4 += 8 * (diag + 2 * 4096 * len(tpairs))
+            for k in KS:
+                for nidx in range(nn):
+                    if nodes[nidx][2] >= 0 and depth[nidx] < k:
+                        hyb[k] += 16 * (int(3 * nsize[nidx]) * (int(3 * nsize[nidx]) + 1) // 2)
+                for key, e in blk.items():
+                    if nodes[key[0]][2] >= 0 and depth[key[0]] < k:
+                        hyb[k] += 16 * 9 * len(e[1]) * int(nsize[key[1]])
+        print(f"{levels:>6} {nmax:>6} | {a_bytes / 1e6:>15.1f} | {b1 / 1e6:>32.1f} | {b2 / 1e6:>18.1f} | {c_bytes / 1e6:>15.1f} | "
+              + " ".join(f"{hyb[k] / 1e6:>9.1f}" for k in KS)
+              + f" | (b3) {b3 / 1e6:.1f}  (b4, 64-tiles) {b4 / 1e6:.1f}")
 
 
 if __name__ == "__main__":
