@@ -87,6 +87,7 @@ def count(name, levels_list, min_split=-1):
                 node_of[offS:offS + sizeS] = idx
                 first[offS:offS + sizeS] = off
         a_bytes = b1 = b2 = c_bytes = b3 = b4 = 0
+        b5 = [0, 0, 0]
         depth = np.zeros(nn, dtype=np.int32)      # children follow their parent in the node list
         for idx, (off, size, a, c, offS, sizeS) in enumerate(nodes):
             if a >= 0:
@@ -141,6 +142,28 @@ def count(name, levels_list, min_split=-1):
             pan = sum(9 * len(e[1]) * int(nsize[key[1]]) for key, e in blk.items())
             b3 += 8 * (diag + 2 * pan)
             b4 += 8 * (diag + 2 * 4096 * len(tpairs))
+            # (b5) = (b4) after re-ordering the vertices INSIDE every separator by the set of descendant nodes their row is non-zero in
+            # (rows with the same set become contiguous; the order inside a node is free).  Panels counted at (TR-row tile of the
+            # separator) x (whole descendant node), TR = 64 / 32 / 16: a tile kernel that skips a node's columns when none of its
+            # rows holds an entry there.
+            sig = {}
+            for (rn, cn), e in blk.items():
+                for i in e[1]:
+                    sig.setdefault(i, set()).add(int(cn))
+            newrank = {}
+            for nidx in range(nn):
+                if nodes[nidx][2] < 0:
+                    continue
+                mem = [i for i in range(len(rows)) if nd_v[i] == nidx]
+                mem.sort(key=lambda i: tuple(sorted(sig.get(i, ()))))
+                for r, i in enumerate(mem):
+                    newrank[i] = r
+            for TR, acc in ((64, 0), (32, 1), (16, 2)):
+                tot = 0
+                for (rn, cn), e in blk.items():
+                    tiles_r = {(3 * newrank[i]) // TR for i in e[1]} | {(3 * newrank[i] + 2) // TR for i in e[1]}
+                    tot += len(tiles_r) * TR * 3 * int(nsize[cn])
+                b5[acc] += 8 * (diag + 2 * tot)
             for k in KS:
                 for nidx in range(nn):
                     if nodes[nidx][2] >= 0 and depth[nidx] < k:
@@ -150,7 +173,8 @@ def count(name, levels_list, min_split=-1):
                         hyb[k] += 16 * 9 * len(e[1]) * int(nsize[key[1]])
         print(f"{levels:>6} {nmax:>6} | {a_bytes / 1e6:>15.1f} | {b1 / 1e6:>32.1f} | {b2 / 1e6:>18.1f} | {c_bytes / 1e6:>15.1f} | "
               + " ".join(f"{hyb[k] / 1e6:>9.1f}" for k in KS)
-              + f" | (b3) {b3 / 1e6:.1f}  (b4, 64-tiles) {b4 / 1e6:.1f}")
+              + f" | (b3) {b3 / 1e6:.1f}  (b4, 64-tiles) {b4 / 1e6:.1f}  (b5: separators re-ordered, row tiles of 64 / 32 / 16) "
+              + " / ".join(f"{x / 1e6:.1f}" for x in b5))
 
 
 if __name__ == "__main__":
