@@ -88,6 +88,7 @@ def count(name, levels_list, min_split=-1):
                 first[offS:offS + sizeS] = off
         a_bytes = b1 = b2 = c_bytes = b3 = b4 = 0
         b5 = [0, 0, 0]
+        b6 = 0
         depth = np.zeros(nn, dtype=np.int32)      # children follow their parent in the node list
         for idx, (off, size, a, c, offS, sizeS) in enumerate(nodes):
             if a >= 0:
@@ -142,6 +143,28 @@ def count(name, levels_list, min_split=-1):
             pan = sum(9 * len(e[1]) * int(nsize[key[1]]) for key, e in blk.items())
             b3 += 8 * (diag + 2 * pan)
             b4 += 8 * (diag + 2 * 4096 * len(tpairs))
+            # (b6) TWO levels only: the leaves against the separator complement G (all separators of the subdomain together).  Leaves'
+            # triangles once, X_GG = today's inverse restricted to separator rows x separator columns once, and the leaf panels
+            # M_GD = L_GD X_DD (rows: the separator vertices next to leaf D, packed) twice.
+            isleaf = np.array([nodes[nidx][2] < 0 for nidx in range(nn)])
+            leaf_tri = sum(int(3 * nsize[nidx]) * (int(3 * nsize[nidx]) + 1) // 2 for nidx in range(nn) if isleaf[nidx])
+            sepcol = np.zeros(nmax + 1, dtype=np.int64)
+            for i, q in enumerate(psort):
+                if not isleaf[nd_v[i]]:
+                    sepcol[q + 1:q + 4] = 1
+            csep = np.cumsum(sepcol)
+            xgg = 0
+            for i, q in enumerate(psort):
+                if not isleaf[nd_v[i]]:
+                    for d in range(3):
+                        r = q + d
+                        xgg += csep[r + 1] - csep[first[r]]
+            lpan = {}
+            for (rn, cn), e in blk.items():
+                if isleaf[cn]:
+                    lpan.setdefault(int(cn), set()).update(e[1])
+            pan6 = sum(9 * len(rs) * int(nsize[cn]) for cn, rs in lpan.items())
+            b6 += 8 * (leaf_tri + xgg + 2 * pan6)
             # (b5) = (b4) after re-ordering the vertices INSIDE every separator by the set of descendant nodes their row is non-zero in
             # (rows with the same set become contiguous; the order inside a node is free).  Panels counted at (TR-row tile of the
             # separator) x (whole descendant node), TR = 64 / 32 / 16: a tile kernel that skips a node's columns when none of its
@@ -174,7 +197,7 @@ def count(name, levels_list, min_split=-1):
         print(f"{levels:>6} {nmax:>6} | {a_bytes / 1e6:>15.1f} | {b1 / 1e6:>32.1f} | {b2 / 1e6:>18.1f} | {c_bytes / 1e6:>15.1f} | "
               + " ".join(f"{hyb[k] / 1e6:>9.1f}" for k in KS)
               + f" | (b3) {b3 / 1e6:.1f}  (b4, 64-tiles) {b4 / 1e6:.1f}  (b5: separators re-ordered, row tiles of 64 / 32 / 16) "
-              + " / ".join(f"{x / 1e6:.1f}" for x in b5))
+              + " / ".join(f"{x / 1e6:.1f}" for x in b5) + f"  (b6: leaves | separator complement) {b6 / 1e6:.1f}")
 
 
 if __name__ == "__main__":
