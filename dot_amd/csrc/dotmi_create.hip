@@ -293,6 +293,10 @@ int build_device_mesh(dotmi_handle *h)
         }
         if (h->tune.fuseLog) fprintf(stderr, "dotmi: dissection: %d levels, regions split down to %d scalars\n", ndLevels, ndMin);
         nd_plan(sets, nV, adj_ptr, adj_idx, h->Xrest.data(), ndLevels, ndMin, h->nd, region);
+        // two-level form of the back-solve (DevTwoLevel): one rank, the block solve as a whole (not GSDD's subdomain at a time), a
+        // tree that has separators at all
+        h->twoLevel = h->tune.twoLevel > 0 && !h->dist && !(h->flags & DOTMI_FLAG_GSDD) && !h->nd.empty() && h->nd[0].a >= 0;
+        if (h->twoLevel) nd_relayout_leaves_first(h->nd);
     }
     P.nmax = h->nd[0].size;
     h->tileMode = P.nParts > 0;   // (a rank without subdomains plans nothing)
@@ -411,14 +415,53 @@ int build_device_mesh(dotmi_handle *h)
             return DOTMI_E_INVALID;
         }
     }
+    // two-level form: a separator's row blocks store the LEAF columns of their sub-tree in a second range (their main range starts
+    // at the sub-tree's first separator column)
+    std::vector<long long> rtOffM(rtab.size(), -1);
+    std::vector<int> rtLdM(rtab.size(), 0), rtC0M(rtab.size(), 0);
+    std::vector<uint8_t> leafTile(ntl, 0);
+    if (h->twoLevel) {
+        std::vector<int> nodeOfRow(P.nmax, -1);
+        for (size_t k = 0; k < h->nd.size(); ++k) {
+            const NdNode &N = h->nd[k];
+            if (N.a < 0)
+                for (int r = N.off; r < N.off + N.size; ++r) leafTile[r / 64] = 1;
+            else
+                for (int r = N.offS; r < N.offS + N.sizeS; ++r) nodeOfRow[r] = (int)k;
+        }
+        for (int ls = 0; ls < P.nParts; ++ls)
+            for (int J = 0; J < ntl; ++J) {
+                const size_t at = (size_t)ls * ntl + J;
+                if (rtab[at].off < 0 || nodeOfRow[64 * J] < 0) continue;
+                const NdNode &N = h->nd[nodeOfRow[64 * J]];
+                rtOffM[at] = (long long)wTotal;
+                // (+ 16: a leaf range is a multiple of 64 columns, often a power of two -- consecutive rows of a panel would then
+                // start on the same HBM channels)
+                rtLdM[at] = N.endL - N.offL + 16;
+                rtC0M[at] = N.offL;
+                wTotal += (size_t)64 * rtLdM[at];
+            }
+        size_t freeB = 0, totalB = 0;
+        HIPCHECK(h, hipMemGetInfo(&freeB, &totalB));
+        if (8.0 * (double)wTotal * 2.1 > 0.9 * (double)freeB) {
+            h->err = "the two-level factors do not fit the free HBM";
+            return DOTMI_E_INVALID;
+        }
+    }
     h->rtOff = rtOff;
     h->rtLd = rtLd;
     h->rtC0 = rtC0;
     h->wTotal = wTotal;
     // offset in W of (memory row r, column c) of owned subdomain ls, or -1 when that place is not stored
     auto waddr = [&](int ls, int r, int c) -> long long {
-        const RowTile &R = rtab[(size_t)ls * ntl + (r >> 6)];
-        if (R.off < 0 || c < R.c0 || c >= R.c0 + R.ld) return -1;
+        const size_t at = (size_t)ls * ntl + (r >> 6);
+        const RowTile &R = rtab[at];
+        if (R.off < 0) return -1;
+        if (c < R.c0) {
+            if (rtOffM[at] < 0 || c < rtC0M[at] || c >= rtC0M[at] + rtLdM[at]) return -1;
+            return rtOffM[at] + (long long)(r & 63) * rtLdM[at] + (c - rtC0M[at]);
+        }
+        if (c >= R.c0 + R.ld) return -1;
         return R.off + (long long)(r & 63) * R.ld + (c - R.c0);
     };
     // dense fill list: per scalar of every 3x3 block of the principal sub-matrix
@@ -496,6 +539,7 @@ int build_device_mesh(dotmi_handle *h)
         // (1 M tets: 75 us per iteration at 0.26 of the HBM peak); the two-launch form reads the partials coalesced in the
         // subdomains' own order and gathers one 24-byte triple per (vertex, subdomain).  Small meshes keep the one launch.
         P.splitMerge = h->tune.splitMerge >= 0 ? (h->tune.splitMerge != 0) : (3ll * nV >= 400000 || ppartN >= (1ll << 31));
+        if (h->twoLevel) P.splitMerge = 1;   // (the leaves' results are finished on the per-subdomain sums psub)
         const bool lists = !P.splitMerge && ppartN < (1ll << 31) && !(h->flags & DOTMI_FLAG_GSDD);
         if (!(h->flags & DOTMI_FLAG_GSDD)) {
             std::vector<int> mp(lists ? (size_t)3 * nV + 1 : 0, 0), ment;
@@ -607,7 +651,9 @@ int build_device_mesh(dotmi_handle *h)
             for (int ls = 0; ls < P.nParts; ++ls)
                 plan_subdomain_tiles(ls, nt, P.W, &rtOff[(size_t)ls * nt], &rtLd[(size_t)ls * nt], &rtC0[(size_t)ls * nt],
                                      live[ls], pat[ls], h->W2, sn, all, S.clearTiles, S.clearLd, S.flops, S.qTiles,
-                                     eagerMin, eagerChunk, 0, true, eagerMinRmul);
+                                     eagerMin, eagerChunk, 0, true, eagerMinRmul,
+                                     h->twoLevel ? &rtOffM[(size_t)ls * nt] : nullptr, h->twoLevel ? &rtLdM[(size_t)ls * nt] : nullptr,
+                                     h->twoLevel ? &rtC0M[(size_t)ls * nt] : nullptr, h->twoLevel ? leafTile.data() : nullptr);
             finish_tile_schedule(all, S);
         }
         if (int rc = upload(h, &h->ttasks, S.tasks)) return rc;
@@ -664,6 +710,112 @@ int build_device_mesh(dotmi_handle *h)
     if (int rc = dalloc(h, &P.psub, (size_t)P.nParts * P.nmax)) return rc;
     if (int rc = dalloc(h, &P.rpad, (size_t)P.nParts * P.nmax + 8)) return rc;
     HIPCHECK(h, hipMemset(P.rpad, 0, sizeof(double) * ((size_t)P.nParts * P.nmax + 8)));
+    P.tl = DevTwoLevel{};
+    if (h->twoLevel) {
+        // panels: per (subdomain, leaf) the separator vertices next to the leaf (a mesh edge into it; no fill path leaves a leaf),
+        // rows ascending in the layout
+        std::vector<int4> panel;
+        std::vector<long long> rowBase, rowDst;
+        std::vector<int> rowPos, gIdx;
+        long long packedN = 0;
+        std::vector<std::vector<int>> sub((size_t)P.nParts * P.nmax);
+        std::vector<int> leafOf(nV, -1), sepPos(nV, -1);
+        long long panelBytes = 0;
+        int maxRows = 0, maxCols = 0;
+        for (int ls = 0; ls < P.nParts; ++ls) {
+            for (size_t k = 0; k < h->nd.size(); ++k) {
+                const NdNode &N = h->nd[k];
+                const auto &rv = region[k][ls];
+                const int ro = nd_region_first_row(N, 3 * (int)rv.size());
+                for (size_t q = 0; q < rv.size(); ++q) {
+                    if (N.a < 0) leafOf[rv[q]] = (int)k;
+                    else sepPos[rv[q]] = ro + 3 * (int)q;
+                }
+            }
+            for (size_t k = 0; k < h->nd.size(); ++k) {
+                const NdNode &N = h->nd[k];
+                if (N.a >= 0 || region[k][ls].empty()) continue;
+                const auto &rv = region[k][ls];
+                std::vector<int> rows;   // padded positions of the coupled separator vertices
+                for (int v : rv)
+                    for (int e = adj_ptr[v]; e < adj_ptr[v + 1]; ++e)
+                        if (sepPos[adj_idx[e]] >= 0) rows.push_back(sepPos[adj_idx[e]]);
+                std::sort(rows.begin(), rows.end());
+                rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+                if (rows.empty()) continue;
+                // (the kernels take two columns per lane: the panel starts on an even column -- one column of the leaf's identity
+                // padding in front when its first live column is odd: zeros in M and in the right-hand side -- and ends at the
+                // leaf's end, a multiple of 64)
+                const int c0 = nd_region_first_row(N, 3 * (int)rv.size()) & ~1, used = N.off + N.size - c0;
+                panel.push_back(make_int4((int)rowBase.size(), 3 * (int)rows.size(), ls * P.nmax + c0, used));
+                maxRows = std::max(maxRows, 3 * (int)rows.size());
+                maxCols = std::max(maxCols, used);
+                panelBytes += 8ll * 3 * (long long)rows.size() * used;
+                for (int rp : rows)
+                    for (int d = 0; d < 3; ++d) {
+                        const long long a = waddr(ls, rp + d, c0);
+                        if (a < 0) {
+                            h->err = "two-level layout: a panel row has no storage";
+                            return DOTMI_E_INVALID;
+                        }
+                        sub[(size_t)ls * P.nmax + rp + d].push_back((int)rowBase.size());
+                        rowBase.push_back(a);
+                        rowDst.push_back(packedN);
+                        packedN += used;
+                        rowPos.push_back(ls * P.nmax + rp + d);
+                    }
+            }
+            for (int v : h->partVerts[h->p0 + ls]) leafOf[v] = sepPos[v] = -1;
+        }
+        std::vector<int> gPtr((size_t)P.nParts * P.nmax + 1, 0);
+        for (size_t i = 0; i < sub.size(); ++i) {
+            gPtr[i] = (int)gIdx.size();
+            gIdx.insert(gIdx.end(), sub[i].begin(), sub[i].end());
+        }
+        gPtr[sub.size()] = (int)gIdx.size();
+        if (gIdx.empty()) gIdx.push_back(0);
+        if (panel.empty()) panel.push_back(make_int4(0, 0, 0, 0));
+        if (rowBase.empty()) {
+            rowBase.push_back(0);
+            rowDst.push_back(0);
+            rowPos.push_back(0);
+        }
+        std::vector<int2> items;
+        for (size_t q = 0; q < panel.size(); ++q)
+            for (int k0 = 0; k0 < panel[q].y; k0 += 8) items.push_back(make_int2((int)q, k0));
+        if (items.empty()) items.push_back(make_int2(0, 0));
+        int2 *dItem = nullptr;
+        if (int rc = upload(h, &dItem, items)) return rc;
+        P.tl.item = dItem;
+        P.tl.nItems = maxRows > 0 ? (int)items.size() : 0;
+        int4 *dPanel = nullptr;
+        long long *dBase = nullptr, *dDst = nullptr;
+        if (int rc = upload(h, &dDst, rowDst)) return rc;
+        if (int rc = dalloc(h, &P.tl.packed, (size_t)std::max<long long>(packedN, 2))) return rc;
+        int *dPos = nullptr, *dPtr = nullptr, *dIdx = nullptr;
+        P.tl.nPanels = maxRows > 0 ? (int)panel.size() : 0;
+        if (int rc = upload(h, &dPanel, panel)) return rc;
+        if (int rc = upload(h, &dBase, rowBase)) return rc;
+        if (int rc = upload(h, &dPos, rowPos)) return rc;
+        if (int rc = upload(h, &dPtr, gPtr)) return rc;
+        if (int rc = upload(h, &dIdx, gIdx)) return rc;
+        if (int rc = dalloc(h, &P.tl.cbuf, rowBase.size())) return rc;
+        if (int rc = dalloc(h, &P.tl.rpad2, (size_t)P.nParts * P.nmax + 8)) return rc;
+        HIPCHECK(h, hipMemset(P.tl.rpad2, 0, sizeof(double) * ((size_t)P.nParts * P.nmax + 8)));
+        P.tl.panel = dPanel;
+        P.tl.rowSrc = dBase;
+        P.tl.rowBase = dDst;
+        P.tl.rowPos = dPos;
+        P.tl.gPtr = dPtr;
+        P.tl.gIdx = dIdx;
+        P.tl.maxRows = maxRows;
+        P.tl.maxCols = maxCols;
+        P.tl.on = 1;
+        h->precond_bytes += 2 * panelBytes;   // (the panels are streamed twice per application)
+        if (h->tune.fuseLog)
+            fprintf(stderr, "dotmi: two-level back-solve: %d panels (at most %d rows x %d columns), %.1f MB of panels (x 2), %.1f MB in all\n",
+                    P.tl.nPanels, maxRows, maxCols, panelBytes / 1e6, h->precond_bytes / 1e6);
+    }
     if (int rc = dalloc(h, &h->info_dev, (size_t)std::max(P.nParts, 1))) return rc;
     HIPCHECK(h, hipHostMalloc((void **)&h->h_info, sizeof(int) * std::max(P.nParts, 1)));
     memset(h->h_info, 0, sizeof(int) * std::max(P.nParts, 1));

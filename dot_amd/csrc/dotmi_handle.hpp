@@ -68,6 +68,8 @@ struct Tuning {
     int tileRowsLong = 0;     // DOTMI_TILE_ROWS_LONG rows per back-solve tile when the rows have more than 1536 columns (0: as the
                               //                      other rows, or ~256 KB tiles where few subdomains leave the launch bound by
                               //                      its longest tile)
+    int twoLevel = 0;         // DOTMI_TWO_LEVEL      1: the back-solve in its two-level form (leaves against the separator complement,
+                              //                      DevTwoLevel); 0: the explicit inverse in one pass
     int splitMerge = -1;      // DOTMI_SPLIT_MERGE    1 / 0: the merge as reduce_partial_p + a gather from psub (the early order included) /
                               //                      as one walk over the tile partials; default: split from 400 k scalar dofs
     bool fuseLog = false;     // DOTMI_FUSE_LOG       print the fused-leaf units
@@ -120,6 +122,7 @@ struct Tuning {
         t.tileRowsLong = geti("DOTMI_TILE_ROWS_LONG", 0);
         if (t.tileRowsLong > 0) t.tileRowsLong = std::min(64, std::max(8, t.tileRowsLong / 8 * 8));
         t.splitMerge = geti("DOTMI_SPLIT_MERGE", -1);
+        t.twoLevel = geti("DOTMI_TWO_LEVEL", 0);
         t.fuseLog = getenv("DOTMI_FUSE_LOG") != nullptr;
         t.factorGraph = geti("DOTMI_FACTOR_GRAPH", 1) != 0;
         t.shardElems = geti("DOTMI_SHARD_ELEMS", -1);
@@ -192,6 +195,7 @@ struct dotmi_handle {
     int nHessElems = 0, nHessBlk = 0;
     // level-scheduled tile factorisation (tile_factor.hpp)
     bool tileMode = false;
+    bool twoLevel = false;                       // the factors are in the two-level form (DevTwoLevel)
     TileTask *ttasks = nullptr;
     TileProd *tprods = nullptr;
     double **tclear = nullptr;

@@ -95,8 +95,32 @@ struct RowTile {
     int ld, c0;
 };
 
+// ---- two-level form of the back-solve (round 6; leaves-first layout, nd_layout.hpp) -----------------------------------------
+// The factor buffer holds X_DD = chol(H_DD)^-1 of every leaf D, X_GG = the inverse of the separator complement's own factor, and in
+// the separator rows' leaf columns M_GD = L_GD X_DD -- non-zero only in the rows of separator vertices NEXT TO leaf D.  One
+// application:  c = M_GD r_D (panel rows, twolevel_forward_kernel) -> t_G = r_G - sum c (twolevel_rhs_kernel) -> the one-pass tile
+// kernels on the leaves' and the separators' own rows (q_D = X_DD^T X_DD r_D, p_G = X_GG^T X_GG t_G) -> p_D = q_D - M_GD^T p_G
+// (twolevel_backward_kernel on the per-subdomain sums psub).  The panels are read twice, everything else once.
+struct DevTwoLevel {
+    int on;
+    int nPanels;                 // (owned subdomain, leaf) pairs with at least one coupled separator row
+    int maxRows, maxCols;        // over the panels
+    int nItems;                  // twolevel_forward_kernel's work items: (panel, first of eight rows)
+    const int2 *item;
+    const int4 *panel;           // x = first panel row, y = rows, z = ls * nmax + the leaf's first live column, w = live columns
+    const long long *rowSrc;     // per panel row: offset in W of (that separator row, the panel's first column): where the
+                                 // factorisation leaves it
+    const long long *rowBase;    // per panel row: offset in `packed` of the row's copy (the rows of a panel one behind the other)
+    double *packed;              // the panels, packed after every factorisation (twolevel_pack_kernel): what the two kernels stream
+    const int *rowPos;           // per panel row: ls * nmax + the separator row's padded position
+    double *cbuf;                // per panel row: c = M[row, leaf columns] . r_leaf
+    const int *gPtr, *gIdx;      // per padded position (nParts * nmax + 1, CSR): the panel rows whose c is subtracted there
+    double *rpad2;               // the right-hand sides with t_G in the separator positions (what the tile kernels read)
+};
+
 // ---- subdomains owned by this rank ---------------------------------------------------------------
 struct DevParts {
+    DevTwoLevel tl;
     int nParts;             // owned
     int nmax;               // padded scalar size of every owned dense block (multiple of 64) = its lda
     int *dofmap;            // owned * nmax: padded local position -> global scalar dof, -1 = padding
@@ -374,6 +398,7 @@ void launch_build_qpad(const DevParts &P, const double *g, const LbfgsArgs &L, c
 // early back-solve: u = merge(tile partials) / dup = -M g;  M y of the newest pair = u_old - u;  z = u - sum_j xi_j M y_j
 // (+ partial dots y_i . z);  first: start of the step (no history, u_old is only set)
 void launch_reduce_partial(const DevParts &P, hipStream_t st, const DevLoop *ctl = nullptr);
+void launch_twolevel_pack(const DevParts &P, hipStream_t st);   // after a factorisation (two-level form): the panels' rows -> P.tl.packed
 // zsum: the all-reduced sum (over all ranks' subdomains) of the undivided partial merges, in a staging buffer
 // ownMask (owner exchange): the y_i . z partials over the vertices this rank owns only
 // kind, pre, zshare (owner exchange with the y_i . z in the packet; zsum = nullptr: the kernel merges this rank's tiles itself):

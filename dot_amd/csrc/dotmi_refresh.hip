@@ -110,6 +110,7 @@ int refactor_issue(dotmi_handle *h, const double *x)
     if (h->P.nParts > 0) {
         HIPCHECK(h, hipMemsetAsync(h->info_dev, 0, sizeof(int) * h->P.nParts, h->st));
         if (int rc = run_factor(h)) return rc;
+        launch_twolevel_pack(h->P, h->st);
         HIPCHECK(h, hipMemcpyAsync(h->h_info, h->info_dev, sizeof(int) * h->P.nParts, hipMemcpyDeviceToHost, h->st));
     }
     HIPCHECK(h, hipEventRecord(h->ev2, h->st));

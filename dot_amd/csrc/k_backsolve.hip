@@ -1128,6 +1128,136 @@ __global__ __launch_bounds__(BSL_THREADS) void backsolve_long_kernel(const int4 
     }
 }
 
+// ---- two-level form (DevTwoLevel, dotmi_internal.hpp): the three kernels around the tile kernels -------------------------------
+// Reference role: the forward and backward substitution of CHOLMODSolver::solve (CHOLMODSolver.cpp:149-163) across the boundary
+// between a subdomain's leaves and its separators; here with the leaves' inverse factors multiplied in (M_GD = L_GD X_DD).
+// c[k] = M[row k, leaf columns] . r_leaf : a WAVEFRONT = eight consecutive rows of a panel (item = (panel, first row): no LDS, no
+// barrier, the waves of a workgroup are independent -- a workgroup per panel was a chain of ~4 us steps per wave behind a ~3 us
+// start, four rounds of them per CU: 181 us for 662 MB at 1 M tets), two columns per lane (a panel starts on an even column and
+// has an even number of them: dotmi_create), the packed rows of a panel one behind the other
+__global__ __launch_bounds__(256) void twolevel_forward_kernel(int nItems, const int2 *__restrict__ item, const int4 *__restrict__ panel,
+                                                               const long long *__restrict__ rowBase, const double *__restrict__ Mp,
+                                                               const double *__restrict__ rpad, double *__restrict__ cbuf,
+                                                               const DevLoop *__restrict__ ctl)
+{
+    if (ctl && ctl->status != 0) return;
+    const int lane = threadIdx.x & 63, it = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (it >= nItems) return;
+    const int2 im = item[it];
+    const int4 pn = panel[im.x];
+    constexpr int RW = 8;
+    const int k0 = im.y, n2 = pn.w >> 1, nr = min(RW, pn.y - k0);
+    const double2 *row0 = reinterpret_cast<const double2 *>(Mp + rowBase[pn.x + k0]);
+    const double2 *r2 = reinterpret_cast<const double2 *>(rpad + pn.z);
+    double acc[RW];
+#pragma unroll
+    for (int u = 0; u < RW; ++u) acc[u] = 0.0;
+    for (int c = lane; c < n2; c += 64) {
+        const double2 rc = r2[c];
+        double2 w[RW];
+#pragma unroll
+        for (int u = 0; u < RW; ++u) w[u] = row0[(size_t)min(u, nr - 1) * n2 + c];
+#pragma unroll
+        for (int u = 0; u < RW; ++u) {
+            acc[u] += w[u].x * rc.x;
+            acc[u] += w[u].y * rc.y;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RW; ++u) {
+        const double t = wave_sum(acc[u]);
+        if (lane == 0 && u < nr) cbuf[pn.x + k0 + u] = t;
+    }
+}
+// the panels' rows from where the factorisation leaves them (rows of the separators' leaf ranges, a leaf range apart) into one
+// packed array, panel after panel, row after row: once per factorisation; workgroup = panel
+__global__ __launch_bounds__(256) void twolevel_pack_kernel(const int4 *__restrict__ panel, const long long *__restrict__ rowSrc,
+                                                            const long long *__restrict__ rowDst, const double *__restrict__ W,
+                                                            double *__restrict__ packed)
+{
+    const int4 pn = panel[blockIdx.x];
+    const int n2 = pn.w >> 1, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = wv; k < pn.y; k += 4) {
+        const double2 *src = reinterpret_cast<const double2 *>(W + rowSrc[pn.x + k]);
+        double2 *dst = reinterpret_cast<double2 *>(packed + rowDst[pn.x + k]);
+        for (int c = lane; c < n2; c += 64) dst[c] = src[c];
+    }
+}
+void launch_twolevel_pack(const DevParts &P, hipStream_t st)
+{
+    if (P.tl.on && P.tl.nPanels > 0)
+        hipLaunchKernelGGL(twolevel_pack_kernel, dim3(P.tl.nPanels), dim3(256), 0, st, P.tl.panel, P.tl.rowSrc, P.tl.rowBase,
+                           (const double *)P.W, P.tl.packed);
+}
+// t = r - sum of the panel rows' c at the separator positions (list order), r itself everywhere else
+__global__ __launch_bounds__(256) void twolevel_rhs_kernel(int total, const int *__restrict__ gPtr, const int *__restrict__ gIdx,
+                                                           const double *__restrict__ rpad, const double *__restrict__ cbuf,
+                                                           double *__restrict__ rpad2, const DevLoop *__restrict__ ctl)
+{
+    if (ctl && ctl->status != 0) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        double v = rpad[i];
+        const int e1 = gPtr[i + 1];
+        for (int e = gPtr[i]; e < e1; ++e) v -= cbuf[gIdx[e]];
+        rpad2[i] = v;
+    }
+}
+// p_leaf -= M[rows, leaf columns]^T p_G[rows] on the per-subdomain sums: workgroup = panel; thread = (column pair, row group):
+// CW column pairs across, 256 / CW row groups that take the rows in turns of eight (ascending inside a group, four interleaved
+// partial sums each); the groups' sums are added in group order
+template <int CW>
+__global__ __launch_bounds__(256) void twolevel_backward_kernel(const int4 *__restrict__ panel, const long long *__restrict__ rowBase,
+                                                                const int *__restrict__ rowPos, const double *__restrict__ W,
+                                                                double *__restrict__ psub, const DevLoop *__restrict__ ctl)
+{
+    extern __shared__ __attribute__((aligned(16))) double tl_lds[];
+    if (ctl && (ctl->status != 0 || ctl->phase != 0)) return;   // (as reduce_partial_p_kernel, whose sums this finishes)
+    constexpr int RG = 256 / CW, RB = 8;
+    const int4 pn = panel[blockIdx.x];
+    const int tid = threadIdx.x, cg = tid % CW, g = tid / CW;
+    const int nr = (pn.y + RB - 1) / RB * RB;
+    double *pg = tl_lds;
+    long long *base = reinterpret_cast<long long *>(tl_lds + nr);
+    double2 *part = reinterpret_cast<double2 *>(base + nr);   // [RG][CW]
+    for (int k = tid; k < nr; k += 256) {
+        pg[k] = k < pn.y ? psub[rowPos[pn.x + k]] : 0.0;
+        base[k] = rowBase[pn.x + min(k, pn.y - 1)];
+    }
+    __syncthreads();
+    const int n2 = pn.w >> 1;
+    for (int c0 = 0; c0 < n2; c0 += CW) {
+        const int c = c0 + cg;
+        double2 a[4] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
+        if (c < n2)
+            for (int k = RB * g; k < nr; k += RB * RG) {
+                double2 w[RB];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) w[u] = reinterpret_cast<const double2 *>(W + base[k + u])[c];
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    a[u & 3].x += w[u].x * pg[k + u];
+                    a[u & 3].y += w[u].y * pg[k + u];
+                }
+            }
+        part[g * CW + cg] = make_double2((a[0].x + a[1].x) + (a[2].x + a[3].x), (a[0].y + a[1].y) + (a[2].y + a[3].y));
+        __syncthreads();
+        if (g == 0 && c < n2) {
+            double2 t = part[cg];
+#pragma unroll
+            for (int q = 1; q < RG; ++q) {
+                t.x += part[q * CW + cg].x;
+                t.y += part[q * CW + cg].y;
+            }
+            double2 *dst = reinterpret_cast<double2 *>(psub + pn.z) + c;
+            double2 v = *dst;
+            v.x -= t.x;
+            v.y -= t.y;
+            *dst = v;
+        }
+        __syncthreads();
+    }
+}
+
 template <int CTL>
 static void launch_gemv_impl(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,
                              const CtlArgs *ca, int spec)
@@ -1138,6 +1268,16 @@ static void launch_gemv_impl(const DevParts &P, const double *q, hipStream_t st,
         int nb = (total + 255) / 256;
         if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(gather_pad_kernel, dim3(nb), dim3(256), 0, st, total, P.dofmap, q, P.rpad);
+    }
+    const double *rhs = P.rpad;
+    if (P.tl.on) {   // two-level form: t_G = r_G - M_GD r_D in front of the tile kernels
+        if (P.tl.nPanels > 0)
+            hipLaunchKernelGGL(twolevel_forward_kernel, dim3((P.tl.nItems + 3) / 4), dim3(256), 0, st, P.tl.nItems, P.tl.item, P.tl.panel,
+                               P.tl.rowBase, (const double *)P.tl.packed, (const double *)P.rpad, P.tl.cbuf, ctl);
+        const int total = P.nParts * P.nmax;
+        hipLaunchKernelGGL(twolevel_rhs_kernel, dim3(std::min((total + 255) / 256, 4096)), dim3(256), 0, st, total, P.tl.gPtr, P.tl.gIdx,
+                           (const double *)P.rpad, (const double *)P.tl.cbuf, P.tl.rpad2, ctl);
+        rhs = P.tl.rpad2;
     }
     // optional events time the streaming kernel alone (the roofline entry of bench.py is about that kernel): they are
     // attached to the dispatch itself (hipExtLaunchKernelGGL: the packet's own begin / end time stamps, what rocprofv3
@@ -1154,34 +1294,48 @@ static void launch_gemv_impl(const DevParts &P, const double *q, hipStream_t st,
     if (nW > 0) {
         if (timed)
             hipExtLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, ev0, nG > 0 ? (hipEvent_t) nullptr : ev1, 0,
-                                  P.tile, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, ctl, spec, nW);
+                                  P.tile, P.dofmap, P.W, P.nmax, P.rt, rhs, P.ppart, P.nbmax, ctl, spec, nW);
         else
-            hipLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax, P.rt, P.rpad,
+            hipLaunchKernelGGL((backsolve_kernel<512>), dim3(nW), dim3(512), 0, st, P.tile, P.dofmap, P.W, P.nmax, P.rt, rhs,
                                P.ppart, P.nbmax, ctl, spec, nW);
     }
     if (nG > 0 && ca) {
         // one workgroup more: the controller (backsolve_ctl_kernel)
         if (timed)
             hipExtLaunchKernelGGL(backsolve_ctl_kernel<CTL>, dim3(nG + 1), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
-                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, *ca, spec, nN);
+                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, rhs, P.ppart, P.nbmax, *ca, spec, nN);
         else
             hipLaunchKernelGGL(backsolve_ctl_kernel<CTL>, dim3(nG + 1), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax, P.rt,
-                               (const double *)P.rpad, P.ppart, P.nbmax, *ca, spec, nN);
+                               rhs, P.ppart, P.nbmax, *ca, spec, nN);
     } else if (nG > 0) {
         if (timed)
             hipExtLaunchKernelGGL((backsolve_kernel<256>), dim3(nG), dim3(256), 0, st, nW > 0 ? (hipEvent_t) nullptr : ev0, ev1, 0,
-                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, (const double *)P.rpad, P.ppart, P.nbmax, ctl, spec, nN);
+                                  P.tile + nW, P.dofmap, P.W, P.nmax, P.rt, rhs, P.ppart, P.nbmax, ctl, spec, nN);
         else
             hipLaunchKernelGGL((backsolve_kernel<256>), dim3(nG), dim3(256), 0, st, P.tile + nW, P.dofmap, P.W, P.nmax, P.rt,
-                               P.rpad, P.ppart, P.nbmax, ctl, spec, nN);
+                               rhs, P.ppart, P.nbmax, ctl, spec, nN);
     }
     if (P.nltiles > 0) {
         hipLaunchKernelGGL((backsolve_long_kernel<0>), dim3(P.nlwork), dim3(BSL_THREADS), 0, st, P.ltile, P.lwork, P.dofmap,
-                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl, spec);
+                           P.W, P.nmax, P.rt, rhs, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl, spec);
         hipLaunchKernelGGL((backsolve_long_kernel<1>), dim3(P.nlwork), dim3(BSL_THREADS), 0, st, P.ltile, P.lwork, P.dofmap,
-                           P.W, P.nmax, P.rt, P.rpad, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl, spec);
+                           P.W, P.nmax, P.rt, rhs, P.tdots, P.maxChunks, P.ppart, P.nbmax, ctl, spec);
     }
     if (!P.mt_ptr) launch_reduce_partial(P, st, ctl);   // (merge_tiles_kernel sums the tile partials itself)
+    if (P.tl.on && P.tl.nPanels > 0)   // p_D = q_D - M_GD^T p_G on the sums just formed
+    {
+        const size_t shm = 16 * (size_t)((P.tl.maxRows + 7) & ~7) + 16 * 256;
+        const int n2 = P.tl.maxCols / 2;
+        if (n2 <= 32)
+            hipLaunchKernelGGL(twolevel_backward_kernel<32>, dim3(P.tl.nPanels), dim3(256), shm, st, P.tl.panel, P.tl.rowBase,
+                               P.tl.rowPos, (const double *)P.tl.packed, P.psub, ctl);
+        else if (n2 <= 64)
+            hipLaunchKernelGGL(twolevel_backward_kernel<64>, dim3(P.tl.nPanels), dim3(256), shm, st, P.tl.panel, P.tl.rowBase,
+                               P.tl.rowPos, (const double *)P.tl.packed, P.psub, ctl);
+        else
+            hipLaunchKernelGGL(twolevel_backward_kernel<128>, dim3(P.tl.nPanels), dim3(256), shm, st, P.tl.panel, P.tl.rowBase,
+                               P.tl.rowPos, (const double *)P.tl.packed, P.psub, ctl);
+    }
 }
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,
                  const CtlArgs *ca, int spec)

@@ -18,6 +18,9 @@ struct NdNode {
     int tail = 0;            // leaf: only its last `tail` rows can couple to the root separator
     int crows = 0;           // rows of this sub-tree that can couple to the root separator (leaf tails + separators)
     int tail1 = 0;           // leaf: only its last `tail1` rows can couple to its PARENT's separator (tail1 >= tail)
+    // leaves-first layouts (nd_relayout_leaves_first, the two-level back-solve): the leaf columns [offL, endL) of this sub-tree;
+    // an internal node's `off` is then the first SEPARATOR column of its sub-tree (endL == offL: the [A | C | S] layout)
+    int offL = 0, endL = 0;
 };
 
 // first padded row of a node's own region (leaf block / separator) in a subdomain that has `used` live
@@ -270,6 +273,48 @@ struct NdBuilder {
     }
 };
 
+
+// Leaves-first layout (round 6, the two-level form of the back-solve): every leaf of the tree in front, in tree order, then every
+// separator in post-order (children's separators before the parent's).  The vertices keep their regions and their order inside a
+// region; only the regions' places change, and the order stays a valid elimination order (a leaf is decoupled from every other
+// leaf; a separator still comes behind everything it separates).  What it buys: the separator complement is ONE contiguous range
+// at the end, inside which the separators of a sub-tree are contiguous -- so "the rows of a separator from its sub-tree's first
+// SEPARATOR column to the diagonal" is a contiguous row range again, the inverse of the separator complement's own factor.
+inline void nd_relayout_leaves_first(std::vector<NdNode> &tree)
+{
+    if (tree.empty() || tree[0].a < 0) return;
+    int at = 0;
+    // leaves, depth first
+    struct L {
+        static void leaves(std::vector<NdNode> &t, int id, int &at)
+        {
+            NdNode &N = t[id];
+            N.offL = at;
+            if (N.a < 0) {
+                N.off = at;
+                at += N.size;
+            } else {
+                leaves(t, N.a, at);
+                leaves(t, N.c, at);
+            }
+            N.endL = at;
+        }
+        static int seps(std::vector<NdNode> &t, int id, int &at)   // returns the first separator column of the sub-tree (-1: none)
+        {
+            NdNode &N = t[id];
+            if (N.a < 0) return -1;
+            const int fa = seps(t, N.a, at), fc = seps(t, N.c, at);
+            N.offS = at;
+            at += N.sizeS;
+            N.off = fa >= 0 ? fa : fc >= 0 ? fc : N.offS;
+            return N.off;
+        }
+    };
+    const int total = tree[0].size;
+    L::leaves(tree, 0, at);
+    L::seps(tree, 0, at);
+    tree[0].size = total;   // (== at: the same regions)
+}
 
 // default depth of the dissection: two levels for the ~2000-dof subdomains of the headline configurations; big
 // subdomains (`timeStepper DOT 6` on a 17k-vertex mesh: ~9800 dofs) go deeper until the leaves are ~1200 dofs.

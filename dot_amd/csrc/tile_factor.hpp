@@ -92,13 +92,27 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
                                  double *W2, size_t &scratchNext, std::vector<TileTaskL> &out,
                                  std::vector<double *> &clearTiles, std::vector<int> &clearLd, double &flops, long long &qTiles,
                                  int eagerMin = 2, int eagerChunk = 1, int eagerMinDiag = 0, bool balance = true,
-                                 int eagerMinRmul = -1)
+                                 int eagerMinRmul = -1, const long long *rtOffM = nullptr, const int *rtLdM = nullptr,
+                                 const int *rtC0M = nullptr, const uint8_t *leafTile = nullptr)
 {
+    // Two-level form (leafTile != nullptr; leaves-first layout, nd_layout.hpp): tile rows of the LEAVES against the separator
+    // complement.  A separator's row block j stores its separator columns in the main table (rtC0[j] = the first separator column
+    // of its sub-tree) and the leaf columns of its sub-tree in a second one (rtOffM / rtLdM / rtC0M).  The factorisation proper is
+    // unchanged (R_ij of a leaf row i and a separator column j lives in that second range); of the inversion only the diagonal
+    // blocks remain -- Q_ij for i, j in one leaf or both in the separator complement -- and a tile (leaf i, separator j) receives
+    //     T_ij = sum over the tiles m >= i of i's leaf of Q_im R_mj          (= the tile of (L_GD X_DD)^T, no product with Q_jj,
+    // no terms through the separators in between): what the two-level back-solve streams instead of the inverse's dense
+    // (separator, leaf) blocks (k_backsolve.hip, twolevel_*).
+    const bool twoLevel = leafTile != nullptr;
     const size_t o0 = out.size();   // this subdomain's tasks are out[o0 ...)
-    auto tile = [&](int i, int j) { return W2 + rtOff[j] + (long long)i * TILE - rtC0[j]; };    // H, then R (work buffer)
-    auto qtile = [&](int i, int j) { return W + rtOff[j] + (long long)i * TILE - rtC0[j]; };    // Q (factor buffer)
+    auto inM = [&](int i, int j) { return twoLevel && (long long)i * TILE < rtC0[j]; };
+    auto toff = [&](int i, int j) {
+        return inM(i, j) ? rtOffM[j] + (long long)i * TILE - rtC0M[j] : rtOff[j] + (long long)i * TILE - rtC0[j];
+    };
+    auto tile = [&](int i, int j) { return W2 + toff(i, j); };    // H, then R (work buffer)
+    auto qtile = [&](int i, int j) { return W + toff(i, j); };    // Q (factor buffer)
     (void)scratchNext;
-    auto tld = [&](int j) { return rtLd[j]; };
+    auto tld = [&](int i, int j) { return inM(i, j) ? rtLdM[j] : rtLd[j]; };
     auto P = [&](int i, int j) -> uint8_t & { return pat[(size_t)i * nt + j]; };
     for (int j = 0; j < nt; ++j)
         if (live[j]) P(j, j) = 1;
@@ -124,7 +138,12 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
         in[j] = 1;
         for (int m = 0; m < j; ++m)
             if (Rp(m, j))
-                for (int i : qcol[m]) in[i] = 1;
+                for (int i : qcol[m]) {
+                    // two-level: a separator column takes a leaf's rows from that leaf's own columns only (T_ij), not through
+                    // the separators in between
+                    if (twoLevel && !leafTile[m] && leafTile[i]) continue;
+                    in[i] = 1;
+                }
         for (int i = 0; i <= j; ++i)
             if (in[i]) {
                 qcol[j].push_back(i);
@@ -197,14 +216,14 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
             pa.clear();
             for (int m = 0; m < k; ++m)
                 if (Rp(m, k) && Rp(m, j))
-                    pa.push_back({{tile(m, k), tile(m, j), tld(k), tld(j)}, std::max(LR(m, k), LR(m, j))});
+                    pa.push_back({{tile(m, k), tile(m, j), tld(m, k), tld(m, j)}, std::max(LR(m, k), LR(m, j))});
             // a pure fill-in tile holds nothing to start from: its first task starts from zero, and nobody has to clear it
-            LR(k, j) = emit(k, TF_FACT, TP_ROW, tile(k, j), tld(j), qtile(k, k), tld(k), 0, pa, lvD[k], Hp(k, j));
+            LR(k, j) = emit(k, TF_FACT, TP_ROW, tile(k, j), tld(k, j), qtile(k, k), tld(k, k), 0, pa, lvD[k], Hp(k, j));
         }
         pa.clear();
         for (int m = 0; m < j; ++m)
-            if (Rp(m, j)) pa.push_back({{tile(m, j), tile(m, j), tld(j), tld(j)}, LR(m, j)});
-        lvD[j] = emit(j, TF_FACT, TP_DIAG, tile(j, j), tld(j), nullptr, 0, j * TILE, pa, 0, true, qtile(j, j));
+            if (Rp(m, j)) pa.push_back({{tile(m, j), tile(m, j), tld(m, j), tld(m, j)}, LR(m, j)});
+        lvD[j] = emit(j, TF_FACT, TP_DIAG, tile(j, j), tld(j, j), nullptr, 0, j * TILE, pa, 0, true, qtile(j, j));
     }
     // levels of the inversion; lvQ(i,j) = level after which tile (i,j) of the factor buffer holds Q_ij
     std::vector<int> lvQ((size_t)nt * nt, 0);
@@ -214,22 +233,24 @@ inline void plan_subdomain_tiles(int sub, int nt, double *W, const long long *rt
     for (int j = 0; j < nt; ++j) {
         if (!live[j]) continue;
         clearTiles.push_back(tile(j, j));
-        clearLd.push_back(tld(j));
+        clearLd.push_back(tld(j, j));
         ++qTiles;
         for (int i : qcol[j]) {
             if (i == j) continue;
             if (Hp(i, j)) {   // only the tiles the fill writes into are read before they are written
                 clearTiles.push_back(tile(i, j));
-                clearLd.push_back(tld(j));
+                clearLd.push_back(tld(i, j));
             }
             ++qTiles;
             pa.clear();
+            const bool panel = twoLevel && leafTile[i] && !leafTile[j];   // T_ij: the leaf's own columns only, stored as it is
             for (int m = i; m < j; ++m)
-                if (Qp(i, m) && Rp(m, j))
-                    pa.push_back({{qtile(i, m), tile(m, j), tld(m), tld(j)}, std::max(LQ(i, m), LR(m, j))});
+                if (Qp(i, m) && Rp(m, j) && !(panel && !leafTile[m]))
+                    pa.push_back({{qtile(i, m), tile(m, j), tld(i, m), tld(m, j)}, std::max(LQ(i, m), LR(m, j))});
             // Q_ij = -(sum) Q_jj: the last task multiplies with Q_jj (ready after DIAG(j)); nothing else is waited for -- R_ij
             // lives in the work buffer and stays there
-            LQ(i, j) = emit(i, TF_INV, TP_RMUL, qtile(i, j), tld(j), qtile(j, j), tld(j), 0, pa, lvD[j], false);
+            if (panel) LQ(i, j) = emit(i, TF_INV, TP_STORE, qtile(i, j), tld(i, j), nullptr, 0, 0, pa, 0, false);
+            else LQ(i, j) = emit(i, TF_INV, TP_RMUL, qtile(i, j), tld(i, j), qtile(j, j), tld(j, j), 0, pa, lvD[j], false);
         }
     }
     if (!balance) return;
