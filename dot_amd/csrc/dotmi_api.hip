@@ -326,6 +326,10 @@ int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *Mout, 
 {
     if (!h || part < h->p0 || part >= h->p1 || !Mout) return DOTMI_E_INVALID;
     HIPCHECK(h, hipSetDevice(h->device));
+    if (inverse && h->twoLevel) {
+        h->err = "the factors are in the two-level form (DOTMI_TWO_LEVEL): there is no explicit inverse of a whole subdomain to return";
+        return DOTMI_E_INVALID;
+    }
     if (inverse) {
         if (int rc = enter_with_factors(h)) return rc;
     } else if (resolve_refresh(h) == DOTMI_E_DEVICE) return DOTMI_E_DEVICE;   // (asynchronous refresh of the last step)
@@ -352,9 +356,20 @@ int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *Mout, 
         if (lo < 0) lo = o;
         hi = o + 64ll * h->rtLd[(size_t)ls * ntl + J];
     }
-    std::vector<double> span((size_t)std::max<long long>(hi - lo, 1));
+    // (two-level form: the separators' row blocks hold their sub-tree's leaf columns in a second range)
+    long long lo2 = -1, hi2 = -1;
+    if (h->twoLevel)
+        for (int J = 0; J < ntl; ++J) {
+            const long long o = h->rtOffM[(size_t)ls * ntl + J];
+            if (o < 0) continue;
+            if (lo2 < 0) lo2 = o;
+            hi2 = o + 64ll * h->rtLdM[(size_t)ls * ntl + J];
+        }
+    std::vector<double> span((size_t)std::max<long long>(hi - lo, 1)), span2((size_t)std::max<long long>(hi2 - lo2, 1));
     hipError_t e = lo >= 0 ? hipMemcpyAsync(span.data(), W + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToHost, h->st)
                            : hipSuccess;
+    if (e == hipSuccess && lo2 >= 0)
+        e = hipMemcpyAsync(span2.data(), W + lo2, sizeof(double) * (size_t)(hi2 - lo2), hipMemcpyDeviceToHost, h->st);
     hipStreamSynchronize(h->st);
     if (tmp) hipFree(tmp);
     HIPCHECK(h, e);
@@ -362,6 +377,8 @@ int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *Mout, 
         const size_t k = (size_t)ls * ntl + (r >> 6);
         const long long o = h->rtOff[k];
         const int c0 = h->rtC0[k], ld = h->rtLd[k];
+        if (o >= 0 && c < c0 && lo2 >= 0 && h->rtOffM[k] >= 0 && c >= h->rtC0M[k] && c < h->rtC0M[k] + h->rtLdM[k])
+            return span2[(size_t)(h->rtOffM[k] - lo2 + (long long)(r & 63) * h->rtLdM[k] + (c - h->rtC0M[k]))];
         if (o < 0 || c < c0 || c >= c0 + ld) return 0.0;
         return span[(size_t)(o - lo + (long long)(r & 63) * ld + (c - c0))];
     };

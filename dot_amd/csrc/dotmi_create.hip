@@ -285,6 +285,16 @@ int build_device_mesh(dotmi_handle *h)
     {
         std::vector<std::vector<int>> sets(P.nParts);
         for (int ls = 0; ls < P.nParts; ++ls) sets[ls] = h->partVerts[h->p0 + ls];
+        // two-level form of the back-solve (DevTwoLevel): one rank, the block solve as a whole (not GSDD's subdomain at a time);
+        // by default where the merge is split as well (big meshes: the three launches around the tile kernels and the split
+        // merge cost ~40 us per iteration, bar17K: loop +0.9 ms against -0.16 ms of factorisation; 1 M tets: step -20 %), and
+        // then on a tree of at least four levels with regions split down to 256 scalars (profiles/r06_two_level.txt)
+        const bool wantTwoLevel = (h->tune.twoLevel > 0 || (h->tune.twoLevel < 0 && 3ll * nV >= 400000)) && !h->dist &&
+                                  !(h->flags & DOTMI_FLAG_GSDD);
+        if (wantTwoLevel && ndLevels < 0 && !getenv("DOTMI_ND_MIN")) {
+            ndLevels = std::max(4, nd_default_levels(h->partVerts));
+            ndMin = 256;
+        }
         if (ndLevels < 0 && !getenv("DOTMI_ND_MIN")) {
             // depth and split threshold from ALL subdomains of the mesh: the same tree on every rank (nd_layout.hpp)
             nd_choose_depth(h->partVerts, nV, adj_ptr, adj_idx, h->Xrest.data(), BS_NARROW, ndMin, ndLevels, ndMin);
@@ -293,9 +303,7 @@ int build_device_mesh(dotmi_handle *h)
         }
         if (h->tune.fuseLog) fprintf(stderr, "dotmi: dissection: %d levels, regions split down to %d scalars\n", ndLevels, ndMin);
         nd_plan(sets, nV, adj_ptr, adj_idx, h->Xrest.data(), ndLevels, ndMin, h->nd, region);
-        // two-level form of the back-solve (DevTwoLevel): one rank, the block solve as a whole (not GSDD's subdomain at a time), a
-        // tree that has separators at all
-        h->twoLevel = h->tune.twoLevel > 0 && !h->dist && !(h->flags & DOTMI_FLAG_GSDD) && !h->nd.empty() && h->nd[0].a >= 0;
+        h->twoLevel = wantTwoLevel && !h->nd.empty() && h->nd[0].a >= 0;   // (a tree that has separators at all)
         if (h->twoLevel) nd_relayout_leaves_first(h->nd);
     }
     P.nmax = h->nd[0].size;
@@ -451,6 +459,9 @@ int build_device_mesh(dotmi_handle *h)
     h->rtOff = rtOff;
     h->rtLd = rtLd;
     h->rtC0 = rtC0;
+    h->rtOffM = rtOffM;
+    h->rtLdM = rtLdM;
+    h->rtC0M = rtC0M;
     h->wTotal = wTotal;
     // offset in W of (memory row r, column c) of owned subdomain ls, or -1 when that place is not stored
     auto waddr = [&](int ls, int r, int c) -> long long {
@@ -1232,6 +1243,9 @@ int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xr
         else levelsUse = nd_default_levels(allSets);
     }
     *nmax = nd_plan(sets, nV, adj_ptr, adj_idx, Xrest, levelsUse, minUse, tree, region);
+    // (the leaves-first layout of the two-level back-solve when the environment forces that form: DOTMI_TWO_LEVEL=1; the automatic
+    // choice of dotmi_create -- from 400 000 dofs on one rank, on at least four levels -- is the caller's to mirror)
+    if (getenv("DOTMI_TWO_LEVEL") && atoi(getenv("DOTMI_TWO_LEVEL")) > 0) nd_relayout_leaves_first(tree);
     *n_nodes = (int32_t)tree.size();
     if (nodes) {
         if ((int)tree.size() > node_cap) return DOTMI_E_INVALID;
@@ -1370,6 +1384,12 @@ int32_t dotmi_factor_kind(const dotmi_handle *h)
 {
     if (!h) return DOTMI_E_INVALID;
     return h->tileFlow ? 2 : h->tileSplit ? 3 : 1;
+}
+
+int32_t dotmi_backsolve_form(const dotmi_handle *h)
+{
+    if (!h) return DOTMI_E_INVALID;
+    return h->twoLevel ? 1 : 0;
 }
 
 int32_t dotmi_comm_ranks(const dotmi_handle *h)

@@ -68,8 +68,8 @@ struct Tuning {
     int tileRowsLong = 0;     // DOTMI_TILE_ROWS_LONG rows per back-solve tile when the rows have more than 1536 columns (0: as the
                               //                      other rows, or ~256 KB tiles where few subdomains leave the launch bound by
                               //                      its longest tile)
-    int twoLevel = 0;         // DOTMI_TWO_LEVEL      1: the back-solve in its two-level form (leaves against the separator complement,
-                              //                      DevTwoLevel); 0: the explicit inverse in one pass
+    int twoLevel = -1;        // DOTMI_TWO_LEVEL      1: the back-solve in its two-level form (leaves against the separator complement,
+                              //                      DevTwoLevel); 0: the explicit inverse in one pass; -1: two-level from 400 000 dofs
     int splitMerge = -1;      // DOTMI_SPLIT_MERGE    1 / 0: the merge as reduce_partial_p + a gather from psub (the early order included) /
                               //                      as one walk over the tile partials; default: split from 400 k scalar dofs
     bool fuseLog = false;     // DOTMI_FUSE_LOG       print the fused-leaf units
@@ -122,7 +122,7 @@ struct Tuning {
         t.tileRowsLong = geti("DOTMI_TILE_ROWS_LONG", 0);
         if (t.tileRowsLong > 0) t.tileRowsLong = std::min(64, std::max(8, t.tileRowsLong / 8 * 8));
         t.splitMerge = geti("DOTMI_SPLIT_MERGE", -1);
-        t.twoLevel = geti("DOTMI_TWO_LEVEL", 0);
+        t.twoLevel = geti("DOTMI_TWO_LEVEL", -1);
         t.fuseLog = getenv("DOTMI_FUSE_LOG") != nullptr;
         t.factorGraph = geti("DOTMI_FACTOR_GRAPH", 1) != 0;
         t.shardElems = geti("DOTMI_SHARD_ELEMS", -1);
@@ -202,6 +202,8 @@ struct dotmi_handle {
     int *tclearLd = nullptr;
     std::vector<long long> rtOff;   // host copy of the RowTile table (dotmi_part_matrix)
     std::vector<int> rtLd, rtC0;
+    std::vector<long long> rtOffM;  // two-level form: the separators' row blocks' second range (their sub-tree's leaf columns)
+    std::vector<int> rtLdM, rtC0M;
     size_t wTotal = 0;
     double *W2 = nullptr;             // tile factorisation: the work buffer (H, then R), laid out like P.W (which holds Q only)
     int nTclear = 0;

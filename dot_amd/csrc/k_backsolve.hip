@@ -1270,10 +1270,19 @@ static void launch_gemv_impl(const DevParts &P, const double *q, hipStream_t st,
         hipLaunchKernelGGL(gather_pad_kernel, dim3(nb), dim3(256), 0, st, total, P.dofmap, q, P.rpad);
     }
     const double *rhs = P.rpad;
+    hipEvent_t evLast = nullptr;   // two-level form: the timed region runs from the forward kernel to the backward kernel
     if (P.tl.on) {   // two-level form: t_G = r_G - M_GD r_D in front of the tile kernels
-        if (P.tl.nPanels > 0)
-            hipLaunchKernelGGL(twolevel_forward_kernel, dim3((P.tl.nItems + 3) / 4), dim3(256), 0, st, P.tl.nItems, P.tl.item, P.tl.panel,
-                               P.tl.rowBase, (const double *)P.tl.packed, (const double *)P.rpad, P.tl.cbuf, ctl);
+        if (P.tl.nPanels > 0) {
+            if (ev0 && ev1) {
+                hipExtLaunchKernelGGL(twolevel_forward_kernel, dim3((P.tl.nItems + 3) / 4), dim3(256), 0, st, ev0, (hipEvent_t) nullptr, 0,
+                                      P.tl.nItems, P.tl.item, P.tl.panel, P.tl.rowBase, (const double *)P.tl.packed,
+                                      (const double *)P.rpad, P.tl.cbuf, ctl);
+                evLast = ev1;
+                ev0 = ev1 = nullptr;
+            } else
+                hipLaunchKernelGGL(twolevel_forward_kernel, dim3((P.tl.nItems + 3) / 4), dim3(256), 0, st, P.tl.nItems, P.tl.item,
+                                   P.tl.panel, P.tl.rowBase, (const double *)P.tl.packed, (const double *)P.rpad, P.tl.cbuf, ctl);
+        }
         const int total = P.nParts * P.nmax;
         hipLaunchKernelGGL(twolevel_rhs_kernel, dim3(std::min((total + 255) / 256, 4096)), dim3(256), 0, st, total, P.tl.gPtr, P.tl.gIdx,
                            (const double *)P.rpad, (const double *)P.tl.cbuf, P.tl.rpad2, ctl);
@@ -1287,7 +1296,7 @@ static void launch_gemv_impl(const DevParts &P, const double *q, hipStream_t st,
     // P.tile = [wide tiles | narrow tiles of more than 256 columns | packs of four small tiles]: job k < nN of the narrow launch
     // is one tile, job nN + k the four tiles P.tile[ntiles + 4 k ..] (one wavefront each, backsolve_wave_tile)
     const int nW = P.ntilesWide, nN = P.ntiles - P.ntilesWide, nG = nN + P.nquad;
-    const bool timed = ev0 && ev1;
+    const bool timed = (ev0 && ev1) || evLast;
     if (ca && spec <= 0) spec = 1;   // (callers pass the slot's epoch: > 0)
     if (ca && nG == 0)   // no launch of the 256-thread kernel to host it: the controller on its own, in front
         launch_loop_control(ca->ctl, ca->partE, ca->nbE, ca->partR, ca->alpha_dev, ca->flags_host, st, ca->init & 1);
@@ -1327,14 +1336,14 @@ static void launch_gemv_impl(const DevParts &P, const double *q, hipStream_t st,
         const size_t shm = 16 * (size_t)((P.tl.maxRows + 7) & ~7) + 16 * 256;
         const int n2 = P.tl.maxCols / 2;
         if (n2 <= 32)
-            hipLaunchKernelGGL(twolevel_backward_kernel<32>, dim3(P.tl.nPanels), dim3(256), shm, st, P.tl.panel, P.tl.rowBase,
-                               P.tl.rowPos, (const double *)P.tl.packed, P.psub, ctl);
+            hipExtLaunchKernelGGL(twolevel_backward_kernel<32>, dim3(P.tl.nPanels), dim3(256), shm, st, (hipEvent_t) nullptr, evLast, 0,
+                                  P.tl.panel, P.tl.rowBase, P.tl.rowPos, (const double *)P.tl.packed, P.psub, ctl);
         else if (n2 <= 64)
-            hipLaunchKernelGGL(twolevel_backward_kernel<64>, dim3(P.tl.nPanels), dim3(256), shm, st, P.tl.panel, P.tl.rowBase,
-                               P.tl.rowPos, (const double *)P.tl.packed, P.psub, ctl);
+            hipExtLaunchKernelGGL(twolevel_backward_kernel<64>, dim3(P.tl.nPanels), dim3(256), shm, st, (hipEvent_t) nullptr, evLast, 0,
+                                  P.tl.panel, P.tl.rowBase, P.tl.rowPos, (const double *)P.tl.packed, P.psub, ctl);
         else
-            hipLaunchKernelGGL(twolevel_backward_kernel<128>, dim3(P.tl.nPanels), dim3(256), shm, st, P.tl.panel, P.tl.rowBase,
-                               P.tl.rowPos, (const double *)P.tl.packed, P.psub, ctl);
+            hipExtLaunchKernelGGL(twolevel_backward_kernel<128>, dim3(P.tl.nPanels), dim3(256), shm, st, (hipEvent_t) nullptr, evLast, 0,
+                                  P.tl.panel, P.tl.rowBase, P.tl.rowPos, (const double *)P.tl.packed, P.psub, ctl);
     }
 }
 void launch_gemv(const DevParts &P, const double *q, hipStream_t st, const DevLoop *ctl, hipEvent_t ev0, hipEvent_t ev1,

@@ -240,6 +240,10 @@ class DOTTimeStepper:
         self._check(self._L.dotmi_part_matrix(self._h, part, int(inverse), dp(M), ip(l2g)), "part_matrix")
         return M, l2g
 
+    def backsolveForm(self) -> int:
+        """0: explicit inverse in one pass; 1: two-level form (dotmi_backsolve_form)"""
+        return int(self._L.dotmi_backsolve_form(self._h))
+
     def benchPrecond(self, reps: int = 50):
         ms = C.c_double(); nb = C.c_int64()
         self._check(self._L.dotmi_bench_precond(self._h, reps, C.cast(C.byref(ms), _lib.c_dp), C.byref(nb)),

@@ -649,3 +649,53 @@ def test_backsolve_job_table_reproduces_the_launches_measured_on_the_gpu():
     assert (nmax, c["n_narrow"] + c["n_packs"], c["n_packs"], c["shallow"]) == (1664, 625, 231, 1)
     _, c, _, nmax, _, _ = _plan_bs_tiles("horse7K_stretch")
     assert (nmax, c["few"], c["shallow"]) == (3456, 1, 0)
+
+
+# ---- leaves-first layout of the two-level back-solve (dot_amd/csrc/nd_layout.hpp nd_relayout_leaves_first; round 6) ----------
+@pytest.mark.parametrize("name,levels,min_split", [("bar17K_twist", -1, -1), ("synbar:40x10x10:8", 4, 256), ("horse7K_stretch", 3, 384)])
+def test_leaves_first_layout_moves_regions_not_vertices(name, levels, min_split):
+    """dotmi_plan_layout under DOTMI_TWO_LEVEL=1 (host only): the same tree, the same vertices in the same order inside every region,
+    the regions re-placed -- every leaf in front (tree order), every separator behind them in post-order.  Checked: same padded size
+    and node sizes; per subdomain the positions are distinct and a vertex keeps its offset INSIDE its region; every leaf row lies in
+    front of every separator row; an internal node's `off` is the first separator column of its sub-tree, its separators a
+    contiguous range that ends with its own."""
+    from dot_amd.sharding import plan_layout
+    from dot_amd.workloads import load_workload
+    sc, ep, n = load_workload(name)
+    old = os.environ.pop("DOTMI_TWO_LEVEL", None)
+    try:
+        nodes0, nmax0, pos0, verts0 = plan_layout(sc.V_rest, sc.T, ep, n, levels=levels, min_split=min_split)
+        os.environ["DOTMI_TWO_LEVEL"] = "1"
+        nodes1, nmax1, pos1, verts1 = plan_layout(sc.V_rest, sc.T, ep, n, levels=levels, min_split=min_split)
+    finally:
+        os.environ.pop("DOTMI_TWO_LEVEL", None)
+        if old is not None:
+            os.environ["DOTMI_TWO_LEVEL"] = old
+    assert nmax0 == nmax1 and nodes0.shape == nodes1.shape and nodes0[0, 2] >= 0
+    leaf = nodes0[:, 2] < 0
+    assert np.array_equal(nodes0[:, 2:4], nodes1[:, 2:4]) and np.array_equal(nodes0[leaf, 1], nodes1[leaf, 1])
+    assert np.array_equal(nodes0[~leaf, 5], nodes1[~leaf, 5])
+
+    def region_of(nodes, q):   # node id and offset of padded position q inside that node's own region
+        for k, (off, size, a, c, offS, sizeS) in enumerate(nodes):
+            if a < 0 and off <= q < off + size:
+                return k, q - off
+            if a >= 0 and offS <= q < offS + sizeS:
+                return k, q - offS
+        raise AssertionError(q)
+
+    first_sep = min(int(r[4]) for r in nodes1 if r[2] >= 0)
+    assert all(int(r[0]) + int(r[1]) <= first_sep for r in nodes1 if r[2] < 0)          # every leaf in front of every separator
+    for p in range(0, n, max(1, n // 6)):
+        assert np.array_equal(verts0[p], verts1[p]) and len(set(pos1[p].tolist())) == len(pos1[p])
+        for q0, q1 in list(zip(pos0[p], pos1[p]))[:: max(1, len(pos0[p]) // 50)]:
+            assert region_of(nodes0, int(q0)) == region_of(nodes1, int(q1))
+
+    def seps(k):   # separator ranges of the sub-tree of node k, in post-order
+        off, size, a, c, offS, sizeS = (int(v) for v in nodes1[k])
+        return [] if a < 0 else seps(a) + seps(c) + [(offS, sizeS)]
+
+    for k in np.nonzero(~leaf)[0]:
+        rng_ = seps(int(k))
+        assert int(nodes1[k, 0]) == rng_[0][0]
+        assert all(rng_[i][0] + rng_[i][1] == rng_[i + 1][0] for i in range(len(rng_) - 1))
