@@ -23,7 +23,9 @@ CLASSES = [("dirstep_kernel", "dirstep"), ("elem_vertex_kernel", "elem_vertex"),
            ("spmv_zp_kernel", "spmv_zp"), ("build_qpad_kernel", "build_qpad"),
            ("build_p_kernel", "build_p"), ("step_forward_kernel", "step_forward"), ("elem_hessian_kernel", "elem_hessian"),
            ("assemble_kernel", "assemble"), ("tile_task_kernel", "tile_task"), ("tile_flow_kernel", "tile_flow"), ("tile_gemm_kernel", "tile_gemm"),
-           ("dense_fill_kernel", "dense_fill"), ("clear_tiles_kernel", "clear_tiles")]
+           ("dense_fill_kernel", "dense_fill"), ("clear_tiles_kernel", "clear_tiles"),
+           ("twolevel_forward_kernel", "twolevel_forward"), ("twolevel_backward_kernel", "twolevel_backward"),
+           ("twolevel_rhs_kernel", "twolevel_rhs"), ("twolevel_pack_kernel", "twolevel_pack")]
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"/tmp/pmc_{c}/**/*counter_collection.csv", recursive=True)
