@@ -404,14 +404,20 @@ def main():
                 "est_ms_per_step": round(tms / max(tn, 1) * calls / steps, 3),
                 "note": "device time between events around ncclAllReduce on rank 0: includes waiting for the slowest rank",
             }
+        two_level = hasattr(ts, "backsolveForm") and hasattr(dl.load(), "dotmi_backsolve_form") and ts.backsolveForm() == 1
         roofline = {
-            "bound": "hbm", "kernel": "backsolve_kernel / backsolve_ctl_kernel (the same tiles with the loop controller as "
+            "bound": "hbm", "kernel": ("twolevel_forward_kernel -> backsolve_kernel / backsolve_ctl_kernel -> twolevel_backward_kernel: the "
+            "block solve in its two-level form (leaves against the separator complement; DESIGN.md section 4a), timed from the first "
+            "kernel's start to the last one's end") if two_level else
+            "backsolve_kernel / backsolve_ctl_kernel (the same tiles with the loop controller as "
             "workgroup 0): subdomain back-solve p_s = X_s^T (X_s r_s), nested-dissection block-sparse inverse factors, "
-            "one streaming pass",
+            "one streaming pass", "form": "two-level" if two_level else "one-pass",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 5),
-            "bytes_definition": "8 x structural non-zeros of the block-sparse X_s this launch streams (each once)",
+            "bytes_definition": ("8 x (structural non-zeros of the leaves' and the separator complement's inverse factors, each once, "
+                                 "+ 2 x the packed panels L_GD X_DD)") if two_level else
+            "8 x structural non-zeros of the block-sparse X_s this launch streams (each once)",
             # the same launch priced with SURVEY 8(d)'s dense formula (what a dense forward + backward substitution
             # would have to read): > 1 means the dissection layout + single pass read that many times fewer bytes
             "dense_8d_bytes_per_launch": dense_bytes,
