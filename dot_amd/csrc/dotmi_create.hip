@@ -285,24 +285,57 @@ int build_device_mesh(dotmi_handle *h)
     {
         std::vector<std::vector<int>> sets(P.nParts);
         for (int ls = 0; ls < P.nParts; ++ls) sets[ls] = h->partVerts[h->p0 + ls];
-        // two-level form of the back-solve (DevTwoLevel): one rank, the block solve as a whole (not GSDD's subdomain at a time);
-        // by default where the merge is split as well (big meshes: the three launches around the tile kernels and the split
-        // merge cost ~40 us per iteration, bar17K: loop +0.9 ms against -0.16 ms of factorisation; 1 M tets: step -20 %), and
-        // then on a tree of at least four levels with regions split down to 256 scalars (profiles/r06_two_level.txt)
-        const bool wantTwoLevel = (h->tune.twoLevel > 0 || (h->tune.twoLevel < 0 && 3ll * nV >= 400000)) && !h->dist &&
-                                  !(h->flags & DOTMI_FLAG_GSDD);
-        if (wantTwoLevel && ndLevels < 0 && !getenv("DOTMI_ND_MIN")) {
-            ndLevels = std::max(4, nd_default_levels(h->partVerts));
-            ndMin = 256;
+        // two-level form of the back-solve (DevTwoLevel): one rank, the block solve as a whole (not GSDD's
+        // subdomain at a time).  By default where the one-pass form would stream at least 240 MB per application on its own
+        // layout: the three launches around the tile kernels and the split merge cost 25-40 us per iteration, the form saves bytes
+        // and a third of the factorisation -- measured (profiles/r06_two_level.txt H): bar17K (197 MB) +21 % per step, monkey
+        // (124 MB) +42 %, horse7K / 8 (107 MB) +8 %; kingkong18K / 18 (245 MB) -10 %, horse7K@r1:64 (681 MB) -12 %, 1 M tets
+        // (3.8 GB) -16 %.  The form wants a tree of at least four levels with regions split down to 256 scalars (the horse at
+        // three levels / 384: +4 % instead of -12 %).
+        const bool eligible = !h->dist && !(h->flags & DOTMI_FLAG_GSDD);
+        const bool userDepth = ndLevels >= 0 || getenv("DOTMI_ND_MIN") != nullptr;
+        bool wantTwoLevel = eligible && h->tune.twoLevel > 0;
+        auto plan = [&](bool twoLevelDepth) {
+            int lv = ndLevels, mn = ndMin;
+            if (twoLevelDepth && !userDepth) {
+                lv = std::max(4, nd_default_levels(h->partVerts));
+                mn = 256;
+            } else if (lv < 0 && !getenv("DOTMI_ND_MIN")) {
+                // depth and split threshold from ALL subdomains of the mesh: the same tree on every rank (nd_layout.hpp)
+                nd_choose_depth(h->partVerts, nV, adj_ptr, adj_idx, h->Xrest.data(), BS_NARROW, mn, lv, mn);
+            } else if (lv < 0) {
+                lv = nd_default_levels(h->partVerts);
+            }
+            if (h->tune.fuseLog) fprintf(stderr, "dotmi: dissection: %d levels, regions split down to %d scalars\n", lv, mn);
+            nd_plan(sets, nV, adj_ptr, adj_idx, h->Xrest.data(), lv, mn, h->nd, region);
+        };
+        plan(wantTwoLevel);
+        if (!wantTwoLevel && eligible && h->tune.twoLevel < 0 && !h->nd.empty() && h->nd[0].a >= 0) {
+            // bytes of the one-pass form on the layout just planned: every row of a region from the region's first column to
+            // its diagonal, live columns only (the count that becomes precond_bytes below)
+            long long nnz = 0;
+            const int nmax0 = h->nd[0].size;
+            std::vector<int> usedBefore(nmax0 + 1);
+            for (int ls = 0; ls < P.nParts; ++ls) {
+                std::vector<uint8_t> live(nmax0, 0);
+                for (size_t k = 0; k < h->nd.size(); ++k) {
+                    const int used = 3 * (int)region[k][ls].size(), ro = nd_region_first_row(h->nd[k], used);
+                    std::fill(live.begin() + ro, live.begin() + ro + used, 1);
+                }
+                usedBefore[0] = 0;
+                for (int c = 0; c < nmax0; ++c) usedBefore[c + 1] = usedBefore[c] + live[c];
+                for (size_t k = 0; k < h->nd.size(); ++k) {
+                    const NdNode &N = h->nd[k];
+                    const int used = 3 * (int)region[k][ls].size(), ro = nd_region_first_row(N, used);
+                    const int cb = N.a < 0 ? (ro & ~15) : N.off;
+                    for (int r = ro; r < ro + used; ++r) nnz += usedBefore[r + 1] - usedBefore[cb];
+                }
+            }
+            if (8 * nnz >= 240000000ll) {
+                wantTwoLevel = true;
+                if (!userDepth) plan(true);
+            }
         }
-        if (ndLevels < 0 && !getenv("DOTMI_ND_MIN")) {
-            // depth and split threshold from ALL subdomains of the mesh: the same tree on every rank (nd_layout.hpp)
-            nd_choose_depth(h->partVerts, nV, adj_ptr, adj_idx, h->Xrest.data(), BS_NARROW, ndMin, ndLevels, ndMin);
-        } else if (ndLevels < 0) {
-            ndLevels = nd_default_levels(h->partVerts);
-        }
-        if (h->tune.fuseLog) fprintf(stderr, "dotmi: dissection: %d levels, regions split down to %d scalars\n", ndLevels, ndMin);
-        nd_plan(sets, nV, adj_ptr, adj_idx, h->Xrest.data(), ndLevels, ndMin, h->nd, region);
         h->twoLevel = wantTwoLevel && !h->nd.empty() && h->nd[0].a >= 0;   // (a tree that has separators at all)
         if (h->twoLevel) nd_relayout_leaves_first(h->nd);
     }
@@ -1244,7 +1277,7 @@ int dotmi_plan_layout(int32_t nV, int32_t nT, const int32_t *T, const double *Xr
     }
     *nmax = nd_plan(sets, nV, adj_ptr, adj_idx, Xrest, levelsUse, minUse, tree, region);
     // (the leaves-first layout of the two-level back-solve when the environment forces that form: DOTMI_TWO_LEVEL=1; the automatic
-    // choice of dotmi_create -- from 400 000 dofs on one rank, on at least four levels -- is the caller's to mirror)
+    // choice of dotmi_create -- where the one-pass form would stream 240 MB or more, on at least four levels -- is the caller's to mirror)
     if (getenv("DOTMI_TWO_LEVEL") && atoi(getenv("DOTMI_TWO_LEVEL")) > 0) nd_relayout_leaves_first(tree);
     *n_nodes = (int32_t)tree.size();
     if (nodes) {

@@ -69,7 +69,7 @@ struct Tuning {
                               //                      other rows, or ~256 KB tiles where few subdomains leave the launch bound by
                               //                      its longest tile)
     int twoLevel = -1;        // DOTMI_TWO_LEVEL      1: the back-solve in its two-level form (leaves against the separator complement,
-                              //                      DevTwoLevel); 0: the explicit inverse in one pass; -1: two-level from 400 000 dofs
+                              //                      DevTwoLevel); 0: the explicit inverse in one pass; -1: two-level where one pass would stream >= 240 MB
     int splitMerge = -1;      // DOTMI_SPLIT_MERGE    1 / 0: the merge as reduce_partial_p + a gather from psub (the early order included) /
                               //                      as one walk over the tile partials; default: split from 400 k scalar dofs
     bool fuseLog = false;     // DOTMI_FUSE_LOG       print the fused-leaf units

@@ -90,7 +90,7 @@ def test_two_level_form_has_no_explicit_inverse_to_return_but_the_subdomain_matr
 
 
 def test_two_level_form_is_the_default_at_1M_tets_and_reads_0p7_of_the_one_pass_bytes():
-    """configs[4]: from 400 000 dofs on one rank the factors are built in the two-level form on a four-level tree; one application
+    """configs[4]: where one pass would stream 240 MB or more per application (here 3.83 GB) the factors are built in the two-level form on a four-level tree; one application
     streams 2.70 GB against the 3.83 GB of the explicit inverse on the round-5 layout (profiles/r06_two_level.txt).  Parity at
     this size: tests/test_gpu_round5.py::test_synbar_1M_tets_full_size_matches_the_oracle_fixture runs on this default."""
     sc, ep, n = load_workload("synbar:140x35x35:256")
