@@ -1122,9 +1122,11 @@ int dotmi_plan_vpatches(int32_t nV, int32_t nT, const int32_t *T, const double *
 //   prods:  4 int64 per product {a offset, b offset, lda, ldb}
 // With tasks == NULL only the counts are returned.  The tests execute the schedule in numpy, level after level, and
 // compare with a dense inverse Cholesky factor (tests/test_tile_schedule.py).
-int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0, int32_t eager_min,
-                             int32_t eager_chunk, int64_t *tasks, int64_t *prods, int64_t *n_tasks, int64_t *n_prods,
-                             int64_t *n_levels, int64_t *storage, int64_t *scratch_base, int64_t *row_off, int32_t *row_ld)
+static int plan_tile_schedule_impl(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0, int32_t eager_min,
+                                   int32_t eager_chunk, int64_t *tasks, int64_t *prods, int64_t *n_tasks, int64_t *n_prods,
+                                   int64_t *n_levels, int64_t *storage, int64_t *scratch_base, int64_t *row_off, int32_t *row_ld,
+                                   const uint8_t *leaf_tile, const int32_t *c0m, const int32_t *ntm, int64_t *row_off_m,
+                                   int32_t *row_ld_m)
 {
     if (nt < 1 || !live || !pattern || !c0 || !n_tasks || !n_prods) return DOTMI_E_INVALID;
     std::vector<long long> rtOff(nt, -1);
@@ -1137,6 +1139,17 @@ int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pat
         rtOff[j] = tot;
         tot += 64ll * rtLd[j];
     }
+    // two-level form: a second range per separator row block, tile columns [c0m[j], c0m[j] + ntm[j])
+    std::vector<long long> rtOffM(nt, -1);
+    std::vector<int> rtLdM(nt, 0), rtC0M(nt, 0);
+    if (leaf_tile)
+        for (int j = 0; j < nt; ++j) {
+            if (!live[j] || leaf_tile[j] || !c0m || !ntm || ntm[j] <= 0) continue;
+            rtC0M[j] = 64 * c0m[j];
+            rtLdM[j] = 64 * ntm[j] + 16;
+            rtOffM[j] = tot;
+            tot += 64ll * rtLdM[j];
+        }
     double *const W = reinterpret_cast<double *>(1ull << 40);   // never dereferenced: only offsets leave this function
     double *const scratch = W + tot;
     std::vector<uint8_t> lv(live, live + nt), pat(pattern, pattern + (size_t)nt * nt);
@@ -1144,7 +1157,9 @@ int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pat
     TileSchedule S;
     size_t sn = 0;
     plan_subdomain_tiles(0, nt, W, rtOff.data(), rtLd.data(), rtC0.data(), lv, pat, scratch, sn, all, S.clearTiles, S.clearLd,
-                         S.flops, S.qTiles, std::max(1, eager_min), std::max(1, eager_chunk));
+                         S.flops, S.qTiles, std::max(1, eager_min), std::max(1, eager_chunk), 0, true, -1,
+                         leaf_tile ? rtOffM.data() : nullptr, leaf_tile ? rtLdM.data() : nullptr, leaf_tile ? rtC0M.data() : nullptr,
+                         leaf_tile);
     std::vector<int> levelOf;
     {
         // finish_tile_schedule reorders inside levels; keep the level of every task
@@ -1162,6 +1177,10 @@ int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pat
         for (int j = 0; j < nt; ++j) row_off[j] = rtOff[j];
     if (row_ld)
         for (int j = 0; j < nt; ++j) row_ld[j] = rtLd[j];
+    if (row_off_m)
+        for (int j = 0; j < nt; ++j) row_off_m[j] = rtOffM[j];
+    if (row_ld_m)
+        for (int j = 0; j < nt; ++j) row_ld_m[j] = rtLdM[j];
     if (!tasks || !prods) return 0;
     size_t pi = 0;
     for (size_t k = 0; k < all.size(); ++k) {
@@ -1187,6 +1206,27 @@ int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pat
         }
     }
     return 0;
+}
+
+int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0, int32_t eager_min,
+                             int32_t eager_chunk, int64_t *tasks, int64_t *prods, int64_t *n_tasks, int64_t *n_prods,
+                             int64_t *n_levels, int64_t *storage, int64_t *scratch_base, int64_t *row_off, int32_t *row_ld)
+{
+    return plan_tile_schedule_impl(nt, live, pattern, c0, eager_min, eager_chunk, tasks, prods, n_tasks, n_prods, n_levels, storage,
+                                   scratch_base, row_off, row_ld, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+// host-only: the same schedule in the TWO-LEVEL form (tile_factor.hpp, twoLevel; a leaves-first block): leaf_tile[t] = tile row t
+// belongs to a leaf; a separator's row block j stores the leaf tile columns [c0m[j], c0m[j] + ntm[j]) of its sub-tree in a second
+// range (row_off_m / row_ld_m) and its main range starts at its sub-tree's first separator column c0[j]
+int dotmi_plan_tile_schedule_two_level(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0,
+                                       const uint8_t *leaf_tile, const int32_t *c0m, const int32_t *ntm, int32_t eager_min,
+                                       int32_t eager_chunk, int64_t *tasks, int64_t *prods, int64_t *n_tasks, int64_t *n_prods,
+                                       int64_t *n_levels, int64_t *storage, int64_t *row_off, int32_t *row_ld, int64_t *row_off_m,
+                                       int32_t *row_ld_m)
+{
+    if (!leaf_tile || !c0m || !ntm) return DOTMI_E_INVALID;
+    return plan_tile_schedule_impl(nt, live, pattern, c0, eager_min, eager_chunk, tasks, prods, n_tasks, n_prods, n_levels, storage,
+                                   nullptr, row_off, row_ld, leaf_tile, c0m, ntm, row_off_m, row_ld_m);
 }
 
 // host-only: the dependencies the dataflow kernel (tile_flow_kernel) waits on, for the task list dotmi_plan_tile_schedule

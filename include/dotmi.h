@@ -237,6 +237,16 @@ int dotmi_plan_vpatches(int32_t nV, int32_t nT, const int32_t *T, const double *
 int dotmi_plan_tile_schedule(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0, int32_t eager_min,
                              int32_t eager_chunk, int64_t *tasks, int64_t *prods, int64_t *n_tasks, int64_t *n_prods,
                              int64_t *n_levels, int64_t *storage, int64_t *scratch_base, int64_t *row_off, int32_t *row_ld);
+/* (host only, round 6) that schedule in the TWO-LEVEL form of the block solve (dotmi_backsolve_form = 1) for a leaves-first block:
+ * leaf_tile[t] = tile row t belongs to a leaf of the dissection; a separator's row block j keeps the leaf tile columns
+ * [c0m[j], c0m[j] + ntm[j]) of its sub-tree in a second storage range (row_off_m / row_ld_m), its main range starts at its
+ * sub-tree's first separator column c0[j].  Tiles (leaf i, separator j) receive T_ij = sum over the tiles m >= i of i's leaf of
+ * Q_im R_mj (post = store); the inverse's other cross terms do not exist.  tests/test_tile_schedule.py runs it in numpy */
+int dotmi_plan_tile_schedule_two_level(int32_t nt, const uint8_t *live, const uint8_t *pattern, const int32_t *c0,
+                                       const uint8_t *leaf_tile, const int32_t *c0m, const int32_t *ntm, int32_t eager_min,
+                                       int32_t eager_chunk, int64_t *tasks, int64_t *prods, int64_t *n_tasks, int64_t *n_prods,
+                                       int64_t *n_levels, int64_t *storage, int64_t *row_off, int32_t *row_ld, int64_t *row_off_m,
+                                       int32_t *row_ld_m);
 /* (host only) the dependencies of that task list for the dataflow form of the factorisation (DOTMI_TILE_FLOW, one launch of
  * persistent workgroups; tile_flow_kernel): task v waits for dep_idx[dep_ptr[v] .. dep_ptr[v+1]).  Same arguments and task
  * order as dotmi_plan_tile_schedule; dep_idx == NULL returns the count only. */
