@@ -285,16 +285,17 @@ int build_device_mesh(dotmi_handle *h)
     {
         std::vector<std::vector<int>> sets(P.nParts);
         for (int ls = 0; ls < P.nParts; ++ls) sets[ls] = h->partVerts[h->p0 + ls];
-        // two-level form of the back-solve (DevTwoLevel): one rank, the block solve as a whole (not GSDD's
-        // subdomain at a time).  By default where the one-pass form would stream at least 240 MB per application on its own
+        // two-level form of the back-solve (DevTwoLevel): the block solve as a whole (not GSDD's subdomain at
+        // a time); per subdomain, so sharded subdomains take it as well.  By default where the one-pass form would stream at least 240 MB per application on its own
         // layout: the three launches around the tile kernels and the split merge cost 25-40 us per iteration, the form saves bytes
         // and a third of the factorisation -- measured (profiles/r06_two_level.txt H): bar17K (197 MB) +21 % per step, monkey
         // (124 MB) +42 %, horse7K / 8 (107 MB) +8 %; kingkong18K / 18 (245 MB) -10 %, horse7K@r1:64 (681 MB) -12 %, 1 M tets
         // (3.8 GB) -16 %.  The form wants a tree of at least four levels with regions split down to 256 scalars (the horse at
         // three levels / 384: +4 % instead of -12 %).
-        const bool eligible = !h->dist && !(h->flags & DOTMI_FLAG_GSDD);
+        const bool eligible = !(h->flags & DOTMI_FLAG_GSDD);
         const bool userDepth = ndLevels >= 0 || getenv("DOTMI_ND_MIN") != nullptr;
         bool wantTwoLevel = eligible && h->tune.twoLevel > 0;
+        int lvUsed = 0, mnUsed = 0;
         auto plan = [&](bool twoLevelDepth) {
             int lv = ndLevels, mn = ndMin;
             if (twoLevelDepth && !userDepth) {
@@ -307,29 +308,45 @@ int build_device_mesh(dotmi_handle *h)
                 lv = nd_default_levels(h->partVerts);
             }
             if (h->tune.fuseLog) fprintf(stderr, "dotmi: dissection: %d levels, regions split down to %d scalars\n", lv, mn);
+            lvUsed = lv;
+            mnUsed = mn;
             nd_plan(sets, nV, adj_ptr, adj_idx, h->Xrest.data(), lv, mn, h->nd, region);
         };
-        plan(wantTwoLevel);
-        if (!wantTwoLevel && eligible && h->tune.twoLevel < 0 && !h->nd.empty() && h->nd[0].a >= 0) {
-            // bytes of the one-pass form on the layout just planned: every row of a region from the region's first column to
-            // its diagonal, live columns only (the count that becomes precond_bytes below)
+        // bytes of the one-pass form on a planned layout: every row of a region from the region's first column to its diagonal,
+        // live columns only (the count that becomes precond_bytes below)
+        auto onePassNnz = [](const std::vector<NdNode> &nd, const std::vector<std::vector<std::vector<int>>> &reg, int nParts) {
             long long nnz = 0;
-            const int nmax0 = h->nd[0].size;
+            const int nmax0 = nd[0].size;
             std::vector<int> usedBefore(nmax0 + 1);
-            for (int ls = 0; ls < P.nParts; ++ls) {
+            for (int ls = 0; ls < nParts; ++ls) {
                 std::vector<uint8_t> live(nmax0, 0);
-                for (size_t k = 0; k < h->nd.size(); ++k) {
-                    const int used = 3 * (int)region[k][ls].size(), ro = nd_region_first_row(h->nd[k], used);
+                for (size_t k = 0; k < nd.size(); ++k) {
+                    const int used = 3 * (int)reg[k][ls].size(), ro = nd_region_first_row(nd[k], used);
                     std::fill(live.begin() + ro, live.begin() + ro + used, 1);
                 }
                 usedBefore[0] = 0;
                 for (int c = 0; c < nmax0; ++c) usedBefore[c + 1] = usedBefore[c] + live[c];
-                for (size_t k = 0; k < h->nd.size(); ++k) {
-                    const NdNode &N = h->nd[k];
-                    const int used = 3 * (int)region[k][ls].size(), ro = nd_region_first_row(N, used);
+                for (size_t k = 0; k < nd.size(); ++k) {
+                    const NdNode &N = nd[k];
+                    const int used = 3 * (int)reg[k][ls].size(), ro = nd_region_first_row(N, used);
                     const int cb = N.a < 0 ? (ro & ~15) : N.off;
                     for (int r = ro; r < ro + used; ++r) nnz += usedBefore[r + 1] - usedBefore[cb];
                 }
+            }
+            return nnz;
+        };
+        plan(wantTwoLevel);
+        if (!wantTwoLevel && eligible && h->tune.twoLevel < 0 && !h->nd.empty() && h->nd[0].a >= 0) {
+            // counted over ALL subdomains of the mesh, so that every rank of a sharded run -- and the single-GPU run it is
+            // compared with -- takes the same form (a rank's own factors are private, but the forms differ in rounding)
+            long long nnz = 0;
+            if (P.nParts == (int)h->partVerts.size()) {
+                nnz = onePassNnz(h->nd, region, P.nParts);
+            } else {
+                std::vector<NdNode> treeAll;
+                std::vector<std::vector<std::vector<int>>> regionAll;
+                nd_plan(h->partVerts, nV, adj_ptr, adj_idx, h->Xrest.data(), lvUsed, mnUsed, treeAll, regionAll);
+                if (!treeAll.empty()) nnz = onePassNnz(treeAll, regionAll, (int)h->partVerts.size());
             }
             if (8 * nnz >= 240000000ll) {
                 wantTwoLevel = true;

@@ -331,7 +331,7 @@ int64_t dotmi_factor_storage_bytes(const dotmi_handle *h);
  * tasks in tile_task_kernel beside the product / row / inverse tasks on half tiles in tile_gemm_kernel (above 64 subdomains) */
 int32_t dotmi_factor_kind(const dotmi_handle *h);
 /* which form of the block solve this handle's factors are in: 0 = the explicit inverse X_s = chol(H_s)^-1 of every subdomain,
- * streamed in one pass (p_s = X_s^T X_s r_s); 1 = the two-level form (round 6; default where form 0 would stream 240 MB or more per application, on one rank,
+ * streamed in one pass (p_s = X_s^T X_s r_s); 1 = the two-level form (round 6; default where form 0 would stream 240 MB or more per application over all subdomains of the mesh,
  * DOTMI_TWO_LEVEL): the inverse factors of the dissection's leaves and of the separator complement, and between them the panels
  * L_GD X_DD of the factor itself -- the forward / backward substitution of CHOLMODSolver::solve (CHOLMODSolver.cpp:149-163) across
  * that one boundary.  dotmi_part_matrix(inverse = 1) is an error in form 1 (there is no explicit inverse of a whole subdomain) */

@@ -104,3 +104,13 @@ def test_two_level_form_is_the_default_at_1M_tets_and_reads_0p7_of_the_one_pass_
         assert 2.5e9 < st.precond_bytes < 0.72 * 3833832864
     finally:
         ts.close()
+
+
+@pytest.mark.parametrize("workload,steps,shard_elems,world", [("horse7K_stretch", 4, "0", 2), ("bar17K_twist", 2, "owner", 4),
+                                                              ("bunny5K_LTSS", 3, "1", 2)])
+def test_sharded_subdomains_take_the_two_level_form_too(workload, steps, shard_elems, world):
+    """The form is per subdomain, so a rank's share of them can be in it: ranks as processes on one GPU (gloo, real partial
+    ownership; tests/test_gpu_two_ranks.py's harness) with the form forced on -- bit-identical ranks, the single-GPU run's
+    iterations and halvings, positions to 1e-9 (all-reduce, sharded element pass, owner exchange)."""
+    from tests.test_gpu_two_ranks import test_ranks_on_one_gpu_reproduce_the_single_gpu_run as harness
+    _with_env({"DOTMI_TWO_LEVEL": "1"}, lambda: harness(workload, steps, shard_elems, world))
