@@ -841,6 +841,11 @@ int build_device_mesh(dotmi_handle *h)
             rowDst.push_back(0);
             rowPos.push_back(0);
         }
+        if (maxRows > 7000) {   // (twolevel_backward_kernel keeps a panel's p_G entries in LDS)
+            h->err = "two-level form: a leaf couples to " + std::to_string(maxRows) + " separator rows (limit 7000): split the regions "
+                     "further (DOTMI_ND_LEVELS / DOTMI_ND_MIN) or use DOTMI_TWO_LEVEL=0";
+            return DOTMI_E_INVALID;
+        }
         std::vector<int2> items;
         for (size_t q = 0; q < panel.size(); ++q)
             for (int k0 = 0; k0 < panel[q].y; k0 += 8) items.push_back(make_int2((int)q, k0));

@@ -1217,14 +1217,13 @@ __global__ __launch_bounds__(256) void twolevel_backward_kernel(const int4 *__re
     const int tid = threadIdx.x, cg = tid % CW, g = tid / CW;
     const int nr = (pn.y + RB - 1) / RB * RB;
     double *pg = tl_lds;
-    long long *base = reinterpret_cast<long long *>(tl_lds + nr);
-    double2 *part = reinterpret_cast<double2 *>(base + nr);   // [RG][CW]
-    for (int k = tid; k < nr; k += 256) {
-        pg[k] = k < pn.y ? psub[rowPos[pn.x + k]] : 0.0;
-        base[k] = rowBase[pn.x + min(k, pn.y - 1)];
-    }
+    double2 *part = reinterpret_cast<double2 *>(tl_lds + nr);   // [RG][CW]
+    for (int k = tid; k < nr; k += 256) pg[k] = k < pn.y ? psub[rowPos[pn.x + k]] : 0.0;
     __syncthreads();
     const int n2 = pn.w >> 1;
+    // (the packed rows of a panel lie one behind the other; the rows past the panel's end -- multiplied by zeros -- re-read its last)
+    const double2 *rows = reinterpret_cast<const double2 *>(W + rowBase[pn.x]);
+    const int last = pn.y - 1;
     for (int c0 = 0; c0 < n2; c0 += CW) {
         const int c = c0 + cg;
         double2 a[4] = {make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0), make_double2(0.0, 0.0)};
@@ -1232,7 +1231,7 @@ __global__ __launch_bounds__(256) void twolevel_backward_kernel(const int4 *__re
             for (int k = RB * g; k < nr; k += RB * RG) {
                 double2 w[RB];
 #pragma unroll
-                for (int u = 0; u < RB; ++u) w[u] = reinterpret_cast<const double2 *>(W + base[k + u])[c];
+                for (int u = 0; u < RB; ++u) w[u] = rows[(size_t)min(k + u, last) * n2 + c];
 #pragma unroll
                 for (int u = 0; u < RB; ++u) {
                     a[u & 3].x += w[u].x * pg[k + u];
@@ -1333,7 +1332,7 @@ static void launch_gemv_impl(const DevParts &P, const double *q, hipStream_t st,
     if (!P.mt_ptr) launch_reduce_partial(P, st, ctl);   // (merge_tiles_kernel sums the tile partials itself)
     if (P.tl.on && P.tl.nPanels > 0)   // p_D = q_D - M_GD^T p_G on the sums just formed
     {
-        const size_t shm = 16 * (size_t)((P.tl.maxRows + 7) & ~7) + 16 * 256;
+        const size_t shm = 8 * (size_t)((P.tl.maxRows + 7) & ~7) + 16 * 256;   // (dotmi_create refuses panels beyond 7000 rows)
         const int n2 = P.tl.maxCols / 2;
         if (n2 <= 32)
             hipExtLaunchKernelGGL(twolevel_backward_kernel<32>, dim3(P.tl.nPanels), dim3(256), shm, st, (hipEvent_t) nullptr, evLast, 0,
