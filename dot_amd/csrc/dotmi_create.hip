@@ -290,7 +290,7 @@ int build_device_mesh(dotmi_handle *h)
         // layout: the three launches around the tile kernels and the split merge cost 25-40 us per iteration, the form saves bytes
         // and a third of the factorisation -- measured (profiles/r06_two_level.txt H): bar17K (197 MB) +21 % per step, monkey
         // (124 MB) +42 %, horse7K / 8 (107 MB) +8 %; kingkong18K / 18 (245 MB) -10 %, horse7K@r1:64 (681 MB) -12 %, 1 M tets
-        // (3.8 GB) -16 %.  The form wants a tree of at least four levels with regions split down to 256 scalars (the horse at
+        // (3.8 GB) -16 %.  The form wants a tree of at least four levels with regions split down to ~200 scalars (the horse at
         // three levels / 384: +4 % instead of -12 %).
         const bool eligible = !(h->flags & DOTMI_FLAG_GSDD);
         const bool userDepth = ndLevels >= 0 || getenv("DOTMI_ND_MIN") != nullptr;
@@ -299,8 +299,14 @@ int build_device_mesh(dotmi_handle *h)
         auto plan = [&](bool twoLevelDepth) {
             int lv = ndLevels, mn = ndMin;
             if (twoLevelDepth && !userDepth) {
+                // sixteen leaves per subdomain where its size allows: four levels, regions split down to a fifteenth of the biggest
+                // subdomain (between 128 and 256 scalars) -- 1 M tets / 256 (3.2 k dofs): 213, the same tree as with 256; 4.2 M tets /
+                // 1024 (2.9 k dofs): 192, 16 leaves instead of 8: 13.8 -> 9.8 GB per application, the step -7 %; 192 k tets / 64:
+                // 433 -> 325 MB, -7.5 % (profiles/r06_two_level.txt J)
                 lv = std::max(4, nd_default_levels(h->partVerts));
-                mn = 256;
+                int nsmax = 0;
+                for (auto &v : h->partVerts) nsmax = std::max(nsmax, 3 * (int)v.size());
+                mn = std::min(256, std::max(128, nsmax / 15));
             } else if (lv < 0 && !getenv("DOTMI_ND_MIN")) {
                 // depth and split threshold from ALL subdomains of the mesh: the same tree on every rank (nd_layout.hpp)
                 nd_choose_depth(h->partVerts, nV, adj_ptr, adj_idx, h->Xrest.data(), BS_NARROW, mn, lv, mn);
