@@ -86,7 +86,10 @@ def test_two_level_form_has_no_explicit_inverse_to_return_but_the_subdomain_matr
     ts = _with_env({"DOTMI_TWO_LEVEL": "0"}, lambda: DOTTimeStepper(sc, ep, n))
     H1, l2g1 = ts.partMatrix(1)
     ts.close()
-    assert np.array_equal(l2g1, l2g2) and np.array_equal(H1, H2)
+    # (the same matrix to rounding, not to the bit: the assembled global Hessian is symmetric only to an ulp -- its (i, j) block and
+    # the transpose of its (j, i) block are separate sums -- and which of the two lands in the stored triangle follows the order of
+    # the two vertices in the layout; the forms' default trees differ)
+    assert np.array_equal(l2g1, l2g2) and np.abs(H1 - H2).max() <= 1e-14 * np.abs(H1).max()
 
 
 def test_two_level_form_is_the_default_at_1M_tets_and_reads_0p7_of_the_one_pass_bytes():
