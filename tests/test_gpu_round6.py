@@ -231,6 +231,7 @@ def test_paired_trials_on_vertex_patches_take_the_same_steps_bit_for_bit(monkeyp
     tests/test_gpu_round5.py), and the rule does pair there."""
     def run(mode):
         monkeypatch.setenv("DOTMI_PAIR_TRIALS", mode)
+        monkeypatch.setenv("DOTMI_VERTEX_PATCHES", "1")   # (forced: by default a paired step keeps the element patches)
         sc, ep, n = load_workload("monkey18K_stiff")
         ts = DOTTimeStepper(sc, ep, n)
         rec, paired, redone = [], 0, 0
