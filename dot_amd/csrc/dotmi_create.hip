@@ -186,6 +186,32 @@ int upload_patches(dotmi_handle *h, const HostPatches &H, DevPatches &D)
     return 0;
 }
 
+// structural non-zeros of the one-pass form (explicit inverse) on a planned layout: every row of a region from the region's first
+// column to its diagonal, live columns only -- x 8 = the bytes one application streams (dotmi_step_stats.precond_bytes)
+static long long one_pass_nnz(const std::vector<NdNode> &nd, const std::vector<std::vector<std::vector<int>>> &reg, int nParts)
+{
+    long long nnz = 0;
+    const int nmax0 = nd[0].size;
+    std::vector<int> usedBefore(nmax0 + 1);
+    for (int ls = 0; ls < nParts; ++ls) {
+        std::vector<uint8_t> live(nmax0, 0);
+        for (size_t k = 0; k < nd.size(); ++k) {
+            const int used = 3 * (int)reg[k][ls].size(), ro = nd_region_first_row(nd[k], used);
+            std::fill(live.begin() + ro, live.begin() + ro + used, 1);
+        }
+        usedBefore[0] = 0;
+        for (int c = 0; c < nmax0; ++c) usedBefore[c + 1] = usedBefore[c] + live[c];
+        for (size_t k = 0; k < nd.size(); ++k) {
+            const NdNode &N = nd[k];
+            const int used = 3 * (int)reg[k][ls].size(), ro = nd_region_first_row(N, used);
+            const int cb = N.a < 0 ? (ro & ~15) : N.off;
+            for (int r = ro; r < ro + used; ++r) nnz += usedBefore[r + 1] - usedBefore[cb];
+        }
+    }
+    return nnz;
+}
+constexpr long long TWO_LEVEL_FROM_BYTES = 240000000ll;   // one-pass bytes per application from which the two-level form is the default
+
 int build_device_mesh(dotmi_handle *h)
 {
     const int nV = h->nV, nT = h->nT;
@@ -318,43 +344,20 @@ int build_device_mesh(dotmi_handle *h)
             mnUsed = mn;
             nd_plan(sets, nV, adj_ptr, adj_idx, h->Xrest.data(), lv, mn, h->nd, region);
         };
-        // bytes of the one-pass form on a planned layout: every row of a region from the region's first column to its diagonal,
-        // live columns only (the count that becomes precond_bytes below)
-        auto onePassNnz = [](const std::vector<NdNode> &nd, const std::vector<std::vector<std::vector<int>>> &reg, int nParts) {
-            long long nnz = 0;
-            const int nmax0 = nd[0].size;
-            std::vector<int> usedBefore(nmax0 + 1);
-            for (int ls = 0; ls < nParts; ++ls) {
-                std::vector<uint8_t> live(nmax0, 0);
-                for (size_t k = 0; k < nd.size(); ++k) {
-                    const int used = 3 * (int)reg[k][ls].size(), ro = nd_region_first_row(nd[k], used);
-                    std::fill(live.begin() + ro, live.begin() + ro + used, 1);
-                }
-                usedBefore[0] = 0;
-                for (int c = 0; c < nmax0; ++c) usedBefore[c + 1] = usedBefore[c] + live[c];
-                for (size_t k = 0; k < nd.size(); ++k) {
-                    const NdNode &N = nd[k];
-                    const int used = 3 * (int)reg[k][ls].size(), ro = nd_region_first_row(N, used);
-                    const int cb = N.a < 0 ? (ro & ~15) : N.off;
-                    for (int r = ro; r < ro + used; ++r) nnz += usedBefore[r + 1] - usedBefore[cb];
-                }
-            }
-            return nnz;
-        };
         plan(wantTwoLevel);
         if (!wantTwoLevel && eligible && h->tune.twoLevel < 0 && !h->nd.empty() && h->nd[0].a >= 0) {
             // counted over ALL subdomains of the mesh, so that every rank of a sharded run -- and the single-GPU run it is
             // compared with -- takes the same form (a rank's own factors are private, but the forms differ in rounding)
             long long nnz = 0;
             if (P.nParts == (int)h->partVerts.size()) {
-                nnz = onePassNnz(h->nd, region, P.nParts);
+                nnz = one_pass_nnz(h->nd, region, P.nParts);
             } else {
                 std::vector<NdNode> treeAll;
                 std::vector<std::vector<std::vector<int>>> regionAll;
                 nd_plan(h->partVerts, nV, adj_ptr, adj_idx, h->Xrest.data(), lvUsed, mnUsed, treeAll, regionAll);
-                if (!treeAll.empty()) nnz = onePassNnz(treeAll, regionAll, (int)h->partVerts.size());
+                if (!treeAll.empty()) nnz = one_pass_nnz(treeAll, regionAll, (int)h->partVerts.size());
             }
-            if (8 * nnz >= 240000000ll) {
+            if (8 * nnz >= TWO_LEVEL_FROM_BYTES) {
                 wantTwoLevel = true;
                 if (!userDepth) plan(true);
             }
@@ -1485,6 +1488,38 @@ int32_t dotmi_factor_kind(const dotmi_handle *h)
 {
     if (!h) return DOTMI_E_INVALID;
     return h->tileFlow ? 2 : h->tileSplit ? 3 : 1;
+}
+
+// host-only: the form of the block solve dotmi_create chooses for this mesh and partition when DOTMI_TWO_LEVEL is unset (0 = explicit
+// inverse in one pass, 1 = two-level), and the bytes per application of the one-pass form on its own layout, counted over all
+// subdomains, that decide it (>= 240 MB and a tree with separators: two-level)
+int dotmi_plan_backsolve_form(int32_t nV, int32_t nT, const int32_t *T, const double *Xrest, const int32_t *epart, int32_t nParts,
+                              int32_t *form, int64_t *one_pass_bytes)
+{
+    if (nV < 1 || nT < 1 || !T || !Xrest || !epart || nParts < 1 || !form) return DOTMI_E_INVALID;
+    for (int e = 0; e < nT; ++e) {
+        if (epart[e] < 0 || epart[e] >= nParts) return DOTMI_E_INVALID;
+        for (int k = 0; k < 4; ++k)
+            if (T[4 * e + k] < 0 || T[4 * e + k] >= nV) return DOTMI_E_INVALID;
+    }
+    std::vector<int> adj_ptr, adj_idx;
+    build_adjacency(nV, nT, T, adj_ptr, adj_idx);
+    std::vector<std::vector<int>> allSets(nParts);
+    for (int e = 0; e < nT; ++e)
+        for (int k = 0; k < 4; ++k) allSets[epart[e]].push_back(T[4 * e + k]);
+    for (auto &v : allSets) {
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+    }
+    int levels = -1, minSplit = ND_MIN_SPLIT;
+    nd_choose_depth(allSets, nV, adj_ptr, adj_idx, Xrest, BS_NARROW, ND_MIN_SPLIT, levels, minSplit);
+    std::vector<NdNode> tree;
+    std::vector<std::vector<std::vector<int>>> region;
+    nd_plan(allSets, nV, adj_ptr, adj_idx, Xrest, levels, minSplit, tree, region);
+    const long long bytes = tree.empty() ? 0 : 8 * one_pass_nnz(tree, region, nParts);
+    *form = (!tree.empty() && tree[0].a >= 0 && bytes >= TWO_LEVEL_FROM_BYTES) ? 1 : 0;
+    if (one_pass_bytes) *one_pass_bytes = bytes;
+    return 0;
 }
 
 int32_t dotmi_backsolve_form(const dotmi_handle *h)

@@ -72,7 +72,7 @@ EXPORTS = [
     "dotmi_get_state", "dotmi_set_dirichlet", "dotmi_refix", "dotmi_step", "dotmi_last_iter_log",
     "dotmi_target_gres", "dotmi_eval_energy", "dotmi_eval_gradient", "dotmi_eval_elem_hessians",
     "dotmi_refactor", "dotmi_apply_precond", "dotmi_spmv", "dotmi_get_features", "dotmi_part_size", "dotmi_padded_size",
-    "dotmi_part_matrix", "dotmi_factor_storage_bytes", "dotmi_factor_kind", "dotmi_backsolve_form", "dotmi_probe_direction", "dotmi_bench_precond", "dotmi_bench_energy", "dotmi_bench_kernel", "dotmi_plan_shards", "dotmi_plan_layout", "dotmi_plan_tile_schedule", "dotmi_plan_tile_schedule_two_level", "dotmi_plan_tile_deps", "dotmi_plan_backsolve_tiles", "dotmi_plan_patches", "dotmi_plan_vpatches", "dotmi_plan_rank", "dotmi_partition",
+    "dotmi_part_matrix", "dotmi_factor_storage_bytes", "dotmi_factor_kind", "dotmi_backsolve_form", "dotmi_plan_backsolve_form", "dotmi_probe_direction", "dotmi_bench_precond", "dotmi_bench_energy", "dotmi_bench_kernel", "dotmi_plan_shards", "dotmi_plan_layout", "dotmi_plan_tile_schedule", "dotmi_plan_tile_schedule_two_level", "dotmi_plan_tile_deps", "dotmi_plan_backsolve_tiles", "dotmi_plan_patches", "dotmi_plan_vpatches", "dotmi_plan_rank", "dotmi_partition",
 ]
 
 _lib = None

@@ -336,6 +336,10 @@ int32_t dotmi_factor_kind(const dotmi_handle *h);
  * L_GD X_DD of the factor itself -- the forward / backward substitution of CHOLMODSolver::solve (CHOLMODSolver.cpp:149-163) across
  * that one boundary.  dotmi_part_matrix(inverse = 1) is an error in form 1 (there is no explicit inverse of a whole subdomain) */
 int32_t dotmi_backsolve_form(const dotmi_handle *h);
+/* (host only) the form dotmi_create chooses on its own for this mesh and partition, and the bytes per application of form 0 on its own
+ * layout (over all subdomains) that decide it; tests/test_host_logic.py pins the choice for the BASELINE workloads */
+int dotmi_plan_backsolve_form(int32_t nV, int32_t nT, const int32_t *T, const double *Xrest, const int32_t *epart, int32_t nParts,
+                              int32_t *form, int64_t *one_pass_bytes);
 int dotmi_part_matrix(dotmi_handle *h, int32_t part, int inverse, double *M, int32_t *l2g);
 
 /* ---- measurement ------------------------------------------------------------------------------ */

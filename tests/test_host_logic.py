@@ -699,3 +699,34 @@ def test_leaves_first_layout_moves_regions_not_vertices(name, levels, min_split)
         rng_ = seps(int(k))
         assert int(nodes1[k, 0]) == rng_[0][0]
         assert all(rng_[i][0] + rng_[i][1] == rng_[i + 1][0] for i in range(len(rng_) - 1))
+
+
+# ---- which form of the block solve a mesh takes by default (dotmi_plan_backsolve_form, host only; round 6) -------------------------
+@pytest.mark.parametrize("name,form,mb", [("bunny5K_LTSS", 0, 41.4), ("horse7K_stretch", 0, 107.3), ("monkey18K_stiff", 0, 123.6),
+                                          ("bar17K_twist", 0, 196.6), ("kingkong18K_SS_1K", 1, 244.6),
+                                          ("horse7K_stretch@r1:64", 1, 681.3)])
+def test_default_form_of_the_block_solve_follows_the_one_pass_bytes(name, form, mb):
+    """dotmi_create takes the two-level form where the explicit inverse would stream 240 MB or more per application on its own
+    layout (counted over all subdomains; profiles/r06_two_level.txt H: the measured crossover).  Pinned here for the BASELINE
+    workloads and the two that switched, with the byte counts the device handles report as precond_bytes in the one-pass form."""
+    import ctypes as C
+    from dot_amd import lib as dl
+    from dot_amd.workloads import load_workload
+    old = os.environ.pop("DOTMI_TWO_LEVEL", None)
+    try:
+        sc, ep, n = load_workload(name)
+        L = dl.load()
+        T = np.ascontiguousarray(sc.T, dtype=np.int32)
+        X = np.ascontiguousarray(sc.V_rest, dtype=np.float64)
+        epa = np.ascontiguousarray(ep, dtype=np.int32)
+        f, b = C.c_int32(-1), C.c_int64(0)
+        L.dotmi_plan_backsolve_form.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                                C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+        rc = L.dotmi_plan_backsolve_form(X.shape[0], T.shape[0], T.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         X.ctypes.data_as(C.POINTER(C.c_double)), epa.ctypes.data_as(C.POINTER(C.c_int32)), n,
+                                         C.byref(f), C.byref(b))
+    finally:
+        if old is not None:
+            os.environ["DOTMI_TWO_LEVEL"] = old
+    assert rc == 0 and f.value == form
+    assert abs(b.value / 1e6 - mb) < 0.06, b.value
